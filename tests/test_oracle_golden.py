@@ -1,0 +1,110 @@
+"""Pin the CPU oracle (oracle/unet_ref.py) against golden vectors produced by the REFERENCE's own
+block modules (tests/golden/gen_golden.py) and against the reference's structural goldens
+(ordered hook-id dumps, feature_len channel sums)."""
+import ast
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import unet_ref as R
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load(name):
+    z = np.load(os.path.join(GOLD, name + ".npz"))
+    W = {k[2:]: torch.from_numpy(z[k].astype(np.float32)) for k in z.files if k.startswith("w:")}
+    I = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("in:")}
+    O = {k[4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("out:")}
+    meta = ast.literal_eval(str(z["meta"]))
+    return W, I, O, meta
+
+
+def check(store, y, O, atol=2e-5):
+    assert torch.allclose(y, O["y"], atol=atol, rtol=1e-5)
+    hooks = {k[5:]: v for k, v in O.items() if k.startswith("hook:")}
+    assert list(store.feats.keys()) == list(hooks.keys())          # same ids, same order
+    for k, v in hooks.items():
+        got = store.feats[k]
+        assert got.shape == v.shape, k
+        assert torch.allclose(got, v, atol=atol, rtol=1e-5), (k, float((got - v).abs().max()))
+
+
+@pytest.mark.parametrize("name", ["resnet_same", "resnet_shortcut"])
+def test_resnet_block(name):
+    W, I, O, meta = load(name)
+    P = {"r." + k: v for k, v in W.items()}
+    st = R.Store(out_dtype=None)
+    y = R.resnet_block(P, "r", I["x"], I["temb"], st, "blk-res")
+    check(st, y, O)
+
+
+def test_down_up_sample():
+    W, I, O, _ = load("downsample")
+    st = R.Store(out_dtype=None)
+    y = R.downsample({"d." + k: v for k, v in W.items()}, "d", I["x"], st, "blk-downsampler")
+    check(st, y, O)
+    W, I, O, _ = load("upsample")
+    st = R.Store(out_dtype=None)
+    y = R.upsample({"u." + k: v for k, v in W.items()}, "u", I["x"], st, "blk-upsampler")
+    check(st, y, O)
+
+
+@pytest.mark.parametrize("name", ["vit_linear_sdpa", "vit_linear_d64", "vit_conv_map", "vit_linear_resize2"])
+def test_transformer_2d(name):
+    W, I, O, meta = load(name)
+    P = {"t." + k: v for k, v in W.items()}
+    st = R.Store(out_dtype=None, resize_ratio=meta["resize_ratio"])
+    y = R.transformer_2d(P, "t", I["x"], I["ctx"], meta["heads"], meta["depth"], meta["linear"], st, "blk-vit",
+                         want_map=meta["use_map"])
+    check(st, y, O)
+    assert list(st.feats.keys()) == meta["order"]
+
+
+def test_hook_id_order_matches_reference_dumps():
+    """feature/configs/config_15_full.json / config_xl_full.json key order (committed as id lists)."""
+    for ver, fn in (("1-5", "ids_15_full.txt"), ("xl", "ids_xl_full.txt")):
+        ref = open(os.path.join(GOLD, fn)).read().split()
+        assert R.stored_hook_ids(R.ARCHS[ver]) == ref
+
+
+def test_hook_ids_from_forward_equal_static_list():
+    for base in ("xl", "1-5"):
+        a = R.tiny_arch(base)
+        P = R.synth_params(a)
+        I = R.synth_inputs(a, 1, 8)
+        st = R.Store()
+        R.unet_forward(P, a, I["sample"], I["timestep"], I["ctx"], I.get("text_embeds"), I.get("time_ids"), store=st)
+        assert st.order == R.hook_ids(a)
+        assert list(st.feats.keys()) == R.stored_hook_ids(a)
+        for v in st.feats.values():
+            assert v.dtype == torch.float16 and v.dim() == 4
+
+
+def test_feature_len_channel_sums():
+    """correspondence/correspondence/config_*.json `feature_len`, scarce_segmentation/README.md:52-57."""
+    def chan(arch, hid):
+        boc = arch["block_out_channels"]; L = len(boc)
+        parts = hid.split("-")
+        lv = int(parts[1][5:])
+        c = boc[lv] if parts[0] == "down" else boc[L - 1 - lv]
+        return 4 * c if hid.endswith("ffn-inner") else c
+    xl, sd = R.ARCHS["xl"], R.ARCHS["1-5"]
+    practical_xl = ["up-level0-repeat0-vit-block7-out", "up-level0-repeat0-vit-block5-out",
+                    "up-level1-repeat0-vit-block0-cross-q", "up-level1-repeat0-vit-block0-out"]
+    assert sum(chan(xl, h) for h in practical_xl) == 3840
+    practical_15 = ["up-level1-repeat1-vit-block0-cross-q", "up-level1-repeat2-res-out",
+                    "up-level2-repeat1-vit-block0-cross-q", "up-level3-repeat0-vit-block0-self-k"]
+    assert sum(chan(sd, h) for h in practical_15) == 3520
+    legacy_xl = ["up-level0-upsampler-out", "up-level1-upsampler-out", "up-level2-repeat2-res-out"]
+    assert sum(chan(xl, h) for h in legacy_xl) == 2240
+
+
+def test_param_counts():
+    n = lambda a: sum(int(np.prod(s)) for s in R.param_shapes(a).values())
+    assert n(R.ARCHS["1-5"]) == 859_520_964      # published SD1.5 UNet parameter count
+    assert n(R.ARCHS["xl"]) == 2_567_463_684     # published SDXL UNet parameter count
