@@ -1,0 +1,137 @@
+"""Hook sink + hook registry of the native path.
+
+Mirrors the interface of the reference's feature/components/feature_extractor.py
+(FeatureStore :8-80, FeatureGatherer :83-89, prepare_feature_extractor :92-288) so callers that read
+`feature_store.to_store`, `.stored_feats`, `.reset()`, `.pause()/.resume()`, `.store_idx` keep working.
+The difference: hooks are not Python callbacks inside the model.  The layer-id JSON is handed to
+libgdf.so, whose kernels write the selected activations straight into caller-owned fp16 buffers;
+`store()` only applies the reference's post-processing that is not already done in HBM.
+"""
+import json
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+class FeatureStore:
+    def __init__(self, to_store, resize_ratio, train_unet):
+        if to_store:
+            self.to_store = to_store
+            self.accept_all = False
+        else:                                   # None / {}: accept every layer (reference :9-15)
+            self.to_store = {}
+            self.accept_all = True
+        self.feats = {}
+        self.status = 'active'
+        self.resize_ratio = resize_ratio
+        self.train_unet = train_unet
+        self.store_idx = None
+
+    def pause(self):
+        self.status = 'pause'
+
+    def resume(self):
+        self.status = 'active'
+
+    def reset(self):
+        self.feats = {}                         # a fresh dict: previously returned dicts stay valid
+
+    def store(self, feat, feat_id):
+        """Same filtering / post-processing order as the reference's store() (:31-76)."""
+        if self.status == 'pause':
+            return
+        if not ((feat_id in self.to_store and self.to_store[feat_id]) or self.accept_all):
+            return
+        if 'cross-k' in feat_id or 'cross-v' in feat_id:     # 77 text tokens are not a square (:38-39)
+            return
+        if feat.dim() == 3:                                   # (B, HW, C) -> (B, C, H, W) view (:46-48)
+            b, n, c = feat.shape
+            s = int(math.sqrt(n))
+            feat = feat.reshape(b, s, n // s, c).permute(0, 3, 1, 2)
+        if self.resize_ratio > 1:                             # feature_resize pooling (:51-53)
+            tgt = (feat.shape[2] // self.resize_ratio, feat.shape[3] // self.resize_ratio)
+            feat = F.adaptive_avg_pool2d(feat.float(), tgt).to(torch.float16)
+        # the reference's TF.normalize(mean=0,std=1) clone (:56) and fp16 cast (:59-60) are already
+        # materialised by the kernels: `feat` is a freshly written fp16 buffer owned by this call.
+        feat = feat.detach()
+        if self.accept_all:                                   # (:65-66)
+            feat = feat.cpu()
+        if self.store_idx is None:
+            self.feats[feat_id] = feat
+        else:                                                 # background extraction (:70-76)
+            entry = self.feats[feat_id] if feat_id in self.feats else {'feat': {}, 'count': 0}
+            current_idx = entry['count'] + 1
+            if current_idx in self.store_idx:
+                entry['feat'][current_idx] = feat
+            entry['count'] = current_idx
+            self.feats[feat_id] = entry
+
+    @property
+    def stored_feats(self):
+        return self.feats
+
+
+class FeatureGatherer:
+    """Kept for API compatibility (reference :83-89): forwards `module_id-feat_id` to the store."""
+
+    def __init__(self, module_id, feature_store):
+        self.module_id = module_id
+        self.feature_store = feature_store
+
+    def gather(self, feat, feat_id):
+        self.feature_store.store(feat, '-'.join([self.module_id, feat_id]))
+
+
+def unet_layer_ids(cfg, include_dropped=False):
+    """Every hook id of a UNet architecture in execution order — the id scheme of the reference's
+    prepare_feature_extractor (:126-249) combined with the gather sites inside the model files.
+    With include_dropped=False this equals the key order of feature/configs/config_*_full.json."""
+    boc = cfg["block_out_channels"]
+    L, nl = len(boc), cfg["layers_per_block"]
+    ids = ["unet-in", "unet-after-conv-in"]
+
+    def res(m):
+        ids.extend([f"{m}-res-increment", f"{m}-res-out"])
+
+    def vit(m, depth):
+        for i in range(depth):
+            b = f"{m}-block{i}"
+            ids.extend([f"{b}-self-q", f"{b}-self-k", f"{b}-self-v", f"{b}-self-map", f"{b}-cross-q"])
+            if include_dropped:
+                ids.extend([f"{b}-cross-k", f"{b}-cross-v"])
+            ids.extend([f"{b}-cross-map", f"{b}-ffn-inner", f"{b}-out"])
+        ids.append(f"{m}-out")
+
+    for lv in range(L):
+        for r in range(nl):
+            res(f"down-level{lv}-repeat{r}")
+            if cfg["has_attn"][lv]:
+                vit(f"down-level{lv}-repeat{r}-vit", cfg["transformer_layers"][lv])
+        if lv != L - 1:
+            ids.append(f"down-level{lv}-downsampler-out")
+    res("mid-repeat0")
+    vit("mid-vit", cfg["transformer_layers"][-1])
+    res("mid-repeat1")
+    for i in range(L):
+        lv = L - 1 - i
+        for r in range(nl + 1):
+            res(f"up-level{i}-repeat{r}")
+            if cfg["has_attn"][lv]:
+                vit(f"up-level{i}-repeat{r}-vit", cfg["transformer_layers"][lv])
+        if i != L - 1:
+            ids.append(f"up-level{i}-upsampler-out")
+    ids.append("unet-out")
+    return ids
+
+
+def prepare_feature_extractor(version, pipe, config, resize_ratio, train_unet):
+    """Same signature as the reference (:92).  `config`: JSON path, dict, or None/{} (= accept all)."""
+    if isinstance(config, str):
+        with open(config, 'r') as f:
+            config = json.load(f)
+    feature_store = FeatureStore(config, resize_ratio, train_unet)
+    if version == 'flux' or hasattr(pipe, 'transformer'):
+        raise NotImplementedError("DiT / Flux denoisers are a later row of the hot-path scope table (SURVEY.md §8f)")
+    pipe.unet.feature_store = feature_store       # the native UNet delivers hook tensors here
+    return feature_store

@@ -1,0 +1,377 @@
+"""ctypes binding of libgdf.so (include/gdf.h) + `NativeUNet`, the MI355X-native stand-in for the
+`pipe.unet` object that the reference calls at feature/diffusion_feature.py:445-465.
+
+There is NO CPU / PyTorch fallback here on purpose: if the HIP library is missing or no GPU is
+visible, construction raises.  PyTorch is only used for device memory, streams and tensor views.
+"""
+import ctypes as C
+import os
+import types
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(os.path.dirname(_HERE), "libgdf.so")
+
+GDF_F16, GDF_F32 = 0, 1
+MAX_LEVELS = 4
+
+
+class ArchDesc(C.Structure):
+    _fields_ = [
+        ("in_channels", C.c_int), ("out_channels", C.c_int), ("n_levels", C.c_int),
+        ("block_out_channels", C.c_int * MAX_LEVELS), ("has_attn", C.c_int * MAX_LEVELS),
+        ("transformer_layers", C.c_int * MAX_LEVELS), ("heads", C.c_int * MAX_LEVELS),
+        ("layers_per_block", C.c_int), ("cross_attention_dim", C.c_int), ("use_linear_projection", C.c_int),
+        ("time_embed_dim", C.c_int), ("addition_embed_text_time", C.c_int), ("addition_time_embed_dim", C.c_int),
+        ("add_in_dim", C.c_int),
+    ]
+
+
+class PlanOpts(C.Structure):
+    _fields_ = [("stream_fp32", C.c_int), ("early_exit", C.c_int), ("reserved", C.c_int * 6)]
+
+
+class HookInfo(C.Structure):
+    _fields_ = [("id", C.c_char_p), ("shape", C.c_int64 * 4), ("stride", C.c_int64 * 4), ("bytes", C.c_size_t)]
+
+
+# symbol -> (restype, argtypes); every symbol declared in include/gdf.h
+SIGNATURES = {
+    "gdf_last_error": (C.c_char_p, []),
+    "gdf_abi_version": (C.c_int, []),
+    "gdf_model_create": (C.c_int, [C.POINTER(ArchDesc), C.POINTER(C.c_void_p)]),
+    "gdf_model_destroy": (None, [C.c_void_p]),
+    "gdf_model_param_count": (C.c_int, [C.c_void_p]),
+    "gdf_model_param_name": (C.c_char_p, [C.c_void_p, C.c_int]),
+    "gdf_model_param_shape": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int64 * 4)]),
+    "gdf_model_set_param": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "gdf_model_ready": (C.c_int, [C.c_void_p]),
+    "gdf_model_weight_bytes": (C.c_size_t, [C.c_void_p]),
+    "gdf_model_hook_count": (C.c_int, [C.c_void_p]),
+    "gdf_model_hook_name": (C.c_char_p, [C.c_void_p, C.c_int]),
+    "gdf_plan_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_char_p), C.c_int,
+                                  C.POINTER(PlanOpts), C.POINTER(C.c_void_p)]),
+    "gdf_plan_destroy": (None, [C.c_void_p]),
+    "gdf_plan_workspace_bytes": (C.c_size_t, [C.c_void_p]),
+    "gdf_plan_num_ops": (C.c_int, [C.c_void_p]),
+    "gdf_plan_hook_count": (C.c_int, [C.c_void_p]),
+    "gdf_plan_hook_info": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(HookInfo)]),
+    "gdf_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                              C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gdf_plan_profile": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.POINTER(C.c_float), C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.c_int]),
+}
+
+_lib = None
+
+
+def lib_path():
+    return _LIB_PATH
+
+
+def load_library():
+    """dlopen libgdf.so and bind every symbol of include/gdf.h. Raises if the library is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise RuntimeError(f"{_LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    lib = C.CDLL(_LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError => header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        msg = load_library().gdf_last_error()
+        raise RuntimeError(f"libgdf {what} failed (status {rc}): {msg.decode() if msg else ''}")
+
+
+# --------------------------------------------------------------------------------------------- #
+# architecture descriptors: the UNet `config.json` fields the reference reads via diffusers
+# (components/models.py:18-56 of the reference select the HF repos these come from)
+# --------------------------------------------------------------------------------------------- #
+ARCH_CONFIGS = {
+    "1-5": dict(in_channels=4, out_channels=4, block_out_channels=(320, 640, 1280, 1280),
+                has_attn=(1, 1, 1, 0), transformer_layers=(1, 1, 1, 1), heads=(8, 8, 8, 8), layers_per_block=2,
+                cross_attention_dim=768, use_linear_projection=0, time_embed_dim=1280, addition_embed_text_time=0,
+                addition_time_embed_dim=0, add_in_dim=0),
+    "xl": dict(in_channels=4, out_channels=4, block_out_channels=(320, 640, 1280),
+               has_attn=(0, 1, 1), transformer_layers=(1, 2, 10), heads=(5, 10, 20), layers_per_block=2,
+               cross_attention_dim=2048, use_linear_projection=1, time_embed_dim=1280, addition_embed_text_time=1,
+               addition_time_embed_dim=256, add_in_dim=2816),
+}
+ARCH_CONFIGS["pgv2"] = ARCH_CONFIGS["xl"]        # Playground-v2 shares the SDXL UNet architecture
+
+
+def arch_desc(cfg):
+    a = ArchDesc()
+    n = len(cfg["block_out_channels"])
+    a.in_channels, a.out_channels, a.n_levels = cfg["in_channels"], cfg["out_channels"], n
+    for i in range(n):
+        a.block_out_channels[i] = cfg["block_out_channels"][i]
+        a.has_attn[i] = int(cfg["has_attn"][i])
+        a.transformer_layers[i] = cfg["transformer_layers"][i]
+        a.heads[i] = cfg["heads"][i]
+    a.layers_per_block = cfg["layers_per_block"]
+    a.cross_attention_dim = cfg["cross_attention_dim"]
+    a.use_linear_projection = int(cfg["use_linear_projection"])
+    a.time_embed_dim = cfg["time_embed_dim"]
+    a.addition_embed_text_time = int(cfg["addition_embed_text_time"])
+    a.addition_time_embed_dim = cfg["addition_time_embed_dim"]
+    a.add_in_dim = cfg["add_in_dim"]
+    return a
+
+
+def config_from_diffusers(uc):
+    """Map a diffusers UNet2DConditionModel.config onto ARCH_CONFIGS fields."""
+    boc = tuple(uc.block_out_channels)
+    n = len(boc)
+    tl = uc.transformer_layers_per_block
+    tl = tuple(tl) if isinstance(tl, (list, tuple)) else (tl,) * n
+    ahd = uc.attention_head_dim
+    ahd = tuple(ahd) if isinstance(ahd, (list, tuple)) else (ahd,) * n
+    text_time = getattr(uc, "addition_embed_type", None) == "text_time"
+    return dict(in_channels=uc.in_channels, out_channels=uc.out_channels, block_out_channels=boc,
+                has_attn=tuple(int("CrossAttn" in t) for t in uc.down_block_types), transformer_layers=tl, heads=ahd,
+                layers_per_block=uc.layers_per_block, cross_attention_dim=uc.cross_attention_dim,
+                use_linear_projection=int(bool(uc.use_linear_projection)), time_embed_dim=boc[0] * 4,
+                addition_embed_text_time=int(text_time),
+                addition_time_embed_dim=(uc.addition_time_embed_dim or 0) if text_time else 0,
+                add_in_dim=(uc.projection_class_embeddings_input_dim or 0) if text_time else 0)
+
+
+class _Plan:
+    def __init__(self, lib, handle):
+        self.lib, self.handle = lib, handle
+        self.ws_bytes = lib.gdf_plan_workspace_bytes(handle)
+        self.hooks = []
+        for i in range(lib.gdf_plan_hook_count(handle)):
+            hi = HookInfo()
+            _check(lib.gdf_plan_hook_info(handle, i, C.byref(hi)), "plan_hook_info")
+            self.hooks.append((hi.id.decode(), tuple(hi.shape), tuple(hi.stride), hi.bytes))
+        self.workspace = None
+
+    def __del__(self):
+        try:
+            self.lib.gdf_plan_destroy(self.handle)
+        except Exception:
+            pass
+
+
+class NativeUNet:
+    """UNet2DConditionModel replacement running entirely in libgdf.so (hand-written HIP, gfx950).
+
+    Call signature mirrors the reference's use at feature/diffusion_feature.py:446-465:
+        unet(latent_model_input, timestep=t, encoder_hidden_states=prompt_embeds,
+             added_cond_kwargs={...}, down_block_additional_residuals=None,
+             mid_block_additional_residual=None, return_dict=False)[0]
+    Hooked activations are delivered to `self.feature_store` (components/feature_extractor.py) in
+    execution order, as (B,C,H,W)-shaped fp16 tensors stored channels-last.
+    """
+
+    def __init__(self, cfg, device="cuda", stream_fp32=True, early_exit=False):
+        if not torch.cuda.is_available():
+            raise RuntimeError("NativeUNet needs an MI355X (HIP device); there is no CPU fallback")
+        self.lib = load_library()
+        self.cfg = dict(cfg)
+        self.device = torch.device(device if str(device) != "cuda" else f"cuda:{torch.cuda.current_device()}")
+        self._arch = arch_desc(cfg)
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _check(self.lib.gdf_model_create(C.byref(self._arch), C.byref(h)), "model_create")
+        self.handle = h
+        self.stream_fp32 = bool(stream_fp32)
+        self.early_exit = bool(early_exit)
+        self.feature_store = None
+        self._plans = {}
+        self.dtype = torch.float16
+        # attributes the reference reads from pipe.unet (diffusion_feature.py:544-547)
+        self.config = types.SimpleNamespace(
+            in_channels=cfg["in_channels"], addition_time_embed_dim=cfg["addition_time_embed_dim"],
+            sample_size=None, cross_attention_dim=cfg["cross_attention_dim"])
+        self.add_embedding = types.SimpleNamespace(linear_1=types.SimpleNamespace(in_features=cfg["add_in_dim"]))
+
+    # ---- nn.Module-like surface used by FeatureExtractor -------------------------------------
+    def parameters(self):
+        return iter(())
+
+    def to(self, *a, **k):
+        return self
+
+    def eval(self):
+        return self
+
+    def __del__(self):
+        try:
+            self._plans.clear()
+            self.lib.gdf_model_destroy(self.handle)
+        except Exception:
+            pass
+
+    # ---- weights ----------------------------------------------------------------------------------
+    def param_shapes(self):
+        out = {}
+        for i in range(self.lib.gdf_model_param_count(self.handle)):
+            shp = (C.c_int64 * 4)()
+            nd = self.lib.gdf_model_param_shape(self.handle, i, C.byref(shp))
+            out[self.lib.gdf_model_param_name(self.handle, i).decode()] = tuple(shp[:nd])
+        return out
+
+    def hook_names(self):
+        return [self.lib.gdf_model_hook_name(self.handle, i).decode()
+                for i in range(self.lib.gdf_model_hook_count(self.handle))]
+
+    def load_state_dict(self, sd, strict=True):
+        """sd: diffusers UNet2DConditionModel state_dict (name -> tensor, any device, fp16/fp32)."""
+        shapes = self.param_shapes()
+        missing = [k for k in shapes if k not in sd]
+        if strict and missing:
+            raise KeyError(f"missing UNet parameters: {missing[:5]} ... ({len(missing)})")
+        stream = torch.cuda.current_stream(self.device)
+        with torch.cuda.device(self.device):
+            for name, shp in shapes.items():
+                if name not in sd:
+                    continue
+                t = sd[name]
+                if tuple(t.shape) != shp:
+                    raise ValueError(f"{name}: expected shape {shp}, got {tuple(t.shape)}")
+                if t.dtype not in (torch.float16, torch.float32):
+                    t = t.float()
+                t = t.to(self.device, non_blocking=True).contiguous()
+                _check(self.lib.gdf_model_set_param(self.handle, name.encode(), C.c_void_p(t.data_ptr()),
+                                                    GDF_F16 if t.dtype == torch.float16 else GDF_F32,
+                                                    C.c_void_p(stream.cuda_stream)), f"set_param({name})")
+                del t
+            stream.synchronize()
+        return self
+
+    def init_synthetic(self, seed=0, chunk_elems=1 << 26):
+        """Seeded synthetic weights generated directly in HBM (no checkpoints exist offline):
+        W ~ N(0, 1/fan_in), bias ~ 0.05 N, norm gamma = 1 + 0.1 N, beta = 0.1 N (fp16-rounded)."""
+        g = torch.Generator(device=self.device).manual_seed(seed)
+        stream = torch.cuda.current_stream(self.device)
+        with torch.cuda.device(self.device):
+            for name, shp in self.param_shapes().items():
+                is_norm = ".norm" in name or name.startswith("conv_norm_out")
+                t = torch.randn(shp, generator=g, device=self.device, dtype=torch.float32)
+                if name.endswith(".weight") and not is_norm:
+                    fan_in = 1
+                    for s in shp[1:]:
+                        fan_in *= s
+                    t.mul_(fan_in ** -0.5)
+                elif name.endswith(".weight"):
+                    t.mul_(0.1).add_(1.0)
+                elif is_norm:
+                    t.mul_(0.1)
+                else:
+                    t.mul_(0.05)
+                t = t.half()
+                _check(self.lib.gdf_model_set_param(self.handle, name.encode(), C.c_void_p(t.data_ptr()), GDF_F16,
+                                                    C.c_void_p(stream.cuda_stream)), f"set_param({name})")
+                stream.synchronize()
+        return self
+
+    def ready(self):
+        return bool(self.lib.gdf_model_ready(self.handle))
+
+    # ---- plans ------------------------------------------------------------------------------------
+    def _plan(self, batch, h, w, n_ctx, hook_ids):
+        key = (batch, h, w, n_ctx, tuple(hook_ids), self.stream_fp32, self.early_exit)
+        p = self._plans.get(key)
+        if p is None:
+            ids = (C.c_char_p * max(1, len(hook_ids)))(*[s.encode() for s in hook_ids])
+            opts = PlanOpts(int(self.stream_fp32), int(self.early_exit))
+            ph = C.c_void_p()
+            _check(self.lib.gdf_plan_create(self.handle, batch, h, w, n_ctx, ids, len(hook_ids), C.byref(opts),
+                                            C.byref(ph)), "plan_create")
+            p = _Plan(self.lib, ph)
+            if len(self._plans) >= 8:
+                self._plans.pop(next(iter(self._plans)))
+            self._plans[key] = p
+        return p
+
+    def requested_ids(self):
+        fs = self.feature_store
+        if fs is None:
+            return []
+        if fs.accept_all:
+            return self.hook_names()
+        return [k for k, v in fs.to_store.items() if v]
+
+    # ---- forward ------------------------------------------------------------------------------------
+    def forward_raw(self, sample, timestep, encoder_hidden_states, text_embeds=None, time_ids=None, hook_ids=None,
+                    profile=False):
+        """Returns (noise_pred (B,4,H,W) view, OrderedDict id -> hook tensor). Inputs must live on self.device."""
+        dev = self.device
+        B, _, H, W = sample.shape
+        sample = sample.to(dev, torch.float16).contiguous()
+        ctx = encoder_hidden_states.to(dev, torch.float16).contiguous()
+        t = torch.as_tensor(timestep, device=dev).float().reshape(-1)
+        if t.numel() == 1:
+            t = t.expand(B)
+        t = t.contiguous()
+        txt = tid = None
+        if self.cfg["addition_embed_text_time"]:
+            if text_embeds is None or time_ids is None:
+                raise ValueError("added_cond_kwargs with text_embeds and time_ids is required for this UNet")
+            txt = text_embeds.to(dev, torch.float16).contiguous()
+            tid = time_ids.to(dev, torch.float32).contiguous()
+            pooled = self.cfg["add_in_dim"] - 6 * self.cfg["addition_time_embed_dim"]
+            if txt.shape != (B, pooled) or tid.shape != (B, 6):
+                raise ValueError(f"text_embeds {tuple(txt.shape)} / time_ids {tuple(tid.shape)} do not match the model "
+                                 f"(expected ({B},{pooled}) / ({B},6))")
+        if ctx.shape[0] != B or ctx.shape[2] != self.cfg["cross_attention_dim"]:
+            raise ValueError("encoder_hidden_states shape mismatch")
+        ids = list(hook_ids) if hook_ids is not None else self.requested_ids()
+        plan = self._plan(B, H, W, ctx.shape[1], ids)
+        with torch.cuda.device(dev):
+            if plan.workspace is None or plan.workspace.numel() < plan.ws_bytes:
+                plan.workspace = torch.empty(plan.ws_bytes, dtype=torch.uint8, device=dev)
+            hooks = [torch.empty(nbytes // 2, dtype=torch.float16, device=dev) for (_, _, _, nbytes) in plan.hooks]
+            hook_ptrs = (C.c_void_p * max(1, len(hooks)))(*[h.data_ptr() for h in hooks])
+            noise = torch.empty(B, H, W, self.cfg["out_channels"], dtype=torch.float16, device=dev)
+            stream = torch.cuda.current_stream(dev)
+            args = (plan.handle, C.c_void_p(sample.data_ptr()), C.c_void_p(t.data_ptr()), C.c_void_p(ctx.data_ptr()),
+                    C.c_void_p(txt.data_ptr() if txt is not None else 0),
+                    C.c_void_p(tid.data_ptr() if tid is not None else 0), hook_ptrs, C.c_void_p(noise.data_ptr()),
+                    C.c_void_p(plan.workspace.data_ptr()), C.c_void_p(stream.cuda_stream))
+            prof = None
+            if profile:
+                n = self.lib.gdf_plan_num_ops(plan.handle)
+                ms = (C.c_float * n)(); names = (C.c_char_p * n)(); fl = (C.c_double * n)()
+                rc = self.lib.gdf_plan_profile(*args, ms, names, fl, n)
+                if rc < 0:
+                    _check(1, "plan_profile")
+                prof = [(names[i].decode(), ms[i], fl[i]) for i in range(n)]
+            else:
+                _check(self.lib.gdf_forward(*args), "forward")
+        out = {}
+        for buf, (hid, shape, stride, _) in zip(hooks, plan.hooks):
+            out[hid] = torch.as_strided(buf, shape, stride)
+        noise_nchw = noise.permute(0, 3, 1, 2)
+        if profile:
+            return noise_nchw, out, prof
+        return noise_nchw, out
+
+    def __call__(self, sample, timestep=None, encoder_hidden_states=None, added_cond_kwargs=None,
+                 down_block_additional_residuals=None, mid_block_additional_residual=None, return_dict=False,
+                 **kwargs):
+        if down_block_additional_residuals is not None or mid_block_additional_residual is not None:
+            raise NotImplementedError("ControlNet residuals are outside the native hot path (SURVEY.md §2 #5)")
+        akw = added_cond_kwargs or {}
+        noise, hooks = self.forward_raw(sample, timestep, encoder_hidden_states, akw.get("text_embeds"),
+                                        akw.get("time_ids"))
+        if self.feature_store is not None:
+            for hid, t in hooks.items():
+                self.feature_store.store(t, hid)
+        if return_dict:
+            return types.SimpleNamespace(sample=noise)
+        return (noise,)

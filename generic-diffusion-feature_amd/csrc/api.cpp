@@ -1,0 +1,91 @@
+// extern "C" surface of libgdf.so — see include/gdf.h for the contract and the reference call sites.
+#include <cstring>
+
+#include "model.h"
+
+using namespace gdf;
+
+struct gdf_model { Model* m; };
+struct gdf_plan { Plan p; gdf_model* owner; };
+
+extern "C" {
+
+const char* gdf_last_error(void) { return last_error(); }
+int gdf_abi_version(void) { return 1; }
+
+int gdf_model_create(const gdf_arch_desc* arch, gdf_model** out) {
+  if (!arch || !out) { set_error("null argument"); return GDF_ERR_ARG; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { set_error("no HIP device: libgdf has no CPU fallback"); return GDF_ERR_HIP; }
+  Model* m = model_create(*arch);
+  if (!m) return GDF_ERR_ARG;
+  *out = new gdf_model{m};
+  return GDF_OK;
+}
+void gdf_model_destroy(gdf_model* m) { if (m) { model_destroy(m->m); delete m; } }
+int gdf_model_param_count(const gdf_model* m) { return m ? (int)m->m->params.size() : 0; }
+const char* gdf_model_param_name(const gdf_model* m, int i) {
+  return (m && i >= 0 && i < (int)m->m->params.size()) ? m->m->params[i].name.c_str() : nullptr;
+}
+int gdf_model_param_shape(const gdf_model* m, int i, int64_t shape[4]) {
+  if (!m || i < 0 || i >= (int)m->m->params.size()) return 0;
+  const ParamRec& p = m->m->params[i];
+  for (int k = 0; k < 4; ++k) shape[k] = k < p.ndim ? p.shape[k] : 1;
+  return p.ndim;
+}
+int gdf_model_set_param(gdf_model* m, const char* name, const void* dev_ptr, int dtype, void* stream) {
+  if (!m || !name || !dev_ptr) { set_error("null argument"); return GDF_ERR_ARG; }
+  return model_set_param(m->m, name, dev_ptr, dtype, (hipStream_t)stream);
+}
+int gdf_model_ready(const gdf_model* m) { return m && m->m->n_set == (int)m->m->params.size(); }
+size_t gdf_model_weight_bytes(const gdf_model* m) { return m ? m->m->weight_bytes : 0; }
+int gdf_model_hook_count(const gdf_model* m) { return m ? (int)m->m->hook_names.size() : 0; }
+const char* gdf_model_hook_name(const gdf_model* m, int i) {
+  return (m && i >= 0 && i < (int)m->m->hook_names.size()) ? m->m->hook_names[i].c_str() : nullptr;
+}
+
+int gdf_plan_create(gdf_model* m, int batch, int lat_h, int lat_w, int n_ctx, const char* const* hook_ids, int n_hooks,
+                    const gdf_plan_opts* opts, gdf_plan** out) {
+  if (!m || !out || (n_hooks > 0 && !hook_ids)) { set_error("null argument"); return GDF_ERR_ARG; }
+  gdf_plan_opts o{};
+  o.stream_fp32 = 1;
+  if (opts) o = *opts;
+  gdf_plan* p = new gdf_plan();
+  p->owner = m;
+  p->p.model = m->m;
+  const int rc = plan_build(*m->m, p->p, batch, lat_h, lat_w, n_ctx, hook_ids, n_hooks, o, false);
+  if (rc != GDF_OK) { delete p; return rc; }
+  *out = p;
+  return GDF_OK;
+}
+void gdf_plan_destroy(gdf_plan* p) { delete p; }
+size_t gdf_plan_workspace_bytes(const gdf_plan* p) { return p ? p->p.ws_bytes : 0; }
+int gdf_plan_num_ops(const gdf_plan* p) { return p ? (int)p->p.ops.size() : 0; }
+int gdf_plan_hook_count(const gdf_plan* p) { return p ? (int)p->p.hooks.size() : 0; }
+int gdf_plan_hook_info(const gdf_plan* p, int i, gdf_hook_info* info) {
+  if (!p || !info || i < 0 || i >= (int)p->p.hooks.size()) { set_error("bad hook index"); return GDF_ERR_ARG; }
+  const HookSlot& h = p->p.hooks[i];
+  info->id = h.id.c_str();
+  for (int k = 0; k < 4; ++k) { info->shape[k] = h.shape[k]; info->stride[k] = h.stride[k]; }
+  info->bytes = h.bytes;
+  return GDF_OK;
+}
+
+int gdf_forward(gdf_plan* p, const void* latents, const float* timesteps, const void* ctx, const void* add_text_embeds,
+                const float* add_time_ids, void* const* hook_out, void* noise_pred, void* workspace, void* stream) {
+  if (!p) { set_error("null plan"); return GDF_ERR_ARG; }
+  return plan_forward(p->p, *p->p.model, latents, timesteps, ctx, add_text_embeds, add_time_ids, hook_out, noise_pred,
+                      workspace, (hipStream_t)stream, nullptr, nullptr, nullptr, 0);
+}
+
+int gdf_plan_profile(gdf_plan* p, const void* latents, const float* timesteps, const void* ctx,
+                     const void* add_text_embeds, const float* add_time_ids, void* const* hook_out, void* noise_pred,
+                     void* workspace, void* stream, float* ms, const char** names, double* flops, int cap) {
+  if (!p || !ms) { set_error("null argument"); return -1; }
+  const int rc = plan_forward(p->p, *p->p.model, latents, timesteps, ctx, add_text_embeds, add_time_ids, hook_out,
+                              noise_pred, workspace, (hipStream_t)stream, ms, names, flops, cap);
+  if (rc != GDF_OK) return -1;
+  return (int)p->p.ops.size();
+}
+
+}  // extern "C"

@@ -1,0 +1,316 @@
+// Flash attention forward for gfx950 (MI355X): fp16 Q/K/V, fp32 online softmax, fp16 output.
+//
+// Replaces, for the UNet hot path, `F.scaled_dot_product_attention(q, k, v)` in
+// AttnProcessor2_0.__call__ (/root/reference/feature/diffusers/models/attention_processor.py:3311-3313,
+// scale = dim_head**-0.5 at :166) for self attention (Sk = H*W) and cross attention (Sk = 77 text tokens).
+//
+// Layout: 4 waves x 32 query rows per workgroup, 64-key K/V tiles staged in LDS.
+//   * scores are computed TRANSPOSED, S^T = K Q^T with mfma_f32_32x32x16_f16, so each lane owns one
+//     query column: row max / row sum / rescale are lane-local (one cross-half exchange for the max).
+//   * P never leaves registers: the S^T accumulator layout is re-used as the B operand of
+//     O^T = V^T P^T by relabelling the key index inside a 16-key step (the contraction is
+//     permutation invariant), and V^T fragments are produced by the gfx950 LDS transpose read
+//     `ds_read_b64_tr_b16` from a row-major V tile.
+//   * head dims 40/64/80/160 (SD1.5: 40,80,160; SDXL: 64) are zero-padded to MFMA granularity in LDS.
+#include "kernels.h"
+
+namespace gdf {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
+#define LDS_AS __attribute__((address_space(3)))
+
+static constexpr int QB = 128;    // query rows per workgroup (4 waves x 32)
+static constexpr int KT = 64;     // keys per tile
+
+template <int D>
+__global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
+  constexpr int DQK = (D + 15) / 16 * 16;        // contraction length of QK^T, padded
+  constexpr int DV = (D + 31) / 32 * 32;         // output rows of O^T, padded
+  constexpr int DP = DV;                         // data halves per LDS row (DV >= DQK)
+  constexpr int LDR = DP + 8;                    // LDS row stride in halves (+16 B: conflict-free b128 reads)
+  constexpr int CPR = DP / 8;                    // 16-B chunks per row
+  constexpr int NCH = (KT * CPR + 255) / 256;    // chunks per thread per tile
+  constexpr int NS = DQK / 16;                   // k-steps of QK^T
+  constexpr int NDB = DV / 32;                   // 32-row blocks of O^T
+
+  __shared__ __attribute__((aligned(16))) _Float16 sK[KT * LDR];
+  __shared__ __attribute__((aligned(16))) _Float16 sV[KT * LDR];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nqb = (p.Sq + QB - 1) / QB;
+  int bid = blockIdx.x;
+  const int qb = bid % nqb; bid /= nqb;
+  const int head = bid % p.heads;
+  const int b = bid / p.heads;
+
+  const int lq = lane & 31, lh = lane >> 5;
+  const int q_row = qb * QB + wave * 32 + lq;              // query index inside the sequence
+  const bool q_ok = q_row < p.Sq;
+
+  // ---- Q fragments (B operand of S^T = K Q^T): Q[q][16 s + 8 lh .. +8] ----
+  f16x8 qf[NS];
+  {
+    const _Float16* qp = p.q + ((size_t)b * p.Sq + (q_ok ? q_row : 0)) * p.ldq + head * D;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const int d0 = 16 * s + 8 * lh;
+      f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (q_ok && d0 < D) v = *(const f16x8*)(qp + d0);
+      qf[s] = v;
+    }
+  }
+
+  f32x16 o[NDB];
+#pragma unroll
+  for (int i = 0; i < NDB; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  const float sl2 = p.scale * 1.44269504088896340736f;    // softmax(x*scale) via exp2
+
+  const _Float16* kbase = p.k + (size_t)b * p.Sk * p.ldk + head * D;
+  const _Float16* vbase = p.v + (size_t)b * p.Sk * p.ldv + head * D;
+  const int ntiles = (p.Sk + KT - 1) / KT;
+
+  f16x8 kreg[NCH], vreg[NCH];
+  auto gload = [&](int t) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int idx = tid + c * 256;
+      const int row = idx / CPR, ch = idx - row * CPR;
+      const int kv = t * KT + row;
+      f16x8 kk = {0, 0, 0, 0, 0, 0, 0, 0}, vv = kk;
+      if (idx < KT * CPR && kv < p.Sk && ch * 8 < D) {
+        kk = *(const f16x8*)(kbase + (size_t)kv * p.ldk + ch * 8);
+        vv = *(const f16x8*)(vbase + (size_t)kv * p.ldv + ch * 8);
+      }
+      kreg[c] = kk; vreg[c] = vv;
+    }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int idx = tid + c * 256;
+      const int row = idx / CPR, ch = idx - row * CPR;
+      if (idx < KT * CPR) {
+        *(f16x8*)(sK + row * LDR + ch * 8) = kreg[c];
+        *(f16x8*)(sV + row * LDR + ch * 8) = vreg[c];
+      }
+    }
+  };
+
+  gload(0);
+  for (int t = 0; t < ntiles; ++t) {
+    __syncthreads();            // every wave finished computing on the previous tile
+    lstore();
+    __syncthreads();
+    if (t + 1 < ntiles) gload(t + 1);   // next tile's HBM latency hides under this tile's MFMAs
+
+    // ---- S^T = K Q^T : two 32-key blocks ----
+    f32x16 s[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+#pragma unroll
+      for (int st = 0; st < NS; ++st) {
+        const f16x8 kf = *(const f16x8*)(sK + (kb * 32 + lq) * LDR + 16 * st + 8 * lh);
+        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[st], s[kb], 0, 0, 0);
+      }
+    }
+    // ---- mask the tail tile, online softmax (per-lane query column) ----
+    if ((t + 1) * KT > p.Sk) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int kv = t * KT + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (kv >= p.Sk) s[kb][r] = -INFINITY;
+        }
+    }
+    float mx = s[0][0];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m_run, mx * sl2);
+    const float alpha = exp2f(m_run - m_new);          // first tile: exp2(-inf) = 0
+    m_run = m_new;
+    float psum = 0.f;
+    f16x8 pf[4];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float e = exp2f(s[kb][r] * sl2 - m_new);
+        const _Float16 eh = (_Float16)e;
+        psum += (float)eh;                              // the sum matches what the MFMA will see
+        pf[kb * 2 + (r >> 3)][r & 7] = eh;
+      }
+    l_run = l_run * alpha + psum;
+#pragma unroll
+    for (int i = 0; i < NDB; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+
+    // ---- O^T += V^T P^T : 4 steps of 16 (relabelled) keys ----
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+#pragma unroll
+      for (int db = 0; db < NDB; ++db) {
+        // V^T fragment: lane (d = db*32 + lq, lh) needs V[16 s4 + 4 lh + {0..3}][d] and V[16 s4 + 8 + 4 lh + {0..3}][d]
+        const int i16 = lane & 15;
+        const int c0 = db * 32 + 16 * ((lane >> 4) & 1) + (i16 & 3) * 4;
+        const int r0 = 16 * s4 + 4 * lh + (i16 >> 2);
+        const fp16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((LDS_AS fp16x4_t*)(sV + r0 * LDR + c0));
+        const fp16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((LDS_AS fp16x4_t*)(sV + (r0 + 8) * LDR + c0));
+        f16x8 vf;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { vf[e] = (_Float16)lo[e]; vf[4 + e] = (_Float16)hi[e]; }
+        o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[s4], o[db], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- finalize: O[q][d] = O^T[d][q] / l ----
+  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  const float inv = 1.0f / l_tot;
+  if (q_ok) {
+    _Float16* op = p.o + ((size_t)b * p.Sq + q_row) * p.ldo + head * D;
+#pragma unroll
+    for (int db = 0; db < NDB; ++db)
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const int d0 = db * 32 + 8 * rq + 4 * lh;
+        if (d0 < D) {
+          f16x4 hv;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) hv[e] = (_Float16)(o[db][rq * 4 + e] * inv);
+          *(f16x4*)(op + d0) = hv;
+        }
+      }
+  }
+}
+
+// -------------------------------------------------------------------------------------------------
+// attention with materialised probabilities ('-map' hooks):
+// AttnStoreProcessor.__call__ (/root/reference/feature/components/attention.py:176-263) +
+// Attention.get_attention_scores (attention_processor.py:640-685): probs = softmax(scale * q k^T),
+// stored as (B, heads, Sq, Sk) fp16, then out = probs v.  One wave per query row; HBM-write bound.
+// -------------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256) void attn_map_kernel(const AttnParams p) {
+  constexpr int DPL = (D + 63) / 64;             // output dims per lane (strided)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long row = (long)blockIdx.x * 4 + wave;   // (b, head, q)
+  const long total = (long)p.B * p.heads * p.Sq;
+  if (row >= total) return;
+  const int qi = row % p.Sq;
+  const int head = (row / p.Sq) % p.heads;
+  const int b = row / ((long)p.Sq * p.heads);
+  const _Float16* qp = p.q + ((size_t)b * p.Sq + qi) * p.ldq + head * D;
+  const _Float16* kb = p.k + (size_t)b * p.Sk * p.ldk + head * D;
+  const _Float16* vb = p.v + (size_t)b * p.Sk * p.ldv + head * D;
+  _Float16* mp = p.map + (size_t)row * p.Sk;
+  float qreg[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) qreg[d] = (float)qp[d];
+  // pass 1: scores for keys lane, lane+64, ... kept in fp32 scratch (the map row itself, as fp16, is written last)
+  float mx = -INFINITY;
+  for (int kv = lane; kv < p.Sk; kv += 64) {
+    const _Float16* kr = kb + (size_t)kv * p.ldk;
+    float acc = 0.f;
+#pragma unroll
+    for (int d = 0; d < D; d += 8) {
+      const f16x8 kk = *(const f16x8*)(kr + d);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc += qreg[d + e] * (float)kk[e];
+    }
+    acc *= p.scale;
+    mx = fmaxf(mx, acc);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+  float sum = 0.f;
+  for (int kv = lane; kv < p.Sk; kv += 64) {
+    const _Float16* kr = kb + (size_t)kv * p.ldk;
+    float acc = 0.f;
+#pragma unroll
+    for (int d = 0; d < D; d += 8) {
+      const f16x8 kk = *(const f16x8*)(kr + d);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc += qreg[d + e] * (float)kk[e];
+    }
+    sum += __expf(acc * p.scale - mx);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+  const float inv = 1.f / sum;
+  float oacc[DPL];
+#pragma unroll
+  for (int i = 0; i < DPL; ++i) oacc[i] = 0.f;
+  for (int kv0 = 0; kv0 < p.Sk; kv0 += 64) {
+    const int kv = kv0 + lane;
+    float pr = 0.f;
+    if (kv < p.Sk) {
+      const _Float16* kr = kb + (size_t)kv * p.ldk;
+      float acc = 0.f;
+#pragma unroll
+      for (int d = 0; d < D; d += 8) {
+        const f16x8 kk = *(const f16x8*)(kr + d);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc += qreg[d + e] * (float)kk[e];
+      }
+      pr = __expf(acc * p.scale - mx) * inv;
+      mp[kv] = (_Float16)pr;
+    }
+    // out += probs * V for this 64-key slab: lanes own output dims d = lane, lane+64, ...
+    const int nk = min(64, p.Sk - kv0);
+    for (int j = 0; j < nk; ++j) {
+      const float pj = __shfl(pr, j);
+      const _Float16* vr = vb + (size_t)(kv0 + j) * p.ldv;
+#pragma unroll
+      for (int i = 0; i < DPL; ++i) {
+        const int d = lane + 64 * i;
+        if (d < D) oacc[i] += pj * (float)vr[d];
+      }
+    }
+  }
+  _Float16* op = p.o + ((size_t)b * p.Sq + qi) * p.ldo + head * D;
+#pragma unroll
+  for (int i = 0; i < DPL; ++i) {
+    const int d = lane + 64 * i;
+    if (d < D) op[d] = (_Float16)oacc[i];
+  }
+}
+
+template <int D>
+static hipError_t launch_d(const AttnParams& p, hipStream_t s) {
+  if (p.map) {
+    const long rows = (long)p.B * p.heads * p.Sq;
+    hipLaunchKernelGGL((attn_map_kernel<D>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, p);
+  } else {
+    const int nqb = (p.Sq + QB - 1) / QB;
+    hipLaunchKernelGGL((attn_kernel<D>), dim3(p.B * p.heads * nqb), dim3(256), 0, s, p);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_attention(const AttnParams& p, hipStream_t s) {
+  if ((p.ldq | p.ldk | p.ldv) & 7) return hipErrorInvalidValue;     // 16-byte aligned rows
+  if (p.ldo & 3) return hipErrorInvalidValue;
+  switch (p.D) {
+    case 32: return launch_d<32>(p, s);
+    case 40: return launch_d<40>(p, s);
+    case 64: return launch_d<64>(p, s);
+    case 80: return launch_d<80>(p, s);
+    case 160: return launch_d<160>(p, s);
+  }
+  return hipErrorInvalidValue;
+}
+
+}  // namespace gdf

@@ -1,0 +1,111 @@
+// Internal launch interface of the gfx950 kernels (C++ linkage; not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef _Float16 half_t;
+
+namespace gdf {
+
+// ------------------------------------------------------------------------------------------------
+// MFMA GEMM / implicit-GEMM convolution:  D[M,N] = A[M,K] * Wt[N,K]^T  (+ fused epilogue)
+// ------------------------------------------------------------------------------------------------
+enum { A_DENSE = 0, A_CONV3 = 1, A_CONV_SMALLC = 2 };
+
+struct GemmParams {
+  // ---- A operand (fp16). DENSE: row-major [M][K] with leading dimension lda (elements).
+  //      CONV3: NHWC activation [B][H][W][lda>=Cin]; rows of the GEMM are output pixels.
+  const half_t* A;
+  int lda;
+  uint32_t a_bytes;      // extent of A in bytes (buffer bounds: loads past it return 0)
+  int M, N, K;           // K = Cin (dense) or 9*Cin (conv3)
+  int mode;
+  int H, W;              // source spatial size (conv)
+  int OH, OW;            // output spatial size (conv)
+  int stride;            // 1 or 2 (conv)
+  int ups;               // 1: source is nearest-upsampled x2 before the conv (Upsample2D fused)
+  int Cin;
+  // ---- B operand: weights [N][K] fp16, K contiguous (conv: K index = tap*Cin + c)
+  const half_t* Wt;
+  uint32_t w_bytes;
+  // ---- epilogue:  v = acc + bias[col] + rowvec[row / rows_per_sample][col]
+  //                 aux16 = fp16(v)                       (pre-residual copy: `res-increment` hook)
+  //                 v += res32|res16[row][col]
+  //                 out16 = fp16(v), out32 = v
+  //      GEGLU: columns come in [32 h | 32 gate] groups; out col = h * gelu(gate), N_out = N/2
+  const float* bias;
+  const float* rowvec;
+  int rows_per_sample;
+  int ldrv;
+  const float* res32;
+  const half_t* res16;
+  int ldres;
+  half_t* out16;
+  int ldo16;
+  float* out32;
+  int ldo32;
+  half_t* aux16;
+  int ldaux;
+  int geglu;
+  int bn;                // 128 (default) or 16 (very narrow N, e.g. conv_out)
+};
+hipError_t launch_gemm(const GemmParams& p, hipStream_t s);
+
+// ------------------------------------------------------------------------------------------------
+// flash attention (self / cross), fp16 in, fp32 softmax, fp16 out
+//   q: rows (b*Sq + i), head h at columns [h*D, h*D+D) with leading dim ldq; same for k, v, o.
+// ------------------------------------------------------------------------------------------------
+struct AttnParams {
+  const half_t* q; int ldq;
+  const half_t* k; int ldk;
+  const half_t* v; int ldv;
+  half_t* o; int ldo;
+  int B, heads, Sq, Sk, D;
+  float scale;
+  half_t* map;           // optional: attention probabilities (B, heads, Sq, Sk) fp16 ('-map' hooks)
+};
+hipError_t launch_attention(const AttnParams& p, hipStream_t s);
+
+// ------------------------------------------------------------------------------------------------
+// normalisation / elementwise
+// ------------------------------------------------------------------------------------------------
+// GroupNorm over NHWC rows x [B][HW][ld] (C channels used, G groups).  Two launches:
+//   gn_stats : per-(sample, channel) affine table ab[b][c] = (rstd*gamma, beta - mean*rstd*gamma)
+//              (`partial` is scratch of gn_partial_floats(B, HW, C) floats)
+//   gn_apply : y = act(x*a + b) as contiguous fp16 [B*HW][C]; silu=1 applies v*sigmoid(v)
+size_t gn_partial_floats(int B, int HW, int C);
+hipError_t launch_gn_stats(const half_t* x16, const float* x32, int ld, int B, int HW, int C, int G, float eps,
+                           const float* gamma, const float* beta, float* partial, float* ab, hipStream_t s);
+hipError_t launch_gn_apply(const half_t* x16, const float* x32, int ld, int B, int HW, int C,
+                           const float* ab, int silu, half_t* y, hipStream_t s);
+// LayerNorm over the last dim (C), rows x [R][ld]; y contiguous fp16 [R][C]
+hipError_t launch_layernorm(const half_t* x16, const float* x32, int ld, int R, int C, float eps,
+                            const float* gamma, const float* beta, half_t* y, hipStream_t s);
+// strided 2-D copy with cast to fp16: dst[r][c] = src[r][c]   (hook stores)
+hipError_t launch_copy2d(const half_t* s16, const float* s32, int lds_, half_t* dst, int ldd, int R, int C,
+                         hipStream_t s);
+// latents NCHW fp16 (B,Cin,H,W) -> NHWC padded to 8 channels (conv_in operand) and optional NHWC hook copy
+hipError_t launch_pack_latents(const half_t* x, int B, int Cin, int H, int W, half_t* nhwc8, half_t* hook_nhwc,
+                               hipStream_t s);
+// sinusoidal embedding: out[b][off + j] (dim entries, [cos|sin] order = flip_sin_to_cos) of t[b*tstride + ti]
+hipError_t launch_sinusoid(const float* t, int B, int n_per_row, int dim, float* out, int ldo, int col_off,
+                           int round_f16, hipStream_t s);
+// widen fp16 vector rows into fp32: out[b][col_off + j] = x[b][j]
+hipError_t launch_widen(const half_t* x, int B, int n, float* out, int ldo, int col_off, hipStream_t s);
+// small-M linear in fp32 vectors: out[m][n] = (accum? out : 0) + bias[n] + sum_k act(x[m][k]) * W[n][k]
+hipError_t launch_small_linear(const float* x, int ldx, int M, int K, const half_t* Wt, const float* bias, int N,
+                               int silu_in, int accumulate, float* out, int ldo, hipStream_t s);
+
+// ------------------------------------------------------------------------------------------------
+// weight re-layout (model load time)
+// ------------------------------------------------------------------------------------------------
+// generic: dst[o][t][i] = src[o][i][t]  (OIHW -> OHWI with T = kh*kw); src f16 or f32; i padded to ipad, t to tpad
+hipError_t launch_relayout_conv(const void* src, int src_f32, half_t* dst, int O, int I, int T, int ipad, int tpad,
+                                hipStream_t s);
+// rows: dst[rowmap(r)][k] = src[r][k] for r in [0,R); rowmap: 0 identity+row_off, 1 GEGLU interleave (half = R/2)
+hipError_t launch_relayout_rows(const void* src, int src_f32, half_t* dst, int R, int K, int row_off, int geglu,
+                                hipStream_t s);
+// vectors to fp32 with the same row mapping
+hipError_t launch_relayout_vec(const void* src, int src_f32, float* dst, int R, int row_off, int geglu, hipStream_t s);
+
+}  // namespace gdf

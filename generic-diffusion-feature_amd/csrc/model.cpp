@@ -1,0 +1,884 @@
+// Host side of libgdf.so: architecture walk, weight arena + re-layout, static plan builder
+// (op program + workspace arena + hook table) and the forward executor.
+//
+// The op program restates, for the reference's single-timestep path, the orchestration of
+//   UNet2DConditionModel.forward        /root/reference/feature/diffusers/models/unet/unet_2d_condition.py:1040-1319
+//   (un-vendored diffusers==0.32.2 unet_2d_blocks wiring: CrossAttnDownBlock2D / DownBlock2D /
+//    UNetMidBlock2DCrossAttn / CrossAttnUpBlock2D / UpBlock2D)
+//   ResnetBlock2D.forward               resnet.py:320-379
+//   Transformer2DModel.forward          transformers/transformer_2d.py:327-530
+//   BasicTransformerBlock.forward       attention.py:469-592
+//   Attention + AttnProcessor2_0        attention_processor.py:3244-3331 (AttnStoreProcessor for '-map')
+//   FeedForward / GEGLU                 attention.py:1249-1258
+//   Downsample2D / Upsample2D           downsampling.py:132-152 / upsampling.py:142-195
+// and of the hook id scheme in components/feature_extractor.py:126-249.
+//
+// Data layout in HBM: every activation is NHWC == token-major [B*H*W][C] fp16 with an explicit leading
+// dimension, so (a) conv and transformer layers share one layout with no permutes, (b) the skip
+// concatenations of the up path are free: producers store straight into channel slices of a
+// pre-allocated concat buffer.  The residual stream additionally keeps an fp32 master copy
+// (stream_fp32) that only the residual adds in GEMM epilogues read and write.
+#include "model.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+namespace gdf {
+
+thread_local std::string g_err;
+void set_error(const std::string& s) { g_err = s; }
+const char* last_error() { return g_err.c_str(); }
+
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// =====================================================================================================
+// Model: walk the architecture once, lay out the weight arena, register diffusers parameter names
+// =====================================================================================================
+struct ModelBuilder {
+  Model& m;
+  size_t cur = 0;
+  explicit ModelBuilder(Model& mm) : m(mm) {}
+
+  size_t take(size_t bytes) { size_t o = cur; cur = align_up(cur + bytes, 256); return o; }
+
+  void reg(const std::string& name, std::initializer_list<int64_t> shape, int kind, size_t dst, int a0 = 0, int a1 = 0,
+           int a2 = 0) {
+    ParamRec p;
+    p.name = name; p.ndim = (int)shape.size();
+    int i = 0;
+    for (auto s : shape) p.shape[i++] = s;
+    p.kind = kind; p.dst = dst; p.a0 = a0; p.a1 = a1; p.a2 = a2;
+    m.index[name] = (int)m.params.size();
+    m.params.push_back(p);
+  }
+
+  NormW norm(const std::string& n, int c) {
+    NormW w; w.c = c; w.g = take(c * 4); w.b = take(c * 4);
+    reg(n + ".weight", {c}, PK_VEC, w.g); reg(n + ".bias", {c}, PK_VEC, w.b);
+    return w;
+  }
+  ConvW conv3(const std::string& n, int co, int ci) {
+    ConvW w; w.cin = ci; w.cout = co; w.w = take((size_t)co * 9 * ci * 2); w.b = take(co * 4);
+    reg(n + ".weight", {co, ci, 3, 3}, PK_CONV3, w.w, co, ci); reg(n + ".bias", {co}, PK_VEC, w.b);
+    return w;
+  }
+  // linear / 1x1 conv into rows [row_off, row_off+n) of a (possibly shared) [ntot][k] matrix
+  void lin_rows(const std::string& n, LinW& w, int rows, int row_off, bool conv1x1, bool bias) {
+    if (conv1x1) reg(n + ".weight", {rows, w.k, 1, 1}, PK_ROWS, w.w, rows, w.k, row_off);
+    else reg(n + ".weight", {rows, w.k}, PK_ROWS, w.w, rows, w.k, row_off);
+    if (bias) reg(n + ".bias", {rows}, PK_VEC_OFF, w.b, rows, row_off);
+  }
+  LinW lin_alloc(int ntot, int k, bool bias) {
+    LinW w; w.n = ntot; w.k = k; w.w = take((size_t)ntot * k * 2); w.b = bias ? take(ntot * 4) : NPOS; w.has_bias = bias;
+    return w;
+  }
+  LinW lin(const std::string& n, int co, int ci, bool bias = true, bool conv1x1 = false) {
+    LinW w = lin_alloc(co, ci, bias);
+    lin_rows(n, w, co, 0, conv1x1, bias);
+    return w;
+  }
+
+  ResnetW resnet(const std::string& p, int ci, int co) {
+    ResnetW r; r.cin = ci; r.cout = co;
+    r.n1 = norm(p + ".norm1", ci);
+    r.c1 = conv3(p + ".conv1", co, ci);
+    r.temb_off = m.temb_total;
+    m.temb_regs.push_back({p + ".time_emb_proj", co, m.temb_total});
+    m.temb_total += co;
+    r.n2 = norm(p + ".norm2", co);
+    r.c2 = conv3(p + ".conv2", co, co);
+    r.has_sc = ci != co;
+    if (r.has_sc) r.sc = lin(p + ".conv_shortcut", co, ci, true, true);
+    return r;
+  }
+
+  VitW vit(const std::string& p, int c, int heads, int depth) {
+    const GdfArch& a = m.arch;
+    VitW v; v.c = c; v.heads = heads;
+    v.gn = norm(p + ".norm", c);
+    v.pin = lin(p + ".proj_in", c, c, true, !a.use_linear_projection);
+    for (int i = 0; i < depth; ++i) {
+      const std::string b = p + ".transformer_blocks." + std::to_string(i);
+      BlockW w;
+      w.ln1 = norm(b + ".norm1", c);
+      w.qkv = lin_alloc(3 * c, c, false);
+      lin_rows(b + ".attn1.to_q", w.qkv, c, 0, false, false);
+      lin_rows(b + ".attn1.to_k", w.qkv, c, c, false, false);
+      lin_rows(b + ".attn1.to_v", w.qkv, c, 2 * c, false, false);
+      w.o1 = lin(b + ".attn1.to_out.0", c, c);
+      w.ln2 = norm(b + ".norm2", c);
+      w.q2 = lin(b + ".attn2.to_q", c, c, false);
+      w.kv2 = lin_alloc(2 * c, a.cross_attention_dim, false);
+      lin_rows(b + ".attn2.to_k", w.kv2, c, 0, false, false);
+      lin_rows(b + ".attn2.to_v", w.kv2, c, c, false, false);
+      w.o2 = lin(b + ".attn2.to_out.0", c, c);
+      w.ln3 = norm(b + ".norm3", c);
+      w.ff1 = lin_alloc(8 * c, c, true);
+      reg(b + ".ff.net.0.proj.weight", {8 * c, c}, PK_ROWS_GEGLU, w.ff1.w, 8 * c, c);
+      reg(b + ".ff.net.0.proj.bias", {8 * c}, PK_VEC_GEGLU, w.ff1.b, 8 * c);
+      w.ff2 = lin(b + ".ff.net.2", c, 4 * c);
+      v.blocks.push_back(w);
+    }
+    v.pout = lin(p + ".proj_out", c, c, true, !a.use_linear_projection);
+    return v;
+  }
+
+  void build() {
+    const GdfArch& a = m.arch;
+    const int L = a.n_levels, nl = a.layers_per_block, te = a.time_embed_dim;
+    const int* boc = a.block_out_channels;
+    // conv_in: [C0][16 taps][8 ch] (9 real taps, Cin real channels)
+    m.conv_in.cin = a.in_channels; m.conv_in.cout = boc[0];
+    m.conv_in.w = take((size_t)boc[0] * 128 * 2); m.conv_in.b = take(boc[0] * 4);
+    reg("conv_in.weight", {boc[0], a.in_channels, 3, 3}, PK_CONV_IN, m.conv_in.w, boc[0], a.in_channels);
+    reg("conv_in.bias", {boc[0]}, PK_VEC, m.conv_in.b);
+    m.te1 = lin("time_embedding.linear_1", te, boc[0]);
+    m.te2 = lin("time_embedding.linear_2", te, te);
+    if (a.addition_embed_text_time) {
+      m.ae1 = lin("add_embedding.linear_1", te, a.add_in_dim);
+      m.ae2 = lin("add_embedding.linear_2", te, te);
+    }
+    int ci = boc[0];
+    for (int lv = 0; lv < L; ++lv) {
+      LevelW lw;
+      const int co = boc[lv];
+      for (int r = 0; r < nl; ++r) {
+        lw.res.push_back(resnet("down_blocks." + std::to_string(lv) + ".resnets." + std::to_string(r), ci, co));
+        if (a.has_attn[lv])
+          lw.vit.push_back(vit("down_blocks." + std::to_string(lv) + ".attentions." + std::to_string(r), co, a.heads[lv],
+                               a.transformer_layers[lv]));
+        ci = co;
+      }
+      lw.has_sampler = lv != L - 1;
+      if (lw.has_sampler) lw.sampler = conv3("down_blocks." + std::to_string(lv) + ".downsamplers.0.conv", co, co);
+      m.down.push_back(lw);
+    }
+    const int cm = boc[L - 1];
+    m.mid_res0 = resnet("mid_block.resnets.0", cm, cm);
+    m.mid_vit = vit("mid_block.attentions.0", cm, a.heads[L - 1], a.transformer_layers[L - 1]);
+    m.mid_res1 = resnet("mid_block.resnets.1", cm, cm);
+    int prev = boc[L - 1];
+    for (int i = 0; i < L; ++i) {
+      LevelW lw;
+      const int lv = L - 1 - i;
+      const int co = boc[lv];
+      const int cin_skip = boc[std::max(lv - 1, 0)];
+      for (int r = 0; r < nl + 1; ++r) {
+        const int skip_c = (r == nl) ? cin_skip : co;
+        const int in_c = (r == 0) ? prev : co;
+        lw.res.push_back(resnet("up_blocks." + std::to_string(i) + ".resnets." + std::to_string(r), in_c + skip_c, co));
+        lw.skip_c.push_back(skip_c);
+        if (a.has_attn[lv])
+          lw.vit.push_back(vit("up_blocks." + std::to_string(i) + ".attentions." + std::to_string(r), co, a.heads[lv],
+                               a.transformer_layers[lv]));
+      }
+      lw.has_sampler = i != L - 1;
+      if (lw.has_sampler) lw.sampler = conv3("up_blocks." + std::to_string(i) + ".upsamplers.0.conv", co, co);
+      m.up.push_back(lw);
+      prev = co;
+    }
+    m.norm_out = norm("conv_norm_out", boc[0]);
+    m.conv_out = conv3("conv_out", a.out_channels, boc[0]);
+    // stacked time_emb_proj: one [sum Cout][te] matrix -> a single launch per forward
+    m.temb_all = lin_alloc(m.temb_total, te, true);
+    for (auto& t : m.temb_regs) lin_rows(t.name, m.temb_all, t.cout, t.off, false, true);
+    m.weight_bytes = cur;
+  }
+};
+
+Model* model_create(const GdfArch& arch) {
+  if (arch.n_levels < 2 || arch.n_levels > 4) { set_error("n_levels must be 2..4"); return nullptr; }
+  for (int i = 0; i < arch.n_levels; ++i) {
+    if (arch.block_out_channels[i] % 64) { set_error("block_out_channels must be multiples of 64"); return nullptr; }
+    if (arch.has_attn[i]) {
+      const int d = arch.block_out_channels[i] / std::max(1, arch.heads[i]);
+      if (!(d == 32 || d == 40 || d == 64 || d == 80 || d == 160)) { set_error("unsupported head dim"); return nullptr; }
+    }
+  }
+  if (arch.cross_attention_dim % 64 || arch.time_embed_dim % 8 || arch.in_channels > 8) {
+    set_error("unsupported cross_attention_dim / time_embed_dim / in_channels"); return nullptr;
+  }
+  if (arch.addition_embed_text_time && (arch.add_in_dim % 8)) { set_error("add_in_dim % 8"); return nullptr; }
+  Model* m = new Model();
+  m->arch = arch;
+  ModelBuilder b(*m);
+  b.build();
+  if (hipMalloc(&m->weights, m->weight_bytes) != hipSuccess) {
+    set_error("hipMalloc(weights) failed"); delete m; return nullptr;
+  }
+  hipMemset(m->weights, 0, m->weight_bytes);
+  // hook ids (dry plan walk)
+  PlanOpts o{}; o.stream_fp32 = 1;
+  Plan dry;
+  plan_build(*m, dry, 1, 8 << (arch.n_levels - 1), 8 << (arch.n_levels - 1), 8, nullptr, 0, o, /*dry=*/true);
+  m->hook_names = dry.dry_ids;
+  return m;
+}
+
+void model_destroy(Model* m) {
+  if (!m) return;
+  if (m->weights) hipFree(m->weights);
+  delete m;
+}
+
+int model_set_param(Model* m, const char* name, const void* src, int dtype, hipStream_t s) {
+  auto it = m->index.find(name);
+  if (it == m->index.end()) { set_error(std::string("unknown parameter: ") + name); return GDF_ERR_ARG; }
+  ParamRec& p = m->params[it->second];
+  const int f32 = dtype == GDF_F32;
+  char* base = (char*)m->weights;
+  hipError_t e = hipSuccess;
+  switch (p.kind) {
+    case PK_VEC: e = launch_relayout_vec(src, f32, (float*)(base + p.dst), (int)p.shape[0], 0, 0, s); break;
+    case PK_VEC_OFF: e = launch_relayout_vec(src, f32, (float*)(base + p.dst), p.a0, p.a1, 0, s); break;
+    case PK_VEC_GEGLU: e = launch_relayout_vec(src, f32, (float*)(base + p.dst), p.a0, 0, 1, s); break;
+    case PK_CONV3: e = launch_relayout_conv(src, f32, (half_t*)(base + p.dst), p.a0, p.a1, 9, p.a1, 9, s); break;
+    case PK_CONV_IN: e = launch_relayout_conv(src, f32, (half_t*)(base + p.dst), p.a0, p.a1, 9, 8, 16, s); break;
+    case PK_ROWS: e = launch_relayout_rows(src, f32, (half_t*)(base + p.dst), p.a0, p.a1, p.a2, 0, s); break;
+    case PK_ROWS_GEGLU: e = launch_relayout_rows(src, f32, (half_t*)(base + p.dst), p.a0, p.a1, 0, 1, s); break;
+    default: set_error("bad param kind"); return GDF_ERR_STATE;
+  }
+  if (e != hipSuccess) { set_error(std::string("relayout launch failed: ") + hipGetErrorString(e)); return GDF_ERR_HIP; }
+  if (!p.set) { p.set = true; m->n_set++; }
+  return GDF_OK;
+}
+
+// =====================================================================================================
+// Plan builder
+// =====================================================================================================
+namespace {
+
+struct Arena {   // plan-time first-fit allocator with coalescing free list
+  struct Blk { size_t off, size; };
+  std::vector<Blk> free_;
+  size_t top = 0, peak = 0;
+  size_t alloc(size_t bytes) {
+    bytes = align_up(std::max<size_t>(bytes, 256), 256);
+    for (size_t i = 0; i < free_.size(); ++i)
+      if (free_[i].size >= bytes) {
+        size_t o = free_[i].off;
+        free_[i].off += bytes; free_[i].size -= bytes;
+        if (!free_[i].size) free_.erase(free_.begin() + i);
+        return o;
+      }
+    // extend: if the last free block touches the top, grow it
+    if (!free_.empty() && free_.back().off + free_.back().size == top) {
+      size_t o = free_.back().off;
+      top = o + bytes; free_.pop_back();
+      peak = std::max(peak, top);
+      return o;
+    }
+    size_t o = top; top += bytes; peak = std::max(peak, top);
+    return o;
+  }
+  void release(size_t off, size_t bytes) {
+    bytes = align_up(std::max<size_t>(bytes, 256), 256);
+    Blk b{off, bytes};
+    auto it = std::lower_bound(free_.begin(), free_.end(), b, [](const Blk& x, const Blk& y) { return x.off < y.off; });
+    it = free_.insert(it, b);
+    if (it + 1 != free_.end() && it->off + it->size == (it + 1)->off) { it->size += (it + 1)->size; free_.erase(it + 1); }
+    if (it != free_.begin() && (it - 1)->off + (it - 1)->size == it->off) { (it - 1)->size += it->size; free_.erase(it); }
+  }
+};
+
+// fp16 activation view (+ optional fp32 master of the same logical tensor, contiguous ld = C)
+struct Act {
+  Ref h{}; int ld = 0;        // fp16 [rows][C] with leading dimension ld
+  Ref f{}; bool has_f = false;
+  int C = 0, H = 0, W = 0;
+  size_t h_alloc = NPOS, h_bytes = 0;   // workspace block owned by h (NPOS: lives in a concat buffer / elsewhere)
+  size_t f_alloc = NPOS, f_bytes = 0;
+};
+
+struct B {   // builder
+  const Model& m;
+  Plan& P;
+  Arena ar;
+  bool dry;
+  int Bn, n_ctx;
+  bool stop = false;
+  int remaining = 0;
+  const PlanOpts& opt;
+  Ref temb_all{};     // [B][temb_total] f32
+
+  B(const Model& mm, Plan& pp, bool d, const PlanOpts& o) : m(mm), P(pp), dry(d), opt(o) {}
+
+  Ref ws(size_t off) const { return Ref{BUF_WS, off}; }
+  Ref wt(size_t off) const { return Ref{BUF_WT, off}; }
+
+  void op(const char* name, double flops, std::function<hipError_t(const Bind&, hipStream_t)> fn) {
+    if (dry || stop) return;
+    P.ops.push_back(Op{name, flops, std::move(fn)});
+  }
+
+  size_t rows(const Act& a) const { return (size_t)Bn * a.H * a.W; }
+
+  Act new_act(int C, int H, int W, bool master) {
+    Act a; a.C = C; a.H = H; a.W = W; a.ld = C;
+    a.h_bytes = (size_t)Bn * H * W * C * 2;
+    a.h_alloc = dry ? 0 : ar.alloc(a.h_bytes);
+    a.h = ws(a.h_alloc);
+    if (master && opt.stream_fp32) add_master(a);
+    return a;
+  }
+  void add_master(Act& a) {
+    a.f_bytes = (size_t)Bn * a.H * a.W * a.C * 4;
+    a.f_alloc = dry ? 0 : ar.alloc(a.f_bytes);
+    a.f = ws(a.f_alloc); a.has_f = true;
+  }
+  // activation whose fp16 image lives inside someone else's buffer (concat slice)
+  Act view_act(Ref h, int ld, int C, int H, int W, bool master) {
+    Act a; a.C = C; a.H = H; a.W = W; a.ld = ld; a.h = h;
+    if (master && opt.stream_fp32) add_master(a);
+    return a;
+  }
+  void free_act(Act& a) {
+    if (dry) return;
+    if (a.h_alloc != NPOS) { ar.release(a.h_alloc, a.h_bytes); a.h_alloc = NPOS; }
+    if (a.f_alloc != NPOS) { ar.release(a.f_alloc, a.f_bytes); a.f_alloc = NPOS; a.has_f = false; }
+  }
+  void free_master(Act& a) {
+    if (dry) return;
+    if (a.f_alloc != NPOS) { ar.release(a.f_alloc, a.f_bytes); a.f_alloc = NPOS; a.has_f = false; }
+  }
+  size_t tmp(size_t bytes) { return dry ? 0 : ar.alloc(bytes); }
+  void untmp(size_t off, size_t bytes) { if (!dry) ar.release(off, bytes); }
+
+  // ---- hooks ------------------------------------------------------------------------------------
+  // returns hook slot (>= 0) if `id` is requested, else -1. Shape is logical (B, C, H, W) stored channels-last.
+  int want(const std::string& id, int C, int H, int W) {
+    if (dry) { P.dry_ids.push_back(id); return -1; }
+    if (stop) return -1;
+    if (!P.requested.count(id)) return -1;
+    HookSlot hs; hs.id = id;
+    hs.shape[0] = Bn; hs.shape[1] = C; hs.shape[2] = H; hs.shape[3] = W;
+    hs.stride[0] = (int64_t)H * W * C; hs.stride[1] = 1; hs.stride[2] = (int64_t)W * C; hs.stride[3] = C;
+    hs.bytes = (size_t)Bn * C * H * W * 2;
+    P.hooks.push_back(hs);
+    return (int)P.hooks.size() - 1;
+  }
+  int want_map(const std::string& id, int heads, int Sq, int Sk) {
+    if (dry) { P.dry_ids.push_back(id); return -1; }
+    if (stop || !P.requested.count(id)) return -1;
+    HookSlot hs; hs.id = id;
+    hs.shape[0] = Bn; hs.shape[1] = heads; hs.shape[2] = Sq; hs.shape[3] = Sk;
+    hs.stride[0] = (int64_t)heads * Sq * Sk; hs.stride[1] = (int64_t)Sq * Sk; hs.stride[2] = Sk; hs.stride[3] = 1;
+    hs.bytes = (size_t)Bn * heads * Sq * Sk * 2;
+    P.hooks.push_back(hs);
+    return (int)P.hooks.size() - 1;
+  }
+  void hook_done() {
+    if (dry) return;
+    if (--remaining == 0 && opt.early_exit) stop = true;
+  }
+  // coalesced hook store: fp16 copy of `rows x C` from (src, ld)
+  void hook_copy(int slot, Ref src, int ld, size_t nrows, int C) {
+    if (slot < 0) return;
+    op("hook_store", 0, [=](const Bind& b, hipStream_t s) {
+      return launch_copy2d((const half_t*)b.p(src), nullptr, ld, (half_t*)b.hook(slot), C, (int)nrows, C, s);
+    });
+    hook_done();
+  }
+  void gather(const std::string& id, const Act& a) { hook_copy(want(id, a.C, a.H, a.W), a.h, a.ld, rows(a), a.C); }
+
+  // ---- primitive emitters -----------------------------------------------------------------------
+  // GroupNorm (+SiLU) of x -> contiguous fp16 tensor (workspace offset returned)
+  size_t groupnorm(const Act& x, const NormW& w, float eps, bool silu) {
+    const size_t n = rows(x);
+    const size_t y = tmp(n * x.C * 2);
+    const size_t part_b = gn_partial_floats(Bn, x.H * x.W, x.C) * 4, ab_b = (size_t)Bn * x.C * 8;
+    const size_t part = tmp(part_b), ab = tmp(ab_b);
+    const Ref xh = x.h; const int ld = x.ld, C = x.C, HW = x.H * x.W, Bq = Bn;
+    const Ref g = wt(w.g), bt = wt(w.b);
+    op("gn_stats", 0, [=](const Bind& b, hipStream_t s) {
+      return launch_gn_stats((const half_t*)b.p(xh), nullptr, ld, Bq, HW, C, 32, eps, (const float*)b.p(g),
+                             (const float*)b.p(bt), (float*)b.ws(part), (float*)b.ws(ab), s);
+    });
+    op(silu ? "gn_apply_silu" : "gn_apply", 0, [=](const Bind& b, hipStream_t s) {
+      return launch_gn_apply((const half_t*)b.p(xh), nullptr, ld, Bq, HW, C, (const float*)b.ws(ab), silu ? 1 : 0,
+                             (half_t*)b.ws(y), s);
+    });
+    untmp(part, part_b); untmp(ab, ab_b);
+    return y;
+  }
+
+  struct Epi {
+    Ref bias{}; bool has_bias = false;
+    Ref rowvec{}; bool has_rv = false; int rps = 1, ldrv = 0;
+    Ref res32{}; bool has_r32 = false; Ref res16{}; bool has_r16 = false; int ldres = 0;
+    Ref out16{}; bool has_o16 = false; int ldo16 = 0;
+    Ref out32{}; bool has_o32 = false; int ldo32 = 0;
+    int aux_slot = -1; int ldaux = 0;
+    bool geglu = false; int bn = 128;
+  };
+  void residual_from(Epi& e, const Act& x) {
+    if (x.has_f) { e.res32 = x.f; e.has_r32 = true; e.ldres = x.C; }
+    else { e.res16 = x.h; e.has_r16 = true; e.ldres = x.ld; }
+  }
+  void out_to(Epi& e, const Act& y) {
+    e.out16 = y.h; e.has_o16 = true; e.ldo16 = y.ld;
+    if (y.has_f) { e.out32 = y.f; e.has_o32 = true; e.ldo32 = y.C; }
+  }
+  static void fill_epi(GemmParams& g, const Epi& e, const Bind& b) {
+    g.bias = e.has_bias ? (const float*)b.p(e.bias) : nullptr;
+    g.rowvec = e.has_rv ? (const float*)b.p(e.rowvec) : nullptr; g.rows_per_sample = e.rps; g.ldrv = e.ldrv;
+    g.res32 = e.has_r32 ? (const float*)b.p(e.res32) : nullptr;
+    g.res16 = e.has_r16 ? (const half_t*)b.p(e.res16) : nullptr; g.ldres = e.ldres;
+    g.out16 = e.has_o16 ? (half_t*)b.p(e.out16) : nullptr; g.ldo16 = e.ldo16;
+    g.out32 = e.has_o32 ? (float*)b.p(e.out32) : nullptr; g.ldo32 = e.ldo32;
+    g.aux16 = e.aux_slot >= 0 ? (half_t*)b.hook(e.aux_slot) : nullptr; g.ldaux = e.ldaux;
+    g.geglu = e.geglu ? 1 : 0; g.bn = e.bn;
+  }
+
+  // dense GEMM: A (fp16 [M][K], lda) x W[N][K]
+  void gemm(const char* name, Ref A, int lda, size_t M, const LinW& w, int N, int K, size_t w_off_bytes, const Epi& e0) {
+    Epi e = e0;
+    const Ref W = wt(w.w + w_off_bytes);
+    op(name, 2.0 * (double)M * N * K, [=](const Bind& b, hipStream_t s) {
+      GemmParams g{};
+      g.A = (const half_t*)b.p(A); g.lda = lda; g.a_bytes = (uint32_t)(((size_t)M - 1) * lda * 2 + (size_t)K * 2);
+      g.M = (int)M; g.N = N; g.K = K; g.mode = A_DENSE;
+      g.Wt = (const half_t*)b.p(W); g.w_bytes = (uint32_t)((size_t)N * K * 2);
+      fill_epi(g, e, b);
+      return launch_gemm(g, s);
+    });
+  }
+  // 3x3 conv as implicit GEMM over NHWC `src` (Bn, H, W, ld>=Cin)
+  void conv3(const char* name, Ref src, int ld, int Cin, int H, int W, int stride, bool ups, const ConvW& w, const Epi& e0) {
+    Epi e = e0;
+    const int IH = ups ? 2 * H : H, IW = ups ? 2 * W : W;
+    const int OH = (IH + 2 - 3) / stride + 1, OW = (IW + 2 - 3) / stride + 1;
+    const size_t M = (size_t)Bn * OH * OW;
+    const Ref Wr = wt(w.w);
+    const int N = w.cout, Bq = Bn;
+    op(name, 2.0 * (double)M * N * 9 * Cin, [=](const Bind& b, hipStream_t s) {
+      GemmParams g{};
+      g.A = (const half_t*)b.p(src); g.lda = ld;
+      g.a_bytes = (uint32_t)(((size_t)Bq * H * W - 1) * ld * 2 + (size_t)Cin * 2);
+      g.M = (int)M; g.N = N; g.K = 9 * Cin; g.mode = A_CONV3; g.H = H; g.W = W; g.OH = OH; g.OW = OW;
+      g.stride = stride; g.ups = ups ? 1 : 0; g.Cin = Cin;
+      g.Wt = (const half_t*)b.p(Wr); g.w_bytes = (uint32_t)((size_t)N * 9 * Cin * 2);
+      fill_epi(g, e, b);
+      return launch_gemm(g, s);
+    });
+  }
+
+  // ---- ResnetBlock2D ------------------------------------------------------------------------------
+  // x -> y (y.h destination prepared by the caller)
+  void resnet(const std::string& id, const ResnetW& w, const Act& x, Act& y) {
+    if (stop) return;
+    const size_t n = rows(x);
+    const int HW = x.H * x.W;
+    const size_t n1 = groupnorm(x, w.n1, 1e-5f, true);
+    const size_t h1_b = n * w.cout * 2;
+    Act h1 = new_act(w.cout, x.H, x.W, false);
+    {
+      Epi e; e.bias = wt(w.c1.b); e.has_bias = true;
+      e.rowvec = Ref{temb_all.buf, temb_all.off + (size_t)w.temb_off * 4}; e.has_rv = true; e.rps = HW; e.ldrv = m.temb_total;
+      out_to(e, h1);
+      conv3("res_conv1", ws(n1), x.C, x.C, x.H, x.W, 1, false, w.c1, e);
+    }
+    untmp(n1, n * x.C * 2);
+    const size_t n2 = groupnorm(h1, w.n2, 1e-5f, true);
+    free_act(h1);
+    (void)h1_b;
+    // shortcut: 1x1 conv of x into an fp32 residual buffer
+    size_t sc = NPOS; const size_t sc_b = n * w.cout * 4;
+    if (w.has_sc) {
+      sc = tmp(sc_b);
+      Epi e; e.bias = wt(w.sc.b); e.has_bias = true; e.out32 = ws(sc); e.has_o32 = true; e.ldo32 = w.cout;
+      gemm("res_shortcut", x.h, x.ld, n, w.sc, w.cout, x.C, 0, e);
+    }
+    {
+      Epi e; e.bias = wt(w.c2.b); e.has_bias = true;
+      e.aux_slot = want(id + "-res-increment", w.cout, x.H, x.W); e.ldaux = w.cout;      // resnet.py:371-372
+      if (w.has_sc) { e.res32 = ws(sc); e.has_r32 = true; e.ldres = w.cout; }
+      else residual_from(e, x);
+      out_to(e, y);
+      conv3("res_conv2", ws(n2), w.cout, w.cout, x.H, x.W, 1, false, w.c2, e);
+      if (e.aux_slot >= 0) hook_done();
+    }
+    untmp(n2, n * w.cout * 2);
+    if (w.has_sc) untmp(sc, sc_b);
+    gather(id + "-res-out", y);                                                           // resnet.py:376-377
+  }
+
+  // ---- attention helper ---------------------------------------------------------------------------
+  void attention(const char* name, Ref q, int ldq, Ref k, int ldk, Ref v, int ldv, Ref o, int ldo, int heads, int Sq,
+                 int Sk, int D, int map_slot) {
+    const int Bq = Bn;
+    const double fl = 4.0 * (double)Bn * heads * Sq * Sk * D;
+    op(name, fl, [=](const Bind& b, hipStream_t s) {
+      AttnParams a{};
+      a.q = (const half_t*)b.p(q); a.ldq = ldq; a.k = (const half_t*)b.p(k); a.ldk = ldk;
+      a.v = (const half_t*)b.p(v); a.ldv = ldv; a.o = (half_t*)b.p(o); a.ldo = ldo;
+      a.B = Bq; a.heads = heads; a.Sq = Sq; a.Sk = Sk; a.D = D; a.scale = 1.0f / sqrtf((float)D);
+      a.map = map_slot >= 0 ? (half_t*)b.hook(map_slot) : nullptr;
+      return launch_attention(a, s);
+    });
+    if (map_slot >= 0) hook_done();
+  }
+
+  // ---- Transformer2DModel ---------------------------------------------------------------------------
+  void vit(const std::string& id, const VitW& w, const Act& x, Act& y) {
+    if (stop) return;
+    const size_t n = rows(x);
+    const int C = x.C, S = x.H * x.W, heads = w.heads, D = C / heads;
+    const bool maps = P.want_maps;
+    // GroupNorm(eps 1e-6) -> proj_in  (conv1x1 == linear in NHWC)
+    const size_t gn = groupnorm(x, w.gn, 1e-6f, false);
+    Act tok = new_act(C, x.H, x.W, true);
+    {
+      Epi e; e.bias = wt(w.pin.b); e.has_bias = true; out_to(e, tok);
+      gemm("proj_in", ws(gn), C, n, w.pin, C, C, 0, e);
+    }
+    untmp(gn, n * C * 2);
+    for (size_t bi = 0; bi < w.blocks.size() && !stop; ++bi) {
+      const BlockW& bw = w.blocks[bi];
+      const std::string bid = id + "-block" + std::to_string(bi);
+      const size_t nb = n * C * 2;
+      // --- self attention ---
+      size_t ln = layernorm(tok, bw.ln1);
+      const size_t qkv = tmp(n * 3 * C * 2);
+      { Epi e; e.out16 = ws(qkv); e.has_o16 = true; e.ldo16 = 3 * C; gemm("attn1_qkv", ws(ln), C, n, bw.qkv, 3 * C, C, 0, e); }
+      untmp(ln, nb);
+      hook_copy(want(bid + "-self-q", C, x.H, x.W), ws(qkv), 3 * C, n, C);                 // attention_processor.py:3291-3294
+      hook_copy(want(bid + "-self-k", C, x.H, x.W), ws(qkv + (size_t)C * 2), 3 * C, n, C);
+      hook_copy(want(bid + "-self-v", C, x.H, x.W), ws(qkv + (size_t)2 * C * 2), 3 * C, n, C);
+      size_t ao = tmp(nb);
+      const int ms = maps ? want_map(bid + "-self-map", heads, S, S) : (dry_map(bid + "-self-map"), -1);
+      attention("attn1", ws(qkv), 3 * C, ws(qkv + (size_t)C * 2), 3 * C, ws(qkv + (size_t)2 * C * 2), 3 * C, ws(ao), C, heads,
+                S, S, D, ms);
+      untmp(qkv, n * 3 * C * 2);
+      { Epi e; e.bias = wt(bw.o1.b); e.has_bias = true; residual_from(e, tok); out_to(e, tok);
+        gemm("attn1_out", ws(ao), C, n, bw.o1, C, C, 0, e); }
+      untmp(ao, nb);
+      if (stop) break;
+      // --- cross attention ---
+      ln = layernorm(tok, bw.ln2);
+      const size_t q2 = tmp(nb);
+      { Epi e; e.out16 = ws(q2); e.has_o16 = true; e.ldo16 = C; gemm("attn2_q", ws(ln), C, n, bw.q2, C, C, 0, e); }
+      untmp(ln, nb);
+      hook_copy(want(bid + "-cross-q", C, x.H, x.W), ws(q2), C, n, C);
+      const size_t nkv = (size_t)Bn * n_ctx;
+      const size_t kv = tmp(nkv * 2 * C * 2);
+      { Epi e; e.out16 = ws(kv); e.has_o16 = true; e.ldo16 = 2 * C;
+        gemm("attn2_kv", Ref{BUF_CTX, 0}, m.arch.cross_attention_dim, nkv, bw.kv2, 2 * C, m.arch.cross_attention_dim, 0, e); }
+      ao = tmp(nb);
+      const int mc = maps ? want_map(bid + "-cross-map", heads, S, n_ctx) : (dry_map(bid + "-cross-map"), -1);
+      attention("attn2", ws(q2), C, ws(kv), 2 * C, ws(kv + (size_t)C * 2), 2 * C, ws(ao), C, heads, S, n_ctx, D, mc);
+      untmp(q2, nb); untmp(kv, nkv * 2 * C * 2);
+      { Epi e; e.bias = wt(bw.o2.b); e.has_bias = true; residual_from(e, tok); out_to(e, tok);
+        gemm("attn2_out", ws(ao), C, n, bw.o2, C, C, 0, e); }
+      untmp(ao, nb);
+      if (stop) break;
+      // --- feed forward (GEGLU) ---
+      ln = layernorm(tok, bw.ln3);
+      const size_t inner = tmp(n * 4 * C * 2);
+      { Epi e; e.bias = wt(bw.ff1.b); e.has_bias = true; e.geglu = true; e.out16 = ws(inner); e.has_o16 = true; e.ldo16 = 4 * C;
+        gemm("ff_geglu", ws(ln), C, n, bw.ff1, 8 * C, C, 0, e); }
+      untmp(ln, nb);
+      hook_copy(want(bid + "-ffn-inner", 4 * C, x.H, x.W), ws(inner), 4 * C, n, 4 * C);   // attention.py:1255-1257
+      { Epi e; e.bias = wt(bw.ff2.b); e.has_bias = true; residual_from(e, tok); out_to(e, tok);
+        gemm("ff_out", ws(inner), 4 * C, n, bw.ff2, C, 4 * C, 0, e); }
+      untmp(inner, n * 4 * C * 2);
+      gather(bid + "-out", tok);                                                           // attention.py:589-590
+    }
+    if (!stop) {
+      Epi e; e.bias = wt(w.pout.b); e.has_bias = true; residual_from(e, x); out_to(e, y);
+      gemm("proj_out", tok.h, tok.ld, n, w.pout, C, C, 0, e);
+    }
+    free_act(tok);
+    gather(id + "-out", y);                                                                // transformer_2d.py:474-475
+  }
+  void dry_map(const std::string& id) { if (dry) P.dry_ids.push_back(id); }
+
+  size_t layernorm(const Act& x, const NormW& w) {
+    const size_t n = rows(x);
+    const size_t y = tmp(n * x.C * 2);
+    const Ref xh = x.h, xf = x.f; const bool hf = x.has_f; const int ld = x.ld, C = x.C;
+    const Ref g = wt(w.g), bt = wt(w.b);
+    op("layernorm", 0, [=](const Bind& b, hipStream_t s) {
+      return launch_layernorm(hf ? nullptr : (const half_t*)b.p(xh), hf ? (const float*)b.p(xf) : nullptr, hf ? C : ld,
+                              (int)n, C, 1e-5f, (const float*)b.p(g), (const float*)b.p(bt), (half_t*)b.ws(y), s);
+    });
+    return y;
+  }
+
+  // ---- whole UNet ---------------------------------------------------------------------------------
+  void build(int H, int W) {
+    const GdfArch& a = m.arch;
+    const int L = a.n_levels, nl = a.layers_per_block, te = a.time_embed_dim;
+    const int* boc = a.block_out_channels;
+    const int Bq = Bn;
+
+    // ---- time / additional embeddings (fp32 vectors) ----
+    const size_t tsin = tmp((size_t)Bn * boc[0] * 4), t1 = tmp((size_t)Bn * te * 4), emb = tmp((size_t)Bn * te * 4);
+    const size_t tall_b = (size_t)Bn * m.temb_total * 4;
+    const size_t tall = tmp(tall_b);
+    temb_all = ws(tall);
+    {
+      const int c0 = boc[0];
+      const Ref w1 = wt(m.te1.w), b1 = wt(m.te1.b), w2 = wt(m.te2.w), b2 = wt(m.te2.b);
+      op("time_embed", 0, [=](const Bind& b, hipStream_t s) {
+        hipError_t e = launch_sinusoid((const float*)b.base[BUF_T], Bq, 1, c0, (float*)b.ws(tsin), c0, 0, 0, s);
+        if (e != hipSuccess) return e;
+        e = launch_small_linear((const float*)b.ws(tsin), c0, Bq, c0, (const half_t*)b.p(w1), (const float*)b.p(b1), te, 0, 0,
+                                (float*)b.ws(t1), te, s);
+        if (e != hipSuccess) return e;
+        return launch_small_linear((const float*)b.ws(t1), te, Bq, te, (const half_t*)b.p(w2), (const float*)b.p(b2), te, 1, 0,
+                                   (float*)b.ws(emb), te, s);
+      });
+      if (a.addition_embed_text_time) {
+        const int ain = a.add_in_dim, atd = a.addition_time_embed_dim, pooled = ain - 6 * atd;
+        const size_t av = tmp((size_t)Bn * ain * 4), a1 = tmp((size_t)Bn * te * 4);
+        const Ref aw1 = wt(m.ae1.w), ab1 = wt(m.ae1.b), aw2 = wt(m.ae2.w), ab2 = wt(m.ae2.b);
+        op("add_embed", 0, [=](const Bind& b, hipStream_t s) {
+          if (!b.base[BUF_TXT] || !b.base[BUF_TID]) return hipErrorInvalidValue;
+          hipError_t e = launch_widen((const half_t*)b.base[BUF_TXT], Bq, pooled, (float*)b.ws(av), ain, 0, s);
+          if (e != hipSuccess) return e;
+          e = launch_sinusoid((const float*)b.base[BUF_TID], Bq, 6, atd, (float*)b.ws(av), ain, pooled, 0, s);
+          if (e != hipSuccess) return e;
+          e = launch_small_linear((const float*)b.ws(av), ain, Bq, ain, (const half_t*)b.p(aw1), (const float*)b.p(ab1), te, 0, 0,
+                                  (float*)b.ws(a1), te, s);
+          if (e != hipSuccess) return e;
+          return launch_small_linear((const float*)b.ws(a1), te, Bq, te, (const half_t*)b.p(aw2), (const float*)b.p(ab2), te, 1,
+                                     1, (float*)b.ws(emb), te, s);
+        });
+        untmp(av, (size_t)Bn * ain * 4); untmp(a1, (size_t)Bn * te * 4);
+      }
+      const Ref tw = wt(m.temb_all.w), tb = wt(m.temb_all.b);
+      const int tt = m.temb_total;
+      op("temb_proj_all", 0, [=](const Bind& b, hipStream_t s) {
+        return launch_small_linear((const float*)b.ws(emb), te, Bq, te, (const half_t*)b.p(tw), (const float*)b.p(tb), tt, 1, 0,
+                                   (float*)b.ws(tall), tt, s);
+      });
+    }
+
+    // ---- concat buffers of the up path: cat([h, skip]) laid out in place --------------------------
+    // skip producers in order: conv_in, every down resnet(+vit) output, every downsampler output
+    struct Cat { size_t off, bytes; int ch, cs, H, W; };
+    std::vector<Cat> cats;        // in up-path consumption order
+    {
+      int prev = boc[L - 1];
+      int hh = H >> (L - 1), ww = W >> (L - 1);
+      for (int i = 0; i < L; ++i) {
+        const int lv = L - 1 - i, co = boc[lv], cin_skip = boc[std::max(lv - 1, 0)];
+        for (int r = 0; r < nl + 1; ++r) {
+          Cat c; c.ch = (r == 0) ? prev : co; c.cs = (r == nl) ? cin_skip : co; c.H = hh; c.W = ww;
+          c.bytes = (size_t)Bn * hh * ww * (c.ch + c.cs) * 2;
+          c.off = tmp(c.bytes);
+          cats.push_back(c);
+        }
+        prev = co; hh *= 2; ww *= 2;
+      }
+    }
+    int n_skips = (int)cats.size();   // == number of skip tensors
+    int skip_idx = 0;                 // k-th produced skip is consumed by cats[n_skips-1-k]
+    auto skip_dst = [&](int C, int hh, int ww) -> Act {
+      const Cat& c = cats[n_skips - 1 - skip_idx++];
+      return view_act(ws(c.off + (size_t)c.ch * 2), c.ch + c.cs, C, hh, ww, true);
+    };
+
+    // ---- conv_in ----
+    const size_t lat8_b = (size_t)Bn * H * W * 16;
+    const size_t lat8 = tmp(lat8_b);
+    {
+      const int slot = want("unet-in", a.in_channels, H, W);                                // unet_2d_condition.py:1169-1170
+      const int cin = a.in_channels;
+      op("pack_latents", 0, [=](const Bind& b, hipStream_t s) {
+        return launch_pack_latents((const half_t*)b.base[BUF_LAT], Bq, cin, H, W, (half_t*)b.ws(lat8),
+                                   slot >= 0 ? (half_t*)b.hook(slot) : nullptr, s);
+      });
+      if (slot >= 0) hook_done();
+    }
+    Act cur = skip_dst(boc[0], H, W);
+    if (!stop) {
+      Epi e; e.bias = wt(m.conv_in.b); e.has_bias = true; out_to(e, cur);
+      Epi ee = e;
+      const Ref Wr = wt(m.conv_in.w); const int N = boc[0];
+      const size_t M = (size_t)Bn * H * W;
+        op("conv_in", 2.0 * (double)M * N * 9 * a.in_channels, [=](const Bind& b, hipStream_t s) {
+        GemmParams g{};
+        g.A = (const half_t*)b.ws(lat8); g.lda = 8; g.a_bytes = (uint32_t)(M * 16);
+        g.M = (int)M; g.N = N; g.K = 128; g.mode = A_CONV_SMALLC; g.H = H; g.W = W; g.OH = H; g.OW = W; g.stride = 1; g.Cin = 8;
+        g.Wt = (const half_t*)b.p(Wr); g.w_bytes = (uint32_t)((size_t)N * 128 * 2);
+        fill_epi(g, ee, b);
+        return launch_gemm(g, s);
+      });
+    }
+    untmp(lat8, lat8_b);
+    gather("unet-after-conv-in", cur);                                                      // :1172-1173
+
+    // ---- down path ----
+    int hh = H, ww = W;
+    for (int lv = 0; lv < L && !stop; ++lv) {
+      const LevelW& lw = m.down[lv];
+      for (int r = 0; r < nl && !stop; ++r) {
+        const std::string id = "down-level" + std::to_string(lv) + "-repeat" + std::to_string(r);
+        const bool attn = a.has_attn[lv];
+        if (attn) {
+          Act mid = new_act(boc[lv], hh, ww, true);
+          resnet(id, lw.res[r], cur, mid);
+          free_master(cur);
+          Act nxt = skip_dst(boc[lv], hh, ww);
+          vit(id + "-vit", lw.vit[r], mid, nxt);
+          free_act(mid);
+          cur = nxt;
+        } else {
+          Act nxt = skip_dst(boc[lv], hh, ww);
+          resnet(id, lw.res[r], cur, nxt);
+          free_master(cur);
+          cur = nxt;
+        }
+      }
+      if (lw.has_sampler && !stop) {
+        Act nxt = skip_dst(boc[lv], hh / 2, ww / 2);
+        Epi e; e.bias = wt(lw.sampler.b); e.has_bias = true; out_to(e, nxt);
+        conv3("downsample", cur.h, cur.ld, cur.C, hh, ww, 2, false, lw.sampler, e);          // downsampling.py:132-152
+        free_master(cur);
+        cur = nxt; hh /= 2; ww /= 2;
+        gather("down-level" + std::to_string(lv) + "-downsampler-out", cur);
+      }
+    }
+    // ---- mid ----
+    if (!stop) {
+      Act a0 = new_act(boc[L - 1], hh, ww, true);
+      resnet("mid-repeat0", m.mid_res0, cur, a0);
+      free_master(cur);
+      Act a1 = new_act(boc[L - 1], hh, ww, true);
+      vit("mid-vit", m.mid_vit, a0, a1);
+      free_act(a0);
+      // mid output feeds cats[0] channel slice [0, ch)
+      Act a2 = view_act(ws(cats[0].off), cats[0].ch + cats[0].cs, boc[L - 1], hh, ww, false);
+      resnet("mid-repeat1", m.mid_res1, a1, a2);
+      free_act(a1);
+      cur = a2;
+    }
+    // ---- up path ----
+    int ci = 0;
+    for (int i = 0; i < L && !stop; ++i) {
+      const LevelW& lw = m.up[i];
+      const int lv = L - 1 - i;
+      for (int r = 0; r < nl + 1 && !stop; ++r, ++ci) {
+        const std::string id = "up-level" + std::to_string(i) + "-repeat" + std::to_string(r);
+        const Cat& c = cats[ci];
+        Act cat = view_act(ws(c.off), c.ch + c.cs, c.ch + c.cs, c.H, c.W, false);            // torch.cat([h, skip], 1)
+        // destination: the h-slice of the next concat buffer, or a fresh tensor at the end of a level
+        const bool last_in_level = (r == nl);
+        const bool attn = a.has_attn[lv];
+        auto make_dst = [&](bool master) -> Act {
+          if (!last_in_level) {
+            const Cat& nc = cats[ci + 1];
+            return view_act(ws(nc.off), nc.ch + nc.cs, boc[lv], c.H, c.W, master);
+          }
+          return new_act(boc[lv], c.H, c.W, master);
+        };
+        if (attn) {
+          Act mid = new_act(boc[lv], c.H, c.W, true);
+          resnet(id, lw.res[r], cat, mid);
+          Act nxt = make_dst(false);
+          vit(id + "-vit", lw.vit[r], mid, nxt);
+          free_act(mid);
+          cur = nxt;
+        } else {
+          Act nxt = make_dst(false);
+          resnet(id, lw.res[r], cat, nxt);
+          cur = nxt;
+        }
+        untmp(c.off, c.bytes);
+      }
+      if (lw.has_sampler && !stop) {
+        const Cat& nc = cats[ci];
+        Act nxt = view_act(ws(nc.off), nc.ch + nc.cs, boc[lv], cur.H * 2, cur.W * 2, false);
+        Epi e; e.bias = wt(lw.sampler.b); e.has_bias = true; out_to(e, nxt);
+        conv3("upsample", cur.h, cur.ld, cur.C, cur.H, cur.W, 1, true, lw.sampler, e);       // upsampling.py:176-193
+        free_act(cur);
+        cur = nxt;
+        gather("up-level" + std::to_string(i) + "-upsampler-out", cur);
+      }
+    }
+    // ---- out ----
+    if (!stop) {
+      const size_t n = rows(cur);
+      const size_t no = groupnorm(cur, m.norm_out, 1e-5f, true);                             // :1304-1306
+      Epi e; e.bias = wt(m.conv_out.b); e.has_bias = true; e.bn = 16;
+      e.out16 = Ref{BUF_NOISE, 0}; e.has_o16 = true; e.ldo16 = a.out_channels;
+      P.writes_noise = true;
+      conv3("conv_out", ws(no), cur.C, cur.C, cur.H, cur.W, 1, false, m.conv_out, e);
+      untmp(no, n * cur.C * 2);
+      const int slot = want("unet-out", a.out_channels, cur.H, cur.W);                       // :1309-1310
+      hook_copy(slot, Ref{BUF_NOISE, 0}, a.out_channels, n, a.out_channels);
+      free_act(cur);
+    }
+    (void)tsin; (void)t1; (void)emb;
+  }
+};
+
+}  // namespace
+
+int plan_build(const Model& m, Plan& P, int batch, int H, int W, int n_ctx, const char* const* ids, int n_ids,
+               const PlanOpts& opts, bool dry) {
+  const int L = m.arch.n_levels;
+  if (batch < 1 || H < 1 || W < 1 || (H % (1 << (L - 1))) || (W % (1 << (L - 1)))) {
+    set_error("latent size must be a positive multiple of 2^(levels-1)"); return GDF_ERR_ARG;
+  }
+  for (int lv = 0; lv < L; ++lv) {   // 32-bit buffer offsets: the widest row (concat / GEGLU inner / qkv) must stay < 2 GiB
+    const size_t r = (size_t)batch * (H >> lv) * (W >> lv), c = m.arch.block_out_channels[lv];
+    if (r * c * 4 * 2 >= (1ull << 31)) {
+      set_error("batch*H*W too large for 32-bit buffer offsets; split the batch"); return GDF_ERR_UNSUPPORTED;
+    }
+  }
+  P.batch = batch; P.H = H; P.W = W; P.n_ctx = n_ctx; P.opts = opts;
+  B b(m, P, dry, opts);
+  b.Bn = batch; b.n_ctx = n_ctx;
+  if (!dry) {
+    std::unordered_set<std::string> known(m.hook_names.begin(), m.hook_names.end());
+    for (int i = 0; i < n_ids; ++i)
+      if (ids[i] && known.count(ids[i])) P.requested.insert(ids[i]);     // unknown ids silently ignored
+    b.remaining = (int)P.requested.size();
+    for (auto& s : P.requested) if (s.find("map") != std::string::npos) P.want_maps = true;   // diffusion_feature.py:72-77
+    if (opts.early_exit && b.remaining == 0) b.stop = true;
+  }
+  b.build(H, W);
+  P.ws_bytes = b.ar.peak + 256;
+  return GDF_OK;
+}
+
+int plan_forward(Plan& P, const Model& m, const void* lat, const float* t, const void* ctx, const void* txt,
+                 const float* tid, void* const* hook_out, void* noise, void* ws, hipStream_t s, float* ms,
+                 const char** names, double* flops, int cap) {
+  if (m.n_set != (int)m.params.size()) { set_error("model weights incomplete"); return GDF_ERR_STATE; }
+  Bind b;
+  b.base[BUF_WS] = (char*)ws; b.base[BUF_WT] = (char*)m.weights; b.base[BUF_LAT] = (char*)lat; b.base[BUF_T] = (char*)t;
+  b.base[BUF_CTX] = (char*)ctx; b.base[BUF_TXT] = (char*)txt; b.base[BUF_TID] = (char*)tid;
+  b.hooks = hook_out;
+  if (!lat || !t || !ctx || !ws) { set_error("null input pointer"); return GDF_ERR_ARG; }
+  if (P.hooks.size() && !hook_out) { set_error("hook_out is null"); return GDF_ERR_ARG; }
+  if (P.writes_noise && !noise) { set_error("noise_pred buffer required (the plan runs conv_out)"); return GDF_ERR_ARG; }
+  b.base[BUF_NOISE] = (char*)noise;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (ms) { hipEventCreate(&e0); hipEventCreate(&e1); }
+  int i = 0;
+  for (auto& op : P.ops) {
+    if (ms && i < cap) hipEventRecord(e0, s);
+    hipError_t e = op.fn(b, s);
+    if (e != hipSuccess) {
+      set_error(std::string("op '") + op.name + "' failed: " + hipGetErrorString(e));
+      return GDF_ERR_HIP;
+    }
+    if (ms && i < cap) {
+      hipEventRecord(e1, s); hipEventSynchronize(e1);
+      hipEventElapsedTime(&ms[i], e0, e1);
+      if (names) names[i] = op.name;
+      if (flops) flops[i] = op.flops;
+    }
+    ++i;
+  }
+  if (ms) { hipEventDestroy(e0); hipEventDestroy(e1); }
+  return GDF_OK;
+}
+
+}  // namespace gdf

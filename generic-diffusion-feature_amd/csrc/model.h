@@ -1,0 +1,90 @@
+// Internal host-side structures of libgdf.so (model = arch + weight arena; plan = static op program).
+#pragma once
+#include <functional>
+#include <string>
+#include <unordered_map>
+#include <unordered_set>
+#include <vector>
+
+#include "../../include/gdf.h"
+#include "kernels.h"
+
+namespace gdf {
+
+typedef gdf_arch_desc GdfArch;
+typedef gdf_plan_opts PlanOpts;
+static const size_t NPOS = (size_t)-1;
+
+void set_error(const std::string& s);
+const char* last_error();
+
+// ---- weights (byte offsets into the model's device arena) ---------------------------------------
+struct NormW { size_t g = 0, b = 0; int c = 0; };                               // fp32 gamma / beta
+struct ConvW { size_t w = 0, b = 0; int cin = 0, cout = 0; };                    // fp16 [cout][9][cin], fp32 bias
+struct LinW { size_t w = 0, b = NPOS; int n = 0, k = 0; bool has_bias = false; };  // fp16 [n][k], fp32 bias
+struct ResnetW { NormW n1, n2; ConvW c1, c2; LinW sc; bool has_sc = false; int cin = 0, cout = 0, temb_off = 0; };
+struct BlockW { NormW ln1, ln2, ln3; LinW qkv, o1, q2, kv2, o2, ff1, ff2; };
+struct VitW { NormW gn; LinW pin, pout; std::vector<BlockW> blocks; int c = 0, heads = 0; };
+struct LevelW { std::vector<ResnetW> res; std::vector<VitW> vit; std::vector<int> skip_c; bool has_sampler = false; ConvW sampler; };
+
+enum ParamKind { PK_VEC, PK_VEC_OFF, PK_VEC_GEGLU, PK_CONV3, PK_CONV_IN, PK_ROWS, PK_ROWS_GEGLU };
+struct ParamRec {
+  std::string name; int ndim = 0; int64_t shape[4] = {0, 0, 0, 0};
+  int kind = 0; size_t dst = 0; int a0 = 0, a1 = 0, a2 = 0; bool set = false;
+};
+struct TembReg { std::string name; int cout; int off; };
+
+struct Model {
+  GdfArch arch{};
+  void* weights = nullptr;
+  size_t weight_bytes = 0;
+  std::vector<ParamRec> params;
+  std::unordered_map<std::string, int> index;
+  int n_set = 0;
+  ConvW conv_in, conv_out;
+  LinW te1, te2, ae1, ae2, temb_all;
+  std::vector<TembReg> temb_regs;
+  int temb_total = 0;
+  std::vector<LevelW> down, up;
+  ResnetW mid_res0, mid_res1;
+  VitW mid_vit;
+  NormW norm_out;
+  std::vector<std::string> hook_names;
+};
+
+// ---- plan ----------------------------------------------------------------------------------------
+enum { BUF_WS = 0, BUF_WT, BUF_LAT, BUF_T, BUF_CTX, BUF_TXT, BUF_TID, BUF_NOISE, BUF_COUNT };
+struct Ref { int buf = BUF_WS; size_t off = 0; };
+struct Bind {
+  char* base[BUF_COUNT] = {nullptr};
+  void* const* hooks = nullptr;
+  void* p(const Ref& r) const { return base[r.buf] + r.off; }
+  void* ws(size_t off) const { return base[BUF_WS] + off; }
+  void* hook(int slot) const { return hooks[slot]; }
+};
+struct Op { const char* name; double flops; std::function<hipError_t(const Bind&, hipStream_t)> fn; };
+struct HookSlot { std::string id; int64_t shape[4]; int64_t stride[4]; size_t bytes; };
+
+struct Plan {
+  const Model* model = nullptr;
+  int batch = 0, H = 0, W = 0, n_ctx = 0;
+  PlanOpts opts{};
+  std::vector<Op> ops;
+  std::vector<HookSlot> hooks;
+  std::unordered_set<std::string> requested;
+  bool want_maps = false;
+  bool writes_noise = false;
+  size_t ws_bytes = 0;
+  std::vector<std::string> dry_ids;
+};
+
+Model* model_create(const GdfArch& arch);
+void model_destroy(Model* m);
+int model_set_param(Model* m, const char* name, const void* src, int dtype, hipStream_t s);
+int plan_build(const Model& m, Plan& P, int batch, int H, int W, int n_ctx, const char* const* ids, int n_ids,
+               const PlanOpts& opts, bool dry);
+int plan_forward(Plan& P, const Model& m, const void* lat, const float* t, const void* ctx, const void* txt,
+                 const float* tid, void* const* hook_out, void* noise, void* ws, hipStream_t s, float* ms,
+                 const char** names, double* flops, int cap);
+
+}  // namespace gdf

@@ -1,0 +1,428 @@
+// HBM-bound normalisation / elementwise kernels for gfx950: GroupNorm (+SiLU), LayerNorm, strided
+// copies (hook stores), input packing, timestep embeddings, small-M linears, weight re-layout.
+//
+// Reference ops replaced (paths under /root/reference/feature/diffusers/models):
+//   GroupNorm(32, C, eps=1e-5)+SiLU in ResnetBlock2D (resnet.py:267,281,325-326,359-361),
+//   GroupNorm(32, C, eps=1e-6) in Transformer2DModel (transformers/transformer_2d.py:175-177,484),
+//   LayerNorm in BasicTransformerBlock (attention.py:494-495,549,566), conv_norm_out+SiLU
+//   (unet/unet_2d_condition.py:1304-1306), Timesteps/TimestepEmbedding/add_embedding
+//   (unet/unet_2d_condition.py:910-934,968-984,1142-1162), time_emb_proj (resnet.py:343-346),
+//   FeatureStore.store's clone+fp16 cast (components/feature_extractor.py:56-60).
+// All are pure streaming kernels: 16-byte-per-lane coalesced accesses over NHWC / token-major rows.
+#include "kernels.h"
+
+namespace gdf {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+static constexpr int GN_SLAB = 256;   // pixel rows per stage-1 block
+
+__device__ __forceinline__ void load8(const half_t* x16, const float* x32, size_t idx, float v[8]) {
+  if (x32) {
+    const f32x4 a = *(const f32x4*)(x32 + idx), b = *(const f32x4*)(x32 + idx + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[e] = a[e]; v[4 + e] = b[e]; }
+  } else {
+    const f16x8 a = *(const f16x8*)(x16 + idx);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (float)a[e];
+  }
+}
+
+size_t gn_partial_floats(int B, int HW, int C) {
+  const int nslab = (HW + GN_SLAB - 1) / GN_SLAB;
+  return (size_t)B * nslab * C * 2;
+}
+
+// stage 1: per (sample, slab) block: per-channel sum / sum of squares over the slab's pixel rows
+__global__ __launch_bounds__(256) void gn_partial_kernel(const half_t* x16, const float* x32, int ld, int HW, int C,
+                                                         float* partial) {
+  extern __shared__ float red[];                  // [rgroups][C][2]
+  const int b = blockIdx.y, slab = blockIdx.x, nslab = gridDim.x;
+  const int CH = C / 8;
+  const int cht = CH < 256 ? CH : 256;            // chunk columns handled in parallel
+  const int rgroups = 256 / cht;                  // row groups working in parallel
+  const int tc = threadIdx.x % cht, tr = threadIdx.x / cht;
+  const int r0 = slab * GN_SLAB, r1 = min(HW, r0 + GN_SLAB);
+  for (int c = tc; c < CH; c += cht) {
+    float s[8], q[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.f;
+    if (tr < rgroups) {
+      for (int r = r0 + tr; r < r1; r += rgroups) {
+        float v[8];
+        load8(x16, x32, ((size_t)b * HW + r) * ld + c * 8, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s[e] += v[e]; q[e] += v[e] * v[e]; }
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        red[(tr * C + c * 8 + e) * 2 + 0] = s[e];
+        red[(tr * C + c * 8 + e) * 2 + 1] = q[e];
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < C * 2; i += 256) {
+    float a = 0.f;
+    for (int g = 0; g < rgroups; ++g) a += red[g * C * 2 + i];
+    partial[((size_t)b * nslab + slab) * C * 2 + i] = a;
+  }
+}
+
+// stage 2: one block per (sample, group): combine slabs (in double), emit the per-channel affine table
+__global__ __launch_bounds__(64) void gn_finalize_kernel(const float* partial, int nslab, int HW, int C, int G, float eps,
+                                                         const float* gamma, const float* beta, float* ab) {
+  const int b = blockIdx.y, g = blockIdx.x, lane = threadIdx.x;
+  const int cpg = C / G;
+  double s = 0.0, q = 0.0;
+  for (int i = lane; i < nslab * cpg; i += 64) {
+    const int sl = i / cpg, c = g * cpg + (i - sl * cpg);
+    const float* pp = partial + (((size_t)b * nslab + sl) * C + c) * 2;
+    s += (double)pp[0]; q += (double)pp[1];
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { s += __shfl_xor(s, off); q += __shfl_xor(q, off); }
+  const double n = (double)HW * cpg;
+  const double mean = s / n;
+  double var = q / n - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  for (int c = g * cpg + lane; c < (g + 1) * cpg; c += 64) {
+    const float a = rstd * gamma[c];
+    ab[((size_t)b * C + c) * 2 + 0] = a;
+    ab[((size_t)b * C + c) * 2 + 1] = beta[c] - (float)mean * a;
+  }
+}
+
+hipError_t launch_gn_stats(const half_t* x16, const float* x32, int ld, int B, int HW, int C, int G, float eps,
+                           const float* gamma, const float* beta, float* partial, float* ab, hipStream_t s) {
+  if (C % 8 || C % G) return hipErrorInvalidValue;
+  const int nslab = (HW + GN_SLAB - 1) / GN_SLAB;
+  const int CH = C / 8, cht = CH < 256 ? CH : 256, rgroups = 256 / cht;
+  const size_t smem = (size_t)rgroups * C * 2 * sizeof(float);
+  hipLaunchKernelGGL(gn_partial_kernel, dim3(nslab, B), dim3(256), smem, s, x16, x32, ld, HW, C, partial);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(G, B), dim3(64), 0, s, partial, nslab, HW, C, G, eps, gamma, beta, ab);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* x16, const float* x32, int ld, int HW, int C,
+                                                       const float* ab, int silu, half_t* y, int rows_per_block) {
+  const int b = blockIdx.y;
+  const int CH = C / 8;
+  const int cht = CH < 256 ? CH : 256, rgroups = 256 / cht;
+  const int tc = threadIdx.x % cht, tr = threadIdx.x / cht;
+  if (tr >= rgroups) return;
+  const int r0 = blockIdx.x * rows_per_block, r1 = min(HW, r0 + rows_per_block);
+  for (int c = tc; c < CH; c += cht) {
+    float a[8], bb[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      a[e] = ab[((size_t)b * C + c * 8 + e) * 2];
+      bb[e] = ab[((size_t)b * C + c * 8 + e) * 2 + 1];
+    }
+    for (int r = r0 + tr; r < r1; r += rgroups) {
+      float v[8];
+      load8(x16, x32, ((size_t)b * HW + r) * ld + c * 8, v);
+      f16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float t = v[e] * a[e] + bb[e];
+        if (silu) t = t / (1.0f + __expf(-t));
+        o[e] = (_Float16)t;
+      }
+      *(f16x8*)(y + ((size_t)b * HW + r) * C + c * 8) = o;
+    }
+  }
+}
+
+hipError_t launch_gn_apply(const half_t* x16, const float* x32, int ld, int B, int HW, int C, const float* ab, int silu,
+                           half_t* y, hipStream_t s) {
+  if (C % 8) return hipErrorInvalidValue;
+  const int rpb = 64;
+  hipLaunchKernelGGL(gn_apply_kernel, dim3((HW + rpb - 1) / rpb, B), dim3(256), 0, s, x16, x32, ld, HW, C, ab, silu, y,
+                     rpb);
+  return hipGetLastError();
+}
+
+// LayerNorm: one wave per row, row kept in registers (C <= 64*8*MAXC), exact two-pass statistics.
+template <int MAXC>
+__global__ __launch_bounds__(256) void layernorm_kernel(const half_t* x16, const float* x32, int ld, int R, int C,
+                                                        float eps, const float* gamma, const float* beta, half_t* y) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= R) return;
+  const int CH = C / 8;
+  float v[MAXC][8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int c = lane + 64 * i;
+    if (c < CH) {
+      load8(x16, x32, (size_t)row * ld + c * 8, v[i]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += v[i][e];
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+  const float mean = s / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int c = lane + 64 * i;
+    if (c < CH) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mean; q += d * d; }
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) q += __shfl_xor(q, off);
+  const float rstd = rsqrtf(q / (float)C + eps);
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int c = lane + 64 * i;
+    if (c < CH) {
+      const f32x4 g0 = *(const f32x4*)(gamma + c * 8), g1 = *(const f32x4*)(gamma + c * 8 + 4);
+      const f32x4 b0 = *(const f32x4*)(beta + c * 8), b1 = *(const f32x4*)(beta + c * 8 + 4);
+      f16x8 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        o[e] = (_Float16)((v[i][e] - mean) * rstd * g0[e] + b0[e]);
+        o[4 + e] = (_Float16)((v[i][4 + e] - mean) * rstd * g1[e] + b1[e]);
+      }
+      *(f16x8*)(y + (size_t)row * C + c * 8) = o;
+    }
+  }
+}
+
+hipError_t launch_layernorm(const half_t* x16, const float* x32, int ld, int R, int C, float eps, const float* gamma,
+                            const float* beta, half_t* y, hipStream_t s) {
+  if (C % 8 || C > 64 * 8 * 4) return hipErrorInvalidValue;
+  const int CH = C / 8;
+  dim3 grid((R + 3) / 4), blk(256);
+  if (CH <= 64) hipLaunchKernelGGL(layernorm_kernel<1>, grid, blk, 0, s, x16, x32, ld, R, C, eps, gamma, beta, y);
+  else if (CH <= 128) hipLaunchKernelGGL(layernorm_kernel<2>, grid, blk, 0, s, x16, x32, ld, R, C, eps, gamma, beta, y);
+  else hipLaunchKernelGGL(layernorm_kernel<4>, grid, blk, 0, s, x16, x32, ld, R, C, eps, gamma, beta, y);
+  return hipGetLastError();
+}
+
+// strided copy + cast (coalesced 16-B stores): the hook write when the producer cannot store directly
+__global__ __launch_bounds__(256) void copy2d_kernel(const half_t* s16, const float* s32, int lds_, half_t* dst, int ldd,
+                                                     long R, int C) {
+  if ((C & 7) == 0 && (lds_ & 7) == 0 && (ldd & 7) == 0) {
+    const int CH = C / 8;
+    const long total = R * CH;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+      const long r = i / CH;
+      const int c = (int)(i - r * CH) * 8;
+      float v[8];
+      load8(s16, s32, (size_t)r * lds_ + c, v);
+      f16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (_Float16)v[e];
+      *(f16x8*)(dst + (size_t)r * ldd + c) = o;
+    }
+  } else {
+    const long total = R * C;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+      const long r = i / C;
+      const int c = (int)(i - r * C);
+      const float v = s32 ? s32[(size_t)r * lds_ + c] : (float)s16[(size_t)r * lds_ + c];
+      dst[(size_t)r * ldd + c] = (_Float16)v;
+    }
+  }
+}
+
+hipError_t launch_copy2d(const half_t* s16, const float* s32, int lds_, half_t* dst, int ldd, int R, int C,
+                         hipStream_t s) {
+  const long work = (long)R * ((C + 7) / 8);
+  long blocks = (work + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(copy2d_kernel, dim3((unsigned)blocks), dim3(256), 0, s, s16, s32, lds_, dst, ldd, (long)R, C);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void pack_latents_kernel(const half_t* x, int Cin, int HW, long total, half_t* nhwc8,
+                                                           half_t* hook) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long b = i / HW;
+    const int pix = (int)(i - b * HW);
+    f16x8 o = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int c = 0; c < Cin && c < 8; ++c) o[c] = x[((size_t)b * Cin + c) * HW + pix];
+    *(f16x8*)(nhwc8 + (size_t)i * 8) = o;
+    if (hook)
+      for (int c = 0; c < Cin; ++c) hook[(size_t)i * Cin + c] = o[c];
+  }
+}
+
+hipError_t launch_pack_latents(const half_t* x, int B, int Cin, int H, int W, half_t* nhwc8, half_t* hook_nhwc,
+                               hipStream_t s) {
+  if (Cin > 8) return hipErrorInvalidValue;
+  const long total = (long)B * H * W;
+  long blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(pack_latents_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, Cin, H * W, total, nhwc8,
+                     hook_nhwc);
+  return hipGetLastError();
+}
+
+// diffusers get_timestep_embedding(flip_sin_to_cos=True, downscale_freq_shift=0): [cos | sin]
+__global__ void sinusoid_kernel(const float* t, int n_per_row, int dim, float* out, int ldo, int col_off, int round_f16,
+                                int total) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int half = dim / 2;
+  const int j = i % dim;
+  const int ti = (i / dim) % n_per_row;
+  const int b = i / (dim * n_per_row);
+  const int f = j < half ? j : j - half;
+  const float freq = expf(-9.210340371976184f * (float)f / (float)half);   // ln(10000)
+  const float arg = t[b * n_per_row + ti] * freq;
+  float v = j < half ? cosf(arg) : sinf(arg);
+  if (round_f16) v = (float)(_Float16)v;
+  out[(size_t)b * ldo + col_off + ti * dim + j] = v;
+}
+
+hipError_t launch_sinusoid(const float* t, int B, int n_per_row, int dim, float* out, int ldo, int col_off,
+                           int round_f16, hipStream_t s) {
+  const int total = B * n_per_row * dim;
+  hipLaunchKernelGGL(sinusoid_kernel, dim3((total + 255) / 256), dim3(256), 0, s, t, n_per_row, dim, out, ldo, col_off,
+                     round_f16, total);
+  return hipGetLastError();
+}
+
+__global__ void widen_kernel(const half_t* x, int n, float* out, int ldo, int col_off, int total) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int b = i / n, j = i - b * n;
+  out[(size_t)b * ldo + col_off + j] = (float)x[i];
+}
+
+hipError_t launch_widen(const half_t* x, int B, int n, float* out, int ldo, int col_off, hipStream_t s) {
+  const int total = B * n;
+  hipLaunchKernelGGL(widen_kernel, dim3((total + 255) / 256), dim3(256), 0, s, x, n, out, ldo, col_off, total);
+  return hipGetLastError();
+}
+
+// small-M linear on fp32 vectors with fp16 weights: one wave per output column, 8 rows at a time
+__global__ __launch_bounds__(256) void small_linear_kernel(const float* x, int ldx, int M, int K, const half_t* Wt,
+                                                           const float* bias, int N, int silu_in, int accumulate,
+                                                           float* out, int ldo) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  const half_t* w = Wt + (size_t)n * K;
+  for (int m0 = 0; m0 < M; m0 += 8) {
+    float acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+    for (int k = lane * 8; k < K; k += 512) {
+      const f16x8 wv = *(const f16x8*)(w + k);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        if (m0 + i < M) {
+          const float* xp = x + (size_t)(m0 + i) * ldx + k;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float xv = xp[e];
+            if (silu_in) xv = xv / (1.0f + expf(-xv));
+            acc[i] += xv * (float)wv[e];
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) acc[i] += __shfl_xor(acc[i], off);
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (m0 + i < M) {
+          float v = acc[i] + (bias ? bias[n] : 0.f);
+          float* op = out + (size_t)(m0 + i) * ldo + n;
+          if (accumulate) v += *op;
+          *op = v;
+        }
+    }
+  }
+}
+
+hipError_t launch_small_linear(const float* x, int ldx, int M, int K, const half_t* Wt, const float* bias, int N,
+                               int silu_in, int accumulate, float* out, int ldo, hipStream_t s) {
+  if (K % 8) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(small_linear_kernel, dim3((N + 3) / 4), dim3(256), 0, s, x, ldx, M, K, Wt, bias, N, silu_in,
+                     accumulate, out, ldo);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// weight re-layout
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float ldsrc(const void* src, int f32, size_t i) {
+  return f32 ? ((const float*)src)[i] : (float)((const half_t*)src)[i];
+}
+__device__ __forceinline__ int geglu_row(int r, int half) {
+  // source row r of the [2*half][K] GEGLU projection -> GEMM row so that every 64-column group is [32 h | 32 gate]
+  const int is_gate = r >= half;
+  const int rr = is_gate ? r - half : r;
+  return (rr / 32) * 64 + (is_gate ? 32 : 0) + (rr % 32);
+}
+
+__global__ void relayout_conv_kernel(const void* src, int f32, half_t* dst, int O, int I, int T, int ipad, int tpad,
+                                     long total) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int ci = (int)(i % ipad);
+    const int t = (int)((i / ipad) % tpad);
+    const int o = (int)(i / ((long)ipad * tpad));
+    float v = 0.f;
+    if (ci < I && t < T) v = ldsrc(src, f32, ((size_t)o * I + ci) * T + t);
+    dst[i] = (_Float16)v;
+  }
+}
+hipError_t launch_relayout_conv(const void* src, int src_f32, half_t* dst, int O, int I, int T, int ipad, int tpad,
+                                hipStream_t s) {
+  const long total = (long)O * ipad * tpad;
+  long blocks = (total + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(relayout_conv_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src, src_f32, dst, O, I, T, ipad,
+                     tpad, total);
+  return hipGetLastError();
+}
+
+__global__ void relayout_rows_kernel(const void* src, int f32, half_t* dst, int R, int K, int row_off, int geglu,
+                                     long total) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int r = (int)(i / K);
+    const int k = (int)(i - (long)r * K);
+    const int dr = geglu ? geglu_row(r, R / 2) : r + row_off;
+    dst[(size_t)dr * K + k] = (_Float16)ldsrc(src, f32, i);
+  }
+}
+hipError_t launch_relayout_rows(const void* src, int src_f32, half_t* dst, int R, int K, int row_off, int geglu,
+                                hipStream_t s) {
+  const long total = (long)R * K;
+  long blocks = (total + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(relayout_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src, src_f32, dst, R, K, row_off,
+                     geglu, total);
+  return hipGetLastError();
+}
+
+__global__ void relayout_vec_kernel(const void* src, int f32, float* dst, int R, int row_off, int geglu) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  const int dr = geglu ? geglu_row(r, R / 2) : r + row_off;
+  dst[dr] = ldsrc(src, f32, r);
+}
+hipError_t launch_relayout_vec(const void* src, int src_f32, float* dst, int R, int row_off, int geglu, hipStream_t s) {
+  hipLaunchKernelGGL(relayout_vec_kernel, dim3((R + 255) / 256), dim3(256), 0, s, src, src_f32, dst, R, row_off, geglu);
+  return hipGetLastError();
+}
+
+}  // namespace gdf

@@ -1,0 +1,104 @@
+// extern "C" kernel-level entry points (include/gdf_ops.h): one launch each, used by tests and micro-benchmarks.
+#include "../../include/gdf_ops.h"
+#include "model.h"
+
+using namespace gdf;
+
+static int fin(hipError_t e, const char* what) {
+  if (e == hipSuccess) return GDF_OK;
+  set_error(std::string(what) + ": " + hipGetErrorString(e));
+  return GDF_ERR_HIP;
+}
+
+extern "C" {
+
+int gdf_op_gemm(const void* A, int lda, const void* W, const float* bias, const float* res32, const void* res16,
+                int ldres, void* out16, int ldo16, float* out32, int ldo32, int M, int N, int K, int flags,
+                void* stream) {
+  GemmParams g{};
+  g.A = (const half_t*)A; g.lda = lda; g.a_bytes = (uint32_t)(((size_t)M - 1) * lda * 2 + (size_t)K * 2);
+  g.M = M; g.N = N; g.K = K; g.mode = A_DENSE;
+  g.Wt = (const half_t*)W; g.w_bytes = (uint32_t)((size_t)N * K * 2);
+  g.bias = bias; g.res32 = res32; g.res16 = (const half_t*)res16; g.ldres = ldres;
+  g.out16 = (half_t*)out16; g.ldo16 = ldo16; g.out32 = out32; g.ldo32 = ldo32;
+  g.geglu = flags & 1; g.bn = (flags & 2) ? 16 : 128; g.rows_per_sample = 1;
+  return fin(launch_gemm(g, (hipStream_t)stream), "gemm");
+}
+
+int gdf_op_conv3x3(const void* x, int ld, int B, int H, int W, int Cin, const void* Wt, int Cout, const float* bias,
+                   const float* rowvec, int stride, int ups, const float* res32, void* aux16, void* out16,
+                   float* out32, int narrow, void* stream) {
+  const int IH = ups ? 2 * H : H, IW = ups ? 2 * W : W;
+  const int OH = (IH - 1) / stride + 1, OW = (IW - 1) / stride + 1;
+  GemmParams g{};
+  g.A = (const half_t*)x; g.lda = ld; g.a_bytes = (uint32_t)(((size_t)B * H * W - 1) * ld * 2 + (size_t)Cin * 2);
+  g.M = B * OH * OW; g.N = Cout; g.K = 9 * Cin; g.mode = A_CONV3; g.H = H; g.W = W; g.OH = OH; g.OW = OW;
+  g.stride = stride; g.ups = ups; g.Cin = Cin;
+  g.Wt = (const half_t*)Wt; g.w_bytes = (uint32_t)((size_t)Cout * 9 * Cin * 2);
+  g.bias = bias; g.rowvec = rowvec; g.rows_per_sample = OH * OW; g.ldrv = Cout;
+  g.res32 = res32; g.ldres = Cout;
+  g.aux16 = (half_t*)aux16; g.ldaux = Cout;
+  g.out16 = (half_t*)out16; g.ldo16 = Cout; g.out32 = out32; g.ldo32 = Cout;
+  g.bn = narrow ? 16 : 128;
+  return fin(launch_gemm(g, (hipStream_t)stream), "conv3x3");
+}
+
+int gdf_op_conv_in(const void* x_nchw, int B, int Cin, int H, int W, const void* w_oihw, const float* bias, int Cout,
+                   void* out16, void* scratch, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  half_t* lat8 = (half_t*)scratch;
+  half_t* w = (half_t*)((char*)scratch + (size_t)B * H * W * 16);
+  hipError_t e = launch_pack_latents((const half_t*)x_nchw, B, Cin, H, W, lat8, nullptr, s);
+  if (e != hipSuccess) return fin(e, "pack_latents");
+  e = launch_relayout_conv(w_oihw, 0, w, Cout, Cin, 9, 8, 16, s);
+  if (e != hipSuccess) return fin(e, "relayout");
+  GemmParams g{};
+  const size_t M = (size_t)B * H * W;
+  g.A = lat8; g.lda = 8; g.a_bytes = (uint32_t)(M * 16);
+  g.M = (int)M; g.N = Cout; g.K = 128; g.mode = A_CONV_SMALLC; g.H = H; g.W = W; g.OH = H; g.OW = W; g.stride = 1; g.Cin = 8;
+  g.Wt = w; g.w_bytes = (uint32_t)((size_t)Cout * 256);
+  g.bias = bias; g.out16 = (half_t*)out16; g.ldo16 = Cout; g.bn = 128; g.rows_per_sample = 1;
+  return fin(launch_gemm(g, s), "conv_in");
+}
+
+int gdf_op_attention(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* o, int ldo,
+                     int B, int heads, int Sq, int Sk, int D, void* map, void* stream) {
+  AttnParams a{};
+  a.q = (const half_t*)q; a.ldq = ldq; a.k = (const half_t*)k; a.ldk = ldk; a.v = (const half_t*)v; a.ldv = ldv;
+  a.o = (half_t*)o; a.ldo = ldo; a.B = B; a.heads = heads; a.Sq = Sq; a.Sk = Sk; a.D = D;
+  a.scale = 1.0f / sqrtf((float)D); a.map = (half_t*)map;
+  return fin(launch_attention(a, (hipStream_t)stream), "attention");
+}
+
+size_t gdf_op_groupnorm_scratch_bytes(int B, int HW, int C) { return gn_partial_floats(B, HW, C) * 4 + (size_t)B * C * 8 + 256; }
+
+int gdf_op_groupnorm(const void* x16, const float* x32, int ld, int B, int HW, int C, int G, float eps,
+                     const float* gamma, const float* beta, int silu, void* y, void* scratch, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  float* partial = (float*)scratch;
+  float* ab = partial + (gn_partial_floats(B, HW, C) + 63) / 64 * 64;
+  hipError_t e = launch_gn_stats((const half_t*)x16, x32, ld, B, HW, C, G, eps, gamma, beta, partial, ab, s);
+  if (e != hipSuccess) return fin(e, "gn_stats");
+  return fin(launch_gn_apply((const half_t*)x16, x32, ld, B, HW, C, ab, silu, (half_t*)y, s), "gn_apply");
+}
+
+int gdf_op_layernorm(const void* x16, const float* x32, int ld, int R, int C, float eps, const float* gamma,
+                     const float* beta, void* y, void* stream) {
+  return fin(launch_layernorm((const half_t*)x16, x32, ld, R, C, eps, gamma, beta, (half_t*)y, (hipStream_t)stream), "layernorm");
+}
+
+int gdf_op_copy2d(const void* s16, const float* s32, int lds, void* dst, int ldd, int R, int C, void* stream) {
+  return fin(launch_copy2d((const half_t*)s16, s32, lds, (half_t*)dst, ldd, R, C, (hipStream_t)stream), "copy2d");
+}
+
+int gdf_op_relayout_conv3(const void* w, void* dst, int O, int I, void* stream) {
+  return fin(launch_relayout_conv(w, 0, (half_t*)dst, O, I, 9, I, 9, (hipStream_t)stream), "relayout_conv3");
+}
+int gdf_op_relayout_geglu(const void* w, const float* bias, void* w_dst, float* bias_dst, int R, int K, void* stream) {
+  hipError_t e = launch_relayout_rows(w, 0, (half_t*)w_dst, R, K, 0, 1, (hipStream_t)stream);
+  if (e != hipSuccess) return fin(e, "relayout_geglu");
+  if (bias) e = launch_relayout_vec(bias, 1, bias_dst, R, 0, 1, (hipStream_t)stream);
+  return fin(e, "relayout_geglu_bias");
+}
+
+}  // extern "C"

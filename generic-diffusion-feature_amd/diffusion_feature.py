@@ -1,0 +1,175 @@
+"""`diffusion_feature.FeatureExtractor` — drop-in for the reference's public API
+(/root/reference/feature/diffusion_feature.py:26-527) with the denoiser forward executed by
+hand-written HIP kernels for MI355X (libgdf.so) instead of patched diffusers modules.
+
+Kept verbatim: constructor keywords (:27-40), `encode_prompt` (:149-206) 4-tuple contract,
+`extract` signature and return contract (:222-235, :517) — dict[layer_id -> (B,C,H,W) fp16 tensor] in hook
+execution order —, `preprocess_image`, `offload_prompt_encoder`, background-extraction accessors,
+the layer-selection config surface (JSON path | dict | None) and the version / dtype strings.
+In scope is the single-timestep path (no `denoising_from`, ControlNet, DDIM inversion: SURVEY.md §2).
+"""
+import copy
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from components.models import get_diffusion_model
+from components.feature_extractor import prepare_feature_extractor
+
+
+class FeatureExtractor(nn.Module):
+    def __init__(self,
+                 layer,            # filename of the layer json, a pre-loaded dict, or None (= all layers)
+                 version,          # '1-5', 'xl', 'pgv2'
+                 device,
+                 dtype='float16',
+                 img_size=1024,    # 512 for 1-5, 1024 otherwise
+                 offline_lora=None,
+                 offline_lora_filename=None,
+                 feature_resize=1,
+                 control=None,
+                 attention=None,
+                 train_unet=False,
+                 external_model=None,
+                 ):
+        super().__init__()
+        if control:
+            raise NotImplementedError("ControlNet conditioning is outside the native hot path (SURVEY.md §2 #5)")
+        if attention:
+            raise NotImplementedError("aggregated attention feature ('attn') is a later row (SURVEY.md §8f rank 3); "
+                                      "request the per-layer '*-map' ids instead")
+        if train_unet:
+            raise NotImplementedError("the native denoiser is inference-only (no backward kernels)")
+        if external_model:
+            pipe = external_model
+        else:
+            pipe = get_diffusion_model(version, dtype, offline_lora, offline_lora_filename, device=device)
+
+        self.feature_store = prepare_feature_extractor(version, pipe, layer, feature_resize, train_unet)
+        self.store_vae_output = bool(self.feature_store.to_store.get('vae-out', False))
+        if self.store_vae_output:
+            raise NotImplementedError("'vae-out' needs the VAE decoder, which is upstream plumbing (SURVEY.md §8f)")
+
+        self.pipe = pipe
+        self.control_pipe = None
+        self.attention_store = None
+        self.scheduler_backup = copy.deepcopy(self.pipe.scheduler)
+        self.version = version
+        self.img_size = img_size
+        self.device = device
+        self.control = control
+        self.attention = attention
+
+        # freeze whatever torch modules the front-end carries (reference :98-111)
+        to_disable = [self.pipe.vae, self.pipe.text_encoder, self.pipe.unet]
+        if version in ['xl', 'pgv2']:
+            to_disable.append(self.pipe.text_encoder_2)
+        for m in to_disable:
+            for p in m.parameters():
+                p.requires_grad = False
+
+    # ------------------------------------------------------------------------------------------
+    def _preprocess_basic(self, x):
+        return x.resize((self.img_size, self.img_size)).convert("RGB")
+
+    def preprocess_image(self, x, is_tensor=False):
+        if not is_tensor:
+            return self.pipe.image_processor.preprocess(self._preprocess_basic(x))
+        return self.pipe.image_processor.preprocess([x[i] for i in range(x.shape[0])])
+
+    def encode_prompt(self, prompt_str=None, prompt_file=None):
+        assert prompt_str != None and prompt_file == None or prompt_str == None and prompt_file != None
+        if prompt_file:
+            with open(prompt_file, 'r') as f:
+                prompts = f.read()
+                print('prompt:', prompts)
+        else:
+            prompts = prompt_str
+        ret = self.pipe.encode_prompt(prompt=prompts, device=self.device, num_images_per_prompt=1,
+                                      negative_prompt='', do_classifier_free_guidance=True)
+        if self.version in ('xl', 'pgv2'):
+            prompt_embeds, negative_prompt_embeds, pooled, negative_pooled = ret
+        else:
+            prompt_embeds, negative_prompt_embeds = ret
+            pooled, negative_pooled = None, None
+        return prompt_embeds, negative_prompt_embeds, pooled, negative_pooled
+
+    def offload_prompt_encoder(self, persistent=False):
+        to_offload = [self.pipe.text_encoder]
+        if hasattr(self.pipe, 'text_encoder_2'):
+            to_offload.append(self.pipe.text_encoder_2)
+        for t in to_offload:
+            if not persistent and hasattr(t, 'to'):
+                t.to('cpu')
+
+    # ------------------------------------------------------------------------------------------
+    def extract(self, prompts, batch_size, image, image_type='image', t=50, denoising_from=None,
+                use_control=False, use_ddim_inversion=False):
+        """One single-timestep denoiser forward; returns {layer_id: (B,C,H,W) fp16}.
+        image_type: 'image' (list of PIL), 'tensors' ((B,3,h,w) in [-1,1]) or — native extension —
+        'latents' (pre-noised latents (B,4,H/8,W/8), skipping the VAE stage)."""
+        if denoising_from or use_control or use_ddim_inversion:
+            raise NotImplementedError("only the single-timestep path is native (SURVEY.md §2 #1)")
+        self.feature_store.reset()
+        device = self.device
+
+        prompt_embeds, _neg, pooled, _negp = prompts
+        prompt_embeds = prompt_embeds.repeat(batch_size, 1, 1)                           # reference :272
+        if pooled is not None:
+            pooled = pooled.repeat(batch_size, 1, 1).squeeze(1)                          # :275
+
+        # timestep selection through the scheduler, as the reference does (:288-295)
+        self.pipe.scheduler = copy.deepcopy(self.scheduler_backup)
+        self.pipe.scheduler.set_timesteps(1000, device=device)
+        timesteps, _ = self.pipe.get_timesteps(1000, t / 1000, device)
+        latent_timestep = timesteps[:1].repeat(batch_size)
+        t = timesteps[:1]
+
+        added_cond_kwargs = {}
+        if self.version in ('xl', 'pgv2'):                                               # :324-354
+            add_time_ids = _get_add_time_ids(self.pipe, (self.img_size, self.img_size), (0, 0),
+                                             (self.img_size, self.img_size), dtype=prompt_embeds.dtype)
+            added_cond_kwargs = {"text_embeds": pooled.to(device),
+                                 "time_ids": add_time_ids.to(device).repeat(batch_size, 1)}
+
+        if image_type == 'latents':
+            latents = image.to(device)
+        else:
+            if image_type == 'image':                                                    # :358-364
+                image = torch.concat([self.preprocess_image(r) for r in image], dim=0)
+            else:
+                image = F.interpolate(image, (self.img_size, self.img_size), mode='bilinear')
+            latents = self.pipe.prepare_latents(image, latent_timestep, 1, batch_size, prompt_embeds.dtype, device)
+
+        latent_model_input = self.pipe.scheduler.scale_model_input(latents, t)          # :405-406
+
+        # ---- the hot path: native UNet forward, hooks written by the kernels (:445-465) ----
+        self.pipe.unet(latent_model_input, timestep=t, encoder_hidden_states=prompt_embeds.to(device),
+                       added_cond_kwargs=added_cond_kwargs, down_block_additional_residuals=None,
+                       mid_block_additional_residual=None, return_dict=False)
+        return self.feature_store.stored_feats                                           # :517
+
+    def set_background_extraction(self, idxs):
+        self.feature_store.store_idx = idxs
+
+    def get_background_extraction(self):
+        return {k: v['feat'] for k, v in self.feature_store.feats.items()}
+
+
+DiffusionFeature = FeatureExtractor      # name used by BASELINE.json's north_star
+
+
+def _get_add_time_ids(pipe, original_size, crops_coords_top_left, target_size, dtype,
+                      aesthetic_score=6.0, negative_aesthetic_score=2.5):
+    """SDXL micro-conditioning vector and its consistency check (reference :534-571)."""
+    if pipe.config.requires_aesthetics_score:
+        ids = list(original_size + crops_coords_top_left + (aesthetic_score,))
+    else:
+        ids = list(original_size + crops_coords_top_left + target_size)
+    passed = pipe.unet.config.addition_time_embed_dim * len(ids) + pipe.text_encoder_2.config.projection_dim
+    expected = pipe.unet.add_embedding.linear_1.in_features
+    if expected != passed:
+        raise ValueError(f"Model expects an added time embedding vector of length {expected}, but a vector of "
+                         f"{passed} was created. Check `requires_aesthetics_score` / `projection_dim`.")
+    return torch.tensor([ids], dtype=dtype)

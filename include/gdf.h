@@ -1,0 +1,124 @@
+/* gdf.h — C ABI of the MI355X-native diffusion-feature hot path (libgdf.so).
+ *
+ * What it replaces in the reference (paths relative to /root/reference/feature):
+ *   - the call `self.pipe.unet(latent_model_input, timestep=t, encoder_hidden_states=prompt_embeds,
+ *     [added_cond_kwargs=...], return_dict=False)[0]`            diffusion_feature.py:445-465
+ *     i.e. UNet2DConditionModel.forward                           diffusers/models/unet/unet_2d_condition.py:1040-1319
+ *   - the side effects of every `feature_gatherer.gather(...)` call inside that forward
+ *     (FeatureGatherer.gather -> FeatureStore.store)              components/feature_extractor.py:31-76,83-89
+ *   - hook registration / id scheme (prepare_feature_extractor)   components/feature_extractor.py:92-288
+ *
+ * Conventions: plain C, no exceptions across the ABI, int status codes (0 = ok), caller owns every
+ * device buffer, every launch is asynchronous on the hipStream_t passed in, one plan per host
+ * thread, no hidden global state besides the per-thread last-error string.
+ * All device pointers are HIP device pointers; activations are fp16 unless stated.
+ */
+#ifndef GDF_H
+#define GDF_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gdf_model gdf_model;
+typedef struct gdf_plan gdf_plan;
+
+enum { GDF_OK = 0, GDF_ERR_ARG = 1, GDF_ERR_HIP = 2, GDF_ERR_STATE = 3, GDF_ERR_UNSUPPORTED = 4 };
+enum { GDF_F16 = 0, GDF_F32 = 1 };
+
+#define GDF_MAX_LEVELS 4
+
+/* UNet2DConditionModel hyper-parameters (the `config.json` the reference downloads,
+ * components/models.py:18-56; registered at unet_2d_condition.py:171-484). */
+typedef struct gdf_arch_desc {
+  int in_channels;                              /* 4 */
+  int out_channels;                             /* 4 */
+  int n_levels;                                 /* 4 (SD1.5) / 3 (SDXL) */
+  int block_out_channels[GDF_MAX_LEVELS];       /* 320,640,1280,1280 / 320,640,1280 */
+  int has_attn[GDF_MAX_LEVELS];                 /* CrossAttnDownBlock2D (1) or DownBlock2D (0) per level */
+  int transformer_layers[GDF_MAX_LEVELS];       /* transformer_layers_per_block */
+  int heads[GDF_MAX_LEVELS];                    /* attention heads per level */
+  int layers_per_block;                         /* 2 */
+  int cross_attention_dim;                      /* 768 / 2048 */
+  int use_linear_projection;                    /* 0 / 1 (same arithmetic in NHWC; kept for weight shapes) */
+  int time_embed_dim;                           /* 1280 */
+  int addition_embed_text_time;                 /* 0 / 1 (SDXL `text_time`) */
+  int addition_time_embed_dim;                  /* 256 */
+  int add_in_dim;                               /* projection_class_embeddings_input_dim, 2816 */
+} gdf_arch_desc;
+
+/* Thread-local description of the last failure. */
+const char* gdf_last_error(void);
+/* Library/ABI version, bumped on any signature change. */
+int gdf_abi_version(void);
+
+/* ---- model: architecture + weights resident in HBM ------------------------------------------ */
+int gdf_model_create(const gdf_arch_desc* arch, gdf_model** out);
+void gdf_model_destroy(gdf_model* m);
+
+/* Number of parameter tensors / i-th name in diffusers `state_dict()` naming
+ * (e.g. "down_blocks.1.attentions.0.transformer_blocks.0.attn1.to_q.weight"). */
+int gdf_model_param_count(const gdf_model* m);
+const char* gdf_model_param_name(const gdf_model* m, int i);
+/* shape in the diffusers layout (OIHW convs, [out,in] linears); returns ndim. */
+int gdf_model_param_shape(const gdf_model* m, int i, int64_t shape[4]);
+
+/* Copy one parameter from a DEVICE buffer in diffusers layout into the model's own MFMA-friendly
+ * layout (OHWI convs, fused QKV / KV, interleaved GEGLU, stacked time projections). dtype GDF_F16|GDF_F32. */
+int gdf_model_set_param(gdf_model* m, const char* name, const void* dev_ptr, int dtype, void* stream);
+/* 1 when every parameter has been set. */
+int gdf_model_ready(const gdf_model* m);
+size_t gdf_model_weight_bytes(const gdf_model* m);
+
+/* Every hook id this architecture can emit, in execution order (== the key order of the
+ * reference's config_*_full.json dumps, extract_feature.py:103-110). */
+int gdf_model_hook_count(const gdf_model* m);
+const char* gdf_model_hook_name(const gdf_model* m, int i);
+
+/* ---- plan: static op program for (batch, latent size, hook selection) ------------------------ */
+typedef struct gdf_plan_opts {
+  int stream_fp32;     /* 1: fp32 master copy of the residual stream (default), 0: fp16 only */
+  int early_exit;      /* 1: stop after the last requested hook (opt-in; noise_pred is then not produced) */
+  int reserved[6];
+} gdf_plan_opts;
+
+int gdf_plan_create(gdf_model* m, int batch, int lat_h, int lat_w, int n_ctx,
+                    const char* const* hook_ids, int n_hooks, const gdf_plan_opts* opts, gdf_plan** out);
+void gdf_plan_destroy(gdf_plan* p);
+size_t gdf_plan_workspace_bytes(const gdf_plan* p);
+int gdf_plan_num_ops(const gdf_plan* p);
+
+/* Hook i of the plan (i indexes the ids ACCEPTED from hook_ids, in execution order; unknown ids are
+ * silently ignored exactly like FeatureStore.store, feature_extractor.py:36).
+ * A hook tensor is returned to the caller as logical (B, C, H, W) stored channels-last:
+ * element (b,c,y,x) at  b*stride[0] + c*stride[1] + y*stride[2] + x*stride[3]  (in fp16 elements). */
+typedef struct gdf_hook_info {
+  const char* id;
+  int64_t shape[4];     /* B, C, H, W   ('-map' hooks: B, heads, Q, K) */
+  int64_t stride[4];
+  size_t bytes;         /* size of the caller-provided buffer */
+} gdf_hook_info;
+int gdf_plan_hook_count(const gdf_plan* p);
+int gdf_plan_hook_info(const gdf_plan* p, int i, gdf_hook_info* info);
+
+/* One single-timestep denoiser forward.  latents (B,4,H,W) fp16 NCHW; timesteps (B) fp32;
+ * ctx (B,n_ctx,cross_dim) fp16; add_text_embeds (B, add_in_dim - 6*addition_time_embed_dim) fp16 or NULL;
+ * add_time_ids (B,6) fp32 or NULL; hook_out[i] = device buffer of gdf_hook_info.bytes;
+ * noise_pred (B,H,W,4) fp16 channels-last or NULL; workspace >= gdf_plan_workspace_bytes. */
+int gdf_forward(gdf_plan* p, const void* latents, const float* timesteps, const void* ctx,
+                const void* add_text_embeds, const float* add_time_ids,
+                void* const* hook_out, void* noise_pred, void* workspace, void* stream);
+
+/* Per-op timing of the last plan (diagnostics; synchronises the stream). Fills up to cap entries
+ * with milliseconds per op, returns the op count. names[i] points into plan-owned storage. */
+int gdf_plan_profile(gdf_plan* p, const void* latents, const float* timesteps, const void* ctx,
+                     const void* add_text_embeds, const float* add_time_ids, void* const* hook_out,
+                     void* noise_pred, void* workspace, void* stream,
+                     float* ms, const char** names, double* flops, int cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GDF_H */

@@ -1,0 +1,59 @@
+/* gdf_ops.h — kernel-level entry points of libgdf.so (diagnostics / unit tests / micro-benchmarks).
+ * Same conventions as gdf.h: plain C, device pointers, asynchronous on `stream`, 0 = ok.
+ * Each call is one launch of the kernel the plan executor uses for that op class.            */
+#ifndef GDF_OPS_H
+#define GDF_OPS_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* out[M,N] = A[M,K](lda) * W[N,K]^T + bias (+ residual).  fp16 operands, fp32 accumulate.
+ * flags: bit0 GEGLU (W rows / bias already in the interleaved [32 h | 32 gate] order; out is [M,N/2]),
+ *        bit1 narrow-N tile (BN=16).  Replaces nn.Linear / 1x1 conv
+ *        (/root/reference/feature/diffusers/models/attention_processor.py:241-267, attention.py:1238-1258). */
+int gdf_op_gemm(const void* A, int lda, const void* W, const float* bias, const float* res32, const void* res16,
+                int ldres, void* out16, int ldo16, float* out32, int ldo32, int M, int N, int K, int flags,
+                void* stream);
+
+/* 3x3 convolution, padding 1, NHWC fp16 x[B,H,W,ld>=Cin], weights [Cout][3][3][Cin] fp16; stride 1|2;
+ * ups=1 fuses a nearest x2 upsample of x in front of the conv.  rowvec: optional [B][Cout] fp32 added per sample.
+ * Replaces nn.Conv2d in resnet.py:269,285, downsampling.py:115-118, upsampling.py:131-134,176-193.       */
+int gdf_op_conv3x3(const void* x, int ld, int B, int H, int W, int Cin, const void* Wt, int Cout, const float* bias,
+                   const float* rowvec, int stride, int ups, const float* res32, void* aux16, void* out16,
+                   float* out32, int narrow, void* stream);
+
+/* conv_in: x NCHW fp16 [B,Cin<=8,H,W] -> NHWC [B,H,W,Cout]; weights in diffusers OIHW fp16 layout.
+ * scratch: B*H*W*16 + Cout*256 bytes.                                                                  */
+int gdf_op_conv_in(const void* x_nchw, int B, int Cin, int H, int W, const void* w_oihw, const float* bias, int Cout,
+                   void* out16, void* scratch, void* stream);
+
+/* softmax(q k^T * D^-0.5) v per head; rows are tokens, head h at columns [h*D, h*D+D).
+ * map != NULL additionally writes the probabilities (B, heads, Sq, Sk) fp16 ('-map' hooks).
+ * Replaces F.scaled_dot_product_attention (attention_processor.py:3311-3313) /
+ * get_attention_scores+bmm (attention_processor.py:640-685, components/attention.py:232-246).          */
+int gdf_op_attention(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* o, int ldo,
+                     int B, int heads, int Sq, int Sk, int D, void* map, void* stream);
+
+/* GroupNorm(G groups, eps) [+SiLU] over NHWC x (fp16, ld) or x32 (fp32, ld); y contiguous fp16 [B*HW][C].
+ * scratch: gdf_op_groupnorm_scratch_bytes(B,HW,C).                                                      */
+size_t gdf_op_groupnorm_scratch_bytes(int B, int HW, int C);
+int gdf_op_groupnorm(const void* x16, const float* x32, int ld, int B, int HW, int C, int G, float eps,
+                     const float* gamma, const float* beta, int silu, void* y, void* scratch, void* stream);
+
+/* LayerNorm over the last dim. */
+int gdf_op_layernorm(const void* x16, const float* x32, int ld, int R, int C, float eps, const float* gamma,
+                     const float* beta, void* y, void* stream);
+
+/* strided fp16/fp32 -> fp16 2-D copy (the hook-store kernel). */
+int gdf_op_copy2d(const void* s16, const float* s32, int lds, void* dst, int ldd, int R, int C, void* stream);
+
+/* weight re-layout helpers used by the tests: OIHW -> OHWI, GEGLU row interleave. */
+int gdf_op_relayout_conv3(const void* w_oihw_f16, void* dst, int O, int I, void* stream);
+int gdf_op_relayout_geglu(const void* w_f16, const float* bias, void* w_dst, float* bias_dst, int R, int K, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -63,13 +63,13 @@ ARCHS["pgv2"] = ARCHS["xl"]
 
 def tiny_arch(base="xl", channels=None, heads=None, cross_dim=64, max_depth=2, time_embed_dim=256):
     """A shrunken architecture with the same topology (second-scale tests).
-    Defaults: xl -> channels (64,128,256), dim_head 64; 1-5 -> channels (160,320,640,640), 4 heads
+    Defaults: xl -> channels (64,128,256), dim_head 64; 1-5 -> channels (320,640,640,640), heads (8,8,4,4)
     (dim_head 40/80/160 like the real model)."""
     a = dict(ARCHS[base])
     if channels is None:
-        channels = (64, 128, 256) if base != "1-5" else (160, 320, 640, 640)
+        channels = (64, 128, 256) if base != "1-5" else (320, 640, 640, 640)
     if heads is None:
-        heads = tuple(max(1, c // 64) for c in channels) if base != "1-5" else (4,) * len(channels)
+        heads = tuple(max(1, c // 64) for c in channels) if base != "1-5" else (8, 8, 4, 4)[:len(channels)]
     a["block_out_channels"] = tuple(channels)
     a["heads"] = tuple(heads)
     a["transformer_layers"] = tuple(min(t, max_depth) for t in a["transformer_layers"])
@@ -130,6 +130,11 @@ def timestep_sinusoid(t, dim, flip_sin_to_cos=True, shift=0.0, max_period=10000)
     return emb
 
 
+def _stream(x):
+    """Identity. Residual-stream write point (precision studies monkeypatch this)."""
+    return x
+
+
 def _lin(P, name, x):
     return F.linear(x, P[name + ".weight"], P.get(name + ".bias"))
 
@@ -166,7 +171,7 @@ def resnet_block(P, pfx, x, emb, store, mid, eps=1e-5, groups=32):
     if (pfx + ".conv_shortcut.weight") in P:                                # :368-369
         x = F.conv2d(x, P[pfx + ".conv_shortcut.weight"], P[pfx + ".conv_shortcut.bias"])
     store.gather(mid, h, "increment")                                       # :371-372
-    out = x + h                                                             # :374 (/1.0)
+    out = _stream(x + h)                                                    # :374 (/1.0)
     store.gather(mid, out, "out")                                           # :376-377
     return out
 
@@ -212,11 +217,11 @@ def basic_transformer_block(P, pfx, x, ctx, heads, store, mid, want_map):
     """BasicTransformerBlock.forward, norm_type == 'layer_norm' — diffusers/models/attention.py:469-592."""
     c = x.shape[-1]
     n = F.layer_norm(x, (c,), P[pfx + ".norm1.weight"], P[pfx + ".norm1.bias"], 1e-5)
-    x = attention(P, pfx + ".attn1", n, None, heads, store, mid + "-self", want_map) + x      # :514-526
+    x = _stream(attention(P, pfx + ".attn1", n, None, heads, store, mid + "-self", want_map) + x)      # :514-526
     n = F.layer_norm(x, (c,), P[pfx + ".norm2.weight"], P[pfx + ".norm2.bias"], 1e-5)
-    x = attention(P, pfx + ".attn2", n, ctx, heads, store, mid + "-cross", want_map) + x      # :535-558
+    x = _stream(attention(P, pfx + ".attn2", n, ctx, heads, store, mid + "-cross", want_map) + x)      # :535-558
     n = F.layer_norm(x, (c,), P[pfx + ".norm3.weight"], P[pfx + ".norm3.bias"], 1e-5)
-    x = feed_forward(P, pfx + ".ff", n, store, mid + "-ffn") + x                               # :564-586
+    x = _stream(feed_forward(P, pfx + ".ff", n, store, mid + "-ffn") + x)                               # :564-586
     store.gather(mid, x, "out")                                                                # :589-590
     return x
 
@@ -242,7 +247,7 @@ def transformer_2d(P, pfx, x, ctx, heads, depth, linear_proj, store, mid, want_m
     else:
         h = h.reshape(b, hh, ww, c).permute(0, 3, 1, 2).contiguous()
         h = F.conv2d(h, P[pfx + ".proj_out.weight"], P[pfx + ".proj_out.bias"])
-    out = h + res
+    out = _stream(h + res)
     store.gather(mid, out, "out")
     return out
 

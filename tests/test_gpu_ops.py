@@ -1,0 +1,220 @@
+"""Kernel-level parity (-m gpu): each HIP kernel of libgdf.so, called through the C ABI (include/gdf_ops.h),
+against a plain PyTorch fp32 CPU computation of the same op on the same fp16-rounded inputs.
+Tolerances: fp16 storage of outputs => relative L2 error <= 1e-3 per tensor (fp32 outputs: 2e-4)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from ops_binding import P, lib, ok, rel, stream
+
+pytestmark = pytest.mark.gpu
+TOL16, TOL32 = 1e-3, 2e-4
+
+
+def rnd(*shape, scale=1.0, seed=0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return (torch.randn(*shape, generator=g) * scale).half()
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 320, 320), (200, 72, 128), (1232, 640, 2048), (64, 1280, 1280)])
+def test_gemm_bias_residual(M, N, K):
+    L = lib()
+    A, W = rnd(M, K), rnd(N, K, scale=K ** -0.5)
+    bias, res = rnd(N).float(), rnd(M, N).float()
+    ref = A.float() @ W.float().t() + bias + res
+    Ad, Wd, bd, rd = A.cuda(), W.cuda(), bias.cuda(), res.cuda()
+    o16 = torch.zeros(M, N, dtype=torch.half, device="cuda"); o32 = torch.zeros(M, N, device="cuda")
+    ok(L.gdf_op_gemm(P(Ad), K, P(Wd), P(bd), P(rd), None, N, P(o16), N, P(o32), N, M, N, K, 0, stream()), L)
+    torch.cuda.synchronize()
+    assert rel(o32, ref) < TOL32 and rel(o16, ref) < TOL16
+    # fp16 residual + strided A / out (leading dimensions larger than the logical width)
+    Abig = torch.zeros(M, K + 64, dtype=torch.half); Abig[:, 32:32 + K] = A
+    obig = torch.zeros(M, N + 24, dtype=torch.half, device="cuda")
+    r16 = res.half().cuda()
+    Ab = Abig.cuda()
+    ok(L.gdf_op_gemm(C_off(Ab, 32), K + 64, P(Wd), P(bd), None, P(r16), N, C_off(obig, 8), N + 24, None, 0, M, N, K, 0,
+                     stream()), L)
+    torch.cuda.synchronize()
+    ref2 = A.float() @ W.float().t() + bias + res.half().float()
+    assert rel(obig[:, 8:8 + N], ref2) < TOL16
+    assert float(obig[:, :8].abs().max()) == 0 and float(obig[:, 8 + N:].abs().max()) == 0
+
+
+def C_off(t, cols):
+    import ctypes
+    return ctypes.c_void_p(t.data_ptr() + cols * t.element_size())
+
+
+def test_gemm_asymmetric_identity():
+    """A = I against an asymmetric B catches row/col swaps in the MFMA C layout."""
+    L = lib()
+    M = N = K = 128
+    A = torch.eye(M).half()
+    W = (torch.arange(N)[:, None] * 0.01 + torch.arange(K)[None, :] * 0.003).half()
+    o32 = torch.zeros(M, N, device="cuda")
+    Ad, Wd = A.cuda(), W.cuda()
+    ok(L.gdf_op_gemm(P(Ad), K, P(Wd), None, None, None, 0, None, 0, P(o32), N, M, N, K, 0, stream()), L)
+    torch.cuda.synchronize()
+    assert torch.allclose(o32.cpu(), W.float().t(), atol=1e-3)
+
+
+@pytest.mark.parametrize("M,C", [(128, 64), (520, 320)])
+def test_gemm_geglu(M, C):
+    L = lib()
+    x, W, b = rnd(M, C), rnd(8 * C, C, scale=C ** -0.5), rnd(8 * C).float()
+    hg = x.float() @ W.float().t() + b
+    h, g = hg.chunk(2, -1)
+    ref = h * F.gelu(g)
+    Wd = torch.empty_like(W, device="cuda"); bd = torch.empty(8 * C, device="cuda")
+    Ws, bs, xd = W.cuda(), b.cuda(), x.cuda()
+    ok(L.gdf_op_relayout_geglu(P(Ws), P(bs), P(Wd), P(bd), 8 * C, C, stream()), L)
+    out = torch.zeros(M, 4 * C, dtype=torch.half, device="cuda")
+    ok(L.gdf_op_gemm(P(xd), C, P(Wd), P(bd), None, None, 0, P(out), 4 * C, None, 0, M, 8 * C, C, 1, stream()), L)
+    torch.cuda.synchronize()
+    assert rel(out, ref) < TOL16
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,stride,ups", [
+    (2, 8, 8, 64, 64, 1, 0), (1, 12, 10, 128, 192, 1, 0), (2, 8, 8, 64, 128, 2, 0), (2, 6, 6, 64, 64, 1, 1),
+    (1, 16, 16, 320, 320, 1, 0)])
+def test_conv3x3(B, H, W, Cin, Cout, stride, ups):
+    L = lib()
+    x = rnd(B, Cin, H, W); w = rnd(Cout, Cin, 3, 3, scale=(9 * Cin) ** -0.5)
+    bias, temb = rnd(Cout).float(), rnd(B, Cout).float()
+    xi = F.interpolate(x.float(), scale_factor=2.0, mode="nearest") if ups else x.float()
+    inc = F.conv2d(xi, w.float(), bias, stride=stride, padding=1) + temb[:, :, None, None]
+    OH, OW = inc.shape[2], inc.shape[3]
+    res = rnd(B, Cout, OH, OW, seed=5).float()
+    ref = inc + res
+    x_nhwc = x.permute(0, 2, 3, 1).contiguous().cuda()
+    wd = torch.empty(Cout, 9 * Cin, dtype=torch.half, device="cuda")
+    ws, bd, td = w.cuda(), bias.cuda(), temb.cuda()
+    ok(L.gdf_op_relayout_conv3(P(ws), P(wd), Cout, Cin, stream()), L)
+    res_nhwc = res.permute(0, 2, 3, 1).contiguous().cuda()
+    aux = torch.zeros(B, OH, OW, Cout, dtype=torch.half, device="cuda")
+    o16 = torch.zeros_like(aux); o32 = torch.zeros(B, OH, OW, Cout, device="cuda")
+    ok(L.gdf_op_conv3x3(P(x_nhwc), Cin, B, H, W, Cin, P(wd), Cout, P(bd), P(td), stride, ups,
+                        P(res_nhwc), P(aux), P(o16), P(o32), 0, stream()), L)
+    torch.cuda.synchronize()
+    assert rel(aux.permute(0, 3, 1, 2), inc) < TOL16
+    assert rel(o32.permute(0, 3, 1, 2), ref) < TOL32
+    assert rel(o16.permute(0, 3, 1, 2), ref) < TOL16
+
+
+def test_conv3x3_narrow_cout4():
+    L = lib()
+    B, H, W, Cin, Cout = 2, 8, 8, 64, 4
+    x = rnd(B, Cin, H, W); w = rnd(Cout, Cin, 3, 3, scale=(9 * Cin) ** -0.5); bias = rnd(Cout).float()
+    ref = F.conv2d(x.float(), w.float(), bias, padding=1)
+    wd = torch.empty(Cout, 9 * Cin, dtype=torch.half, device="cuda")
+    ws, bd, xd = w.cuda(), bias.cuda(), x.permute(0, 2, 3, 1).contiguous().cuda()
+    ok(L.gdf_op_relayout_conv3(P(ws), P(wd), Cout, Cin, stream()), L)
+    o16 = torch.zeros(B, H, W, Cout, dtype=torch.half, device="cuda")
+    ok(L.gdf_op_conv3x3(P(xd), Cin, B, H, W, Cin, P(wd), Cout, P(bd), None,
+                        1, 0, None, None, P(o16), None, 1, stream()), L)
+    torch.cuda.synchronize()
+    assert rel(o16.permute(0, 3, 1, 2), ref) < TOL16
+
+
+def test_conv_in():
+    L = lib()
+    B, H, W, Cout = 2, 8, 12, 64
+    x = rnd(B, 4, H, W); w = rnd(Cout, 4, 3, 3, scale=1 / 6.0); bias = rnd(Cout).float()
+    ref = F.conv2d(x.float(), w.float(), bias, padding=1)
+    out = torch.zeros(B, H, W, Cout, dtype=torch.half, device="cuda")
+    scratch = torch.zeros(B * H * W * 16 + Cout * 256, dtype=torch.uint8, device="cuda")
+    xd, wd, bd = x.cuda(), w.cuda(), bias.cuda()
+    ok(L.gdf_op_conv_in(P(xd), B, 4, H, W, P(wd), P(bd), Cout, P(out), P(scratch), stream()), L)
+    torch.cuda.synchronize()
+    assert rel(out.permute(0, 3, 1, 2), ref) < TOL16
+
+
+@pytest.mark.parametrize("B,heads,Sq,Sk,D", [(1, 2, 64, 64, 64), (2, 2, 36, 36, 32), (2, 3, 200, 77, 64),
+                                              (1, 4, 256, 256, 40), (1, 2, 130, 77, 80), (1, 1, 64, 200, 160),
+                                              (1, 2, 1024, 1024, 64)])
+def test_attention(B, heads, Sq, Sk, D):
+    L = lib()
+    C = heads * D
+    q, k, v = rnd(B, Sq, C), rnd(B, Sk, C, seed=1), rnd(B, Sk, C, seed=2)
+    qh = q.float().view(B, Sq, heads, D).transpose(1, 2)
+    kh = k.float().view(B, Sk, heads, D).transpose(1, 2)
+    vh = v.float().view(B, Sk, heads, D).transpose(1, 2)
+    probs = torch.softmax(qh @ kh.transpose(-1, -2) * D ** -0.5, -1)
+    ref = (probs @ vh).transpose(1, 2).reshape(B, Sq, C)
+    o = torch.zeros(B, Sq, C, dtype=torch.half, device="cuda")
+    qd, kd, vd = q.cuda(), k.cuda(), v.cuda()
+    ok(L.gdf_op_attention(P(qd), C, P(kd), C, P(vd), C, P(o), C, B, heads, Sq, Sk, D, None, stream()), L)
+    torch.cuda.synchronize()
+    assert rel(o, ref) < 2e-3
+    if Sq * Sk <= 256 * 256:
+        o2 = torch.zeros_like(o); mp = torch.zeros(B, heads, Sq, Sk, dtype=torch.half, device="cuda")
+        ok(L.gdf_op_attention(P(qd), C, P(kd), C, P(vd), C, P(o2), C, B, heads, Sq, Sk, D, P(mp), stream()), L)
+        torch.cuda.synchronize()
+        assert rel(mp, probs) < TOL16 and rel(o2, ref) < TOL16
+
+
+def test_attention_forced_rescale():
+    """A key that spikes late in the sequence forces the online-softmax rescale branch."""
+    L = lib()
+    B, heads, S, D = 1, 1, 256, 64
+    q, k, v = rnd(B, S, D), rnd(B, S, D, seed=1), rnd(B, S, D, seed=2)
+    k[0, 200] = q[0, 7] * 4.0
+    s = (q.float() @ k.float().transpose(-1, -2)) * D ** -0.5
+    ref = torch.softmax(s, -1) @ v.float()
+    o = torch.zeros(B, S, D, dtype=torch.half, device="cuda")
+    qd, kd, vd = q.cuda(), k.cuda(), v.cuda()
+    ok(L.gdf_op_attention(P(qd), D, P(kd), D, P(vd), D, P(o), D, B, heads, S, S, D, None, stream()), L)
+    torch.cuda.synchronize()
+    assert rel(o, ref) < 2e-3 and rel(o[0, 7], ref[0, 7]) < 2e-3
+
+
+@pytest.mark.parametrize("B,HW,C,ld,silu,eps,f32", [(2, 64, 64, 64, 1, 1e-5, 0), (2, 300, 320, 384, 1, 1e-5, 0),
+                                                    (1, 1024, 2560, 2560, 0, 1e-6, 0), (2, 64, 128, 128, 1, 1e-5, 1)])
+def test_groupnorm(B, HW, C, ld, silu, eps, f32):
+    L = lib()
+    x = rnd(B, HW, ld, scale=2.0) + 0.5
+    gamma, beta = (1 + 0.1 * rnd(C).float()), 0.1 * rnd(C, seed=3).float()
+    xr = x[:, :, :C].float().permute(0, 2, 1)
+    ref = F.group_norm(xr, 32, gamma, beta, eps)
+    if silu:
+        ref = F.silu(ref)
+    ref = ref.permute(0, 2, 1)
+    y = torch.zeros(B, HW, C, dtype=torch.half, device="cuda")
+    scratch = torch.zeros(L.gdf_op_groupnorm_scratch_bytes(B, HW, C) + 1024, dtype=torch.uint8, device="cuda")
+    xd = x.float().cuda() if f32 else x.cuda()
+    gd, bd = gamma.cuda(), beta.cuda()
+    ok(L.gdf_op_groupnorm(None if f32 else P(xd), P(xd) if f32 else None, ld, B, HW, C, 32, eps, P(gd),
+                          P(bd), silu, P(y), P(scratch), stream()), L)
+    torch.cuda.synchronize()
+    assert rel(y, ref) < TOL16
+
+
+@pytest.mark.parametrize("R,C,f32", [(100, 64, 0), (257, 320, 1), (64, 640, 0), (33, 1280, 1)])
+def test_layernorm(R, C, f32):
+    L = lib()
+    x = rnd(R, C, scale=3.0) + 1.0
+    gamma, beta = (1 + 0.1 * rnd(C).float()), 0.1 * rnd(C, seed=3).float()
+    ref = F.layer_norm(x.float(), (C,), gamma, beta, 1e-5)
+    y = torch.zeros(R, C, dtype=torch.half, device="cuda")
+    xd = x.float().cuda() if f32 else x.cuda()
+    gd, bd = gamma.cuda(), beta.cuda()
+    ok(L.gdf_op_layernorm(None if f32 else P(xd), P(xd) if f32 else None, C, R, C, 1e-5, P(gd), P(bd),
+                          P(y), stream()), L)
+    torch.cuda.synchronize()
+    assert rel(y, ref) < TOL16
+
+
+def test_copy2d_hook_store():
+    L = lib()
+    src = rnd(50, 96)
+    dst = torch.zeros(50, 40, dtype=torch.half, device="cuda")
+    sd = src.cuda()
+    ok(L.gdf_op_copy2d(C_off(sd, 16), None, 96, P(dst), 40, 50, 40, stream()), L)
+    s4 = rnd(37, 4)
+    s4d = s4.cuda()
+    d4 = torch.zeros(37, 4, dtype=torch.half, device="cuda")
+    ok(L.gdf_op_copy2d(P(s4d), None, 4, P(d4), 4, 37, 4, stream()), L)
+    torch.cuda.synchronize()
+    assert torch.equal(dst.cpu(), src[:, 16:56]) and torch.equal(d4.cpu(), s4)      # bit-exact: pure byte movement
