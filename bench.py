@@ -1,0 +1,352 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: SDXL 1024^2 single-timestep feature extraction (BASELINE.json configs[2]).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 16] [--version xl]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A step = one UNet forward over one batch of `--batch` synthetic 1024x1024 images' pre-noised latents
+(already resident in HBM) with the `config_xl_practical` hooks written to HBM.  One process per GPU, the
+image batch is sharded (weak scaling: every rank runs its own `--batch`), weights are generated on rank 0
+and broadcast once over RCCL, no collective in the hot loop.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "generic-diffusion-feature_amd")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+
+PRACTICAL = {
+    "xl": ["up-level0-repeat0-vit-block7-out", "up-level0-repeat0-vit-block5-out",
+           "up-level1-repeat0-vit-block0-cross-q", "up-level1-repeat0-vit-block0-out"],
+    "1-5": ["up-level1-repeat1-vit-block0-cross-q", "up-level1-repeat2-res-out",
+            "up-level2-repeat1-vit-block0-cross-q", "up-level3-repeat0-vit-block0-self-k"],
+}
+MFMA_PEAK_TFLOPS = 2500.0      # dense fp16/bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+
+def unet_flops_per_image(cfg, lat):
+    """Algorithmic FLOPs (2*MACs of convs, linears, QK^T, PV) per image — SURVEY.md §8(d)."""
+    boc = cfg["block_out_channels"]; L = len(boc); nl = cfg["layers_per_block"]; cd = cfg["cross_attention_dim"]
+    f = dict(conv=0.0, attn_linear=0.0, ff=0.0, self_attn=0.0, cross_attn=0.0)
+
+    def conv(ci, co, hw, k=9):
+        f["conv"] += 2.0 * hw * ci * co * k
+
+    def resnet(ci, co, hw):
+        conv(ci, co, hw); conv(co, co, hw)
+        f["attn_linear"] += 2.0 * 1280 * co            # time_emb_proj (per image)
+        if ci != co:
+            conv(ci, co, hw, 1)
+
+    def vit(c, hw, depth):
+        f["attn_linear"] += 2 * 2.0 * hw * c * c       # proj_in / proj_out
+        for _ in range(depth):
+            f["attn_linear"] += 2.0 * hw * c * c * 4   # self q,k,v,out
+            f["attn_linear"] += 2.0 * hw * c * c * 2   # cross q,out
+            f["attn_linear"] += 2.0 * 77 * cd * c * 2  # cross k,v
+            f["ff"] += 2.0 * hw * c * 8 * c + 2.0 * hw * 4 * c * c
+            f["self_attn"] += 4.0 * hw * hw * c
+            f["cross_attn"] += 4.0 * hw * 77 * c
+
+    hw = lat * lat
+    conv(cfg["in_channels"], boc[0], hw)
+    ci = boc[0]
+    for lv in range(L):
+        for _ in range(nl):
+            resnet(ci, boc[lv], hw)
+            if cfg["has_attn"][lv]:
+                vit(boc[lv], hw, cfg["transformer_layers"][lv])
+            ci = boc[lv]
+        if lv != L - 1:
+            conv(boc[lv], boc[lv], hw // 4); hw //= 4
+    resnet(boc[-1], boc[-1], hw); vit(boc[-1], hw, cfg["transformer_layers"][-1]); resnet(boc[-1], boc[-1], hw)
+    prev = boc[-1]
+    for i in range(L):
+        lv = L - 1 - i
+        co = boc[lv]; cskip = boc[max(lv - 1, 0)]
+        for r in range(nl + 1):
+            resnet((prev if r == 0 else co) + (cskip if r == nl else co), co, hw)
+            if cfg["has_attn"][lv]:
+                vit(co, hw, cfg["transformer_layers"][lv])
+        if i != L - 1:
+            hw *= 4; conv(co, co, hw)
+        prev = co
+    conv(boc[0], cfg["out_channels"], hw)
+    return f
+
+
+def cpu_baseline(version, lat_full, budget_s=45.0):
+    """Time the CPU oracle (oracle/unet_ref.py, fp32, all host cores) on a bounded sample of the same workload."""
+    from oracle import unet_ref as R
+    arch = R.ARCHS[version]
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    t0 = time.time()
+    P = {}
+    g = torch.Generator().manual_seed(0)
+    for name, shape in R.param_shapes(arch).items():
+        is_norm = ".norm" in name or name.startswith("conv_norm_out")
+        w = torch.empty(shape).normal_(generator=g)
+        if name.endswith(".weight") and not is_norm:
+            fan = 1
+            for s in shape[1:]:
+                fan *= s
+            w.mul_(fan ** -0.5)
+        elif name.endswith(".weight"):
+            w.mul_(0.1).add_(1.0)
+        else:
+            w.mul_(0.05)
+        P[name] = w
+    t_init = time.time() - t0
+    ids = PRACTICAL[version]
+
+    def run(lat):
+        I = R.synth_inputs(arch, 1, lat, seed=1)
+        st = R.Store({k: True for k in ids})
+        t = time.time()
+        with torch.no_grad():
+            R.unet_forward(P, arch, I["sample"], I["timestep"], I["ctx"], I.get("text_embeds"), I.get("time_ids"), store=st)
+        return time.time() - t
+
+    lat_small = lat_full // 4
+    run(lat_small)                                   # warm-up (thread pools, allocator)
+    t_small = run(lat_small)
+    cfg = _cfg(version)
+    fl_small = sum(unet_flops_per_image(cfg, lat_small).values())
+    fl_full = sum(unet_flops_per_image(cfg, lat_full).values())
+    est_full = t_small * fl_full / fl_small
+    if est_full <= budget_s:
+        t_full = run(lat_full)
+        return dict(value=1.0 / t_full, unit="images/s", cores=cores, kind="port",
+                    sample=f"oracle/unet_ref.py fp32, 1 image at full {lat_full * 8}x{lat_full * 8} resolution, "
+                           f"{t_full:.1f} s on {cores} host threads (weights init {t_init:.0f} s not timed)")
+    return dict(value=1.0 / est_full, unit="images/s", cores=cores, kind="port",
+                sample=f"oracle/unet_ref.py fp32, 1 image at {lat_small * 8}x{lat_small * 8} ({t_small:.1f} s) scaled by the "
+                       f"algorithmic FLOP ratio {fl_full / fl_small:.1f}x to {lat_full * 8}x{lat_full * 8}; {cores} host threads")
+
+
+def _cfg(version):
+    from components.native import ARCH_CONFIGS
+    return ARCH_CONFIGS[version]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=16, help="images per GPU per step")
+    ap.add_argument("--version", default="xl", choices=("xl", "1-5"))
+    ap.add_argument("--img", type=int, default=0, help="image size (default 1024 for xl, 512 for 1-5)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fp16-stream", action="store_true", help="disable the fp32 master of the residual stream")
+    ap.add_argument("--early-exit", action="store_true", help="opt-in: stop after the last requested hook")
+    ap.add_argument("--profile-ops", action="store_true", help="print a per-op time table (extra synchronising pass)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X (no CPU fallback for the measured path)")
+    torch.cuda.set_device(local)
+    dev = torch.device(f"cuda:{local}")
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from components.native import NativeUNet
+    import ctypes as C
+    cfg = _cfg(args.version)
+    img = args.img or (1024 if args.version == "xl" else 512)
+    lat = img // 8
+    B = args.batch
+
+    # ---- weights: generated on rank 0 in HBM, broadcast once over RCCL in <=512 MiB fp16 buckets ----
+    unet = NativeUNet(cfg, device=dev, stream_fp32=not args.fp16_stream, early_exit=args.early_exit)
+    t0 = time.time()
+    if world == 1:
+        unet.init_synthetic(seed=0)
+    else:
+        shapes = unet.param_shapes()
+        names = list(shapes)
+        gen = torch.Generator(device=dev).manual_seed(0)
+        i = 0
+        while i < len(names):
+            j, tot = i, 0
+            while j < len(names) and (tot == 0 or tot + _numel(shapes[names[j]]) <= (1 << 28)):
+                tot += _numel(shapes[names[j]]); j += 1
+            flat = torch.empty(tot, dtype=torch.float16, device=dev)
+            if rank == 0:
+                off = 0
+                for n in names[i:j]:
+                    k = _numel(shapes[n])
+                    flat[off:off + k] = _synth(n, shapes[n], gen, dev).reshape(-1); off += k
+            dist.broadcast(flat, src=0)
+            off = 0
+            sd = {}
+            for n in names[i:j]:
+                k = _numel(shapes[n]); sd[n] = flat[off:off + k].view(shapes[n]); off += k
+            unet.load_state_dict(sd, strict=False)
+            i = j
+        assert unet.ready()
+    torch.cuda.synchronize()
+    t_weights = time.time() - t0
+
+    # ---- synthetic inputs, resident in HBM: one prompt repeated, t = 100 (random data, never zeros) ----
+    g = torch.Generator(device=dev).manual_seed(1 + rank)
+    x = torch.randn(B, 4, lat, lat, generator=g, device=dev).half()
+    ctx = torch.randn(1, 77, cfg["cross_attention_dim"], generator=g, device=dev).half().expand(B, -1, -1).contiguous()
+    t = torch.full((B,), 100.0, device=dev)
+    txt = tid = None
+    if cfg["addition_embed_text_time"]:
+        pooled = cfg["add_in_dim"] - 6 * cfg["addition_time_embed_dim"]
+        txt = torch.randn(1, pooled, generator=g, device=dev).half().expand(B, -1).contiguous()
+        tid = torch.tensor([[img, img, 0, 0, img, img]], dtype=torch.float32, device=dev).repeat(B, 1)
+    ids = PRACTICAL[args.version]
+
+    def step():
+        return unet.forward_raw(x, t, ctx, txt, tid, hook_ids=ids)
+
+    prof = None
+    for w in range(max(1, args.warmup)):
+        step()
+    torch.cuda.synchronize()
+    # pick the dominant kernel from a synchronising per-op pass (untimed), then time it live with HIP events
+    _, _, prof = unet.forward_raw(x, t, ctx, txt, tid, hook_ids=ids, profile=True)
+    lib = unet.lib
+    plan = unet._plan(B, lat, lat, 77, ids)
+    by_label = {}
+    label_of = _label_map(lib)
+    for name, ms, fl in prof:
+        lab = label_of(name)
+        d = by_label.setdefault(lab, [0.0, 0.0, 0])
+        d[0] += ms; d[1] += fl; d[2] += 1
+    dominant = max(by_label, key=lambda k: by_label[k][0])
+    rc = lib.gdf_plan_set_timing(plan.handle, dominant.encode())
+    assert rc == 0, lib.gdf_last_error()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+    barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize(); barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    ms_tot = C.c_double(); launches = C.c_long(); fl_tot = C.c_double()
+    lib.gdf_plan_read_timing(plan.handle, C.byref(ms_tot), C.byref(launches), C.byref(fl_tot))
+    lib.gdf_plan_set_timing(plan.handle, None)
+    hook_bytes = sum(v.numel() * 2 for v in out[1].values())
+    for v in out[1].values():
+        assert torch.isfinite(v.float()).all()
+
+    if rank == 0:
+        fl = unet_flops_per_image(cfg, lat)
+        fl_img = sum(fl.values())
+        ips = world * B * args.steps / dt
+        achieved = (fl_tot.value / 1e12) / (ms_tot.value / 1e3) if ms_tot.value > 0 else 0.0
+        res = {
+            "metric": "images/sec feature-extract, SDXL 1024^2 single-timestep" if args.version == "xl"
+                      else "images/sec feature-extract, SD1.5 512^2 single-timestep",
+            "value": round(ips, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": f"{'SDXL' if args.version == 'xl' else 'SD1.5'} UNet {img}x{img} (latent {lat}x{lat}), "
+                                   f"batch {B}/GPU, t=100, hooks=config_{'xl' if args.version == 'xl' else '15'}_practical "
+                                   f"({len(ids)} ids, {hook_bytes / B / 1e6:.2f} MB/img), full forward"
+                                   + (" with early exit" if args.early_exit else ""),
+                       "global_batch": world * B, "parallelism": f"dp{world} (batch sharded, weights broadcast once)",
+                       "residual_stream": "fp16" if args.fp16_stream else "fp32 master + fp16 shadow",
+                       "tflop_per_image": round(fl_img / 1e12, 3),
+                       "model_tflops_per_s": round(ips * fl_img / 1e12, 1),
+                       "weights_init_s": round(t_weights, 1)},
+            "roofline": {"bound": "mfma", "kernel": dominant, "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "launches": int(launches.value), "avg_launch_ms": round(ms_tot.value / max(1, launches.value), 4),
+                         "flops_per_launch_g": round(fl_tot.value / max(1, launches.value) / 1e9, 2),
+                         "share_of_step_time": round(by_label[dominant][0] / sum(v[0] for v in by_label.values()), 3)},
+            "kernel_time_share": {k: round(v[0] / sum(x[0] for x in by_label.values()), 3)
+                                  for k, v in sorted(by_label.items(), key=lambda kv: -kv[1][0])[:8]},
+            "kernel_tflops": {k: round(v[1] / 1e9 / v[0], 1) for k, v in by_label.items() if v[1] > 0 and v[0] > 0},
+        }
+        if args.profile_ops:
+            rows = {}
+            for name, ms, f_ in prof:
+                r = rows.setdefault(name, [0.0, 0.0, 0]); r[0] += ms; r[1] += f_; r[2] += 1
+            for name, r in sorted(rows.items(), key=lambda kv: -kv[1][0]):
+                print(f"# {name:16s} n={r[2]:4d} {r[0]:9.3f} ms  {r[1] / 1e9 / max(r[0], 1e-9):8.1f} TFLOP/s", file=sys.stderr)
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(args.version, lat)
+            res["config"]["gpu_over_cpu"] = round(ips / res["cpu_baseline"]["value"], 1)
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def _numel(shape):
+    n = 1
+    for s in shape:
+        n *= s
+    return n
+
+
+def _synth(name, shp, gen, dev):
+    is_norm = ".norm" in name or name.startswith("conv_norm_out")
+    t = torch.randn(shp, generator=gen, device=dev, dtype=torch.float32)
+    if name.endswith(".weight") and not is_norm:
+        fan = 1
+        for s in shp[1:]:
+            fan *= s
+        t.mul_(fan ** -0.5)
+    elif name.endswith(".weight"):
+        t.mul_(0.1).add_(1.0)
+    elif is_norm:
+        t.mul_(0.1)
+    else:
+        t.mul_(0.05)
+    return t.half()
+
+
+def _label_map(lib):
+    """op name -> kernel label; mirrors csrc/model.cpp::kernel_label()."""
+    conv = {"res_conv1", "res_conv2", "downsample", "upsample"}
+    dense = {"proj_in", "proj_out", "attn1_qkv", "attn1_out", "attn2_q", "attn2_kv", "attn2_out", "ff_out", "res_shortcut"}
+
+    def f(n):
+        if n in conv:
+            return "gemm_kernel<conv3x3,BN128>"
+        if n == "conv_out":
+            return "gemm_kernel<conv3x3,BN16>"
+        if n == "conv_in":
+            return "gemm_kernel<conv_smallc,BN128>"
+        if n == "ff_geglu":
+            return "gemm_kernel<dense,BN128,geglu>"
+        if n in dense:
+            return "gemm_kernel<dense,BN128>"
+        if n in ("attn1", "attn2"):
+            return "attn_kernel"
+        return n
+    return f
+
+
+if __name__ == "__main__":
+    main()

@@ -88,4 +88,17 @@ int gdf_plan_profile(gdf_plan* p, const void* latents, const float* timesteps, c
   return (int)p->p.ops.size();
 }
 
+int gdf_plan_num_kernel_labels(const gdf_plan* p) { return p ? (int)p->p.labels.size() : 0; }
+const char* gdf_plan_kernel_label(const gdf_plan* p, int i) {
+  return (p && i >= 0 && i < (int)p->p.labels.size()) ? p->p.labels[i].c_str() : nullptr;
+}
+int gdf_plan_set_timing(gdf_plan* p, const char* kernel_label) {
+  if (!p) { set_error("null plan"); return GDF_ERR_ARG; }
+  return plan_set_timing(p->p, kernel_label);
+}
+int gdf_plan_read_timing(gdf_plan* p, double* ms_total, long* launches, double* flops_total) {
+  if (!p) { set_error("null plan"); return GDF_ERR_ARG; }
+  return plan_read_timing(p->p, ms_total, launches, flops_total);
+}
+
 }  // extern "C"

@@ -310,7 +310,13 @@ struct B {   // builder
 
   void op(const char* name, double flops, std::function<hipError_t(const Bind&, hipStream_t)> fn) {
     if (dry || stop) return;
-    P.ops.push_back(Op{name, flops, std::move(fn)});
+    Op o{name, flops, std::move(fn)};
+    const std::string lab = kernel_label(name);
+    size_t li = 0;
+    for (; li < P.labels.size(); ++li) if (P.labels[li] == lab) break;
+    if (li == P.labels.size()) P.labels.push_back(lab);
+    o.label = (int)li;
+    P.ops.push_back(std::move(o));
   }
 
   size_t rows(const Act& a) const { return (size_t)Bn * a.H * a.W; }
@@ -847,6 +853,57 @@ int plan_build(const Model& m, Plan& P, int batch, int H, int W, int n_ctx, cons
   return GDF_OK;
 }
 
+const char* kernel_label(const char* n) {
+  auto is = [&](const char* x) { return strcmp(n, x) == 0; };
+  if (is("res_conv1") || is("res_conv2") || is("downsample") || is("upsample")) return "gemm_kernel<conv3x3,BN128>";
+  if (is("conv_out")) return "gemm_kernel<conv3x3,BN16>";
+  if (is("conv_in")) return "gemm_kernel<conv_smallc,BN128>";
+  if (is("ff_geglu")) return "gemm_kernel<dense,BN128,geglu>";
+  if (is("proj_in") || is("proj_out") || is("attn1_qkv") || is("attn1_out") || is("attn2_q") || is("attn2_kv") ||
+      is("attn2_out") || is("ff_out") || is("res_shortcut")) return "gemm_kernel<dense,BN128>";
+  if (is("attn1") || is("attn2")) return "attn_kernel";
+  return n;
+}
+
+Plan::~Plan() {
+  for (auto& v : ev) for (auto e : v) hipEventDestroy(e);
+}
+
+static void timing_collect(Plan& P, int set) {
+  if (!P.ev_used[set]) return;
+  auto& v = P.ev[set];
+  size_t k = 0;
+  for (auto& op : P.ops) {
+    if (op.label != P.timing_label) continue;
+    float ms = 0.f;
+    hipEventSynchronize(v[k + 1]);
+    if (hipEventElapsedTime(&ms, v[k], v[k + 1]) == hipSuccess) { P.t_ms += ms; P.t_flops += op.flops; P.t_launches++; }
+    k += 2;
+  }
+  P.ev_used[set] = false;
+}
+
+int plan_set_timing(Plan& P, const char* label) {
+  for (int s = 0; s < Plan::EV_RING; ++s) timing_collect(P, s);
+  P.timing_label = -1; P.t_ms = 0; P.t_flops = 0; P.t_launches = 0;
+  if (!label) return GDF_OK;
+  for (size_t i = 0; i < P.labels.size(); ++i) if (P.labels[i] == label) P.timing_label = (int)i;
+  if (P.timing_label < 0) { set_error(std::string("no op with kernel label ") + label); return GDF_ERR_ARG; }
+  size_t n = 0;
+  for (auto& op : P.ops) n += op.label == P.timing_label;
+  for (int s = 0; s < Plan::EV_RING; ++s)
+    while (P.ev[s].size() < 2 * n) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) { set_error("hipEventCreate"); return GDF_ERR_HIP; } P.ev[s].push_back(e); }
+  return GDF_OK;
+}
+
+int plan_read_timing(Plan& P, double* ms, long* launches, double* flops) {
+  for (int s = 0; s < Plan::EV_RING; ++s) timing_collect(P, s);
+  if (ms) *ms = P.t_ms;
+  if (launches) *launches = P.t_launches;
+  if (flops) *flops = P.t_flops;
+  return GDF_OK;
+}
+
 int plan_forward(Plan& P, const Model& m, const void* lat, const float* t, const void* ctx, const void* txt,
                  const float* tid, void* const* hook_out, void* noise, void* ws, hipStream_t s, float* ms,
                  const char** names, double* flops, int cap) {
@@ -862,9 +919,18 @@ int plan_forward(Plan& P, const Model& m, const void* lat, const float* t, const
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (ms) { hipEventCreate(&e0); hipEventCreate(&e1); }
   int i = 0;
+  int evset = -1; size_t evk = 0;
+  if (P.timing_label >= 0 && !ms) {
+    evset = P.ev_next; P.ev_next = (P.ev_next + 1) % Plan::EV_RING;
+    timing_collect(P, evset);           // results of the forward that used this set EV_RING calls ago
+    P.ev_used[evset] = true;
+  }
   for (auto& op : P.ops) {
     if (ms && i < cap) hipEventRecord(e0, s);
+    const bool timed = evset >= 0 && op.label == P.timing_label;
+    if (timed) hipEventRecord(P.ev[evset][evk], s);
     hipError_t e = op.fn(b, s);
+    if (timed) { hipEventRecord(P.ev[evset][evk + 1], s); evk += 2; }
     if (e != hipSuccess) {
       set_error(std::string("op '") + op.name + "' failed: " + hipGetErrorString(e));
       return GDF_ERR_HIP;

@@ -62,7 +62,7 @@ struct Bind {
   void* ws(size_t off) const { return base[BUF_WS] + off; }
   void* hook(int slot) const { return hooks[slot]; }
 };
-struct Op { const char* name; double flops; std::function<hipError_t(const Bind&, hipStream_t)> fn; };
+struct Op { const char* name; double flops; std::function<hipError_t(const Bind&, hipStream_t)> fn; int label = 0; };
 struct HookSlot { std::string id; int64_t shape[4]; int64_t stride[4]; size_t bytes; };
 
 struct Plan {
@@ -76,7 +76,19 @@ struct Plan {
   bool writes_noise = false;
   size_t ws_bytes = 0;
   std::vector<std::string> dry_ids;
+  // live per-kernel timing (bench roofline): HIP events around every op of one kernel label
+  std::vector<std::string> labels;
+  int timing_label = -1;
+  static const int EV_RING = 4;
+  std::vector<hipEvent_t> ev[EV_RING];
+  bool ev_used[EV_RING] = {false, false, false, false};
+  int ev_next = 0;
+  double t_ms = 0, t_flops = 0; long t_launches = 0;
+  ~Plan();
 };
+const char* kernel_label(const char* opname);
+int plan_set_timing(Plan& P, const char* label);
+int plan_read_timing(Plan& P, double* ms, long* launches, double* flops);
 
 Model* model_create(const GdfArch& arch);
 void model_destroy(Model* m);

@@ -118,6 +118,15 @@ int gdf_plan_profile(gdf_plan* p, const void* latents, const float* timesteps, c
                      void* noise_pred, void* workspace, void* stream,
                      float* ms, const char** names, double* flops, int cap);
 
+/* Live per-kernel timing for roofline reporting: HIP events are recorded on `stream` around every op
+ * whose kernel label (e.g. "gemm_kernel<dense,BN128>") matches; gdf_forward stays asynchronous.
+ * gdf_plan_read_timing waits for the recorded events and returns the accumulated kernel time,
+ * launch count and algorithmic FLOPs since gdf_plan_set_timing.  NULL label disables timing. */
+int gdf_plan_num_kernel_labels(const gdf_plan* p);
+const char* gdf_plan_kernel_label(const gdf_plan* p, int i);
+int gdf_plan_set_timing(gdf_plan* p, const char* kernel_label);
+int gdf_plan_read_timing(gdf_plan* p, double* ms_total, long* launches, double* flops_total);
+
 #ifdef __cplusplus
 }
 #endif
