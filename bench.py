@@ -181,27 +181,10 @@ def main():
     if world == 1:
         unet.init_synthetic(seed=0)
     else:
-        shapes = unet.param_shapes()
-        names = list(shapes)
+        from components import dist as D
         gen = torch.Generator(device=dev).manual_seed(0)
-        i = 0
-        while i < len(names):
-            j, tot = i, 0
-            while j < len(names) and (tot == 0 or tot + _numel(shapes[names[j]]) <= (1 << 28)):
-                tot += _numel(shapes[names[j]]); j += 1
-            flat = torch.empty(tot, dtype=torch.float16, device=dev)
-            if rank == 0:
-                off = 0
-                for n in names[i:j]:
-                    k = _numel(shapes[n])
-                    flat[off:off + k] = _synth(n, shapes[n], gen, dev).reshape(-1); off += k
-            dist.broadcast(flat, src=0)
-            off = 0
-            sd = {}
-            for n in names[i:j]:
-                k = _numel(shapes[n]); sd[n] = flat[off:off + k].view(shapes[n]); off += k
-            unet.load_state_dict(sd, strict=False)
-            i = j
+        D.broadcast_state_dict(unet.param_shapes(), lambda n, shp: D.synthetic_param(n, shp, gen, dev),
+                               lambda sd: unet.load_state_dict(sd, strict=False), dev)
         assert unet.ready()
     torch.cuda.synchronize()
     t_weights = time.time() - t0
@@ -300,30 +283,6 @@ def main():
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()
-
-
-def _numel(shape):
-    n = 1
-    for s in shape:
-        n *= s
-    return n
-
-
-def _synth(name, shp, gen, dev):
-    is_norm = ".norm" in name or name.startswith("conv_norm_out")
-    t = torch.randn(shp, generator=gen, device=dev, dtype=torch.float32)
-    if name.endswith(".weight") and not is_norm:
-        fan = 1
-        for s in shp[1:]:
-            fan *= s
-        t.mul_(fan ** -0.5)
-    elif name.endswith(".weight"):
-        t.mul_(0.1).add_(1.0)
-    elif is_norm:
-        t.mul_(0.1)
-    else:
-        t.mul_(0.05)
-    return t.half()
 
 
 def _label_map(lib):

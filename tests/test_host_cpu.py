@@ -1,0 +1,116 @@
+"""CPU-side checks (no GPU): the C-ABI library loads and exports every symbol include/*.h declares, and the
+host-side mirror of the reference interface (FeatureStore filtering, id scheme, config surface, error behaviour)."""
+import ctypes
+import json
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def _declared(header):
+    src = open(os.path.join(ROOT, "include", header)).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(gdf_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    import __graft_entry__ as G
+    G.build()                                              # hipcc cross-compiles gfx950 without a GPU
+    lib = ctypes.CDLL(G.LIB)
+    names = _declared("gdf.h") + _declared("gdf_ops.h")
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(lib, n), n
+    assert lib.gdf_abi_version() == 1
+
+
+def test_binding_covers_header():
+    from components import native
+    assert sorted(native.SIGNATURES) == _declared("gdf.h")
+
+
+def test_native_path_fails_loudly_without_gpu():
+    from components import native
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError):
+        native.NativeUNet(native.ARCH_CONFIGS["1-5"])
+    # the C ABI itself also refuses (no CPU fallback inside the library)
+    lib = native.load_library()
+    h = ctypes.c_void_p()
+    a = native.arch_desc(native.ARCH_CONFIGS["1-5"])
+    assert lib.gdf_model_create(ctypes.byref(a), ctypes.byref(h)) != 0
+    assert b"no HIP device" in lib.gdf_last_error()
+
+
+def test_layer_ids_match_reference_dumps():
+    from components.feature_extractor import unet_layer_ids
+    from components.native import ARCH_CONFIGS
+    for ver, fn in (("1-5", "ids_15_full.txt"), ("xl", "ids_xl_full.txt")):
+        assert unet_layer_ids(ARCH_CONFIGS[ver]) == open(os.path.join(GOLD, fn)).read().split()
+
+
+def test_shipped_configs_are_subsets_of_the_id_space():
+    from components.feature_extractor import unet_layer_ids
+    from components.native import ARCH_CONFIGS
+    cdir = os.path.join(ROOT, "generic-diffusion-feature_amd", "configs")
+    for f in sorted(os.listdir(cdir)):
+        if not f.endswith(".json"):
+            continue
+        ver = "1-5" if "_15_" in f else "xl"
+        ids = set(unet_layer_ids(ARCH_CONFIGS[ver]))
+        cfg = json.load(open(os.path.join(cdir, f)))
+        assert cfg and all(isinstance(v, bool) for v in cfg.values())
+        assert set(cfg) <= ids, (f, sorted(set(cfg) - ids)[:3])
+
+
+def test_feature_store_semantics():
+    from components.feature_extractor import FeatureGatherer, FeatureStore
+    st = FeatureStore({"a-out": True, "a-cross-k": True, "b-out": False}, 1, False)
+    g = FeatureGatherer("a", st)
+    tok = torch.randn(2, 16, 8).half()
+    g.gather(tok, "out"); g.gather(tok, "cross-k"); FeatureGatherer("b", st).gather(tok, "out")
+    assert list(st.stored_feats) == ["a-out"]                       # filtered: cross-k dropped, b-out not requested
+    v = st.stored_feats["a-out"]
+    assert v.shape == (2, 8, 4, 4) and torch.equal(v.permute(0, 2, 3, 1).reshape(2, 16, 8), tok)
+    old = st.stored_feats
+    st.reset()
+    assert st.stored_feats == {} and list(old) == ["a-out"]         # previously returned dict stays valid
+    st.pause(); g.gather(tok, "out"); assert st.stored_feats == {}
+    st.resume()
+    pooled = FeatureStore({"a-out": True}, 2, False)
+    FeatureGatherer("a", pooled).gather(tok, "out")
+    assert pooled.stored_feats["a-out"].shape == (2, 8, 2, 2)
+    allst = FeatureStore(None, 1, False)
+    assert allst.accept_all and allst.to_store == {}
+    bg = FeatureStore({"a-out": True}, 1, False); bg.store_idx = [2]
+    for _ in range(3):
+        FeatureGatherer("a", bg).gather(tok, "out")
+    assert bg.stored_feats["a-out"]["count"] == 3 and list(bg.stored_feats["a-out"]["feat"]) == [2]
+
+
+def test_model_registry_error_behaviour(monkeypatch):
+    from components import models
+    with pytest.raises(NotImplementedError):
+        models.get_diffusion_model("xl", "bfloat16")                 # reference models.py:11-16
+    with pytest.raises(NotImplementedError):
+        models.get_diffusion_model("no-such-version", "float16")     # reference models.py:173-174
+    with pytest.raises(NotImplementedError):
+        models.get_diffusion_model("flux", "float16")
+    monkeypatch.delenv("GDF_SYNTHETIC_WEIGHTS", raising=False)
+    with pytest.raises(RuntimeError):
+        models.get_diffusion_model("1-5", "float16")                 # no diffusers, no synthetic opt-in: loud failure
+
+
+def test_bench_flop_model_matches_survey_totals():
+    import bench
+    from components.native import ARCH_CONFIGS
+    xl = bench.unet_flops_per_image(ARCH_CONFIGS["xl"], 128)
+    sd = bench.unet_flops_per_image(ARCH_CONFIGS["1-5"], 64)
+    assert abs(sum(xl.values()) / 1e12 - 6.761) < 2e-3 and abs(sum(sd.values()) / 1e12 - 0.803) < 1e-3
+    assert abs(xl["self_attn"] / 1e12 - 0.752) < 1e-3 and abs(xl["ff"] / 1e12 - 2.819) < 1e-3
