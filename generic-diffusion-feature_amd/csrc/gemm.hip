@@ -10,14 +10,16 @@
 //   Downsample2D.conv stride 2 (downsampling.py:115-118), Upsample2D nearest x2 + conv (upsampling.py:176-193),
 //   UNet conv_in / conv_out (unet/unet_2d_condition.py:260-262,480-482).
 //
-// Structure: 128 x BN x 64 block tile, 4 waves (64-lane), mfma_f32_16x16x32_f16.
+// Structure: BM x BN x 64 block tile, one 64x64 (or 32x16) sub-tile per 64-lane wave, mfma_f32_16x16x32_f16.
+//   * main variant 256x128, 8 waves, 3-stage LDS ring (144 KiB): tiles kt+1 and kt+2 are in flight while
+//     tile kt is multiplied; waits are COUNTED (`s_waitcnt vmcnt(N)`, never 0 in steady state) and the
+//     workgroup barrier is the raw `s_barrier`, one per K-tile.
+//   * small variant 128x128 / 128x16, 4 waves, 2-stage ring, 2 workgroups per CU (narrow N, few tiles).
 //   * Both operands are streamed HBM -> LDS with `buffer_load_dwordx4 ... lds` (no VGPR round trip).
 //     The LDS image is lane-linear, so the bank-conflict XOR swizzle is applied on the SOURCE address
 //     (chunk ^= row&7) and mirrored on the ds_read_b128 side.
 //   * Convolution zero padding, M/N tails and the nearest-x2 upsample are all done in the address
 //     generator: out-of-image taps get an out-of-range buffer offset, which the hardware returns as 0.
-//   * Double-buffered LDS, one barrier per K-tile; the next tile's DMA is issued before the MFMAs
-//     of the current one.
 //   * Epilogue is staged per wave through LDS so every global store / residual load is a full
 //     16-byte-per-lane, 128-byte-per-row access.
 #include "kernels.h"
@@ -29,15 +31,28 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define LDS_AS __attribute__((address_space(3)))
 
-static constexpr int BM = 128;
-static constexpr int BK = 64;             // halves per K-tile -> 128-byte LDS rows
+static constexpr int BK = 64;                  // halves per K-tile -> 128-byte LDS rows
 static constexpr uint32_t OOB = 0x80000000u;   // any offset >= num_records reads as zero
 
 __device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rsrc, char* lds_wave_base, uint32_t voff) {
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (LDS_AS void*)lds_wave_base, 16, voff, 0, 0, 0);
 }
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// exact (erf) GELU.  erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, far below the fp16 output rounding):
+// one v_exp_f32 + one v_rcp_f32 instead of libm's branchy erff (the GEGLU epilogue evaluates 32 of these per lane).
+__device__ __forceinline__ float gelu_erf(float x) {
+  const float z = fabsf(x) * 0.70710678118654752f;
+  const float t = __frcp_rn(1.0f + 0.3275911f * z);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float erf_abs = 1.0f - poly * __expf(-z * z);
+  const float erf_x = copysignf(erf_abs, x);
+  return 0.5f * x * (1.0f + erf_x);
+}
 
 // XCD-aware bijective remap: consecutive tiles (which share the same A row-block) land on one XCD's L2.
 __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
@@ -47,18 +62,22 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
   return base + idx;
 }
 
-template <int MODE, int BN, bool GEGLU>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
-  constexpr int WGN = (BN == 128) ? 2 : 1;       // waves along N
-  constexpr int WGM = 4 / WGN;                   // waves along M
+template <int MODE, int BM, int BN, int STAGES, bool GEGLU>
+__global__ __launch_bounds__(BM * 2, 2) void gemm_kernel(const GemmParams p) {
+  constexpr int NW = BM / 32;                    // waves per workgroup (4 or 8)
+  constexpr int WGN = (BN >= 128) ? 2 : 1;       // waves along N
+  constexpr int WGM = NW / WGN;                  // waves along M
   constexpr int WTM = BM / WGM;                  // 64 or 32
-  constexpr int WTN = BN / WGN;                  // 64 or 16
+  constexpr int WTN = BN / WGN;                  // 80, 64 or 16
   constexpr int FM = WTM / 16, FN = WTN / 16;
   constexpr int A_TILE = BM * 128;               // bytes
   constexpr int B_TILE = BN * 128;
   constexpr int STAGE = A_TILE + B_TILE;
+  constexpr int A_PER_WAVE = BM / 8 / NW;        // 1-KiB wave-instructions of the A tile per wave (4)
   constexpr int B_INSTR = BN / 8;                // 1-KiB wave-instructions per B tile
-  constexpr int B_PER_WAVE = (B_INSTR + 3) / 4;
+  constexpr int B_PER_WAVE = (B_INSTR + NW - 1) / NW;
+  constexpr int LPT = A_PER_WAVE + B_PER_WAVE;   // DMA instructions per wave per K-tile (uniform when BN == 128)
+  static_assert(STAGES == 2 || (STAGES == 3 && B_INSTR % NW == 0), "3-stage ring needs a uniform per-wave load count");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -74,14 +93,14 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, p.a_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.Wt, 0, p.w_bytes, 0x00020000);
 
-  // ---- per-lane load geometry: every wave issues 4 A instructions (8 rows x 128 B each) ----
+  // ---- per-lane load geometry: one wave-instruction moves 8 rows x 128 B ----
   const int lrow = lane >> 3;                         // row inside an 8-row instruction
   const int chunk = (lane & 7) ^ lrow;                // source 16-B chunk (swizzle on the source side)
-  uint32_t a_off[4];                                  // DENSE: byte offset of (row, chunk); CONV: pixel row base
-  int a_oy[4], a_ox[4];
+  uint32_t a_off[A_PER_WAVE];                         // DENSE: byte offset of (row, chunk); CONV: pixel base of sample
+  int a_oy[A_PER_WAVE], a_ox[A_PER_WAVE];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int m = m0 + (wave * 4 + j) * 8 + lrow;
+  for (int j = 0; j < A_PER_WAVE; ++j) {
+    const int m = m0 + (wave * A_PER_WAVE + j) * 8 + lrow;
     if (MODE == A_DENSE) {
       a_off[j] = (m < p.M) ? (uint32_t)m * (uint32_t)p.lda * 2u + (uint32_t)chunk * 16u : OOB;
     } else {
@@ -108,29 +127,31 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
   const int cpb = (MODE == A_CONV3) ? p.Cin / BK : 1;  // K-tiles per filter tap
   const int IH = p.ups ? 2 * p.H : p.H, IW = p.ups ? 2 * p.W : p.W;
 
-  auto issue = [&](int kt, int buf, int tap, int cb) {
+  int tap = 0, cb = 0;                                 // filter tap / channel block of the NEXT tile to issue
+  auto issue = [&](int kt, int buf) {
     char* sA = smem + buf * STAGE;
     char* sB = sA + A_TILE;
+    int ky = 0, kx = 0;
+    if (MODE == A_CONV3) { ky = tap / 3; kx = tap - ky * 3; }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < A_PER_WAVE; ++j) {
       uint32_t off;
       if (MODE == A_DENSE) {
         off = a_off[j] + (uint32_t)kt * 128u;          // OOB stays >= 2^31
       } else if (MODE == A_CONV3) {
-        const int ky = tap / 3, kx = tap - ky * 3;
         const int iy = a_oy[j] + ky, ix = a_ox[j] + kx;
-        const bool ok = (iy >= 0) & (iy < IH) & (ix >= 0) & (ix < IW);
+        const bool okk = (iy >= 0) & (iy < IH) & (ix >= 0) & (ix < IW);
         const int sy = p.ups ? (iy >> 1) : iy, sx = p.ups ? (ix >> 1) : ix;
-        off = ok ? (a_off[j] + (uint32_t)(sy * p.W + sx)) * (uint32_t)p.lda * 2u + (uint32_t)(cb * BK + chunk * 8) * 2u
-                 : OOB;
+        off = okk ? (a_off[j] + (uint32_t)(sy * p.W + sx)) * (uint32_t)p.lda * 2u + (uint32_t)(cb * BK + chunk * 8) * 2u
+                  : OOB;
       } else {  // SMALLC: 8 channels per pixel = one 16-B chunk per tap; chunk index == tap - 8*kt
         const int tp = kt * 8 + chunk;
-        const int ky = tp / 3, kx = tp - ky * 3;
-        const int iy = a_oy[j] + ky, ix = a_ox[j] + kx;
-        const bool ok = (tp < 9) & (iy >= 0) & (iy < p.H) & (ix >= 0) & (ix < p.W);
-        off = ok ? (a_off[j] + (uint32_t)(iy * p.W + ix)) * 16u : OOB;
+        const int kyy = tp / 3, kxx = tp - kyy * 3;
+        const int iy = a_oy[j] + kyy, ix = a_ox[j] + kxx;
+        const bool okk = (tp < 9) & (iy >= 0) & (iy < p.H) & (ix >= 0) & (ix < p.W);
+        off = okk ? (a_off[j] + (uint32_t)(iy * p.W + ix)) * 16u : OOB;
       }
-      glds16(rsA, sA + (wave * 4 + j) * 1024, off);
+      glds16(rsA, sA + (wave * A_PER_WAVE + j) * 1024, off);
     }
 #pragma unroll
     for (int j = 0; j < B_PER_WAVE; ++j) {
@@ -139,6 +160,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
         glds16(rsB, sB + (wave * B_PER_WAVE + j) * 1024, off);
       }
     }
+    if (MODE == A_CONV3) { if (++cb == cpb) { cb = 0; ++tap; } }
   };
 
   // ---- accumulators ----
@@ -151,17 +173,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
   const int wm = wave / WGN, wn = wave - wm * WGN;
   const int frow = lane & 15, fk = lane >> 4;
 
-  int tap = 0, cb = 0;
-  issue(0, 0, 0, 0);
-  for (int kt = 0; kt < nk; ++kt) {
-    // tile kt has landed (all outstanding DMA of this wave) and every wave is done reading buf[(kt+1)&1]
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (kt + 1 < nk) {
-      if (MODE == A_CONV3) { if (++cb == cpb) { cb = 0; ++tap; } }
-      issue(kt + 1, (kt + 1) & 1, tap, cb);
-    }
-    const char* sA = smem + (kt & 1) * STAGE;
+  auto compute = [&](int buf) {
+    const char* sA = smem + buf * STAGE;
     const char* sB = sA + A_TILE;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
@@ -182,22 +195,102 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
     }
+  };
+
+  if (STAGES == 2) {
+    issue(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+      // tile kt has landed (all outstanding DMA of this wave) and every wave is done reading buf[(kt+1)&1]
+      wait_vmcnt<0>();
+      __syncthreads();
+      if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+      compute(kt & 1);
+    }
+  } else {
+    // 3-stage ring: DMA of tiles kt+1 and kt+2 overlaps the MFMAs of tile kt; counted waits, raw barrier.
+    // (A two-group ping-pong schedule with 2 barriers per K-tile was measured slower: 903 vs 1002 TFLOP/s at 8192^3.)
+    issue(0, 0);
+    if (nk > 1) issue(1, 1);
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt + 1 < nk) wait_vmcnt<LPT>(); else wait_vmcnt<0>();   // this wave's share of tile kt has landed
+      __builtin_amdgcn_s_barrier();                                // ... everyone's has; tile kt-1 fully consumed
+      int nxt2 = cur + 2; if (nxt2 >= 3) nxt2 -= 3;
+      if (kt + 2 < nk) issue(kt + 2, nxt2);
+      compute(cur);
+      if (++cur == 3) cur = 0;
+    }
   }
   __syncthreads();   // all waves finished reading the last tile: LDS is free for epilogue staging
 
   // ---- epilogue: per-wave staging of 32-row slabs through LDS ----
+  // Every epilogue operand (bias, temb row vector, residual) is fetched BEFORE the staging pass that needs
+  // it, so the pass itself is LDS + stores only (a dependent global load per iteration made the first
+  // version of this epilogue latency bound: ~17k cycles per tile).
   constexpr int SLD = WTN + 4;                         // padded row length (floats)
   constexpr int PASSES = WTM / 32;                     // 2 (64-row wave tile) or 1
   constexpr int FPP = FM / PASSES;                     // 16-row fragments per pass (2)
   float* st = (float*)(smem) + wave * (32 * SLD);
   constexpr int OUTW = GEGLU ? WTN / 2 : WTN;          // output columns produced by this wave tile
   constexpr int LPR = OUTW / 8;                        // lanes per row (8 output columns per lane)
-  constexpr int RPI = 64 / LPR;                        // rows per iteration
+  constexpr int RPI = 64 / LPR;                        // rows per iteration (lanes >= RPI*LPR idle when LPR = 5 or 10)
+  constexpr int NIT = (32 + RPI - 1) / RPI;            // iterations per pass
+  constexpr int GOFF = WTN / 2;                        // GEGLU: gate columns follow the h columns inside a wave tile
+  const bool lane_ok = lane < RPI * LPR;
   const int Nout = GEGLU ? p.N / 2 : p.N;
   const int ocol0 = GEGLU ? (n0 + wn * WTN) / 2 : (n0 + wn * WTN);
+  const int lc = (lane % LPR) * 8;
+  const int col = ocol0 + lc;                          // this lane's 8 output columns (fixed for the whole tile)
+  const int nv = (col < Nout) ? ((Nout - col >= 8) ? 8 : (Nout - col)) : 0;
+  const bool full = nv == 8;
+
+  float bv[8], bg[8];                                  // bias (GEGLU: h-part / gate-part, interleaved column order)
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { bv[e] = 0.f; bg[e] = 0.f; }
+  if (p.bias) {
+    if (GEGLU) {
+      const int bcol = n0 + wn * WTN + lc;
+      if (lane_ok && bcol + GOFF + 8 <= p.N) {
+        const f32x4 a0 = *(const f32x4*)(p.bias + bcol), a1 = *(const f32x4*)(p.bias + bcol + 4);
+        const f32x4 c0 = *(const f32x4*)(p.bias + bcol + GOFF), c1 = *(const f32x4*)(p.bias + bcol + GOFF + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { bv[e] = a0[e]; bv[4 + e] = a1[e]; bg[e] = c0[e]; bg[4 + e] = c1[e]; }
+      }
+    } else if (full) {
+      const f32x4 a0 = *(const f32x4*)(p.bias + col), a1 = *(const f32x4*)(p.bias + col + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { bv[e] = a0[e]; bv[4 + e] = a1[e]; }
+    } else {
+      for (int e = 0; e < nv; ++e) bv[e] = p.bias[col + e];
+    }
+  }
 
 #pragma unroll
   for (int ps = 0; ps < PASSES; ++ps) {
+    // ---- prefetch this pass's residual / row-vector operands (overlaps the LDS staging below) ----
+    // `opnd` holds the fp32 residual, or the temb row vector when there is no fp32 residual (the plan never
+    // combines the two: conv1 = bias + temb, conv2 / out-projections = bias + residual).
+    f32x4 opnd[NIT][2];
+    f16x8 r16[NIT];
+    const bool rv_in_opnd = p.rowvec && !p.res32;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int lrp = it * RPI + lane / LPR;
+      const int row = m0 + wm * WTM + ps * 32 + lrp;
+      const bool okr = full && lane_ok && lrp < 32 && row < p.M;
+      opnd[it][0] = opnd[it][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+      r16[it] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      if (okr) {
+        if (p.res32) {
+          const f32x4* rp = (const f32x4*)(p.res32 + (size_t)row * p.ldres + col);
+          opnd[it][0] = rp[0]; opnd[it][1] = rp[1];
+        } else if (p.rowvec) {
+          const f32x4* rv = (const f32x4*)(p.rowvec + (size_t)(row / p.rows_per_sample) * p.ldrv + col);
+          opnd[it][0] = rv[0]; opnd[it][1] = rv[1];
+        }
+        if (p.res16 && !p.res32) r16[it] = *(const f16x8*)(p.res16 + (size_t)row * p.ldres + col);
+      }
+    }
 #pragma unroll
     for (int i2 = 0; i2 < FPP; ++i2)
 #pragma unroll
@@ -208,43 +301,35 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
     // same-wave LDS RAW across lanes: DS ops of one wave execute in order
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int it = 0; it < 32 / RPI; ++it) {
-      const int lr = it * RPI + lane / LPR;
-      const int lc = (lane % LPR) * 8;
+    for (int it = 0; it < NIT; ++it) {
+      int lr = it * RPI + lane / LPR;
+      const bool act = lane_ok && lr < 32;
+      if (!act) lr = 0;
       const int row = m0 + wm * WTM + ps * 32 + lr;
-      const int col = ocol0 + lc;
       float v[8];
       if (GEGLU) {
         const f32x4 h0 = *(const f32x4*)(st + lr * SLD + lc), h1 = *(const f32x4*)(st + lr * SLD + lc + 4);
-        const f32x4 g0 = *(const f32x4*)(st + lr * SLD + 32 + lc), g1 = *(const f32x4*)(st + lr * SLD + 32 + lc + 4);
-        const int bcol = n0 + wn * WTN + lc;           // bias is stored in the interleaved GEMM column order
+        const f32x4 g0 = *(const f32x4*)(st + lr * SLD + GOFF + lc), g1 = *(const f32x4*)(st + lr * SLD + GOFF + lc + 4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          float hb0 = h0[e], hb1 = h1[e], gb0 = g0[e], gb1 = g1[e];
-          if (p.bias) {
-            if (bcol + e < p.N) { hb0 += p.bias[bcol + e]; gb0 += p.bias[bcol + 32 + e]; }
-            if (bcol + 4 + e < p.N) { hb1 += p.bias[bcol + 4 + e]; gb1 += p.bias[bcol + 32 + 4 + e]; }
-          }
-          v[e] = hb0 * gelu_erf(gb0);
-          v[4 + e] = hb1 * gelu_erf(gb1);
+          v[e] = (h0[e] + bv[e]) * gelu_erf(g0[e] + bg[e]);
+          v[4 + e] = (h1[e] + bv[4 + e]) * gelu_erf(g1[e] + bg[4 + e]);
         }
       } else {
         const f32x4 x0 = *(const f32x4*)(st + lr * SLD + lc), x1 = *(const f32x4*)(st + lr * SLD + lc + 4);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { v[e] = x0[e]; v[4 + e] = x1[e]; }
+        for (int e = 0; e < 4; ++e) { v[e] = x0[e] + bv[e]; v[4 + e] = x1[e] + bv[4 + e]; }
       }
-      if (row < p.M && col < Nout) {
-        const int nv = (Nout - col >= 8) ? 8 : (Nout - col);
-        if (!GEGLU && p.bias) {
+      if (act && row < p.M && nv > 0) {
+        if (full) {
+          if (rv_in_opnd) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) if (e < nv) v[e] += p.bias[col + e];
-        }
-        if (p.rowvec) {
-          const float* rv = p.rowvec + (size_t)(row / p.rows_per_sample) * p.ldrv + col;
+            for (int e = 0; e < 4; ++e) { v[e] += opnd[it][0][e]; v[4 + e] += opnd[it][1][e]; }
+          } else if (p.rowvec) {                       // (not produced by the plan) temb AND fp32 residual: late load
+            const f32x4* rv = (const f32x4*)(p.rowvec + (size_t)(row / p.rows_per_sample) * p.ldrv + col);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) if (e < nv) v[e] += rv[e];
-        }
-        if (nv == 8) {
+            for (int e = 0; e < 4; ++e) { v[e] += rv[0][e]; v[4 + e] += rv[1][e]; }
+          }
           if (p.aux16) {
             f16x8 hv;
 #pragma unroll
@@ -252,15 +337,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
             *(f16x8*)(p.aux16 + (size_t)row * p.ldaux + col) = hv;
           }
           if (p.res32) {
-            const f32x4* rp = (const f32x4*)(p.res32 + (size_t)row * p.ldres + col);
-            const f32x4 r0 = rp[0], r1 = rp[1];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
-          } else if (p.res16) {
-            const f16x8 r = *(const f16x8*)(p.res16 + (size_t)row * p.ldres + col);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += (float)r[e];
+            for (int e = 0; e < 4; ++e) { v[e] += opnd[it][0][e]; v[4 + e] += opnd[it][1][e]; }
           }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += (float)r16[it][e];
           if (p.out16) {
             f16x8 hv;
 #pragma unroll
@@ -272,9 +353,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
             op[0] = f32x4{v[0], v[1], v[2], v[3]};
             op[1] = f32x4{v[4], v[5], v[6], v[7]};
           }
-        } else {
+        } else {                                         // ragged N tail (e.g. conv_out, N = 4): scalar path
           for (int e = 0; e < nv; ++e) {
             float x = v[e];
+            if (p.rowvec) x += p.rowvec[(size_t)(row / p.rows_per_sample) * p.ldrv + col + e];
             if (p.aux16) p.aux16[(size_t)row * p.ldaux + col + e] = (_Float16)x;
             if (p.res32) x += p.res32[(size_t)row * p.ldres + col + e];
             else if (p.res16) x += (float)p.res16[(size_t)row * p.ldres + col + e];
@@ -284,41 +366,69 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
         }
       }
     }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_sched_barrier(0);                   // keep the next pass's prefetch from being hoisted (VGPR pressure)
   }
 }
 
-template <int MODE, int BN, bool GEGLU>
+template <int MODE, int BM, int BN, int STAGES, bool GEGLU>
 static hipError_t launch_t(const GemmParams& p, hipStream_t s) {
   const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
-  const int smem = 2 * (BM * 128 + BN * 128);
+  const int smem = STAGES * (BM * 128 + BN * 128);
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel<MODE, BN, GEGLU>,
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel<MODE, BM, BN, STAGES, GEGLU>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return e;
     attr_done = true;
   }
-  hipLaunchKernelGGL((gemm_kernel<MODE, BN, GEGLU>), dim3(tiles_m * tiles_n), dim3(256), smem, s, p);
+  hipLaunchKernelGGL((gemm_kernel<MODE, BM, BN, STAGES, GEGLU>), dim3(tiles_m * tiles_n), dim3(BM * 2), smem, s, p);
   return hipGetLastError();
+}
+
+// Tile selection.  Every channel count of the SD / SDXL UNets is a multiple of 160 (320 k), so the 128x160 tile
+// (2 workgroups per CU, 72 KiB LDS each) covers N without a ragged last column tile and makes M/128 * N/160 a
+// multiple of the 512 workgroup slots for the SDXL batch-16 shapes (no tail round).  128x128 serves other N;
+// 256x128 (8 waves, 3-stage ring) wins for very large problems.
+static int pick_variant(const GemmParams& p) {
+  if (p.bn == 16) return 16;
+  if (p.variant) return p.variant;
+  const long tiles256 = (long)((p.M + 255) / 256) * ((p.N + 127) / 128);
+  if (p.geglu) return tiles256 >= 512 ? 256 : 128;                       // measured: 801 vs 662 TFLOP/s (C=1280)
+  if (p.mode != A_DENSE) return (p.N % 160 == 0) ? 160 : 128;            // convs: 1000-1107 vs 800-1020
+  if (p.N % 160 == 0 && p.K >= 1024) return 160;                         // ff_out 914, qkv 858, attn2_q 889
+  if ((long)p.M * p.N >= (1L << 26) && tiles256 >= 512) return 256;      // short-K, large MxN (qkv @ C=640): 706 vs 645
+  return 128;
 }
 
 hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {
   if (p.M <= 0 || p.N <= 0) return hipSuccess;
   if (p.mode != A_CONV_SMALLC && (p.K % BK) != 0) return hipErrorInvalidValue;
   if (p.mode == A_CONV3 && (p.Cin % BK) != 0) return hipErrorInvalidValue;
+  const int v = pick_variant(p);
   if (p.geglu) {
-    if (p.mode != A_DENSE || p.bn == 16 || (p.N % 64) != 0) return hipErrorInvalidValue;
-    return launch_t<A_DENSE, 128, true>(p, s);
+    // the weight rows were interleaved for one specific wave-tile width: group 40 <-> BN 160, group 32 <-> BN 128/256x128
+    if (p.mode != A_DENSE) return hipErrorInvalidValue;
+    if (p.geglu == 40) return (p.N % 80) ? hipErrorInvalidValue : launch_t<A_DENSE, 128, 160, 2, true>(p, s);
+    if (p.N % 64) return hipErrorInvalidValue;
+    return v == 256 ? launch_t<A_DENSE, 256, 128, 3, true>(p, s) : launch_t<A_DENSE, 128, 128, 2, true>(p, s);
   }
-  if (p.bn == 16) {
-    if (p.mode == A_CONV3) return launch_t<A_CONV3, 16, false>(p, s);
-    if (p.mode == A_DENSE) return launch_t<A_DENSE, 16, false>(p, s);
+  if (v == 16) {
+    if (p.mode == A_CONV3) return launch_t<A_CONV3, 128, 16, 2, false>(p, s);
+    if (p.mode == A_DENSE) return launch_t<A_DENSE, 128, 16, 2, false>(p, s);
     return hipErrorInvalidValue;
   }
   switch (p.mode) {
-    case A_DENSE: return launch_t<A_DENSE, 128, false>(p, s);
-    case A_CONV3: return launch_t<A_CONV3, 128, false>(p, s);
-    case A_CONV_SMALLC: return launch_t<A_CONV_SMALLC, 128, false>(p, s);
+    case A_DENSE:
+      if (v == 160) return launch_t<A_DENSE, 128, 160, 2, false>(p, s);
+      if (v == 256) return launch_t<A_DENSE, 256, 128, 3, false>(p, s);
+      return launch_t<A_DENSE, 128, 128, 2, false>(p, s);
+    case A_CONV3:
+      if (v == 160) return launch_t<A_CONV3, 128, 160, 2, false>(p, s);
+      if (v == 256) return launch_t<A_CONV3, 256, 128, 3, false>(p, s);
+      return launch_t<A_CONV3, 128, 128, 2, false>(p, s);
+    case A_CONV_SMALLC:
+      return v == 160 ? launch_t<A_CONV_SMALLC, 128, 160, 2, false>(p, s) : launch_t<A_CONV_SMALLC, 128, 128, 2, false>(p, s);
   }
   return hipErrorInvalidValue;
 }

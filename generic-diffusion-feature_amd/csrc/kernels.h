@@ -46,8 +46,9 @@ struct GemmParams {
   int ldo32;
   half_t* aux16;
   int ldaux;
-  int geglu;
+  int geglu;             // 0, or the interleave group of the weight rows: 32 (BN 128) / 40 (BN 160)
   int bn;                // 128 (default) or 16 (very narrow N, e.g. conv_out)
+  int variant;           // 0 = auto; 128 / 160 / 256 force the 128x128, 128x160 or 256x128 tile (diagnostics)
 };
 hipError_t launch_gemm(const GemmParams& p, hipStream_t s);
 
@@ -103,7 +104,7 @@ hipError_t launch_small_linear(const float* x, int ldx, int M, int K, const half
 hipError_t launch_relayout_conv(const void* src, int src_f32, half_t* dst, int O, int I, int T, int ipad, int tpad,
                                 hipStream_t s);
 // rows: dst[rowmap(r)][k] = src[r][k] for r in [0,R); rowmap: 0 identity+row_off, 1 GEGLU interleave (half = R/2)
-hipError_t launch_relayout_rows(const void* src, int src_f32, half_t* dst, int R, int K, int row_off, int geglu,
+hipError_t launch_relayout_rows(const void* src, int src_f32, half_t* dst, int R, int K, int row_off, int geglu /*0|32|40*/,
                                 hipStream_t s);
 // vectors to fp32 with the same row mapping
 hipError_t launch_relayout_vec(const void* src, int src_f32, float* dst, int R, int row_off, int geglu, hipStream_t s);

@@ -223,6 +223,9 @@ void model_destroy(Model* m) {
   delete m;
 }
 
+// GEGLU interleave group of an [8C][C] projection: 40 when the 128x160 tile applies (8C % 160 == 0), else 32
+static int geglu_group(int rows) { return (rows % 160 == 0) ? 40 : 32; }
+
 int model_set_param(Model* m, const char* name, const void* src, int dtype, hipStream_t s) {
   auto it = m->index.find(name);
   if (it == m->index.end()) { set_error(std::string("unknown parameter: ") + name); return GDF_ERR_ARG; }
@@ -233,11 +236,11 @@ int model_set_param(Model* m, const char* name, const void* src, int dtype, hipS
   switch (p.kind) {
     case PK_VEC: e = launch_relayout_vec(src, f32, (float*)(base + p.dst), (int)p.shape[0], 0, 0, s); break;
     case PK_VEC_OFF: e = launch_relayout_vec(src, f32, (float*)(base + p.dst), p.a0, p.a1, 0, s); break;
-    case PK_VEC_GEGLU: e = launch_relayout_vec(src, f32, (float*)(base + p.dst), p.a0, 0, 1, s); break;
+    case PK_VEC_GEGLU: e = launch_relayout_vec(src, f32, (float*)(base + p.dst), p.a0, 0, geglu_group(p.a0), s); break;
     case PK_CONV3: e = launch_relayout_conv(src, f32, (half_t*)(base + p.dst), p.a0, p.a1, 9, p.a1, 9, s); break;
     case PK_CONV_IN: e = launch_relayout_conv(src, f32, (half_t*)(base + p.dst), p.a0, p.a1, 9, 8, 16, s); break;
     case PK_ROWS: e = launch_relayout_rows(src, f32, (half_t*)(base + p.dst), p.a0, p.a1, p.a2, 0, s); break;
-    case PK_ROWS_GEGLU: e = launch_relayout_rows(src, f32, (half_t*)(base + p.dst), p.a0, p.a1, 0, 1, s); break;
+    case PK_ROWS_GEGLU: e = launch_relayout_rows(src, f32, (half_t*)(base + p.dst), p.a0, p.a1, 0, geglu_group(p.a0), s); break;
     default: set_error("bad param kind"); return GDF_ERR_STATE;
   }
   if (e != hipSuccess) { set_error(std::string("relayout launch failed: ") + hipGetErrorString(e)); return GDF_ERR_HIP; }
@@ -417,7 +420,7 @@ struct B {   // builder
     Ref out16{}; bool has_o16 = false; int ldo16 = 0;
     Ref out32{}; bool has_o32 = false; int ldo32 = 0;
     int aux_slot = -1; int ldaux = 0;
-    bool geglu = false; int bn = 128;
+    int geglu = 0; int bn = 128;
   };
   void residual_from(Epi& e, const Act& x) {
     if (x.has_f) { e.res32 = x.f; e.has_r32 = true; e.ldres = x.C; }
@@ -435,7 +438,7 @@ struct B {   // builder
     g.out16 = e.has_o16 ? (half_t*)b.p(e.out16) : nullptr; g.ldo16 = e.ldo16;
     g.out32 = e.has_o32 ? (float*)b.p(e.out32) : nullptr; g.ldo32 = e.ldo32;
     g.aux16 = e.aux_slot >= 0 ? (half_t*)b.hook(e.aux_slot) : nullptr; g.ldaux = e.ldaux;
-    g.geglu = e.geglu ? 1 : 0; g.bn = e.bn;
+    g.geglu = e.geglu; g.bn = e.bn;
   }
 
   // dense GEMM: A (fp16 [M][K], lda) x W[N][K]
@@ -583,7 +586,7 @@ struct B {   // builder
       // --- feed forward (GEGLU) ---
       ln = layernorm(tok, bw.ln3);
       const size_t inner = tmp(n * 4 * C * 2);
-      { Epi e; e.bias = wt(bw.ff1.b); e.has_bias = true; e.geglu = true; e.out16 = ws(inner); e.has_o16 = true; e.ldo16 = 4 * C;
+      { Epi e; e.bias = wt(bw.ff1.b); e.has_bias = true; e.geglu = geglu_group(8 * C); e.out16 = ws(inner); e.has_o16 = true; e.ldo16 = 4 * C;
         gemm("ff_geglu", ws(ln), C, n, bw.ff1, 8 * C, C, 0, e); }
       untmp(ln, nb);
       hook_copy(want(bid + "-ffn-inner", 4 * C, x.H, x.W), ws(inner), 4 * C, n, 4 * C);   // attention.py:1255-1257

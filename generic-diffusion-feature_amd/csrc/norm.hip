@@ -367,11 +367,11 @@ hipError_t launch_small_linear(const float* x, int ldx, int M, int K, const half
 __device__ __forceinline__ float ldsrc(const void* src, int f32, size_t i) {
   return f32 ? ((const float*)src)[i] : (float)((const half_t*)src)[i];
 }
-__device__ __forceinline__ int geglu_row(int r, int half) {
-  // source row r of the [2*half][K] GEGLU projection -> GEMM row so that every 64-column group is [32 h | 32 gate]
+__device__ __forceinline__ int geglu_row(int r, int half, int g) {
+  // source row r of the [2*half][K] GEGLU projection -> GEMM row so that every 2g-column group is [g h | g gate]
   const int is_gate = r >= half;
   const int rr = is_gate ? r - half : r;
-  return (rr / 32) * 64 + (is_gate ? 32 : 0) + (rr % 32);
+  return (rr / g) * 2 * g + (is_gate ? g : 0) + (rr % g);
 }
 
 __global__ void relayout_conv_kernel(const void* src, int f32, half_t* dst, int O, int I, int T, int ipad, int tpad,
@@ -400,7 +400,7 @@ __global__ void relayout_rows_kernel(const void* src, int f32, half_t* dst, int 
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int r = (int)(i / K);
     const int k = (int)(i - (long)r * K);
-    const int dr = geglu ? geglu_row(r, R / 2) : r + row_off;
+    const int dr = geglu ? geglu_row(r, R / 2, geglu) : r + row_off;
     dst[(size_t)dr * K + k] = (_Float16)ldsrc(src, f32, i);
   }
 }
@@ -417,7 +417,7 @@ hipError_t launch_relayout_rows(const void* src, int src_f32, half_t* dst, int R
 __global__ void relayout_vec_kernel(const void* src, int f32, float* dst, int R, int row_off, int geglu) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= R) return;
-  const int dr = geglu ? geglu_row(r, R / 2) : r + row_off;
+  const int dr = geglu ? geglu_row(r, R / 2, geglu) : r + row_off;
   dst[dr] = ldsrc(src, f32, r);
 }
 hipError_t launch_relayout_vec(const void* src, int src_f32, float* dst, int R, int row_off, int geglu, hipStream_t s) {

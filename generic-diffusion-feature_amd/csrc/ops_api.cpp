@@ -21,7 +21,7 @@ int gdf_op_gemm(const void* A, int lda, const void* W, const float* bias, const 
   g.Wt = (const half_t*)W; g.w_bytes = (uint32_t)((size_t)N * K * 2);
   g.bias = bias; g.res32 = res32; g.res16 = (const half_t*)res16; g.ldres = ldres;
   g.out16 = (half_t*)out16; g.ldo16 = ldo16; g.out32 = out32; g.ldo32 = ldo32;
-  g.geglu = flags & 1; g.bn = (flags & 2) ? 16 : 128; g.rows_per_sample = 1;
+  g.geglu = (flags & 1) ? ((flags & 8) ? 40 : 32) : 0; g.bn = (flags & 2) ? 16 : 128; g.variant = flags >> 8; g.rows_per_sample = 1;
   return fin(launch_gemm(g, (hipStream_t)stream), "gemm");
 }
 
@@ -39,7 +39,7 @@ int gdf_op_conv3x3(const void* x, int ld, int B, int H, int W, int Cin, const vo
   g.res32 = res32; g.ldres = Cout;
   g.aux16 = (half_t*)aux16; g.ldaux = Cout;
   g.out16 = (half_t*)out16; g.ldo16 = Cout; g.out32 = out32; g.ldo32 = Cout;
-  g.bn = narrow ? 16 : 128;
+  g.bn = (narrow & 1) ? 16 : 128; g.variant = narrow >> 8;
   return fin(launch_gemm(g, (hipStream_t)stream), "conv3x3");
 }
 
@@ -94,10 +94,10 @@ int gdf_op_copy2d(const void* s16, const float* s32, int lds, void* dst, int ldd
 int gdf_op_relayout_conv3(const void* w, void* dst, int O, int I, void* stream) {
   return fin(launch_relayout_conv(w, 0, (half_t*)dst, O, I, 9, I, 9, (hipStream_t)stream), "relayout_conv3");
 }
-int gdf_op_relayout_geglu(const void* w, const float* bias, void* w_dst, float* bias_dst, int R, int K, void* stream) {
-  hipError_t e = launch_relayout_rows(w, 0, (half_t*)w_dst, R, K, 0, 1, (hipStream_t)stream);
+int gdf_op_relayout_geglu(const void* w, const float* bias, void* w_dst, float* bias_dst, int R, int K, int group, void* stream) {
+  hipError_t e = launch_relayout_rows(w, 0, (half_t*)w_dst, R, K, 0, group, (hipStream_t)stream);
   if (e != hipSuccess) return fin(e, "relayout_geglu");
-  if (bias) e = launch_relayout_vec(bias, 1, bias_dst, R, 0, 1, (hipStream_t)stream);
+  if (bias) e = launch_relayout_vec(bias, 1, bias_dst, R, 0, group, (hipStream_t)stream);
   return fin(e, "relayout_geglu_bias");
 }
 

@@ -10,8 +10,9 @@ extern "C" {
 #endif
 
 /* out[M,N] = A[M,K](lda) * W[N,K]^T + bias (+ residual).  fp16 operands, fp32 accumulate.
- * flags: bit0 GEGLU (W rows / bias already in the interleaved [32 h | 32 gate] order; out is [M,N/2]),
- *        bit1 narrow-N tile (BN=16).  Replaces nn.Linear / 1x1 conv
+ * flags: bit0 GEGLU (W rows / bias already interleaved by gdf_op_relayout_geglu; out is [M,N/2]); bit3 = the
+ *        interleave group is 40 (128x160 tile) instead of 32; bit1 narrow-N tile (BN=16);
+ *        bits 8.. force a tile variant (128 / 160 / 256, 0 = auto).  Replaces nn.Linear / 1x1 conv
  *        (/root/reference/feature/diffusers/models/attention_processor.py:241-267, attention.py:1238-1258). */
 int gdf_op_gemm(const void* A, int lda, const void* W, const float* bias, const float* res32, const void* res16,
                 int ldres, void* out16, int ldo16, float* out32, int ldo32, int M, int N, int K, int flags,
@@ -22,7 +23,7 @@ int gdf_op_gemm(const void* A, int lda, const void* W, const float* bias, const 
  * Replaces nn.Conv2d in resnet.py:269,285, downsampling.py:115-118, upsampling.py:131-134,176-193.       */
 int gdf_op_conv3x3(const void* x, int ld, int B, int H, int W, int Cin, const void* Wt, int Cout, const float* bias,
                    const float* rowvec, int stride, int ups, const float* res32, void* aux16, void* out16,
-                   float* out32, int narrow, void* stream);
+                   float* out32, int narrow /* bit0: BN=16; bits 8..: tile variant */, void* stream);
 
 /* conv_in: x NCHW fp16 [B,Cin<=8,H,W] -> NHWC [B,H,W,Cout]; weights in diffusers OIHW fp16 layout.
  * scratch: B*H*W*16 + Cout*256 bytes.                                                                  */
@@ -51,7 +52,7 @@ int gdf_op_copy2d(const void* s16, const float* s32, int lds, void* dst, int ldd
 
 /* weight re-layout helpers used by the tests: OIHW -> OHWI, GEGLU row interleave. */
 int gdf_op_relayout_conv3(const void* w_oihw_f16, void* dst, int O, int I, void* stream);
-int gdf_op_relayout_geglu(const void* w_f16, const float* bias, void* w_dst, float* bias_dst, int R, int K, void* stream);
+int gdf_op_relayout_geglu(const void* w_f16, const float* bias, void* w_dst, float* bias_dst, int R, int K, int group /*32|40*/, void* stream);
 
 #ifdef __cplusplus
 }

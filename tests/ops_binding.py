@@ -20,7 +20,7 @@ OPS = {
     "gdf_op_layernorm": (ci, [vp, vp, ci, ci, ci, fp, vp, vp, vp, vp]),
     "gdf_op_copy2d": (ci, [vp, vp, ci, vp, ci, ci, ci, vp]),
     "gdf_op_relayout_conv3": (ci, [vp, vp, ci, ci, vp]),
-    "gdf_op_relayout_geglu": (ci, [vp, vp, vp, vp, ci, ci, vp]),
+    "gdf_op_relayout_geglu": (ci, [vp, vp, vp, vp, ci, ci, ci, vp]),
 }
 
 

@@ -18,15 +18,16 @@ def rnd(*shape, scale=1.0, seed=0):
     return (torch.randn(*shape, generator=g) * scale).half()
 
 
+@pytest.mark.parametrize("variant", [0, 128, 160, 256])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 320, 320), (200, 72, 128), (1232, 640, 2048), (64, 1280, 1280)])
-def test_gemm_bias_residual(M, N, K):
+def test_gemm_bias_residual(M, N, K, variant):
     L = lib()
     A, W = rnd(M, K), rnd(N, K, scale=K ** -0.5)
     bias, res = rnd(N).float(), rnd(M, N).float()
     ref = A.float() @ W.float().t() + bias + res
     Ad, Wd, bd, rd = A.cuda(), W.cuda(), bias.cuda(), res.cuda()
     o16 = torch.zeros(M, N, dtype=torch.half, device="cuda"); o32 = torch.zeros(M, N, device="cuda")
-    ok(L.gdf_op_gemm(P(Ad), K, P(Wd), P(bd), P(rd), None, N, P(o16), N, P(o32), N, M, N, K, 0, stream()), L)
+    ok(L.gdf_op_gemm(P(Ad), K, P(Wd), P(bd), P(rd), None, N, P(o16), N, P(o32), N, M, N, K, variant << 8, stream()), L)
     torch.cuda.synchronize()
     assert rel(o32, ref) < TOL32 and rel(o16, ref) < TOL16
     # fp16 residual + strided A / out (leading dimensions larger than the logical width)
@@ -34,8 +35,8 @@ def test_gemm_bias_residual(M, N, K):
     obig = torch.zeros(M, N + 24, dtype=torch.half, device="cuda")
     r16 = res.half().cuda()
     Ab = Abig.cuda()
-    ok(L.gdf_op_gemm(C_off(Ab, 32), K + 64, P(Wd), P(bd), None, P(r16), N, C_off(obig, 8), N + 24, None, 0, M, N, K, 0,
-                     stream()), L)
+    ok(L.gdf_op_gemm(C_off(Ab, 32), K + 64, P(Wd), P(bd), None, P(r16), N, C_off(obig, 8), N + 24, None, 0, M, N, K,
+                     variant << 8, stream()), L)
     torch.cuda.synchronize()
     ref2 = A.float() @ W.float().t() + bias + res.half().float()
     assert rel(obig[:, 8:8 + N], ref2) < TOL16
@@ -60,8 +61,8 @@ def test_gemm_asymmetric_identity():
     assert torch.allclose(o32.cpu(), W.float().t(), atol=1e-3)
 
 
-@pytest.mark.parametrize("M,C", [(128, 64), (520, 320)])
-def test_gemm_geglu(M, C):
+@pytest.mark.parametrize("M,C,group", [(128, 64, 32), (520, 320, 32), (520, 320, 40), (300, 640, 40)])
+def test_gemm_geglu(M, C, group):
     L = lib()
     x, W, b = rnd(M, C), rnd(8 * C, C, scale=C ** -0.5), rnd(8 * C).float()
     hg = x.float() @ W.float().t() + b
@@ -69,17 +70,18 @@ def test_gemm_geglu(M, C):
     ref = h * F.gelu(g)
     Wd = torch.empty_like(W, device="cuda"); bd = torch.empty(8 * C, device="cuda")
     Ws, bs, xd = W.cuda(), b.cuda(), x.cuda()
-    ok(L.gdf_op_relayout_geglu(P(Ws), P(bs), P(Wd), P(bd), 8 * C, C, stream()), L)
+    ok(L.gdf_op_relayout_geglu(P(Ws), P(bs), P(Wd), P(bd), 8 * C, C, group, stream()), L)
     out = torch.zeros(M, 4 * C, dtype=torch.half, device="cuda")
-    ok(L.gdf_op_gemm(P(xd), C, P(Wd), P(bd), None, None, 0, P(out), 4 * C, None, 0, M, 8 * C, C, 1, stream()), L)
+    ok(L.gdf_op_gemm(P(xd), C, P(Wd), P(bd), None, None, 0, P(out), 4 * C, None, 0, M, 8 * C, C, 1 | (8 if group == 40 else 0), stream()), L)
     torch.cuda.synchronize()
     assert rel(out, ref) < TOL16
 
 
+@pytest.mark.parametrize("variant", [0, 128, 160, 256])
 @pytest.mark.parametrize("B,H,W,Cin,Cout,stride,ups", [
     (2, 8, 8, 64, 64, 1, 0), (1, 12, 10, 128, 192, 1, 0), (2, 8, 8, 64, 128, 2, 0), (2, 6, 6, 64, 64, 1, 1),
     (1, 16, 16, 320, 320, 1, 0)])
-def test_conv3x3(B, H, W, Cin, Cout, stride, ups):
+def test_conv3x3(B, H, W, Cin, Cout, stride, ups, variant):
     L = lib()
     x = rnd(B, Cin, H, W); w = rnd(Cout, Cin, 3, 3, scale=(9 * Cin) ** -0.5)
     bias, temb = rnd(Cout).float(), rnd(B, Cout).float()
@@ -96,7 +98,7 @@ def test_conv3x3(B, H, W, Cin, Cout, stride, ups):
     aux = torch.zeros(B, OH, OW, Cout, dtype=torch.half, device="cuda")
     o16 = torch.zeros_like(aux); o32 = torch.zeros(B, OH, OW, Cout, device="cuda")
     ok(L.gdf_op_conv3x3(P(x_nhwc), Cin, B, H, W, Cin, P(wd), Cout, P(bd), P(td), stride, ups,
-                        P(res_nhwc), P(aux), P(o16), P(o32), 0, stream()), L)
+                        P(res_nhwc), P(aux), P(o16), P(o32), variant << 8, stream()), L)
     torch.cuda.synchronize()
     assert rel(aux.permute(0, 3, 1, 2), inc) < TOL16
     assert rel(o32.permute(0, 3, 1, 2), ref) < TOL32
