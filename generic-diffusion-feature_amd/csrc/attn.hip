@@ -22,11 +22,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
 #define LDS_AS __attribute__((address_space(3)))
 
-static constexpr int QB = 128;    // query rows per workgroup (4 waves x 32)
 static constexpr int KT = 64;     // keys per tile
 
-template <int D>
-__global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
+template <int D, int QW>
+__global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
   constexpr int DQK = (D + 15) / 16 * 16;        // contraction length of QK^T, padded
   constexpr int DV = (D + 31) / 32 * 32;         // output rows of O^T, padded
   constexpr int DP = DV;                         // data halves per LDS row (DV >= DQK)
@@ -35,40 +34,49 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
   constexpr int NCH = (KT * CPR + 255) / 256;    // chunks per thread per tile
   constexpr int NS = DQK / 16;                   // k-steps of QK^T
   constexpr int NDB = DV / 32;                   // 32-row blocks of O^T
+  constexpr int QBW = 32 * QW;                   // query rows per wave
+  constexpr int QBLK = 4 * QBW;                  // query rows per workgroup
 
-  __shared__ __attribute__((aligned(16))) _Float16 sK[KT * LDR];
-  __shared__ __attribute__((aligned(16))) _Float16 sV[KT * LDR];
+  // double-buffered K / V tiles: one barrier per tile
+  __shared__ __attribute__((aligned(16))) _Float16 sK[2][KT * LDR];
+  __shared__ __attribute__((aligned(16))) _Float16 sV[2][KT * LDR];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int nqb = (p.Sq + QB - 1) / QB;
+  const int nqb = (p.Sq + QBLK - 1) / QBLK;
   int bid = blockIdx.x;
   const int qb = bid % nqb; bid /= nqb;
   const int head = bid % p.heads;
   const int b = bid / p.heads;
 
   const int lq = lane & 31, lh = lane >> 5;
-  const int q_row = qb * QB + wave * 32 + lq;              // query index inside the sequence
-  const bool q_ok = q_row < p.Sq;
-
+  int q_row[QW];
+  bool q_ok[QW];
   // ---- Q fragments (B operand of S^T = K Q^T): Q[q][16 s + 8 lh .. +8] ----
-  f16x8 qf[NS];
-  {
-    const _Float16* qp = p.q + ((size_t)b * p.Sq + (q_ok ? q_row : 0)) * p.ldq + head * D;
+  f16x8 qf[QW][NS];
+#pragma unroll
+  for (int w = 0; w < QW; ++w) {
+    q_row[w] = qb * QBLK + wave * QBW + w * 32 + lq;       // query index inside the sequence
+    q_ok[w] = q_row[w] < p.Sq;
+    const _Float16* qp = p.q + ((size_t)b * p.Sq + (q_ok[w] ? q_row[w] : 0)) * p.ldq + head * D;
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
       const int d0 = 16 * s + 8 * lh;
       f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (q_ok && d0 < D) v = *(const f16x8*)(qp + d0);
-      qf[s] = v;
+      if (q_ok[w] && d0 < D) v = *(const f16x8*)(qp + d0);
+      qf[w][s] = v;
     }
   }
 
-  f32x16 o[NDB];
+  f32x16 o[QW][NDB];
+  float m_run[QW], l_run[QW];
 #pragma unroll
-  for (int i = 0; i < NDB; ++i)
+  for (int w = 0; w < QW; ++w) {
+    m_run[w] = -INFINITY; l_run[w] = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
-  float m_run = -INFINITY, l_run = 0.f;
+    for (int i = 0; i < NDB; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[w][i][r] = 0.f;
+  }
   const float sl2 = p.scale * 1.44269504088896340736f;    // softmax(x*scale) via exp2
 
   const _Float16* kbase = p.k + (size_t)b * p.Sk * p.ldk + head * D;
@@ -90,74 +98,92 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
       kreg[c] = kk; vreg[c] = vv;
     }
   };
-  auto lstore = [&]() {
+  auto lstore = [&](int buf) {
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       const int idx = tid + c * 256;
       const int row = idx / CPR, ch = idx - row * CPR;
       if (idx < KT * CPR) {
-        *(f16x8*)(sK + row * LDR + ch * 8) = kreg[c];
-        *(f16x8*)(sV + row * LDR + ch * 8) = vreg[c];
+        *(f16x8*)(&sK[buf][row * LDR + ch * 8]) = kreg[c];
+        *(f16x8*)(&sV[buf][row * LDR + ch * 8]) = vreg[c];
       }
     }
   };
 
   gload(0);
+  lstore(0);
+  __syncthreads();
+  if (ntiles > 1) gload(1);
   for (int t = 0; t < ntiles; ++t) {
-    __syncthreads();            // every wave finished computing on the previous tile
-    lstore();
-    __syncthreads();
-    if (t + 1 < ntiles) gload(t + 1);   // next tile's HBM latency hides under this tile's MFMAs
+    const _Float16* cK = sK[t & 1];
+    const _Float16* cV = sV[t & 1];
 
-    // ---- S^T = K Q^T : two 32-key blocks ----
-    f32x16 s[2];
+    // ---- S^T = K Q^T : two 32-key blocks; every K fragment feeds QW query blocks ----
+    f32x16 s[QW][2];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
-#pragma unroll
       for (int st = 0; st < NS; ++st) {
-        const f16x8 kf = *(const f16x8*)(sK + (kb * 32 + lq) * LDR + 16 * st + 8 * lh);
-        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[st], s[kb], 0, 0, 0);
+        const f16x8 kf = *(const f16x8*)(cK + (kb * 32 + lq) * LDR + 16 * st + 8 * lh);
+#pragma unroll
+        for (int w = 0; w < QW; ++w) {
+          if (st == 0) {
+            const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            s[w][kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[w][st], z, 0, 0, 0);
+          } else {
+            s[w][kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[w][st], s[w][kb], 0, 0, 0);
+          }
+        }
       }
     }
     // ---- mask the tail tile, online softmax (per-lane query column) ----
     if ((t + 1) * KT > p.Sk) {
 #pragma unroll
+      for (int w = 0; w < QW; ++w)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int kv = t * KT + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (kv >= p.Sk) s[w][kb][r] = -INFINITY;
+          }
+    }
+    f16x8 pf[QW][4];
+#pragma unroll
+    for (int w = 0; w < QW; ++w) {
+      float mx = s[w][0][0];
+#pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int kv = t * KT + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          if (kv >= p.Sk) s[kb][r] = -INFINITY;
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[w][kb][r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      const float m_new = fmaxf(m_run[w], mx * sl2);
+      const float alpha = __builtin_amdgcn_exp2f(m_run[w] - m_new);   // raw v_exp_f32; first tile: exp2(-inf) = 0
+      float psum = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          const float e0 = __builtin_amdgcn_exp2f(s[w][kb][r] * sl2 - m_new);
+          const float e1 = __builtin_amdgcn_exp2f(s[w][kb][r + 1] * sl2 - m_new);
+          psum += e0 + e1;
+          typedef float f32x2 __attribute__((ext_vector_type(2)));
+          typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+          const f16x2 h2 = __builtin_convertvector(f32x2{e0, e1}, f16x2);     // v_cvt_pk_f16_f32
+          pf[w][kb * 2 + (r >> 3)][r & 7] = h2[0];
+          pf[w][kb * 2 + (r >> 3)][(r & 7) + 1] = h2[1];
         }
-    }
-    float mx = s[0][0];
+      l_run[w] = l_run[w] * alpha + psum;
+      if (m_new != m_run[w]) {                            // the running max rarely grows after the first tiles
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+        for (int i = 0; i < NDB; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
-    const float m_new = fmaxf(m_run, mx * sl2);
-    const float alpha = exp2f(m_run - m_new);          // first tile: exp2(-inf) = 0
-    m_run = m_new;
-    float psum = 0.f;
-    f16x8 pf[4];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float e = exp2f(s[kb][r] * sl2 - m_new);
-        const _Float16 eh = (_Float16)e;
-        psum += (float)eh;                              // the sum matches what the MFMA will see
-        pf[kb * 2 + (r >> 3)][r & 7] = eh;
+          for (int r = 0; r < 16; ++r) o[w][i][r] *= alpha;
       }
-    l_run = l_run * alpha + psum;
-#pragma unroll
-    for (int i = 0; i < NDB; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+      m_run[w] = m_new;
+    }
 
-    // ---- O^T += V^T P^T : 4 steps of 16 (relabelled) keys ----
+    // ---- O^T += V^T P^T : 4 steps of 16 (relabelled) keys; every V^T fragment feeds QW query blocks ----
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4) {
 #pragma unroll
@@ -166,33 +192,42 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
         const int i16 = lane & 15;
         const int c0 = db * 32 + 16 * ((lane >> 4) & 1) + (i16 & 3) * 4;
         const int r0 = 16 * s4 + 4 * lh + (i16 >> 2);
-        const fp16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((LDS_AS fp16x4_t*)(sV + r0 * LDR + c0));
-        const fp16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((LDS_AS fp16x4_t*)(sV + (r0 + 8) * LDR + c0));
-        f16x8 vf;
+        const fp16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((LDS_AS fp16x4_t*)(cV + r0 * LDR + c0));
+        const fp16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((LDS_AS fp16x4_t*)(cV + (r0 + 8) * LDR + c0));
+        union { fp16x4_t q[2]; f16x8 h; } vf;            // pure register re-interpretation, no conversion
+        vf.q[0] = lo; vf.q[1] = hi;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { vf[e] = (_Float16)lo[e]; vf[4 + e] = (_Float16)hi[e]; }
-        o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[s4], o[db], 0, 0, 0);
+        for (int w = 0; w < QW; ++w)
+          o[w][db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf.h, pf[w][s4], o[w][db], 0, 0, 0);
       }
     }
+
+    // ---- stage tile t+1 into the other buffer (last read during tile t-1, fenced by the previous barrier) ----
+    if (t + 1 < ntiles) lstore((t + 1) & 1);
+    __syncthreads();
+    if (t + 2 < ntiles) gload(t + 2);               // HBM latency hides under the next tile's MFMAs
   }
 
   // ---- finalize: O[q][d] = O^T[d][q] / l ----
-  const float l_tot = l_run + __shfl_xor(l_run, 32);
-  const float inv = 1.0f / l_tot;
-  if (q_ok) {
-    _Float16* op = p.o + ((size_t)b * p.Sq + q_row) * p.ldo + head * D;
 #pragma unroll
-    for (int db = 0; db < NDB; ++db)
+  for (int w = 0; w < QW; ++w) {
+    const float l_tot = l_run[w] + __shfl_xor(l_run[w], 32);
+    const float inv = 1.0f / l_tot;
+    if (q_ok[w]) {
+      _Float16* op = p.o + ((size_t)b * p.Sq + q_row[w]) * p.ldo + head * D;
 #pragma unroll
-      for (int rq = 0; rq < 4; ++rq) {
-        const int d0 = db * 32 + 8 * rq + 4 * lh;
-        if (d0 < D) {
-          f16x4 hv;
+      for (int db = 0; db < NDB; ++db)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) hv[e] = (_Float16)(o[db][rq * 4 + e] * inv);
-          *(f16x4*)(op + d0) = hv;
+        for (int rq = 0; rq < 4; ++rq) {
+          const int d0 = db * 32 + 8 * rq + 4 * lh;
+          if (d0 < D) {
+            f16x4 hv;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) hv[e] = (_Float16)(o[w][db][rq * 4 + e] * inv);
+            *(f16x4*)(op + d0) = hv;
+          }
         }
-      }
+    }
   }
 }
 
@@ -294,8 +329,16 @@ static hipError_t launch_d(const AttnParams& p, hipStream_t s) {
     const long rows = (long)p.B * p.heads * p.Sq;
     hipLaunchKernelGGL((attn_map_kernel<D>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, p);
   } else {
-    const int nqb = (p.Sq + QB - 1) / QB;
-    hipLaunchKernelGGL((attn_kernel<D>), dim3(p.B * p.heads * nqb), dim3(256), 0, s, p);
+    // 64 query rows per wave (every K / V fragment feeds two MFMAs) when the sequence is long and the
+    // accumulators fit (D <= 64); 32 rows per wave otherwise
+    constexpr bool can2 = D <= 64;
+    if (can2 && p.Sq >= 512) {
+      const int nqb = (p.Sq + 255) / 256;
+      hipLaunchKernelGGL((attn_kernel<D, can2 ? 2 : 1>), dim3(p.B * p.heads * nqb), dim3(256), 0, s, p);
+    } else {
+      const int nqb = (p.Sq + 127) / 128;
+      hipLaunchKernelGGL((attn_kernel<D, 1>), dim3(p.B * p.heads * nqb), dim3(256), 0, s, p);
+    }
   }
   return hipGetLastError();
 }
