@@ -65,7 +65,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 template <int MODE, int BM, int BN, int STAGES, bool GEGLU>
 __global__ __launch_bounds__(BM * 2, 2) void gemm_kernel(const GemmParams p) {
   constexpr int NW = BM / 32;                    // waves per workgroup (4 or 8)
-  constexpr int WGN = (BN >= 128) ? 2 : 1;       // waves along N
+  constexpr int WGN = (BN == 320) ? 4 : (BN >= 128) ? 2 : 1;   // waves along N
   constexpr int WGM = NW / WGN;                  // waves along M
   constexpr int WTM = BM / WGM;                  // 64 or 32
   constexpr int WTN = BN / WGN;                  // 80, 64 or 16
@@ -173,29 +173,38 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_kernel(const GemmParams p) {
   const int wm = wave / WGN, wn = wave - wm * WGN;
   const int frow = lane & 15, fk = lane >> 4;
 
-  auto compute = [&](int buf) {
+  // One K-tile = two 32-deep MFMA steps (kk = 0, 1): 2 x (FM + FN) ds_read_b128 and 2 x FM x FN MFMAs per wave.
+  // A wave issues in order, so its own DMA issue (a `buffer_load ... lds` costs ~60-180 issue cycles) cannot overlap
+  // its own MFMAs; the overlap comes from the partner wave on the same SIMD.  With 8 waves the two waves of a SIMD
+  // (w, w+4) therefore run the head of a K-tile in opposite orders (EARLY_MMA): one issues the next tile's DMA
+  // while the other already multiplies.  (Measured and rejected: rotating the loop by half a tile so that MFMAs from
+  // registers follow the barrier, 929 -> 684 TFLOP/s on the 256x320 GEGLU GEMM; a two-group ping-pong with 2 barriers
+  // per K-tile, 1002 -> 903 at 8192^3.)
+  f16x8 af[FM], bf[FN];
+  auto read_kk = [&](int buf, int kk) {
     const char* sA = smem + buf * STAGE;
     const char* sB = sA + A_TILE;
+    const int kc = kk * 4 + fk;
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      f16x8 af[FM], bf[FN];
-      const int kc = kk * 4 + fk;
+    for (int i = 0; i < FM; ++i) {
+      const int r = wm * WTM + i * 16 + frow;
+      af[i] = *(const f16x8*)(sA + r * 128 + ((kc ^ (r & 7)) << 4));
+    }
 #pragma unroll
-      for (int i = 0; i < FM; ++i) {
-        const int r = wm * WTM + i * 16 + frow;
-        af[i] = *(const f16x8*)(sA + r * 128 + ((kc ^ (r & 7)) << 4));
-      }
-#pragma unroll
-      for (int j = 0; j < FN; ++j) {
-        const int r = wn * WTN + j * 16 + frow;
-        bf[j] = *(const f16x8*)(sB + r * 128 + ((kc ^ (r & 7)) << 4));
-      }
-#pragma unroll
-      for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+    for (int j = 0; j < FN; ++j) {
+      const int r = wn * WTN + j * 16 + frow;
+      bf[j] = *(const f16x8*)(sB + r * 128 + ((kc ^ (r & 7)) << 4));
     }
   };
+  auto mma = [&]() {
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+  };
+  // compile-time off for the 256x320 variant: its 160 accumulator VGPRs leave no room for the second code path
+  constexpr bool EARLY_OK = (NW == 8) && (FM * FN <= 16);
+  const bool early_mma = EARLY_OK && !p.no_early_mma && (wave >= 4);
 
   if (STAGES == 2) {
     issue(0, 0);
@@ -203,12 +212,17 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_kernel(const GemmParams p) {
       // tile kt has landed (all outstanding DMA of this wave) and every wave is done reading buf[(kt+1)&1]
       wait_vmcnt<0>();
       __syncthreads();
-      if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
-      compute(kt & 1);
+      if (early_mma) {
+        read_kk(kt & 1, 0); mma();
+        if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+      } else {
+        if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+        read_kk(kt & 1, 0); mma();
+      }
+      read_kk(kt & 1, 1); mma();
     }
   } else {
-    // 3-stage ring: DMA of tiles kt+1 and kt+2 overlaps the MFMAs of tile kt; counted waits, raw barrier.
-    // (A two-group ping-pong schedule with 2 barriers per K-tile was measured slower: 903 vs 1002 TFLOP/s at 8192^3.)
+    // 3-stage ring: DMA of tiles kt+1 and kt+2 overlaps the MFMAs of tile kt; counted waits (never 0 in steady state)
     issue(0, 0);
     if (nk > 1) issue(1, 1);
     int cur = 0;
@@ -216,8 +230,14 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_kernel(const GemmParams p) {
       if (kt + 1 < nk) wait_vmcnt<LPT>(); else wait_vmcnt<0>();   // this wave's share of tile kt has landed
       __builtin_amdgcn_s_barrier();                                // ... everyone's has; tile kt-1 fully consumed
       int nxt2 = cur + 2; if (nxt2 >= 3) nxt2 -= 3;
-      if (kt + 2 < nk) issue(kt + 2, nxt2);
-      compute(cur);
+      if (early_mma) {
+        read_kk(cur, 0); mma();
+        if (kt + 2 < nk) issue(kt + 2, nxt2);
+      } else {
+        if (kt + 2 < nk) issue(kt + 2, nxt2);
+        read_kk(cur, 0); mma();
+      }
+      read_kk(cur, 1); mma();
       if (++cur == 3) cur = 0;
     }
   }
@@ -228,13 +248,14 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_kernel(const GemmParams p) {
   // it, so the pass itself is LDS + stores only (a dependent global load per iteration made the first
   // version of this epilogue latency bound: ~17k cycles per tile).
   constexpr int SLD = WTN + 4;                         // padded row length (floats)
-  constexpr int PASSES = WTM / 32;                     // 2 (64-row wave tile) or 1
-  constexpr int FPP = FM / PASSES;                     // 16-row fragments per pass (2)
-  float* st = (float*)(smem) + wave * (32 * SLD);
+  constexpr int PR = (FM >= 8) ? 16 : 32;              // rows per staging pass (16 for the 128-row wave tile: VGPR budget)
+  constexpr int PASSES = WTM / PR;
+  constexpr int FPP = FM / PASSES;                     // 16-row fragments per pass
+  float* st = (float*)(smem) + wave * (PR * SLD);
   constexpr int OUTW = GEGLU ? WTN / 2 : WTN;          // output columns produced by this wave tile
   constexpr int LPR = OUTW / 8;                        // lanes per row (8 output columns per lane)
   constexpr int RPI = 64 / LPR;                        // rows per iteration (lanes >= RPI*LPR idle when LPR = 5 or 10)
-  constexpr int NIT = (32 + RPI - 1) / RPI;            // iterations per pass
+  constexpr int NIT = (PR + RPI - 1) / RPI;            // iterations per pass
   constexpr int GOFF = WTN / 2;                        // GEGLU: gate columns follow the h columns inside a wave tile
   const bool lane_ok = lane < RPI * LPR;
   const int Nout = GEGLU ? p.N / 2 : p.N;
@@ -270,16 +291,14 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_kernel(const GemmParams p) {
     // ---- prefetch this pass's residual / row-vector operands (overlaps the LDS staging below) ----
     // `opnd` holds the fp32 residual, or the temb row vector when there is no fp32 residual (the plan never
     // combines the two: conv1 = bias + temb, conv2 / out-projections = bias + residual).
-    f32x4 opnd[NIT][2];
-    f16x8 r16[NIT];
+    f32x4 opnd[NIT][2];                                  // an fp16 residual travels as raw bits in opnd[it][0]
     const bool rv_in_opnd = p.rowvec && !p.res32;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int lrp = it * RPI + lane / LPR;
-      const int row = m0 + wm * WTM + ps * 32 + lrp;
-      const bool okr = full && lane_ok && lrp < 32 && row < p.M;
+      const int row = m0 + wm * WTM + ps * PR + lrp;
+      const bool okr = full && lane_ok && lrp < PR && row < p.M;
       opnd[it][0] = opnd[it][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-      r16[it] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
       if (okr) {
         if (p.res32) {
           const f32x4* rp = (const f32x4*)(p.res32 + (size_t)row * p.ldres + col);
@@ -288,7 +307,7 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_kernel(const GemmParams p) {
           const f32x4* rv = (const f32x4*)(p.rowvec + (size_t)(row / p.rows_per_sample) * p.ldrv + col);
           opnd[it][0] = rv[0]; opnd[it][1] = rv[1];
         }
-        if (p.res16 && !p.res32) r16[it] = *(const f16x8*)(p.res16 + (size_t)row * p.ldres + col);
+        if (p.res16 && !p.res32 && !p.rowvec) opnd[it][0] = *(const f32x4*)(p.res16 + (size_t)row * p.ldres + col);
       }
     }
 #pragma unroll
@@ -303,9 +322,9 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_kernel(const GemmParams p) {
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       int lr = it * RPI + lane / LPR;
-      const bool act = lane_ok && lr < 32;
+      const bool act = lane_ok && lr < PR;
       if (!act) lr = 0;
-      const int row = m0 + wm * WTM + ps * 32 + lr;
+      const int row = m0 + wm * WTM + ps * PR + lr;
       float v[8];
       if (GEGLU) {
         const f32x4 h0 = *(const f32x4*)(st + lr * SLD + lc), h1 = *(const f32x4*)(st + lr * SLD + lc + 4);
@@ -340,8 +359,13 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_kernel(const GemmParams p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v[e] += opnd[it][0][e]; v[4 + e] += opnd[it][1][e]; }
           }
+          else if (p.res16) {
+            f16x8 rh;
+            if (!p.rowvec) rh = __builtin_bit_cast(f16x8, opnd[it][0]);
+            else rh = *(const f16x8*)(p.res16 + (size_t)row * p.ldres + col);     // (not produced by the plan)
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += (float)r16[it][e];
+            for (int e = 0; e < 8; ++e) v[e] += (float)rh[e];
+          }
           if (p.out16) {
             f16x8 hv;
 #pragma unroll
@@ -394,10 +418,15 @@ static int pick_variant(const GemmParams& p) {
   if (p.bn == 16) return 16;
   if (p.variant) return p.variant;
   const long tiles256 = (long)((p.M + 255) / 256) * ((p.N + 127) / 128);
-  if (p.geglu) return tiles256 >= 512 ? 256 : 128;                       // measured: 801 vs 662 TFLOP/s (C=1280)
-  if (p.mode != A_DENSE) return (p.N % 160 == 0) ? 160 : 128;            // convs: 1000-1107 vs 800-1020
-  if (p.N % 160 == 0 && p.K >= 1024) return 160;                         // ff_out 914, qkv 858, attn2_q 889
-  if ((long)p.M * p.N >= (1L << 26) && tiles256 >= 512) return 256;      // short-K, large MxN (qkv @ C=640): 706 vs 645
+  const long tiles320 = (long)((p.M + 255) / 256) * ((p.N + 319) / 320);
+  if (p.geglu == 40) return (p.N % 320 == 0 && tiles320 >= 128) ? 320 : 160;   // 929 TFLOP/s at C = 1280 (812 with 256x128)
+  if (p.geglu) return tiles256 >= 512 ? 256 : 128;
+  if (p.mode != A_DENSE) {                                                 // convs (K = 9 Cin is long)
+    if (p.N % 320 == 0 && p.K >= 5760 && tiles320 >= 128) return 320;     // 1070-1236 TFLOP/s
+    return (p.N % 160 == 0) ? 160 : 128;                                   // 1000-1107
+  }
+  if (p.N % 160 == 0 && p.K >= 1024) return 160;                           // ff_out 908, qkv 857, attn2_q 880
+  if ((long)p.M * p.N >= (1L << 26) && tiles256 >= 512) return 256;        // short-K, large MxN (qkv @ C=640): 712 vs 642
   return 128;
 }
 
@@ -409,7 +438,10 @@ hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {
   if (p.geglu) {
     // the weight rows were interleaved for one specific wave-tile width: group 40 <-> BN 160, group 32 <-> BN 128/256x128
     if (p.mode != A_DENSE) return hipErrorInvalidValue;
-    if (p.geglu == 40) return (p.N % 80) ? hipErrorInvalidValue : launch_t<A_DENSE, 128, 160, 2, true>(p, s);
+    if (p.geglu == 40) {
+      if (p.N % 80) return hipErrorInvalidValue;
+      return v == 320 ? launch_t<A_DENSE, 256, 320, 2, true>(p, s) : launch_t<A_DENSE, 128, 160, 2, true>(p, s);
+    }
     if (p.N % 64) return hipErrorInvalidValue;
     return v == 256 ? launch_t<A_DENSE, 256, 128, 3, true>(p, s) : launch_t<A_DENSE, 128, 128, 2, true>(p, s);
   }
@@ -421,10 +453,12 @@ hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {
   switch (p.mode) {
     case A_DENSE:
       if (v == 160) return launch_t<A_DENSE, 128, 160, 2, false>(p, s);
+      if (v == 320) return launch_t<A_DENSE, 256, 320, 2, false>(p, s);
       if (v == 256) return launch_t<A_DENSE, 256, 128, 3, false>(p, s);
       return launch_t<A_DENSE, 128, 128, 2, false>(p, s);
     case A_CONV3:
       if (v == 160) return launch_t<A_CONV3, 128, 160, 2, false>(p, s);
+      if (v == 320) return launch_t<A_CONV3, 256, 320, 2, false>(p, s);
       if (v == 256) return launch_t<A_CONV3, 256, 128, 3, false>(p, s);
       return launch_t<A_CONV3, 128, 128, 2, false>(p, s);
     case A_CONV_SMALLC:

@@ -48,6 +48,7 @@ struct GemmParams {
   int ldaux;
   int geglu;             // 0, or the interleave group of the weight rows: 32 (BN 128) / 40 (BN 160)
   int bn;                // 128 (default) or 16 (very narrow N, e.g. conv_out)
+  int no_early_mma;      // diagnostics: disable the opposite-order heads of the two waves sharing a SIMD (256x128 variant)
   int variant;           // 0 = auto; 128 / 160 / 256 force the 128x128, 128x160 or 256x128 tile (diagnostics)
 };
 hipError_t launch_gemm(const GemmParams& p, hipStream_t s);

@@ -21,7 +21,7 @@ int gdf_op_gemm(const void* A, int lda, const void* W, const float* bias, const 
   g.Wt = (const half_t*)W; g.w_bytes = (uint32_t)((size_t)N * K * 2);
   g.bias = bias; g.res32 = res32; g.res16 = (const half_t*)res16; g.ldres = ldres;
   g.out16 = (half_t*)out16; g.ldo16 = ldo16; g.out32 = out32; g.ldo32 = ldo32;
-  g.geglu = (flags & 1) ? ((flags & 8) ? 40 : 32) : 0; g.bn = (flags & 2) ? 16 : 128; g.variant = flags >> 8; g.rows_per_sample = 1;
+  g.geglu = (flags & 1) ? ((flags & 8) ? 40 : 32) : 0; g.bn = (flags & 2) ? 16 : 128; g.variant = (flags >> 8) & 0xfff; g.no_early_mma = (flags >> 20) & 1; g.rows_per_sample = 1;
   return fin(launch_gemm(g, (hipStream_t)stream), "gemm");
 }
 
@@ -39,7 +39,7 @@ int gdf_op_conv3x3(const void* x, int ld, int B, int H, int W, int Cin, const vo
   g.res32 = res32; g.ldres = Cout;
   g.aux16 = (half_t*)aux16; g.ldaux = Cout;
   g.out16 = (half_t*)out16; g.ldo16 = Cout; g.out32 = out32; g.ldo32 = Cout;
-  g.bn = (narrow & 1) ? 16 : 128; g.variant = narrow >> 8;
+  g.bn = (narrow & 1) ? 16 : 128; g.variant = (narrow >> 8) & 0xfff; g.no_early_mma = (narrow >> 20) & 1;
   return fin(launch_gemm(g, (hipStream_t)stream), "conv3x3");
 }
 
