@@ -47,7 +47,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 // one v_exp_f32 + one v_rcp_f32 instead of libm's branchy erff (the GEGLU epilogue evaluates 32 of these per lane).
 __device__ __forceinline__ float gelu_erf(float x) {
   const float z = fabsf(x) * 0.70710678118654752f;
-  const float t = __frcp_rn(1.0f + 0.3275911f * z);
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);     // v_rcp_f32 (1 ulp), not the IEEE division sequence
   const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
   const float erf_abs = 1.0f - poly * __expf(-z * z);
   const float erf_x = copysignf(erf_abs, x);
@@ -65,7 +65,9 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 template <int MODE, int BM, int BN, int STAGES, bool GEGLU>
 __global__ __launch_bounds__(BM * 2, 2) void gemm_kernel(const GemmParams p) {
   constexpr int NW = BM / 32;                    // waves per workgroup (4 or 8)
-  constexpr int WGN = (BN == 320) ? 4 : (BN >= 128) ? 2 : 1;   // waves along N
+  // waves along N (the GEGLU form of the 256x320 tile uses 4x2 waves of 64x160: an EVEN number of 16-column fragments,
+  // so that every h fragment has its gate fragment in the same lane and register index)
+  constexpr int WGN = (BN == 320 && !GEGLU) ? 4 : (BN >= 128) ? 2 : 1;
   constexpr int WGM = NW / WGN;                  // waves along M
   constexpr int WTM = BM / WGM;                  // 64 or 32
   constexpr int WTN = BN / WGN;                  // 80, 64 or 16
@@ -247,16 +249,21 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_kernel(const GemmParams p) {
   // Every epilogue operand (bias, temb row vector, residual) is fetched BEFORE the staging pass that needs
   // it, so the pass itself is LDS + stores only (a dependent global load per iteration made the first
   // version of this epilogue latency bound: ~17k cycles per tile).
-  constexpr int SLD = WTN + 4;                         // padded row length (floats)
-  constexpr int PR = (FM >= 8) ? 16 : 32;              // rows per staging pass (16 for the 128-row wave tile: VGPR budget)
+  // GEGLU is evaluated IN REGISTERS before staging: weight rows are interleaved [16 h | 16 gate], fragment 2q holds h and
+  // fragment 2q+1 the gate of the same 16 output columns in the same lane / register index -> all 64 lanes busy, half
+  // the staging traffic (the first version staged h and gate and ran the GELU on 40 of 64 lanes: 17 us per tile).
+  static_assert(!GEGLU || (FN % 2 == 0), "GEGLU needs an even number of column fragments per wave");
+  constexpr int FNV = GEGLU ? FN / 2 : FN;             // staged 16-column fragments
+  constexpr int WTNV = FNV * 16;                       // staged (= output) columns of this wave tile
+  constexpr int SLD = WTNV + 4;                        // padded row length (floats)
+  constexpr int PR = (FM * FN >= 40) ? 16 : 32;        // rows per staging pass (16 for the 160-accumulator tiles: VGPR budget)
   constexpr int PASSES = WTM / PR;
   constexpr int FPP = FM / PASSES;                     // 16-row fragments per pass
   float* st = (float*)(smem) + wave * (PR * SLD);
-  constexpr int OUTW = GEGLU ? WTN / 2 : WTN;          // output columns produced by this wave tile
+  constexpr int OUTW = WTNV;                           // output columns produced by this wave tile
   constexpr int LPR = OUTW / 8;                        // lanes per row (8 output columns per lane)
   constexpr int RPI = 64 / LPR;                        // rows per iteration (lanes >= RPI*LPR idle when LPR = 5 or 10)
   constexpr int NIT = (PR + RPI - 1) / RPI;            // iterations per pass
-  constexpr int GOFF = WTN / 2;                        // GEGLU: gate columns follow the h columns inside a wave tile
   const bool lane_ok = lane < RPI * LPR;
   const int Nout = GEGLU ? p.N / 2 : p.N;
   const int ocol0 = GEGLU ? (n0 + wn * WTN) / 2 : (n0 + wn * WTN);
@@ -265,121 +272,155 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_kernel(const GemmParams p) {
   const int nv = (col < Nout) ? ((Nout - col >= 8) ? 8 : (Nout - col)) : 0;
   const bool full = nv == 8;
 
-  float bv[8], bg[8];                                  // bias (GEGLU: h-part / gate-part, interleaved column order)
+  float bv[8];                                         // bias of this lane's 8 output columns (plain epilogue)
+  float bh[FNV], bgt[FNV];                             // GEGLU: bias of this lane's h / gate accumulator column per fragment pair
 #pragma unroll
-  for (int e = 0; e < 8; ++e) { bv[e] = 0.f; bg[e] = 0.f; }
+  for (int e = 0; e < 8; ++e) bv[e] = 0.f;
+#pragma unroll
+  for (int j = 0; j < FNV; ++j) { bh[j] = 0.f; bgt[j] = 0.f; }
   if (p.bias) {
     if (GEGLU) {
-      const int bcol = n0 + wn * WTN + lc;
-      if (lane_ok && bcol + GOFF + 8 <= p.N) {
-        const f32x4 a0 = *(const f32x4*)(p.bias + bcol), a1 = *(const f32x4*)(p.bias + bcol + 4);
-        const f32x4 c0 = *(const f32x4*)(p.bias + bcol + GOFF), c1 = *(const f32x4*)(p.bias + bcol + GOFF + 4);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { bv[e] = a0[e]; bv[4 + e] = a1[e]; bg[e] = c0[e]; bg[4 + e] = c1[e]; }
+      for (int j = 0; j < FNV; ++j) {
+        const int bcol = n0 + wn * WTN + j * 32 + frow;  // bias is stored in the interleaved GEMM column order
+        if (bcol + 16 < p.N) { bh[j] = p.bias[bcol]; bgt[j] = p.bias[bcol + 16]; }
       }
     } else if (full) {
       const f32x4 a0 = *(const f32x4*)(p.bias + col), a1 = *(const f32x4*)(p.bias + col + 4);
 #pragma unroll
       for (int e = 0; e < 4; ++e) { bv[e] = a0[e]; bv[4 + e] = a1[e]; }
-    } else {
+    } else if (BN == 16) {
       for (int e = 0; e < nv; ++e) bv[e] = p.bias[col + e];
     }
   }
 
+  // Uniform epilogue flags are tested OUTSIDE the per-iteration loops (one scalar branch per flag and pass; the
+  // first version branched inside every unrolled iteration: ~800 basic blocks, no overlap between iterations).
+  constexpr bool RAGGED = (BN == 16);                    // only the narrow-N variant handles N % 8 != 0 (host-checked)
+  const bool rv_in_opnd = p.rowvec && !p.res32;
 #pragma unroll
   for (int ps = 0; ps < PASSES; ++ps) {
     // ---- prefetch this pass's residual / row-vector operands (overlaps the LDS staging below) ----
     // `opnd` holds the fp32 residual, or the temb row vector when there is no fp32 residual (the plan never
     // combines the two: conv1 = bias + temb, conv2 / out-projections = bias + residual).
     f32x4 opnd[NIT][2];                                  // an fp16 residual travels as raw bits in opnd[it][0]
-    const bool rv_in_opnd = p.rowvec && !p.res32;
+    int rowi[NIT];
+    bool okr[NIT];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int lrp = it * RPI + lane / LPR;
-      const int row = m0 + wm * WTM + ps * PR + lrp;
-      const bool okr = full && lane_ok && lrp < PR && row < p.M;
+      rowi[it] = m0 + wm * WTM + ps * PR + lrp;
+      okr[it] = (RAGGED ? nv > 0 : full) && lane_ok && lrp < PR && rowi[it] < p.M;
       opnd[it][0] = opnd[it][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (okr) {
-        if (p.res32) {
-          const f32x4* rp = (const f32x4*)(p.res32 + (size_t)row * p.ldres + col);
-          opnd[it][0] = rp[0]; opnd[it][1] = rp[1];
-        } else if (p.rowvec) {
-          const f32x4* rv = (const f32x4*)(p.rowvec + (size_t)(row / p.rows_per_sample) * p.ldrv + col);
-          opnd[it][0] = rv[0]; opnd[it][1] = rv[1];
-        }
-        if (p.res16 && !p.res32 && !p.rowvec) opnd[it][0] = *(const f32x4*)(p.res16 + (size_t)row * p.ldres + col);
+    }
+    if (!RAGGED) {
+      if (p.res32) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it)
+          if (okr[it]) {
+            const f32x4* rp = (const f32x4*)(p.res32 + (size_t)rowi[it] * p.ldres + col);
+            opnd[it][0] = rp[0]; opnd[it][1] = rp[1];
+          }
+      } else if (p.rowvec) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it)
+          if (okr[it]) {
+            const f32x4* rv = (const f32x4*)(p.rowvec + (size_t)(rowi[it] / p.rows_per_sample) * p.ldrv + col);
+            opnd[it][0] = rv[0]; opnd[it][1] = rv[1];
+          }
+      } else if (p.res16) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it)
+          if (okr[it]) opnd[it][0] = *(const f32x4*)(p.res16 + (size_t)rowi[it] * p.ldres + col);
       }
     }
 #pragma unroll
     for (int i2 = 0; i2 < FPP; ++i2)
 #pragma unroll
-      for (int j = 0; j < FN; ++j)
+      for (int j = 0; j < FNV; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          st[(i2 * 16 + fk * 4 + r) * SLD + j * 16 + frow] = acc[ps * FPP + i2][j][r];
+        for (int r = 0; r < 4; ++r) {
+          float x;
+          if (GEGLU) x = (acc[ps * FPP + i2][2 * j][r] + bh[j]) * gelu_erf(acc[ps * FPP + i2][2 * j + 1][r] + bgt[j]);
+          else x = acc[ps * FPP + i2][j][r];
+          st[(i2 * 16 + fk * 4 + r) * SLD + j * 16 + frow] = x;
+        }
     // same-wave LDS RAW across lanes: DS ops of one wave execute in order
     __builtin_amdgcn_wave_barrier();
+    float v[NIT][8];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       int lr = it * RPI + lane / LPR;
-      const bool act = lane_ok && lr < PR;
-      if (!act) lr = 0;
-      const int row = m0 + wm * WTM + ps * PR + lr;
-      float v[8];
-      if (GEGLU) {
-        const f32x4 h0 = *(const f32x4*)(st + lr * SLD + lc), h1 = *(const f32x4*)(st + lr * SLD + lc + 4);
-        const f32x4 g0 = *(const f32x4*)(st + lr * SLD + GOFF + lc), g1 = *(const f32x4*)(st + lr * SLD + GOFF + lc + 4);
+      if (!(lane_ok && lr < PR)) lr = 0;
+      const f32x4 x0 = *(const f32x4*)(st + lr * SLD + lc), x1 = *(const f32x4*)(st + lr * SLD + lc + 4);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          v[e] = (h0[e] + bv[e]) * gelu_erf(g0[e] + bg[e]);
-          v[4 + e] = (h1[e] + bv[4 + e]) * gelu_erf(g1[e] + bg[4 + e]);
-        }
-      } else {
-        const f32x4 x0 = *(const f32x4*)(st + lr * SLD + lc), x1 = *(const f32x4*)(st + lr * SLD + lc + 4);
+      for (int e = 0; e < 4; ++e) { v[it][e] = x0[e] + bv[e]; v[it][4 + e] = x1[e] + bv[4 + e]; }
+    }
+    if (!RAGGED) {
+      if (rv_in_opnd) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { v[e] = x0[e] + bv[e]; v[4 + e] = x1[e] + bv[4 + e]; }
+        for (int it = 0; it < NIT; ++it)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { v[it][e] += opnd[it][0][e]; v[it][4 + e] += opnd[it][1][e]; }
+      } else if (p.rowvec) {                             // (not produced by the plan) temb AND fp32 residual: late load
+#pragma unroll
+        for (int it = 0; it < NIT; ++it)
+          if (okr[it]) {
+            const f32x4* rv = (const f32x4*)(p.rowvec + (size_t)(rowi[it] / p.rows_per_sample) * p.ldrv + col);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[it][e] += rv[0][e]; v[it][4 + e] += rv[1][e]; }
+          }
       }
-      if (act && row < p.M && nv > 0) {
-        if (full) {
-          if (rv_in_opnd) {
+      if (p.aux16) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { v[e] += opnd[it][0][e]; v[4 + e] += opnd[it][1][e]; }
-          } else if (p.rowvec) {                       // (not produced by the plan) temb AND fp32 residual: late load
-            const f32x4* rv = (const f32x4*)(p.rowvec + (size_t)(row / p.rows_per_sample) * p.ldrv + col);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { v[e] += rv[0][e]; v[4 + e] += rv[1][e]; }
-          }
-          if (p.aux16) {
+        for (int it = 0; it < NIT; ++it)
+          if (okr[it]) {
             f16x8 hv;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) hv[e] = (_Float16)v[e];
-            *(f16x8*)(p.aux16 + (size_t)row * p.ldaux + col) = hv;
+            for (int e = 0; e < 8; ++e) hv[e] = (_Float16)v[it][e];
+            *(f16x8*)(p.aux16 + (size_t)rowi[it] * p.ldaux + col) = hv;
           }
-          if (p.res32) {
+      }
+      if (p.res32) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { v[e] += opnd[it][0][e]; v[4 + e] += opnd[it][1][e]; }
-          }
-          else if (p.res16) {
-            f16x8 rh;
-            if (!p.rowvec) rh = __builtin_bit_cast(f16x8, opnd[it][0]);
-            else rh = *(const f16x8*)(p.res16 + (size_t)row * p.ldres + col);     // (not produced by the plan)
+        for (int it = 0; it < NIT; ++it)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += (float)rh[e];
-          }
-          if (p.out16) {
+          for (int e = 0; e < 4; ++e) { v[it][e] += opnd[it][0][e]; v[it][4 + e] += opnd[it][1][e]; }
+      } else if (p.res16) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+          f16x8 rh = __builtin_bit_cast(f16x8, opnd[it][0]);
+          if (p.rowvec && okr[it]) rh = *(const f16x8*)(p.res16 + (size_t)rowi[it] * p.ldres + col);   // (not produced by the plan)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[it][e] += (float)rh[e];
+        }
+      }
+      if (p.out16) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it)
+          if (okr[it]) {
             f16x8 hv;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) hv[e] = (_Float16)v[e];
-            *(f16x8*)(p.out16 + (size_t)row * p.ldo16 + col) = hv;
+            for (int e = 0; e < 8; ++e) hv[e] = (_Float16)v[it][e];
+            *(f16x8*)(p.out16 + (size_t)rowi[it] * p.ldo16 + col) = hv;
           }
-          if (p.out32) {
-            f32x4* op = (f32x4*)(p.out32 + (size_t)row * p.ldo32 + col);
-            op[0] = f32x4{v[0], v[1], v[2], v[3]};
-            op[1] = f32x4{v[4], v[5], v[6], v[7]};
+      }
+      if (p.out32) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it)
+          if (okr[it]) {
+            f32x4* op = (f32x4*)(p.out32 + (size_t)rowi[it] * p.ldo32 + col);
+            op[0] = f32x4{v[it][0], v[it][1], v[it][2], v[it][3]};
+            op[1] = f32x4{v[it][4], v[it][5], v[it][6], v[it][7]};
           }
-        } else {                                         // ragged N tail (e.g. conv_out, N = 4): scalar path
+      }
+    } else {                                             // narrow / ragged N (conv_out, N = 4): scalar path
+#pragma unroll
+      for (int it = 0; it < NIT; ++it)
+        if (okr[it]) {
+          const int row = rowi[it];
           for (int e = 0; e < nv; ++e) {
-            float x = v[e];
+            float x = v[it][e];
             if (p.rowvec) x += p.rowvec[(size_t)(row / p.rows_per_sample) * p.ldrv + col + e];
             if (p.aux16) p.aux16[(size_t)row * p.ldaux + col + e] = (_Float16)x;
             if (p.res32) x += p.res32[(size_t)row * p.ldres + col + e];
@@ -388,7 +429,6 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_kernel(const GemmParams p) {
             if (p.out32) p.out32[(size_t)row * p.ldo32 + col + e] = x;
           }
         }
-      }
     }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_sched_barrier(0);                   // keep the next pass's prefetch from being hoisted (VGPR pressure)
@@ -419,13 +459,16 @@ static int pick_variant(const GemmParams& p) {
   if (p.variant) return p.variant;
   const long tiles256 = (long)((p.M + 255) / 256) * ((p.N + 127) / 128);
   const long tiles320 = (long)((p.M + 255) / 256) * ((p.N + 319) / 320);
-  if (p.geglu == 40) return (p.N % 320 == 0 && tiles320 >= 128) ? 320 : 160;   // 929 TFLOP/s at C = 1280 (812 with 256x128)
-  if (p.geglu) return tiles256 >= 512 ? 256 : 128;
+  if (p.geglu) {
+    if (p.N % 320 == 0 && tiles320 >= 128) return 320;
+    return tiles256 >= 512 ? 256 : 128;
+  }
   if (p.mode != A_DENSE) {                                                 // convs (K = 9 Cin is long)
     if (p.N % 320 == 0 && p.K >= 5760 && tiles320 >= 128) return 320;     // 1070-1236 TFLOP/s
     return (p.N % 160 == 0) ? 160 : 128;                                   // 1000-1107
   }
-  if (p.N % 160 == 0 && p.K >= 1024) return 160;                           // ff_out 908, qkv 857, attn2_q 880
+  if (p.N % 320 == 0 && tiles320 >= 128) return 320;                       // qkv 1049, ff_out 1009, attn2_q 1046, shortcut 1044
+  if (p.N % 160 == 0 && p.K >= 1024) return 160;
   if ((long)p.M * p.N >= (1L << 26) && tiles256 >= 512) return 256;        // short-K, large MxN (qkv @ C=640): 712 vs 642
   return 128;
 }
@@ -435,14 +478,11 @@ hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {
   if (p.mode != A_CONV_SMALLC && (p.K % BK) != 0) return hipErrorInvalidValue;
   if (p.mode == A_CONV3 && (p.Cin % BK) != 0) return hipErrorInvalidValue;
   const int v = pick_variant(p);
+  if (v != 16 && ((p.geglu ? p.N / 2 : p.N) % 8) != 0) return hipErrorInvalidValue;   // ragged N only in the BN = 16 variant
   if (p.geglu) {
-    // the weight rows were interleaved for one specific wave-tile width: group 40 <-> BN 160, group 32 <-> BN 128/256x128
-    if (p.mode != A_DENSE) return hipErrorInvalidValue;
-    if (p.geglu == 40) {
-      if (p.N % 80) return hipErrorInvalidValue;
-      return v == 320 ? launch_t<A_DENSE, 256, 320, 2, true>(p, s) : launch_t<A_DENSE, 128, 160, 2, true>(p, s);
-    }
-    if (p.N % 64) return hipErrorInvalidValue;
+    // weight rows / bias interleaved [16 h | 16 gate] (launch_relayout_rows geglu = 16)
+    if (p.mode != A_DENSE || (p.N % 32) != 0) return hipErrorInvalidValue;
+    if (v == 320) return launch_t<A_DENSE, 256, 320, 2, true>(p, s);
     return v == 256 ? launch_t<A_DENSE, 256, 128, 3, true>(p, s) : launch_t<A_DENSE, 128, 128, 2, true>(p, s);
   }
   if (v == 16) {

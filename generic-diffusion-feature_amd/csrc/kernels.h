@@ -46,7 +46,7 @@ struct GemmParams {
   int ldo32;
   half_t* aux16;
   int ldaux;
-  int geglu;             // 0, or the interleave group of the weight rows: 32 (BN 128) / 40 (BN 160)
+  int geglu;             // != 0: weight rows / bias are interleaved [16 h | 16 gate]; out = (h) * gelu(gate), N_out = N/2
   int bn;                // 128 (default) or 16 (very narrow N, e.g. conv_out)
   int no_early_mma;      // diagnostics: disable the opposite-order heads of the two waves sharing a SIMD (256x128 variant)
   int variant;           // 0 = auto; 128 / 160 / 256 force the 128x128, 128x160 or 256x128 tile (diagnostics)
@@ -105,7 +105,7 @@ hipError_t launch_small_linear(const float* x, int ldx, int M, int K, const half
 hipError_t launch_relayout_conv(const void* src, int src_f32, half_t* dst, int O, int I, int T, int ipad, int tpad,
                                 hipStream_t s);
 // rows: dst[rowmap(r)][k] = src[r][k] for r in [0,R); rowmap: 0 identity+row_off, 1 GEGLU interleave (half = R/2)
-hipError_t launch_relayout_rows(const void* src, int src_f32, half_t* dst, int R, int K, int row_off, int geglu /*0|32|40*/,
+hipError_t launch_relayout_rows(const void* src, int src_f32, half_t* dst, int R, int K, int row_off, int geglu /*0 or interleave group (16)*/,
                                 hipStream_t s);
 // vectors to fp32 with the same row mapping
 hipError_t launch_relayout_vec(const void* src, int src_f32, float* dst, int R, int row_off, int geglu, hipStream_t s);

@@ -223,9 +223,8 @@ void model_destroy(Model* m) {
   delete m;
 }
 
-// GEGLU interleave group of an [8C][C] projection: 40 (80-column wave tiles of the 256x320 / 128x160 GEMM variants)
-// when 8C is a multiple of 320 — true for every SD / SDXL level — else 32 (64-column wave tiles)
-static int geglu_group(int rows) { return (rows % 320 == 0) ? 40 : 32; }
+// GEGLU projections are stored with rows interleaved [16 h | 16 gate] so the GEMM epilogue can gate in registers
+static int geglu_group(int) { return 16; }
 
 int model_set_param(Model* m, const char* name, const void* src, int dtype, hipStream_t s) {
   auto it = m->index.find(name);

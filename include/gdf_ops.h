@@ -10,8 +10,8 @@ extern "C" {
 #endif
 
 /* out[M,N] = A[M,K](lda) * W[N,K]^T + bias (+ residual).  fp16 operands, fp32 accumulate.
- * flags: bit0 GEGLU (W rows / bias already interleaved by gdf_op_relayout_geglu; out is [M,N/2]); bit3 = the
- *        interleave group is 40 (128x160 tile) instead of 32; bit1 narrow-N tile (BN=16);
+ * flags: bit0 GEGLU (W rows / bias already interleaved [16 h | 16 gate] by gdf_op_relayout_geglu(group 16); out is
+ *        [M,N/2]); bit1 narrow-N tile (BN=16);
  *        bits 8.. force a tile variant (128 / 160 / 256, 0 = auto).  Replaces nn.Linear / 1x1 conv
  *        (/root/reference/feature/diffusers/models/attention_processor.py:241-267, attention.py:1238-1258). */
 int gdf_op_gemm(const void* A, int lda, const void* W, const float* bias, const float* res32, const void* res16,
@@ -52,7 +52,7 @@ int gdf_op_copy2d(const void* s16, const float* s32, int lds, void* dst, int ldd
 
 /* weight re-layout helpers used by the tests: OIHW -> OHWI, GEGLU row interleave. */
 int gdf_op_relayout_conv3(const void* w_oihw_f16, void* dst, int O, int I, void* stream);
-int gdf_op_relayout_geglu(const void* w_f16, const float* bias, void* w_dst, float* bias_dst, int R, int K, int group /*32|40*/, void* stream);
+int gdf_op_relayout_geglu(const void* w_f16, const float* bias, void* w_dst, float* bias_dst, int R, int K, int group /*16*/, void* stream);
 
 #ifdef __cplusplus
 }
