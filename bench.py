@@ -228,16 +228,16 @@ def main():
     ids = PRACTICAL[args.version]
 
     def step():
-        return unet.forward_raw(x, t, ctx, txt, tid, hook_ids=ids)
+        return unet.forward_raw(x, t, ctx, txt, tid, hook_ids=ids, shared_ctx=True)   # one prompt repeated
 
     prof = None
     for w in range(max(1, args.warmup)):
         step()
     torch.cuda.synchronize()
     # pick the dominant kernel from a synchronising per-op pass (untimed), then time it live with HIP events
-    _, _, prof = unet.forward_raw(x, t, ctx, txt, tid, hook_ids=ids, profile=True)
+    _, _, prof = unet.forward_raw(x, t, ctx, txt, tid, hook_ids=ids, profile=True, shared_ctx=True)
     lib = unet.lib
-    plan = unet._plan(B, lat, lat, 77, ids)
+    plan = unet._plan(B, lat, lat, 77, ids, True)
     by_label = {}
     label_of = _label_map(lib)
     for name, ms, fl in prof:

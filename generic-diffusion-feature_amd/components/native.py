@@ -195,6 +195,7 @@ class NativeUNet:
         self.stream_fp32 = bool(stream_fp32)
         self.early_exit = bool(early_exit)
         self.feature_store = None
+        self.shared_ctx = False          # set by FeatureExtractor.extract (it repeats one prompt over the batch)
         self._plans = {}
         self.dtype = torch.float16
         # attributes the reference reads from pipe.unet (diffusion_feature.py:544-547)
@@ -287,12 +288,13 @@ class NativeUNet:
         return bool(self.lib.gdf_model_ready(self.handle))
 
     # ---- plans ------------------------------------------------------------------------------------
-    def _plan(self, batch, h, w, n_ctx, hook_ids):
-        key = (batch, h, w, n_ctx, tuple(hook_ids), self.stream_fp32, self.early_exit)
+    def _plan(self, batch, h, w, n_ctx, hook_ids, shared_ctx=False):
+        key = (batch, h, w, n_ctx, tuple(hook_ids), self.stream_fp32, self.early_exit, bool(shared_ctx))
         p = self._plans.get(key)
         if p is None:
             ids = (C.c_char_p * max(1, len(hook_ids)))(*[s.encode() for s in hook_ids])
             opts = PlanOpts(int(self.stream_fp32), int(self.early_exit))
+            opts.reserved[0] = int(bool(shared_ctx))
             ph = C.c_void_p()
             _check(self.lib.gdf_plan_create(self.handle, batch, h, w, n_ctx, ids, len(hook_ids), C.byref(opts),
                                             C.byref(ph)), "plan_create")
@@ -312,8 +314,10 @@ class NativeUNet:
 
     # ---- forward ------------------------------------------------------------------------------------
     def forward_raw(self, sample, timestep, encoder_hidden_states, text_embeds=None, time_ids=None, hook_ids=None,
-                    profile=False):
-        """Returns (noise_pred (B,4,H,W) view, OrderedDict id -> hook tensor). Inputs must live on self.device."""
+                    profile=False, shared_ctx=False):
+        """Returns (noise_pred (B,4,H,W) view, OrderedDict id -> hook tensor). Inputs must live on self.device.
+        shared_ctx=True promises that every row-block of encoder_hidden_states equals the first one (one prompt repeated
+        over the batch, as FeatureExtractor.extract does): the text K/V projections are then computed once per call."""
         dev = self.device
         B, _, H, W = sample.shape
         sample = sample.to(dev, torch.float16).contiguous()
@@ -335,7 +339,7 @@ class NativeUNet:
         if ctx.shape[0] != B or ctx.shape[2] != self.cfg["cross_attention_dim"]:
             raise ValueError("encoder_hidden_states shape mismatch")
         ids = list(hook_ids) if hook_ids is not None else self.requested_ids()
-        plan = self._plan(B, H, W, ctx.shape[1], ids)
+        plan = self._plan(B, H, W, ctx.shape[1], ids, shared_ctx)
         with torch.cuda.device(dev):
             if plan.workspace is None or plan.workspace.numel() < plan.ws_bytes:
                 plan.workspace = torch.empty(plan.ws_bytes, dtype=torch.uint8, device=dev)
@@ -372,7 +376,7 @@ class NativeUNet:
             raise NotImplementedError("ControlNet residuals are outside the native hot path (SURVEY.md §2 #5)")
         akw = added_cond_kwargs or {}
         noise, hooks = self.forward_raw(sample, timestep, encoder_hidden_states, akw.get("text_embeds"),
-                                        akw.get("time_ids"))
+                                        akw.get("time_ids"), shared_ctx=self.shared_ctx)
         if self.feature_store is not None:
             for hid, t in hooks.items():
                 self.feature_store.store(t, hid)

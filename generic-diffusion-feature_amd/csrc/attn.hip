@@ -79,8 +79,8 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
   }
   const float sl2 = p.scale * 1.44269504088896340736f;    // softmax(x*scale) via exp2
 
-  const _Float16* kbase = p.k + (size_t)b * p.Sk * p.ldk + head * D;
-  const _Float16* vbase = p.v + (size_t)b * p.Sk * p.ldv + head * D;
+  const _Float16* kbase = p.k + (size_t)b * p.kv_bstride * p.ldk + head * D;
+  const _Float16* vbase = p.v + (size_t)b * p.kv_bstride * p.ldv + head * D;
   const int ntiles = (p.Sk + KT - 1) / KT;
 
   f16x8 kreg[NCH], vreg[NCH];
@@ -248,8 +248,8 @@ __global__ __launch_bounds__(256) void attn_map_kernel(const AttnParams p) {
   const int head = (row / p.Sq) % p.heads;
   const int b = row / ((long)p.Sq * p.heads);
   const _Float16* qp = p.q + ((size_t)b * p.Sq + qi) * p.ldq + head * D;
-  const _Float16* kb = p.k + (size_t)b * p.Sk * p.ldk + head * D;
-  const _Float16* vb = p.v + (size_t)b * p.Sk * p.ldv + head * D;
+  const _Float16* kb = p.k + (size_t)b * p.kv_bstride * p.ldk + head * D;
+  const _Float16* vb = p.v + (size_t)b * p.kv_bstride * p.ldv + head * D;
   _Float16* mp = p.map + (size_t)row * p.Sk;
   float qreg[D];
 #pragma unroll

@@ -93,7 +93,8 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_kernel(const GemmParams p) {
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, p.a_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.Wt, 0, p.w_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Wt + (size_t)blockIdx.y * p.w_bstride), 0, p.w_bytes, 0x00020000);
+  _Float16* const out16 = p.out16 ? p.out16 + (size_t)blockIdx.y * p.o_bstride : nullptr;
 
   // ---- per-lane load geometry: one wave-instruction moves 8 rows x 128 B ----
   const int lrow = lane >> 3;                         // row inside an 8-row instruction
@@ -395,14 +396,14 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_kernel(const GemmParams p) {
           for (int e = 0; e < 8; ++e) v[it][e] += (float)rh[e];
         }
       }
-      if (p.out16) {
+      if (out16) {
 #pragma unroll
         for (int it = 0; it < NIT; ++it)
           if (okr[it]) {
             f16x8 hv;
 #pragma unroll
             for (int e = 0; e < 8; ++e) hv[e] = (_Float16)v[it][e];
-            *(f16x8*)(p.out16 + (size_t)rowi[it] * p.ldo16 + col) = hv;
+            *(f16x8*)(out16 + (size_t)rowi[it] * p.ldo16 + col) = hv;
           }
       }
       if (p.out32) {
@@ -425,7 +426,7 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_kernel(const GemmParams p) {
             if (p.aux16) p.aux16[(size_t)row * p.ldaux + col + e] = (_Float16)x;
             if (p.res32) x += p.res32[(size_t)row * p.ldres + col + e];
             else if (p.res16) x += (float)p.res16[(size_t)row * p.ldres + col + e];
-            if (p.out16) p.out16[(size_t)row * p.ldo16 + col + e] = (_Float16)x;
+            if (out16) out16[(size_t)row * p.ldo16 + col + e] = (_Float16)x;
             if (p.out32) p.out32[(size_t)row * p.ldo32 + col + e] = x;
           }
         }
@@ -446,7 +447,7 @@ static hipError_t launch_t(const GemmParams& p, hipStream_t s) {
     if (e != hipSuccess) return e;
     attr_done = true;
   }
-  hipLaunchKernelGGL((gemm_kernel<MODE, BM, BN, STAGES, GEGLU>), dim3(tiles_m * tiles_n), dim3(BM * 2), smem, s, p);
+  hipLaunchKernelGGL((gemm_kernel<MODE, BM, BN, STAGES, GEGLU>), dim3(tiles_m * tiles_n, p.batch > 1 ? p.batch : 1), dim3(BM * 2), smem, s, p);
   return hipGetLastError();
 }
 

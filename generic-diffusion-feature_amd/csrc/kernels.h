@@ -48,6 +48,9 @@ struct GemmParams {
   int ldaux;
   int geglu;             // != 0: weight rows / bias are interleaved [16 h | 16 gate]; out = (h) * gelu(gate), N_out = N/2
   int bn;                // 128 (default) or 16 (very narrow N, e.g. conv_out)
+  int batch;             // > 1: blockIdx.y selects one of `batch` independent problems sharing A (grouped text-K/V projections)
+  long w_bstride;        // elements between consecutive weight matrices
+  long o_bstride;        // elements between consecutive out16 matrices
   int no_early_mma;      // diagnostics: disable the opposite-order heads of the two waves sharing a SIMD (256x128 variant)
   int variant;           // 0 = auto; 128 / 160 / 256 force the 128x128, 128x160 or 256x128 tile (diagnostics)
 };
@@ -63,6 +66,7 @@ struct AttnParams {
   const half_t* v; int ldv;
   half_t* o; int ldo;
   int B, heads, Sq, Sk, D;
+  int kv_bstride;        // rows between consecutive samples' K/V (Sk normally; 0 = all samples share one K/V set)
   float scale;
   half_t* map;           // optional: attention probabilities (B, heads, Sq, Sk) fp16 ('-map' hooks)
 };

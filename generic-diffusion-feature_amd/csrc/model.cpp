@@ -110,7 +110,14 @@ struct ModelBuilder {
       w.o1 = lin(b + ".attn1.to_out.0", c, c);
       w.ln2 = norm(b + ".norm2", c);
       w.q2 = lin(b + ".attn2.to_q", c, c, false);
-      w.kv2 = lin_alloc(2 * c, a.cross_attention_dim, false);
+      {  // slot inside the contiguous group of this width (grouped GEMM over all blocks at plan start)
+        int gi = 0;
+        for (; gi < (int)m.kv_groups.size(); ++gi) if (m.kv_groups[gi].C == c) break;
+        KvGroup& g = m.kv_groups[gi];
+        w.kv_group = gi; w.kv_index = g.next++;
+        w.kv2.n = 2 * c; w.kv2.k = a.cross_attention_dim; w.kv2.has_bias = false; w.kv2.b = NPOS;
+        w.kv2.w = g.base + (size_t)w.kv_index * g.stride;
+      }
       lin_rows(b + ".attn2.to_k", w.kv2, c, 0, false, false);
       lin_rows(b + ".attn2.to_v", w.kv2, c, c, false, false);
       w.o2 = lin(b + ".attn2.to_out.0", c, c);
@@ -139,6 +146,22 @@ struct ModelBuilder {
     if (a.addition_embed_text_time) {
       m.ae1 = lin("add_embedding.linear_1", te, a.add_in_dim);
       m.ae2 = lin("add_embedding.linear_2", te, te);
+    }
+    // contiguous arenas for the cross-attention K/V projection weights, one per channel width
+    for (int lv = 0; lv < L; ++lv) {
+      if (!a.has_attn[lv] && lv != L - 1) continue;
+      int cnt = 0;
+      if (a.has_attn[lv]) cnt += (nl + (nl + 1)) * a.transformer_layers[lv];
+      if (lv == L - 1) cnt += a.transformer_layers[lv];
+      if (!cnt) continue;
+      KvGroup* g = nullptr;
+      for (auto& x : m.kv_groups) if (x.C == boc[lv]) g = &x;
+      if (!g) { m.kv_groups.push_back(KvGroup{}); g = &m.kv_groups.back(); g->C = boc[lv]; }
+      g->count += cnt;
+    }
+    for (auto& g : m.kv_groups) {
+      g.stride = align_up((size_t)2 * g.C * a.cross_attention_dim * 2, 256);
+      g.base = take(g.stride * g.count);
     }
     int ci = boc[0];
     for (int lv = 0; lv < L; ++lv) {
@@ -305,6 +328,7 @@ struct B {   // builder
   int remaining = 0;
   const PlanOpts& opt;
   Ref temb_all{};     // [B][temb_total] f32
+  std::vector<std::pair<size_t, size_t>> kv_bufs;   // per KvGroup: (workspace offset, bytes per block) of the text K/V
 
   B(const Model& mm, Plan& pp, bool d, const PlanOpts& o) : m(mm), P(pp), dry(d), opt(o) {}
 
@@ -426,8 +450,10 @@ struct B {   // builder
     if (x.has_f) { e.res32 = x.f; e.has_r32 = true; e.ldres = x.C; }
     else { e.res16 = x.h; e.has_r16 = true; e.ldres = x.ld; }
   }
-  void out_to(Epi& e, const Act& y) {
-    e.out16 = y.h; e.has_o16 = true; e.ldo16 = y.ld;
+  // need_shadow = false: the fp16 image of a stream tensor is not stored when its only consumers read the fp32
+  // master (LayerNorm + the next residual add): saves one 2-byte/element write per residual GEMM
+  void out_to(Epi& e, const Act& y, bool need_shadow = true) {
+    if (need_shadow || !y.has_f) { e.out16 = y.h; e.has_o16 = true; e.ldo16 = y.ld; }
     if (y.has_f) { e.out32 = y.f; e.has_o32 = true; e.ldo32 = y.C; }
   }
   static void fill_epi(GemmParams& g, const Epi& e, const Bind& b) {
@@ -516,7 +542,8 @@ struct B {   // builder
 
   // ---- attention helper ---------------------------------------------------------------------------
   void attention(const char* name, Ref q, int ldq, Ref k, int ldk, Ref v, int ldv, Ref o, int ldo, int heads, int Sq,
-                 int Sk, int D, int map_slot) {
+                 int Sk, int D, int map_slot, int kv_rows_per_batch = -1) {
+    if (kv_rows_per_batch < 0) kv_rows_per_batch = Sk;
     const int Bq = Bn;
     const double fl = 4.0 * (double)Bn * heads * Sq * Sk * D;
     op(name, fl, [=](const Bind& b, hipStream_t s) {
@@ -524,6 +551,7 @@ struct B {   // builder
       a.q = (const half_t*)b.p(q); a.ldq = ldq; a.k = (const half_t*)b.p(k); a.ldk = ldk;
       a.v = (const half_t*)b.p(v); a.ldv = ldv; a.o = (half_t*)b.p(o); a.ldo = ldo;
       a.B = Bq; a.heads = heads; a.Sq = Sq; a.Sk = Sk; a.D = D; a.scale = 1.0f / sqrtf((float)D);
+      a.kv_bstride = kv_rows_per_batch;
       a.map = map_slot >= 0 ? (half_t*)b.hook(map_slot) : nullptr;
       return launch_attention(a, s);
     });
@@ -540,7 +568,7 @@ struct B {   // builder
     const size_t gn = groupnorm(x, w.gn, 1e-6f, false);
     Act tok = new_act(C, x.H, x.W, true);
     {
-      Epi e; e.bias = wt(w.pin.b); e.has_bias = true; out_to(e, tok);
+      Epi e; e.bias = wt(w.pin.b); e.has_bias = true; out_to(e, tok, /*need_shadow=*/w.blocks.empty());
       gemm("proj_in", ws(gn), C, n, w.pin, C, C, 0, e);
     }
     untmp(gn, n * C * 2);
@@ -561,7 +589,7 @@ struct B {   // builder
       attention("attn1", ws(qkv), 3 * C, ws(qkv + (size_t)C * 2), 3 * C, ws(qkv + (size_t)2 * C * 2), 3 * C, ws(ao), C, heads,
                 S, S, D, ms);
       untmp(qkv, n * 3 * C * 2);
-      { Epi e; e.bias = wt(bw.o1.b); e.has_bias = true; residual_from(e, tok); out_to(e, tok);
+      { Epi e; e.bias = wt(bw.o1.b); e.has_bias = true; residual_from(e, tok); out_to(e, tok, false);
         gemm("attn1_out", ws(ao), C, n, bw.o1, C, C, 0, e); }
       untmp(ao, nb);
       if (stop) break;
@@ -571,15 +599,16 @@ struct B {   // builder
       { Epi e; e.out16 = ws(q2); e.has_o16 = true; e.ldo16 = C; gemm("attn2_q", ws(ln), C, n, bw.q2, C, C, 0, e); }
       untmp(ln, nb);
       hook_copy(want(bid + "-cross-q", C, x.H, x.W), ws(q2), C, n, C);
-      const size_t nkv = (size_t)Bn * n_ctx;
-      const size_t kv = tmp(nkv * 2 * C * 2);
-      { Epi e; e.out16 = ws(kv); e.has_o16 = true; e.ldo16 = 2 * C;
-        gemm("attn2_kv", Ref{BUF_CTX, 0}, m.arch.cross_attention_dim, nkv, bw.kv2, 2 * C, m.arch.cross_attention_dim, 0, e); }
+      // text K/V: precomputed for all blocks by the grouped GEMM at the head of the plan; with one prompt repeated over
+      // the batch (reference diffusion_feature.py:272, opts.reserved[0]) there is a single K/V set per block
+      const bool shared = opt.reserved[0] != 0;
+      const size_t kv = dry ? 0 : kv_bufs[bw.kv_group].first + (size_t)bw.kv_index * kv_bufs[bw.kv_group].second;
       ao = tmp(nb);
       const int mc = maps ? want_map(bid + "-cross-map", heads, S, n_ctx) : (dry_map(bid + "-cross-map"), -1);
-      attention("attn2", ws(q2), C, ws(kv), 2 * C, ws(kv + (size_t)C * 2), 2 * C, ws(ao), C, heads, S, n_ctx, D, mc);
-      untmp(q2, nb); untmp(kv, nkv * 2 * C * 2);
-      { Epi e; e.bias = wt(bw.o2.b); e.has_bias = true; residual_from(e, tok); out_to(e, tok);
+      attention("attn2", ws(q2), C, ws(kv), 2 * C, ws(kv + (size_t)C * 2), 2 * C, ws(ao), C, heads, S, n_ctx, D, mc,
+                shared ? 0 : n_ctx);
+      untmp(q2, nb);
+      { Epi e; e.bias = wt(bw.o2.b); e.has_bias = true; residual_from(e, tok); out_to(e, tok, false);
         gemm("attn2_out", ws(ao), C, n, bw.o2, C, C, 0, e); }
       untmp(ao, nb);
       if (stop) break;
@@ -590,7 +619,9 @@ struct B {   // builder
         gemm("ff_geglu", ws(ln), C, n, bw.ff1, 8 * C, C, 0, e); }
       untmp(ln, nb);
       hook_copy(want(bid + "-ffn-inner", 4 * C, x.H, x.W), ws(inner), 4 * C, n, 4 * C);   // attention.py:1255-1257
-      { Epi e; e.bias = wt(bw.ff2.b); e.has_bias = true; residual_from(e, tok); out_to(e, tok);
+      { // the fp16 image of the block output is only needed by the `blockN-out` hook and by proj_out (last block)
+        const bool shadow = (bi + 1 == w.blocks.size()) || (!dry && P.requested.count(bid + "-out"));
+        Epi e; e.bias = wt(bw.ff2.b); e.has_bias = true; residual_from(e, tok); out_to(e, tok, shadow);
         gemm("ff_out", ws(inner), 4 * C, n, bw.ff2, C, 4 * C, 0, e); }
       untmp(inner, n * 4 * C * 2);
       gather(bid + "-out", tok);                                                           // attention.py:589-590
@@ -664,6 +695,30 @@ struct B {   // builder
         return launch_small_linear((const float*)b.ws(emb), te, Bq, te, (const half_t*)b.p(tw), (const float*)b.p(tb), tt, 1, 0,
                                    (float*)b.ws(tall), tt, s);
       });
+    }
+
+    // ---- text K/V of every transformer block: one grouped GEMM per channel width (blockIdx.y = block) ----
+    kv_bufs.clear();
+    {
+      const bool shared = opt.reserved[0] != 0;
+      const size_t nkv = (size_t)(shared ? 1 : Bn) * n_ctx;
+      for (const KvGroup& g : m.kv_groups) {
+        const size_t per = align_up(nkv * 2 * g.C * 2, 256);
+        const size_t off = tmp(per * g.count);
+        kv_bufs.push_back({off, per});
+        const Ref W = wt(g.base);
+        const int N = 2 * g.C, K = a.cross_attention_dim, cnt = g.count;
+        const long wst = (long)(g.stride / 2), ost = (long)(per / 2);
+        op("attn2_kv", 2.0 * (double)nkv * N * K * cnt, [=](const Bind& b, hipStream_t s) {
+          GemmParams gp{};
+          gp.A = (const half_t*)b.base[BUF_CTX]; gp.lda = K; gp.a_bytes = (uint32_t)(nkv * K * 2);
+          gp.M = (int)nkv; gp.N = N; gp.K = K; gp.mode = A_DENSE;
+          gp.Wt = (const half_t*)b.p(W); gp.w_bytes = (uint32_t)((size_t)N * K * 2);
+          gp.out16 = (half_t*)b.ws(off); gp.ldo16 = N; gp.bn = 128; gp.rows_per_sample = 1;
+          gp.batch = cnt; gp.w_bstride = wst; gp.o_bstride = ost;
+          return launch_gemm(gp, s);
+        });
+      }
     }
 
     // ---- concat buffers of the up path: cat([h, skip]) laid out in place --------------------------

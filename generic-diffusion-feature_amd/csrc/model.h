@@ -23,7 +23,9 @@ struct NormW { size_t g = 0, b = 0; int c = 0; };                               
 struct ConvW { size_t w = 0, b = 0; int cin = 0, cout = 0; };                    // fp16 [cout][9][cin], fp32 bias
 struct LinW { size_t w = 0, b = NPOS; int n = 0, k = 0; bool has_bias = false; };  // fp16 [n][k], fp32 bias
 struct ResnetW { NormW n1, n2; ConvW c1, c2; LinW sc; bool has_sc = false; int cin = 0, cout = 0, temb_off = 0; };
-struct BlockW { NormW ln1, ln2, ln3; LinW qkv, o1, q2, kv2, o2, ff1, ff2; };
+struct BlockW { NormW ln1, ln2, ln3; LinW qkv, o1, q2, kv2, o2, ff1, ff2; int kv_group = 0, kv_index = 0; };
+// text K/V projection weights of all transformer blocks with the same width live contiguously: one grouped GEMM per width
+struct KvGroup { int C = 0, count = 0, next = 0; size_t base = 0, stride = 0; };
 struct VitW { NormW gn; LinW pin, pout; std::vector<BlockW> blocks; int c = 0, heads = 0; };
 struct LevelW { std::vector<ResnetW> res; std::vector<VitW> vit; std::vector<int> skip_c; bool has_sampler = false; ConvW sampler; };
 
@@ -50,6 +52,7 @@ struct Model {
   VitW mid_vit;
   NormW norm_out;
   std::vector<std::string> hook_names;
+  std::vector<KvGroup> kv_groups;
 };
 
 // ---- plan ----------------------------------------------------------------------------------------

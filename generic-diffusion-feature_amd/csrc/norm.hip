@@ -17,7 +17,14 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-static constexpr int GN_SLAB = 256;   // pixel rows per stage-1 block
+// pixel rows per stage-1 block: sized so that the stage-1 grid has >= ~2048 workgroups (32x32 levels used to run
+// 64 workgroups at 1 TB/s)
+static int gn_slab(int B, int HW) {
+  long s = (long)B * HW / 2048;
+  int slab = 16;
+  while (slab < s && slab < 256) slab *= 2;
+  return slab;
+}
 
 __device__ __forceinline__ void load8(const half_t* x16, const float* x32, size_t idx, float v[8]) {
   if (x32) {
@@ -32,20 +39,21 @@ __device__ __forceinline__ void load8(const half_t* x16, const float* x32, size_
 }
 
 size_t gn_partial_floats(int B, int HW, int C) {
-  const int nslab = (HW + GN_SLAB - 1) / GN_SLAB;
+  const int slab = gn_slab(B, HW);
+  const int nslab = (HW + slab - 1) / slab;
   return (size_t)B * nslab * C * 2;
 }
 
 // stage 1: per (sample, slab) block: per-channel sum / sum of squares over the slab's pixel rows
 __global__ __launch_bounds__(256) void gn_partial_kernel(const half_t* x16, const float* x32, int ld, int HW, int C,
-                                                         float* partial) {
+                                                         float* partial, int slab_rows) {
   extern __shared__ float red[];                  // [rgroups][C][2]
   const int b = blockIdx.y, slab = blockIdx.x, nslab = gridDim.x;
   const int CH = C / 8;
   const int cht = CH < 256 ? CH : 256;            // chunk columns handled in parallel
   const int rgroups = 256 / cht;                  // row groups working in parallel
   const int tc = threadIdx.x % cht, tr = threadIdx.x / cht;
-  const int r0 = slab * GN_SLAB, r1 = min(HW, r0 + GN_SLAB);
+  const int r0 = slab * slab_rows, r1 = min(HW, r0 + slab_rows);
   for (int c = tc; c < CH; c += cht) {
     float s[8], q[8];
 #pragma unroll
@@ -100,10 +108,11 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const float* partial, i
 hipError_t launch_gn_stats(const half_t* x16, const float* x32, int ld, int B, int HW, int C, int G, float eps,
                            const float* gamma, const float* beta, float* partial, float* ab, hipStream_t s) {
   if (C % 8 || C % G) return hipErrorInvalidValue;
-  const int nslab = (HW + GN_SLAB - 1) / GN_SLAB;
+  const int slab = gn_slab(B, HW);
+  const int nslab = (HW + slab - 1) / slab;
   const int CH = C / 8, cht = CH < 256 ? CH : 256, rgroups = 256 / cht;
   const size_t smem = (size_t)rgroups * C * 2 * sizeof(float);
-  hipLaunchKernelGGL(gn_partial_kernel, dim3(nslab, B), dim3(256), smem, s, x16, x32, ld, HW, C, partial);
+  hipLaunchKernelGGL(gn_partial_kernel, dim3(nslab, B), dim3(256), smem, s, x16, x32, ld, HW, C, partial, slab);
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(G, B), dim3(64), 0, s, partial, nslab, HW, C, G, eps, gamma, beta, ab);
   return hipGetLastError();
 }

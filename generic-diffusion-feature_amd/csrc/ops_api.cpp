@@ -65,7 +65,7 @@ int gdf_op_attention(const void* q, int ldq, const void* k, int ldk, const void*
                      int B, int heads, int Sq, int Sk, int D, void* map, void* stream) {
   AttnParams a{};
   a.q = (const half_t*)q; a.ldq = ldq; a.k = (const half_t*)k; a.ldk = ldk; a.v = (const half_t*)v; a.ldv = ldv;
-  a.o = (half_t*)o; a.ldo = ldo; a.B = B; a.heads = heads; a.Sq = Sq; a.Sk = Sk; a.D = D;
+  a.o = (half_t*)o; a.ldo = ldo; a.B = B; a.heads = heads; a.Sq = Sq; a.Sk = Sk; a.D = D; a.kv_bstride = Sk;
   a.scale = 1.0f / sqrtf((float)D); a.map = (half_t*)map;
   return fin(launch_attention(a, (hipStream_t)stream), "attention");
 }

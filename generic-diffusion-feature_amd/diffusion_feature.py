@@ -145,6 +145,8 @@ class FeatureExtractor(nn.Module):
         latent_model_input = self.pipe.scheduler.scale_model_input(latents, t)          # :405-406
 
         # ---- the hot path: native UNet forward, hooks written by the kernels (:445-465) ----
+        if hasattr(self.pipe.unet, 'shared_ctx'):
+            self.pipe.unet.shared_ctx = True      # prompt_embeds.repeat(batch_size, 1, 1) above: one prompt for the whole batch
         self.pipe.unet(latent_model_input, timestep=t, encoder_hidden_states=prompt_embeds.to(device),
                        added_cond_kwargs=added_cond_kwargs, down_block_additional_residuals=None,
                        mid_block_additional_residual=None, return_dict=False)

@@ -81,7 +81,8 @@ const char* gdf_model_hook_name(const gdf_model* m, int i);
 typedef struct gdf_plan_opts {
   int stream_fp32;     /* 1: fp32 master copy of the residual stream (default), 0: fp16 only */
   int early_exit;      /* 1: stop after the last requested hook (opt-in; noise_pred is then not produced) */
-  int reserved[6];
+  int reserved[6];     /* reserved[0] = shared_ctx: every sample uses ctx row-block 0 (one prompt repeated over the batch,
+                          reference diffusion_feature.py:272): text K/V projections are computed once, not per sample */
 } gdf_plan_opts;
 
 int gdf_plan_create(gdf_model* m, int batch, int lat_h, int lat_w, int n_ctx,

@@ -79,6 +79,21 @@ def test_early_exit_matches_full_run():
         assert torch.equal(full[k], ee[k])                          # same kernels, same inputs: bit-identical
 
 
+def test_shared_ctx_plan_equals_per_sample_ctx():
+    """shared_ctx (one prompt repeated, reference diffusion_feature.py:272) computes text K/V once: same numbers."""
+    arch = R.tiny_arch("xl")
+    P = R.synth_params(arch, seed=0)
+    I = R.synth_inputs(arch, 3, 16, seed=1, same_prompt=True)
+    ids = ["down-level1-repeat0-vit-block0-cross-q", "mid-vit-block1-out", "up-level1-repeat2-vit-out"]
+    u = native(arch, P)
+    g = lambda k: I[k].cuda()
+    _, a = u.forward_raw(g("sample"), g("timestep"), g("ctx"), g("text_embeds"), g("time_ids"), hook_ids=ids)
+    _, b = u.forward_raw(g("sample"), g("timestep"), g("ctx"), g("text_embeds"), g("time_ids"), hook_ids=ids, shared_ctx=True)
+    torch.cuda.synchronize()
+    for k in ids:
+        assert torch.equal(a[k], b[k]), k
+
+
 def test_determinism_and_fresh_outputs():
     arch = R.tiny_arch("1-5")
     P = R.synth_params(arch, seed=0)
