@@ -239,9 +239,7 @@ def main():
     lib = unet.lib
     plan = unet._plan(B, lat, lat, 77, ids, True)
     by_label = {}
-    label_of = _label_map(lib)
-    for name, ms, fl in prof:
-        lab = label_of(name)
+    for name, ms, fl, lab in prof:
         d = by_label.setdefault(lab, [0.0, 0.0, 0])
         d[0] += ms; d[1] += fl; d[2] += 1
     dominant = max(by_label, key=lambda k: by_label[k][0])
@@ -299,7 +297,7 @@ def main():
         }
         if args.profile_ops:
             rows = {}
-            for name, ms, f_ in prof:
+            for name, ms, f_, _k in prof:
                 r = rows.setdefault(name, [0.0, 0.0, 0]); r[0] += ms; r[1] += f_; r[2] += 1
             for name, r in sorted(rows.items(), key=lambda kv: -kv[1][0]):
                 print(f"# {name:16s} n={r[2]:4d} {r[0]:9.3f} ms  {r[1] / 1e9 / max(r[0], 1e-9):8.1f} TFLOP/s", file=sys.stderr)
@@ -309,28 +307,6 @@ def main():
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()
-
-
-def _label_map(lib):
-    """op name -> kernel label; mirrors csrc/model.cpp::kernel_label()."""
-    conv = {"res_conv1", "res_conv2", "downsample", "upsample"}
-    dense = {"proj_in", "proj_out", "attn1_qkv", "attn1_out", "attn2_q", "attn2_kv", "attn2_out", "ff_out", "res_shortcut"}
-
-    def f(n):
-        if n in conv:
-            return "gemm_kernel<conv3x3,BN128>"
-        if n == "conv_out":
-            return "gemm_kernel<conv3x3,BN16>"
-        if n == "conv_in":
-            return "gemm_kernel<conv_smallc,BN128>"
-        if n == "ff_geglu":
-            return "gemm_kernel<dense,BN128,geglu>"
-        if n in dense:
-            return "gemm_kernel<dense,BN128>"
-        if n in ("attn1", "attn2"):
-            return "attn_kernel"
-        return n
-    return f
 
 
 if __name__ == "__main__":

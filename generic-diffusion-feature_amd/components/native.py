@@ -62,6 +62,7 @@ SIGNATURES = {
     "gdf_plan_profile": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.POINTER(C.c_float), C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.c_int]),
+    "gdf_plan_op_kernel": (C.c_char_p, [C.c_void_p, C.c_int]),
     "gdf_plan_num_kernel_labels": (C.c_int, [C.c_void_p]),
     "gdf_plan_kernel_label": (C.c_char_p, [C.c_void_p, C.c_int]),
     "gdf_plan_set_timing": (C.c_int, [C.c_void_p, C.c_char_p]),
@@ -358,7 +359,8 @@ class NativeUNet:
                 rc = self.lib.gdf_plan_profile(*args, ms, names, fl, n)
                 if rc < 0:
                     _check(1, "plan_profile")
-                prof = [(names[i].decode(), ms[i], fl[i]) for i in range(n)]
+                prof = [(names[i].decode(), ms[i], fl[i], self.lib.gdf_plan_op_kernel(plan.handle, i).decode())
+                        for i in range(n)]
             else:
                 _check(self.lib.gdf_forward(*args), "forward")
         out = {}

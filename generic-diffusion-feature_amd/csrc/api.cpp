@@ -88,6 +88,9 @@ int gdf_plan_profile(gdf_plan* p, const void* latents, const float* timesteps, c
   return (int)p->p.ops.size();
 }
 
+const char* gdf_plan_op_kernel(const gdf_plan* p, int i) {
+  return (p && i >= 0 && i < (int)p->p.ops.size()) ? p->p.labels[p->p.ops[i].label].c_str() : nullptr;
+}
 int gdf_plan_num_kernel_labels(const gdf_plan* p) { return p ? (int)p->p.labels.size() : 0; }
 const char* gdf_plan_kernel_label(const gdf_plan* p, int i) {
   return (p && i >= 0 && i < (int)p->p.labels.size()) ? p->p.labels[i].c_str() : nullptr;

@@ -23,6 +23,8 @@
 //   * Epilogue is staged per wave through LDS so every global store / residual load is a full
 //     16-byte-per-lane, 128-byte-per-row access.
 #include "kernels.h"
+#include <cstdio>
+#include <cstring>
 
 namespace gdf {
 
@@ -88,8 +90,22 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_kernel(const GemmParams p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tiles_n = (p.N + BN - 1) / BN;
   const int nblk = gridDim.x;
-  const int t = xcd_remap(blockIdx.x, nblk);
-  const int tile_m = t / tiles_n, tile_n = t - tile_m * tiles_n;
+  int tile_m, tile_n;
+  if (p.sb_gn > 0) {
+    // 2-D super-block order: the workgroups one XCD runs concurrently cover sb_gm x sb_gn tiles, so its private L2
+    // fetches sb_gm A panels + sb_gn B panels per round instead of one A panel + a whole row of B panels
+    // (N = 10240 GEGLU: 27 MB -> 8.5 MB of L2 fills per XCD and round; the "fixed cost" of that GEMM was this traffic).
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int conc = p.sb_gm * p.sb_gn;
+    const int sb = (j / conc) * 8 + xcd, li = j - (j / conc) * conc;
+    const int sbn = tiles_n / p.sb_gn;
+    const int sbr = sb / sbn, sbc = sb - sbr * sbn;
+    tile_m = sbr * p.sb_gm + li / p.sb_gn;
+    tile_n = sbc * p.sb_gn + li % p.sb_gn;
+  } else {
+    const int t = xcd_remap(blockIdx.x, nblk);
+    tile_m = t / tiles_n; tile_n = t - tile_m * tiles_n;
+  }
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, p.a_bytes, 0x00020000);
@@ -447,7 +463,19 @@ static hipError_t launch_t(const GemmParams& p, hipStream_t s) {
     if (e != hipSuccess) return e;
     attr_done = true;
   }
-  hipLaunchKernelGGL((gemm_kernel<MODE, BM, BN, STAGES, GEGLU>), dim3(tiles_m * tiles_n, p.batch > 1 ? p.batch : 1), dim3(BM * 2), smem, s, p);
+  GemmParams q = p;
+  q.sb_gm = q.sb_gn = 0;
+  if (!p.no_superblock) {
+    const int conc = 32 * ((BM == 256) ? 1 : 2);         // workgroups one XCD keeps resident (32 CUs x 1 or 2)
+    for (int gn = 4; gn >= 2; gn >>= 1) {
+      const int gm = conc / gn;
+      if (tiles_n % gn == 0 && tiles_m % gm == 0 && ((tiles_m / gm) * (tiles_n / gn)) % 8 == 0 && tiles_n > gn) {
+        q.sb_gm = gm; q.sb_gn = gn;
+        break;
+      }
+    }
+  }
+  hipLaunchKernelGGL((gemm_kernel<MODE, BM, BN, STAGES, GEGLU>), dim3(tiles_m * tiles_n, p.batch > 1 ? p.batch : 1), dim3(BM * 2), smem, s, q);
   return hipGetLastError();
 }
 
@@ -472,6 +500,21 @@ static int pick_variant(const GemmParams& p) {
   if (p.N % 160 == 0 && p.K >= 1024) return 160;
   if ((long)p.M * p.N >= (1L << 26) && tiles256 >= 512) return 256;        // short-K, large MxN (qkv @ C=640): 712 vs 642
   return 128;
+}
+
+// kernel symbol (as rocprofv3 prints it) that launch_gemm would pick for these parameters
+const char* gemm_kernel_name(const GemmParams& p) {
+  const int v = pick_variant(p);
+  static char buf[16][64];
+  static int nb = 0;
+  int bm = 128, bn = 128, st = 2;
+  if (v == 16) bn = 16; else if (v == 160) bn = 160; else if (v == 256) { bm = 256; st = 3; } else if (v == 320) { bm = 256; bn = 320; }
+  if (p.mode == A_CONV_SMALLC && v != 160) { bm = 128; bn = 128; st = 2; }
+  char tmp[64];
+  snprintf(tmp, sizeof tmp, "gemm_kernel<%d, %d, %d, %d, %s>", p.mode, bm, bn, st, p.geglu ? "true" : "false");
+  for (int i = 0; i < nb; ++i) if (!strcmp(buf[i], tmp)) return buf[i];
+  if (nb < 16) { strcpy(buf[nb], tmp); return buf[nb++]; }
+  return "gemm_kernel<...>";
 }
 
 hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {

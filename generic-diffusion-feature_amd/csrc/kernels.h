@@ -51,10 +51,13 @@ struct GemmParams {
   int batch;             // > 1: blockIdx.y selects one of `batch` independent problems sharing A (grouped text-K/V projections)
   long w_bstride;        // elements between consecutive weight matrices
   long o_bstride;        // elements between consecutive out16 matrices
+  int sb_gm, sb_gn;      // (set by launch_gemm) tiles per XCD super-block, 0 = linear XCD-chunked order
+  int no_superblock;     // diagnostics: force the linear order
   int no_early_mma;      // diagnostics: disable the opposite-order heads of the two waves sharing a SIMD (256x128 variant)
   int variant;           // 0 = auto; 128 / 160 / 256 force the 128x128, 128x160 or 256x128 tile (diagnostics)
 };
 hipError_t launch_gemm(const GemmParams& p, hipStream_t s);
+const char* gemm_kernel_name(const GemmParams& p);   // kernel symbol launch_gemm would pick (only M,N,K,mode,geglu,bn,variant are read)
 
 // ------------------------------------------------------------------------------------------------
 // flash attention (self / cross), fp16 in, fp32 softmax, fp16 out

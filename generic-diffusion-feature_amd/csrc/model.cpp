@@ -335,10 +335,11 @@ struct B {   // builder
   Ref ws(size_t off) const { return Ref{BUF_WS, off}; }
   Ref wt(size_t off) const { return Ref{BUF_WT, off}; }
 
-  void op(const char* name, double flops, std::function<hipError_t(const Bind&, hipStream_t)> fn) {
+  void op(const char* name, double flops, std::function<hipError_t(const Bind&, hipStream_t)> fn,
+          const char* kernel = nullptr) {
     if (dry || stop) return;
     Op o{name, flops, std::move(fn)};
-    const std::string lab = kernel_label(name);
+    const std::string lab = kernel ? kernel : kernel_label(name);
     size_t li = 0;
     for (; li < P.labels.size(); ++li) if (P.labels[li] == lab) break;
     if (li == P.labels.size()) P.labels.push_back(lab);
@@ -471,6 +472,7 @@ struct B {   // builder
   void gemm(const char* name, Ref A, int lda, size_t M, const LinW& w, int N, int K, size_t w_off_bytes, const Epi& e0) {
     Epi e = e0;
     const Ref W = wt(w.w + w_off_bytes);
+    GemmParams gk{}; gk.M = (int)M; gk.N = N; gk.K = K; gk.mode = A_DENSE; gk.geglu = e.geglu; gk.bn = e.bn;
     op(name, 2.0 * (double)M * N * K, [=](const Bind& b, hipStream_t s) {
       GemmParams g{};
       g.A = (const half_t*)b.p(A); g.lda = lda; g.a_bytes = (uint32_t)(((size_t)M - 1) * lda * 2 + (size_t)K * 2);
@@ -478,7 +480,7 @@ struct B {   // builder
       g.Wt = (const half_t*)b.p(W); g.w_bytes = (uint32_t)((size_t)N * K * 2);
       fill_epi(g, e, b);
       return launch_gemm(g, s);
-    });
+    }, gemm_kernel_name(gk));
   }
   // 3x3 conv as implicit GEMM over NHWC `src` (Bn, H, W, ld>=Cin)
   void conv3(const char* name, Ref src, int ld, int Cin, int H, int W, int stride, bool ups, const ConvW& w, const Epi& e0) {
@@ -488,6 +490,7 @@ struct B {   // builder
     const size_t M = (size_t)Bn * OH * OW;
     const Ref Wr = wt(w.w);
     const int N = w.cout, Bq = Bn;
+    GemmParams gk{}; gk.M = (int)M; gk.N = N; gk.K = 9 * Cin; gk.mode = A_CONV3; gk.bn = e.bn;
     op(name, 2.0 * (double)M * N * 9 * Cin, [=](const Bind& b, hipStream_t s) {
       GemmParams g{};
       g.A = (const half_t*)b.p(src); g.lda = ld;
@@ -497,7 +500,7 @@ struct B {   // builder
       g.Wt = (const half_t*)b.p(Wr); g.w_bytes = (uint32_t)((size_t)N * 9 * Cin * 2);
       fill_epi(g, e, b);
       return launch_gemm(g, s);
-    });
+    }, gemm_kernel_name(gk));
   }
 
   // ---- ResnetBlock2D ------------------------------------------------------------------------------
@@ -911,15 +914,16 @@ int plan_build(const Model& m, Plan& P, int batch, int H, int W, int n_ctx, cons
   return GDF_OK;
 }
 
+// kernel symbol of ops that do not go through gemm()/conv3() (those ask gemm_kernel_name() for the tile variant)
 const char* kernel_label(const char* n) {
   auto is = [&](const char* x) { return strcmp(n, x) == 0; };
-  if (is("res_conv1") || is("res_conv2") || is("downsample") || is("upsample")) return "gemm_kernel<conv3x3,BN128>";
-  if (is("conv_out")) return "gemm_kernel<conv3x3,BN16>";
-  if (is("conv_in")) return "gemm_kernel<conv_smallc,BN128>";
-  if (is("ff_geglu")) return "gemm_kernel<dense,BN128,geglu>";
-  if (is("proj_in") || is("proj_out") || is("attn1_qkv") || is("attn1_out") || is("attn2_q") || is("attn2_kv") ||
-      is("attn2_out") || is("ff_out") || is("res_shortcut")) return "gemm_kernel<dense,BN128>";
+  if (is("conv_in")) return "gemm_kernel<2, 128, 128, 2, false>";
+  if (is("attn2_kv")) return "gemm_kernel<0, 128, 128, 2, false>";
   if (is("attn1") || is("attn2")) return "attn_kernel";
+  if (is("layernorm")) return "layernorm_kernel";
+  if (is("gn_stats")) return "gn_partial_kernel+gn_finalize_kernel";
+  if (is("gn_apply") || is("gn_apply_silu")) return "gn_apply_kernel";
+  if (is("hook_store")) return "copy2d_kernel";
   return n;
 }
 

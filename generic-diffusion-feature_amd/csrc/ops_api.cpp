@@ -21,7 +21,7 @@ int gdf_op_gemm(const void* A, int lda, const void* W, const float* bias, const 
   g.Wt = (const half_t*)W; g.w_bytes = (uint32_t)((size_t)N * K * 2);
   g.bias = bias; g.res32 = res32; g.res16 = (const half_t*)res16; g.ldres = ldres;
   g.out16 = (half_t*)out16; g.ldo16 = ldo16; g.out32 = out32; g.ldo32 = ldo32;
-  g.geglu = (flags & 1) ? 16 : 0; g.bn = (flags & 2) ? 16 : 128; g.variant = (flags >> 8) & 0xfff; g.no_early_mma = (flags >> 20) & 1; g.rows_per_sample = 1;
+  g.geglu = (flags & 1) ? 16 : 0; g.bn = (flags & 2) ? 16 : 128; g.variant = (flags >> 8) & 0xfff; g.no_early_mma = (flags >> 20) & 1; g.no_superblock = (flags >> 21) & 1; g.rows_per_sample = 1;
   return fin(launch_gemm(g, (hipStream_t)stream), "gemm");
 }
 

@@ -124,6 +124,8 @@ int gdf_plan_profile(gdf_plan* p, const void* latents, const float* timesteps, c
  * gdf_plan_read_timing waits for the recorded events and returns the accumulated kernel time,
  * launch count and algorithmic FLOPs since gdf_plan_set_timing.  NULL label disables timing. */
 int gdf_plan_num_kernel_labels(const gdf_plan* p);
+/* kernel symbol (as rocprofv3 prints it, e.g. "gemm_kernel<0, 256, 320, 2, false>") that op i of the plan launches */
+const char* gdf_plan_op_kernel(const gdf_plan* p, int i);
 const char* gdf_plan_kernel_label(const gdf_plan* p, int i);
 int gdf_plan_set_timing(gdf_plan* p, const char* kernel_label);
 int gdf_plan_read_timing(gdf_plan* p, double* ms_total, long* launches, double* flops_total);
