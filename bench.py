@@ -270,6 +270,12 @@ def main():
         fl = unet_flops_per_image(cfg, lat)
         fl_img = sum(fl.values())
         ips = world * B * args.steps / dt
+        traffic = None        # HBM bytes/launch of the dominant kernel from the committed rocprofv3 --pmc passes (same command)
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            traffic = tj[dominant]["hbm_bytes_per_launch"] if (args.version == "xl" and B == 16 and dominant in tj) else None
+        except Exception:
+            traffic = None
         achieved = (fl_tot.value / 1e12) / (ms_tot.value / 1e3) if ms_tot.value > 0 else 0.0
         res = {
             "metric": "images/sec feature-extract, SDXL 1024^2 single-timestep" if args.version == "xl"
@@ -287,7 +293,7 @@ def main():
                        "model_tflops_per_s": round(ips * fl_img / 1e12, 1),
                        "weights_init_s": round(t_weights, 1)},
             "roofline": {"bound": "mfma", "kernel": dominant, "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                          "launches": int(launches.value), "avg_launch_ms": round(ms_tot.value / max(1, launches.value), 4),
                          "flops_per_launch_g": round(fl_tot.value / max(1, launches.value) / 1e9, 2),
                          "share_of_step_time": round(by_label[dominant][0] / sum(v[0] for v in by_label.values()), 3)},

@@ -235,99 +235,229 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
 // attention with materialised probabilities ('-map' hooks):
 // AttnStoreProcessor.__call__ (/root/reference/feature/components/attention.py:176-263) +
 // Attention.get_attention_scores (attention_processor.py:640-685): probs = softmax(scale * q k^T),
-// stored as (B, heads, Sq, Sk) fp16, then out = probs v.  One wave per query row; HBM-write bound.
+// stored as (B, heads, Sq, Sk) fp16, then out = probs v.
+//
+// HBM-write bound (SD1.5 level 0: 268 MB per image and layer).  Same MFMA skeleton as attn_kernel (4 waves x 32
+// queries, S^T = K Q^T), two passes over the keys: pass A only tracks the row max / row sum, pass B recomputes
+// the scores, normalises, feeds O^T += V^T P^T and writes the probability tile: each wave transposes its
+// 32 x 64 tile through LDS so that the global stores are 16 B per lane, 128 contiguous bytes per query row.
 // -------------------------------------------------------------------------------------------------
 template <int D>
-__global__ __launch_bounds__(256) void attn_map_kernel(const AttnParams p) {
-  constexpr int DPL = (D + 63) / 64;             // output dims per lane (strided)
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const long row = (long)blockIdx.x * 4 + wave;   // (b, head, q)
-  const long total = (long)p.B * p.heads * p.Sq;
-  if (row >= total) return;
-  const int qi = row % p.Sq;
-  const int head = (row / p.Sq) % p.heads;
-  const int b = row / ((long)p.Sq * p.heads);
-  const _Float16* qp = p.q + ((size_t)b * p.Sq + qi) * p.ldq + head * D;
-  const _Float16* kb = p.k + (size_t)b * p.kv_bstride * p.ldk + head * D;
-  const _Float16* vb = p.v + (size_t)b * p.kv_bstride * p.ldv + head * D;
-  _Float16* mp = p.map + (size_t)row * p.Sk;
-  float qreg[D];
+__global__ __launch_bounds__(256, 2) void attn_map_kernel(const AttnParams p) {
+  constexpr int DQK = (D + 15) / 16 * 16;
+  constexpr int DV = (D + 31) / 32 * 32;
+  constexpr int DP = DV;
+  constexpr int LDR = DP + 8;
+  constexpr int CPR = DP / 8;
+  constexpr int NCH = (KT * CPR + 255) / 256;
+  constexpr int NS = DQK / 16;
+  constexpr int NDB = DV / 32;
+  constexpr int PLD = KT + 8;                     // staging row stride (halves) of the probability tile
+
+  __shared__ __attribute__((aligned(16))) _Float16 sK[2][KT * LDR];
+  __shared__ __attribute__((aligned(16))) _Float16 sV[2][KT * LDR];
+  __shared__ __attribute__((aligned(16))) _Float16 sP[4][32 * PLD];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nqb = (p.Sq + 127) / 128;
+  int bid = blockIdx.x;
+  const int qb = bid % nqb; bid /= nqb;
+  const int head = bid % p.heads;
+  const int b = bid / p.heads;
+  const int lq = lane & 31, lh = lane >> 5;
+  const int q0 = qb * 128 + wave * 32;             // first query row of this wave
+  const int q_row = q0 + lq;
+  const bool q_ok = q_row < p.Sq;
+
+  f16x8 qf[NS];
+  {
+    const _Float16* qp = p.q + ((size_t)b * p.Sq + (q_ok ? q_row : 0)) * p.ldq + head * D;
 #pragma unroll
-  for (int d = 0; d < D; ++d) qreg[d] = (float)qp[d];
-  // pass 1: scores for keys lane, lane+64, ... kept in fp32 scratch (the map row itself, as fp16, is written last)
-  float mx = -INFINITY;
-  for (int kv = lane; kv < p.Sk; kv += 64) {
-    const _Float16* kr = kb + (size_t)kv * p.ldk;
-    float acc = 0.f;
-#pragma unroll
-    for (int d = 0; d < D; d += 8) {
-      const f16x8 kk = *(const f16x8*)(kr + d);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) acc += qreg[d + e] * (float)kk[e];
+    for (int s = 0; s < NS; ++s) {
+      const int d0 = 16 * s + 8 * lh;
+      f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (q_ok && d0 < D) v = *(const f16x8*)(qp + d0);
+      qf[s] = v;
     }
-    acc *= p.scale;
-    mx = fmaxf(mx, acc);
   }
+  const float sl2 = p.scale * 1.44269504088896340736f;
+  const _Float16* kbase = p.k + (size_t)b * p.kv_bstride * p.ldk + head * D;
+  const _Float16* vbase = p.v + (size_t)b * p.kv_bstride * p.ldv + head * D;
+  const int ntiles = (p.Sk + KT - 1) / KT;
+
+  f16x8 kreg[NCH], vreg[NCH];
+  auto gload = [&](int t, bool with_v) {
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
-  float sum = 0.f;
-  for (int kv = lane; kv < p.Sk; kv += 64) {
-    const _Float16* kr = kb + (size_t)kv * p.ldk;
-    float acc = 0.f;
-#pragma unroll
-    for (int d = 0; d < D; d += 8) {
-      const f16x8 kk = *(const f16x8*)(kr + d);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) acc += qreg[d + e] * (float)kk[e];
-    }
-    sum += __expf(acc * p.scale - mx);
-  }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
-  const float inv = 1.f / sum;
-  float oacc[DPL];
-#pragma unroll
-  for (int i = 0; i < DPL; ++i) oacc[i] = 0.f;
-  for (int kv0 = 0; kv0 < p.Sk; kv0 += 64) {
-    const int kv = kv0 + lane;
-    float pr = 0.f;
-    if (kv < p.Sk) {
-      const _Float16* kr = kb + (size_t)kv * p.ldk;
-      float acc = 0.f;
-#pragma unroll
-      for (int d = 0; d < D; d += 8) {
-        const f16x8 kk = *(const f16x8*)(kr + d);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) acc += qreg[d + e] * (float)kk[e];
+    for (int c = 0; c < NCH; ++c) {
+      const int idx = tid + c * 256;
+      const int row = idx / CPR, ch = idx - row * CPR;
+      const int kv = t * KT + row;
+      f16x8 kk = {0, 0, 0, 0, 0, 0, 0, 0}, vv = kk;
+      if (idx < KT * CPR && kv < p.Sk && ch * 8 < D) {
+        kk = *(const f16x8*)(kbase + (size_t)kv * p.ldk + ch * 8);
+        if (with_v) vv = *(const f16x8*)(vbase + (size_t)kv * p.ldv + ch * 8);
       }
-      pr = __expf(acc * p.scale - mx) * inv;
-      mp[kv] = (_Float16)pr;
+      kreg[c] = kk; vreg[c] = vv;
     }
-    // out += probs * V for this 64-key slab: lanes own output dims d = lane, lane+64, ...
-    const int nk = min(64, p.Sk - kv0);
-    for (int j = 0; j < nk; ++j) {
-      const float pj = __shfl(pr, j);
-      const _Float16* vr = vb + (size_t)(kv0 + j) * p.ldv;
+  };
+  auto lstore = [&](int buf, bool with_v) {
 #pragma unroll
-      for (int i = 0; i < DPL; ++i) {
-        const int d = lane + 64 * i;
-        if (d < D) oacc[i] += pj * (float)vr[d];
+    for (int c = 0; c < NCH; ++c) {
+      const int idx = tid + c * 256;
+      const int row = idx / CPR, ch = idx - row * CPR;
+      if (idx < KT * CPR) {
+        *(f16x8*)(&sK[buf][row * LDR + ch * 8]) = kreg[c];
+        if (with_v) *(f16x8*)(&sV[buf][row * LDR + ch * 8]) = vreg[c];
       }
     }
-  }
-  _Float16* op = p.o + ((size_t)b * p.Sq + qi) * p.ldo + head * D;
+  };
+  auto scores = [&](const _Float16* cK, int t, f32x16 (&s)[2]) {
 #pragma unroll
-  for (int i = 0; i < DPL; ++i) {
-    const int d = lane + 64 * i;
-    if (d < D) op[d] = (_Float16)oacc[i];
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int st = 0; st < NS; ++st) {
+        const f16x8 kf = *(const f16x8*)(cK + (kb * 32 + lq) * LDR + 16 * st + 8 * lh);
+        if (st == 0) {
+          const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[st], z, 0, 0, 0);
+        } else {
+          s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[st], s[kb], 0, 0, 0);
+        }
+      }
+    if ((t + 1) * KT > p.Sk) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int kv = t * KT + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (kv >= p.Sk) s[kb][r] = -INFINITY;
+        }
+    }
+  };
+
+  // ---------------- pass A: row max and row sum ----------------
+  float m_run = -INFINITY, l_run = 0.f;
+  gload(0, false); lstore(0, false);
+  __syncthreads();
+  if (ntiles > 1) gload(1, false);
+  for (int t = 0; t < ntiles; ++t) {
+    f32x16 s[2];
+    scores(sK[t & 1], t, s);
+    float mx = s[0][0];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m_run, mx * sl2);
+    float psum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) psum += __builtin_amdgcn_exp2f(s[kb][r] * sl2 - m_new);
+    l_run = l_run * __builtin_amdgcn_exp2f(m_run - m_new) + psum;
+    m_run = m_new;
+    if (t + 1 < ntiles) lstore((t + 1) & 1, false);
+    __syncthreads();
+    if (t + 2 < ntiles) gload(t + 2, false);
+  }
+  const float inv_l = 1.0f / (l_run + __shfl_xor(l_run, 32));
+
+  // ---------------- pass B: probabilities -> HBM, O^T += V^T P^T ----------------
+  f32x16 o[NDB];
+#pragma unroll
+  for (int i = 0; i < NDB; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+  _Float16* sPw = sP[wave];
+  _Float16* mbase = p.map + (((size_t)b * p.heads + head) * p.Sq) * p.Sk;
+  const bool vec_ok = (p.Sk & 7) == 0;            // 16-byte aligned probability rows
+  gload(0, true); lstore(0, true);
+  __syncthreads();
+  if (ntiles > 1) gload(1, true);
+  for (int t = 0; t < ntiles; ++t) {
+    const _Float16* cV = sV[t & 1];
+    f32x16 s[2];
+    scores(sK[t & 1], t, s);
+    f16x8 pf[4];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const float e0 = __builtin_amdgcn_exp2f(s[kb][r] * sl2 - m_run) * inv_l;
+        const float e1 = __builtin_amdgcn_exp2f(s[kb][r + 1] * sl2 - m_run) * inv_l;
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+        const f16x2 h2 = __builtin_convertvector(f32x2{e0, e1}, f16x2);
+        pf[kb * 2 + (r >> 3)][r & 7] = h2[0];
+        pf[kb * 2 + (r >> 3)][(r & 7) + 1] = h2[1];
+      }
+    // transpose the 32 x 64 probability tile through this wave's LDS slab: lane (q = lq, lh) owns keys
+    // kb*32 + 8*g + 4*lh + {0..3}  (g = r >> 2)  ->  row q, 4 consecutive halves
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f16x4 w4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w4[e] = pf[kb * 2 + (g >> 1)][(g & 1) * 4 + e];
+        *(f16x4*)(sPw + lq * PLD + kb * 32 + 8 * g + 4 * lh) = w4;
+      }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int row = it * 8 + (lane >> 3), ch = lane & 7;
+      const int q = q0 + row, kv = t * KT + ch * 8;
+      if (q < p.Sq && kv < p.Sk) {
+        const f16x8 v8 = *(const f16x8*)(sPw + row * PLD + ch * 8);
+        _Float16* dst = mbase + (size_t)q * p.Sk + kv;
+        if (vec_ok) {
+          *(f16x8*)dst = v8;
+        } else {
+          for (int e = 0; e < 8; ++e) if (kv + e < p.Sk) dst[e] = v8[e];
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+      for (int db = 0; db < NDB; ++db) {
+        const int i16 = lane & 15;
+        const int c0 = db * 32 + 16 * ((lane >> 4) & 1) + (i16 & 3) * 4;
+        const int r0 = 16 * s4 + 4 * lh + (i16 >> 2);
+        const fp16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((LDS_AS fp16x4_t*)(cV + r0 * LDR + c0));
+        const fp16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((LDS_AS fp16x4_t*)(cV + (r0 + 8) * LDR + c0));
+        union { fp16x4_t q[2]; f16x8 h; } vf;
+        vf.q[0] = lo; vf.q[1] = hi;
+        o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf.h, pf[s4], o[db], 0, 0, 0);
+      }
+    if (t + 1 < ntiles) lstore((t + 1) & 1, true);
+    __syncthreads();
+    if (t + 2 < ntiles) gload(t + 2, true);
+  }
+  if (q_ok) {
+    _Float16* op = p.o + ((size_t)b * p.Sq + q_row) * p.ldo + head * D;
+#pragma unroll
+    for (int db = 0; db < NDB; ++db)
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const int d0 = db * 32 + 8 * rq + 4 * lh;
+        if (d0 < D) {
+          f16x4 hv;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) hv[e] = (_Float16)o[db][rq * 4 + e];
+          *(f16x4*)(op + d0) = hv;
+        }
+      }
   }
 }
 
 template <int D>
 static hipError_t launch_d(const AttnParams& p, hipStream_t s) {
   if (p.map) {
-    const long rows = (long)p.B * p.heads * p.Sq;
-    hipLaunchKernelGGL((attn_map_kernel<D>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, p);
+    const int nqb = (p.Sq + 127) / 128;
+    hipLaunchKernelGGL((attn_map_kernel<D>), dim3(p.B * p.heads * nqb), dim3(256), 0, s, p);
   } else {
     // 64 query rows per wave (every K / V fragment feeds two MFMAs) when the sequence is long and the
     // accumulators fit (D <= 64); 32 rows per wave otherwise
