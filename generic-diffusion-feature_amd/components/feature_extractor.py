@@ -135,3 +135,54 @@ def prepare_feature_extractor(version, pipe, config, resize_ratio, train_unet):
         raise NotImplementedError("DiT / Flux denoisers are a later row of the hot-path scope table (SURVEY.md §8f)")
     pipe.unet.feature_store = feature_store       # the native UNet delivers hook tensors here
     return feature_store
+
+
+ATTENTION_CATEGORIES = ('down_cross', 'mid_cross', 'up_cross', 'down_self', 'mid_self', 'up_self')
+
+
+def layer_grid(cfg, layer_id, lat):
+    """Spatial size (tokens per side) of the UNet level a layer id belongs to, for a lat x lat latent."""
+    L = len(cfg["block_out_channels"])
+    parts = layer_id.split('-')
+    if parts[0] == 'mid':
+        lv = L - 1
+    else:
+        lv = int(parts[1][5:])
+        if parts[0] == 'up':
+            lv = L - 1 - lv
+    return lat >> lv
+
+
+def attention_map_ids(cfg, all_ids, categories, lat, min_size, max_size):
+    """'*-map' ids feeding the aggregated `attention=[...]` feature: the reference's AttentionStore keeps the maps whose
+    query grid lies in [min_size, max_size] (components/attention.py:109-115, sizes img/32 .. img/16 at :541)."""
+    out = {c: [] for c in categories}
+    for i in all_ids:
+        if not i.endswith('-map'):
+            continue
+        place = i.split('-')[0]
+        kind = 'cross' if i.endswith('-cross-map') else 'self'
+        key = f"{place}_{kind}"
+        if key in out and min_size <= layer_grid(cfg, i, lat) <= max_size:
+            out[key].append(i)
+    return out
+
+
+def aggregate_attention(maps_by_category, out_size):
+    """Reference AttentionStore.aggregate_attention (components/attention.py:141-161) + diffusion_feature.py:492-500:
+    head-mean maps (B,Q,K) -> (B,K,h,w), averaged over the layers of the same category and size, nearest-resized to
+    out_size and concatenated over the channel dim, in category order then first-seen size order."""
+    import torch
+    import torch.nn.functional as F
+    all_attns = []
+    for cat, maps in maps_by_category.items():
+        by_size = {}
+        for m in maps:                                     # m: (B, heads, Q, K) probabilities
+            a = m.float().mean(1)                          # to_store.mean(1), components/attention.py:241
+            b, q, k = a.shape
+            size = int(math.sqrt(q))
+            by_size.setdefault(size, []).append(a.reshape(b, size, q // size, k).permute(0, 3, 1, 2))
+        for size, lst in by_size.items():
+            avg = torch.stack(lst).mean(0)
+            all_attns.append(F.interpolate(avg, size=(out_size, out_size)).to(torch.float16))
+    return torch.cat(all_attns, dim=-3)

@@ -197,6 +197,8 @@ class NativeUNet:
         self.early_exit = bool(early_exit)
         self.feature_store = None
         self.shared_ctx = False          # set by FeatureExtractor.extract (it repeats one prompt over the batch)
+        self.extra_hook_ids = []         # hooks FeatureExtractor needs internally (aggregated `attention=` feature)
+        self.last_extra = {}
         self._plans = {}
         self.dtype = torch.float16
         # attributes the reference reads from pipe.unet (diffusion_feature.py:544-547)
@@ -377,11 +379,16 @@ class NativeUNet:
         if down_block_additional_residuals is not None or mid_block_additional_residual is not None:
             raise NotImplementedError("ControlNet residuals are outside the native hot path (SURVEY.md §2 #5)")
         akw = added_cond_kwargs or {}
+        ids = self.requested_ids()
+        have = set(ids)
+        ids = ids + [i for i in self.extra_hook_ids if i not in have]
         noise, hooks = self.forward_raw(sample, timestep, encoder_hidden_states, akw.get("text_embeds"),
-                                        akw.get("time_ids"), shared_ctx=self.shared_ctx)
+                                        akw.get("time_ids"), hook_ids=ids, shared_ctx=self.shared_ctx)
+        self.last_extra = {k: v for k, v in hooks.items() if k in set(self.extra_hook_ids)}
         if self.feature_store is not None:
             for hid, t in hooks.items():
-                self.feature_store.store(t, hid)
+                if hid in have:
+                    self.feature_store.store(t, hid)
         if return_dict:
             return types.SimpleNamespace(sample=noise)
         return (noise,)

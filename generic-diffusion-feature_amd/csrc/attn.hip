@@ -24,6 +24,17 @@ typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
 
 static constexpr int KT = 64;     // keys per tile
 
+// combine a value with the one held by lane ^ 32 (the other half-wave owns the other keys of the same query):
+// v_permlane32_swap instead of an LDS round trip (ds_bpermute)
+__device__ __forceinline__ float half_max(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float half_sum(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
 template <int D, int QW>
 __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
   constexpr int DQK = (D + 15) / 16 * 16;        // contraction length of QK^T, padded
@@ -156,7 +167,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[w][kb][r]);
-      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      mx = half_max(mx);
       const float m_new = fmaxf(m_run[w], mx * sl2);
       const float alpha = __builtin_amdgcn_exp2f(m_run[w] - m_new);   // raw v_exp_f32; first tile: exp2(-inf) = 0
       float psum = 0.f;
@@ -211,7 +222,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
   // ---- finalize: O[q][d] = O^T[d][q] / l ----
 #pragma unroll
   for (int w = 0; w < QW; ++w) {
-    const float l_tot = l_run[w] + __shfl_xor(l_run[w], 32);
+    const float l_tot = half_sum(l_run[w]);
     const float inv = 1.0f / l_tot;
     if (q_ok[w]) {
       _Float16* op = p.o + ((size_t)b * p.Sq + q_row[w]) * p.ldo + head * D;
@@ -348,7 +359,7 @@ __global__ __launch_bounds__(256, 2) void attn_map_kernel(const AttnParams p) {
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    mx = half_max(mx);
     const float m_new = fmaxf(m_run, mx * sl2);
     float psum = 0.f;
 #pragma unroll
@@ -361,7 +372,7 @@ __global__ __launch_bounds__(256, 2) void attn_map_kernel(const AttnParams p) {
     __syncthreads();
     if (t + 2 < ntiles) gload(t + 2, false);
   }
-  const float inv_l = 1.0f / (l_run + __shfl_xor(l_run, 32));
+  const float inv_l = 1.0f / half_sum(l_run);
 
   // ---------------- pass B: probabilities -> HBM, O^T += V^T P^T ----------------
   f32x16 o[NDB];

@@ -15,7 +15,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from components.models import get_diffusion_model
-from components.feature_extractor import prepare_feature_extractor
+from components.feature_extractor import (ATTENTION_CATEGORIES, aggregate_attention, attention_map_ids,
+                                          prepare_feature_extractor)
 
 
 class FeatureExtractor(nn.Module):
@@ -37,8 +38,9 @@ class FeatureExtractor(nn.Module):
         if control:
             raise NotImplementedError("ControlNet conditioning is outside the native hot path (SURVEY.md §2 #5)")
         if attention:
-            raise NotImplementedError("aggregated attention feature ('attn') is a later row (SURVEY.md §8f rank 3); "
-                                      "request the per-layer '*-map' ids instead")
+            bad = [a for a in attention if a not in ATTENTION_CATEGORIES]
+            if bad:
+                raise ValueError(f"unknown attention categories {bad}; choose from {ATTENTION_CATEGORIES}")
         if train_unet:
             raise NotImplementedError("the native denoiser is inference-only (no backward kernels)")
         if external_model:
@@ -144,12 +146,26 @@ class FeatureExtractor(nn.Module):
 
         latent_model_input = self.pipe.scheduler.scale_model_input(latents, t)          # :405-406
 
+        # aggregated `attention=[...]` feature (reference :67-68, :492-500): the needed '*-map' hooks are requested
+        # internally; AttentionStore keeps query grids in [img/32, img/16] (components/attention.py:541)
+        attn_ids = None
+        if self.attention and hasattr(self.pipe.unet, 'extra_hook_ids'):
+            lat = latents.shape[-1]
+            attn_ids = attention_map_ids(self.pipe.unet.cfg, self.pipe.unet.hook_names(), self.attention, lat,
+                                         self.img_size // 32, self.img_size // 16)
+            self.pipe.unet.extra_hook_ids = [i for ids in attn_ids.values() for i in ids]
+
         # ---- the hot path: native UNet forward, hooks written by the kernels (:445-465) ----
         if hasattr(self.pipe.unet, 'shared_ctx'):
             self.pipe.unet.shared_ctx = True      # prompt_embeds.repeat(batch_size, 1, 1) above: one prompt for the whole batch
         self.pipe.unet(latent_model_input, timestep=t, encoder_hidden_states=prompt_embeds.to(device),
                        added_cond_kwargs=added_cond_kwargs, down_block_additional_residuals=None,
                        mid_block_additional_residual=None, return_dict=False)
+        if attn_ids is not None:
+            extra = self.pipe.unet.last_extra
+            maps = {c: [extra[i] for i in ids if i in extra] for c, ids in attn_ids.items()}
+            self.feature_store.stored_feats['attn'] = aggregate_attention(maps, self.img_size // 8)
+            self.pipe.unet.last_extra = {}
         return self.feature_store.stored_feats                                           # :517
 
     def set_background_extraction(self, idxs):

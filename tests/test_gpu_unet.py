@@ -129,3 +129,23 @@ def test_feature_extractor_api_synthetic(tmp_path, monkeypatch):
     assert sum(s[1] for s in shapes.values()) == 3520               # correspondence config `feature_len`
     for v in feats.values():
         assert v.dtype == torch.float16 and v.is_cuda and torch.isfinite(v.float()).all()
+
+
+def test_aggregated_attention_feature(monkeypatch):
+    """`attention=[...]` (reference diffusion_feature.py:67-68, 492-500): feats['attn'] = head-mean maps grouped by size."""
+    monkeypatch.setenv("GDF_SYNTHETIC_WEIGHTS", "1")
+    import diffusion_feature
+    from components.feature_extractor import aggregate_attention
+    layer = {"up-level1-repeat0-vit-block0-cross-map": True, "up-level2-repeat2-vit-block0-cross-map": True}
+    df = diffusion_feature.FeatureExtractor(layer=layer, version='1-5', img_size=256, device='cuda', attention=['up_cross'])
+    prompt = df.encode_prompt('a photo of a cat')
+    lat = torch.randn(2, 4, 32, 32, generator=torch.Generator().manual_seed(0)).half()
+    feats = df.extract(prompt, batch_size=2, image=lat, image_type='latents', t=100)
+    assert list(feats.keys()) == list(layer.keys()) + ['attn']
+    # grids in [256/32, 256/16] = [8, 16]: up-level1 (8x8) and up-level2 (16x16), 77 text tokens each
+    assert feats['attn'].shape == (2, 154, 32, 32)
+    # the two explicitly requested maps are members of the two size groups; each group averages 3 layers, so only check
+    # normalisation: every map row sums to 1 over the 77 keys -> channel sum == 1 everywhere
+    s = feats['attn'].float()
+    assert torch.allclose(s[:, :77].sum(1), torch.ones(2, 32, 32, device=s.device), atol=5e-3)
+    assert torch.allclose(s[:, 77:].sum(1), torch.ones(2, 32, 32, device=s.device), atol=5e-3)

@@ -114,3 +114,39 @@ def test_bench_flop_model_matches_survey_totals():
     sd = bench.unet_flops_per_image(ARCH_CONFIGS["1-5"], 64)
     assert abs(sum(xl.values()) / 1e12 - 6.761) < 2e-3 and abs(sum(sd.values()) / 1e12 - 0.803) < 1e-3
     assert abs(xl["self_attn"] / 1e12 - 0.752) < 1e-3 and abs(xl["ff"] / 1e12 - 2.819) < 1e-3
+
+
+def test_aggregate_attention_matches_reference_attention_store():
+    """components.feature_extractor.aggregate_attention vs the reference's AttentionStore (components/attention.py:102-161)
+    + the interpolate/cat of diffusion_feature.py:492-500, fed with the same random probability maps."""
+    from oracle import ref_blocks as RB
+    if not RB.available():
+        pytest.skip("reference tree not present (GPU box)")
+    import sys
+    import torch.nn.functional as F
+    RB.attn_store_processor()
+    AttentionStore = sys.modules["gdf_ref_attention"].AttentionStore
+    from components.feature_extractor import aggregate_attention
+    g = torch.Generator().manual_seed(0)
+    store = AttentionStore(min_size=4, max_size=8)
+    maps = {"up_cross": [], "down_self": []}
+    for place, cross, q, k in (("up", True, 16, 77), ("up", True, 64, 77), ("up", True, 16, 77), ("down", False, 64, 64)):
+        probs = torch.softmax(torch.randn(2, 4, q, k, generator=g), -1)
+        store(probs.mean(1), cross, place)                            # what AttnStoreProcessor passes (attention.py:241)
+        maps[f"{place}_{'cross' if cross else 'self'}"].append(probs)
+    sel = ["up_cross", "down_self"]
+    ref = store.aggregate_attention(sel)
+    ref = torch.cat([F.interpolate(a, size=(16, 16)) for c in sel for a in ref[c].values()], dim=-3)
+    got = aggregate_attention({c: maps[c] for c in sel}, 16)
+    assert got.shape == ref.shape == (2, 77 + 77 + 64, 16, 16)
+    assert torch.allclose(got.float(), ref, atol=1e-3)
+
+
+def test_attention_map_id_selection():
+    from components.feature_extractor import attention_map_ids, unet_layer_ids
+    from components.native import ARCH_CONFIGS
+    cfg = ARCH_CONFIGS["1-5"]
+    ids = attention_map_ids(cfg, unet_layer_ids(cfg), ["up_cross", "mid_self"], 64, 512 // 32, 512 // 16)
+    # AttentionStore(img/32, img/16) keeps 16x16 and 32x32 grids: up-level1 (16^2) and up-level2 (32^2); mid is 8x8 -> dropped
+    assert ids["mid_self"] == []
+    assert ids["up_cross"] == [f"up-level{l}-repeat{r}-vit-block0-cross-map" for l in (1, 2) for r in range(3)]
