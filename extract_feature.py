@@ -1,0 +1,166 @@
+#!/usr/bin/env python3
+"""Feature-extraction CLI for the MI355X-native extractor — same flags and on-disk layout as the reference's
+extract_feature.py (/root/reference/extract_feature.py:18-43 flags, :113-148 output stage, figures/output_format.jpg):
+
+  per-layer mode      <output_dir>/<layer_id>/<name>.npy            (C,H,W) fp16        [default]
+  --sample_name_first <output_dir>/<name>/<layer_id>.npy
+  --aggregate_output  <output_dir>/<name>.npy                       all layers nearest-resized to the largest H,W and
+                                                                    concatenated over channels
+  <name> = original file stem (--use_original_filename; parent-dir/stem with --nested_input_dir) or <split><index>.
+
+The reference's own script also runs unchanged against this package (it only needs `import diffusion_feature`);
+this version overlaps the device->host copies of batch i with the extraction of batch i+1 through pinned buffers.
+"""
+import argparse
+import glob
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "generic-diffusion-feature_amd"))
+import diffusion_feature  # noqa: E402
+
+
+def parse_args(argv=None):
+    p = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    # model / extractor settings (constructor keywords of FeatureExtractor)
+    p.add_argument('--layer', type=str, help="layer-selection json ({layer_id: bool})")
+    p.add_argument('--version', type=str, default='xl')
+    p.add_argument('--dtype', type=str, default='float16', choices=('float16', 'float32'))
+    p.add_argument('--offline_lora', type=str, default=None)
+    p.add_argument('--offline_lora_filename', type=str, default=None)
+    p.add_argument('--feature_resize', type=int, default=1)
+    p.add_argument('--control', type=str, nargs='+', default=None)
+    p.add_argument('--attention', type=str, nargs='+', default=None,
+                   choices=('down_cross', 'mid_cross', 'up_cross', 'down_self', 'mid_self', 'up_self'))
+    p.add_argument('--img_size', type=int, default=1024)
+    # extraction settings
+    p.add_argument('--batch_size', '-b', type=int, default=2)
+    p.add_argument('--t', type=int, help='timestep at which features are extracted')
+    p.add_argument('--denoising_from', type=int, default=None)
+    p.add_argument('--use_ddim_inversion', action='store_true')
+    # io settings
+    p.add_argument('--input_dir', type=str, default=None, help='glob pattern of the input images')
+    p.add_argument('--nested_input_dir', action='store_true')
+    p.add_argument('--prompt_file', type=str, default='prompt.txt')
+    p.add_argument('--output_dir', type=str, default='./output/')
+    p.add_argument('--aggregate_output', action='store_true')
+    p.add_argument('--use_original_filename', action='store_true')
+    p.add_argument('--split', type=str, default='train')
+    p.add_argument('--sample_name_first', action='store_true')
+    p.add_argument('--show_all_layers', action='store_true')
+    return p.parse_args(argv)
+
+
+def sample_name(path, nested):
+    stem = os.path.splitext(os.path.basename(path))[0]
+    return os.path.join(os.path.basename(os.path.dirname(path)), stem) if nested else stem
+
+
+class HostWriter:
+    """Device -> pinned host -> .npy, one batch behind the GPU."""
+
+    def __init__(self, args):
+        self.args = args
+        self.pending = None
+        self.stream = torch.cuda.Stream() if torch.cuda.is_available() else None
+
+    def submit(self, feats, names):
+        self.flush()
+        host = {}
+        if self.stream is not None:
+            self.stream.wait_stream(torch.cuda.current_stream())
+        ctx = torch.cuda.stream(self.stream) if self.stream is not None else _null()
+        with ctx:
+            if self.args.aggregate_output:
+                size = max(v.shape[-1] for v in feats.values())
+                agg = torch.cat([torch.nn.functional.interpolate(v, size) for v in feats.values()], dim=1)
+                feats = {None: agg}
+            for k, v in feats.items():
+                v = v.detach()
+                if v.is_cuda:
+                    buf = torch.empty(v.shape, dtype=v.dtype, pin_memory=True)
+                    buf.copy_(v, non_blocking=True)
+                    v.record_stream(self.stream)
+                    host[k] = buf
+                else:
+                    host[k] = v
+        ev = torch.cuda.Event() if self.stream is not None else None
+        if ev is not None:
+            ev.record(self.stream)
+        self.pending = (host, names, ev)
+
+    def flush(self):
+        if self.pending is None:
+            return
+        host, names, ev = self.pending
+        self.pending = None
+        if ev is not None:
+            ev.synchronize()
+        a = self.args
+        for j, name in enumerate(names):
+            for k, v in host.items():
+                arr = v[j].numpy()
+                if k is None:                                       # aggregated: <output_dir>/<name>.npy
+                    path = os.path.join(a.output_dir, name)
+                elif a.sample_name_first:
+                    path = os.path.join(a.output_dir, name, k)
+                else:
+                    path = os.path.join(a.output_dir, k, name)
+                os.makedirs(os.path.dirname(path) or '.', exist_ok=True)
+                np.save(path, arr)
+
+
+class _null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+def main(argv=None):
+    from PIL import Image
+    args = parse_args(argv)
+    os.makedirs(args.output_dir, exist_ok=True)
+    print(f'Run folder: {args.output_dir}')
+    if args.show_all_layers:
+        args.layer = None
+    df = diffusion_feature.FeatureExtractor(
+        args.layer, args.version, device='cuda', dtype=args.dtype, offline_lora=args.offline_lora,
+        offline_lora_filename=args.offline_lora_filename, feature_resize=args.feature_resize, control=args.control,
+        attention=args.attention, img_size=args.img_size)
+
+    paths = sorted(glob.glob(args.input_dir, recursive=True))
+    with open(args.prompt_file, 'r') as f:
+        prompt_text = f.read()
+    print('prompt:', prompt_text)
+    prompts = df.encode_prompt(prompt_text)
+
+    writer = HostWriter(args)
+    with torch.no_grad():
+        for i in range(0, len(paths), args.batch_size):
+            chunk = paths[i:i + args.batch_size]
+            images = [Image.open(p) for p in chunk]
+            feats = df.extract(prompts, len(images), images, t=args.t, denoising_from=args.denoising_from,
+                               use_control=args.control is not None, use_ddim_inversion=args.use_ddim_inversion)
+            if args.show_all_layers:                               # dump the id list and stop (reference :103-110)
+                for k, v in feats.items():
+                    print(k, tuple(v[0].shape))
+                with open('layer_record.json', 'w') as f:
+                    json.dump({k: True for k in feats}, f)
+                return
+            names = [sample_name(p, args.nested_input_dir) if args.use_original_filename else f'{args.split}{i + j}'
+                     for j, p in enumerate(chunk)]
+            writer.submit(feats, names)
+            print(f'{min(i + len(chunk), len(paths))}/{len(paths)}', end='\r')
+    writer.flush()
+    print()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,47 @@
+"""extract_feature.py CLI (-m gpu): flags and on-disk layout of the reference's output stage
+(/root/reference/extract_feature.py:113-148, figures/output_format.jpg) on the synthetic front-end."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _setup(tmp_path):
+    from PIL import Image
+    rs = np.random.RandomState(0)
+    (tmp_path / "imgs").mkdir()
+    for n in ("a", "b", "c"):
+        Image.fromarray((rs.rand(200, 240, 3) * 255).astype(np.uint8)).save(tmp_path / "imgs" / f"{n}.png")
+    (tmp_path / "prompt.txt").write_text("a photo of a cat")
+    layers = {"up-level1-repeat2-res-out": True, "up-level3-repeat0-vit-block0-self-k": True}
+    (tmp_path / "layers.json").write_text(json.dumps(layers))
+    return layers
+
+
+def test_cli_layouts(tmp_path, monkeypatch):
+    monkeypatch.setenv("GDF_SYNTHETIC_WEIGHTS", "1")
+    sys.path.insert(0, ROOT)
+    import extract_feature as cli
+    layers = _setup(tmp_path)
+    base = ["--layer", str(tmp_path / "layers.json"), "--version", "1-5", "--img_size", "256", "--t", "100", "-b", "2",
+            "--input_dir", str(tmp_path / "imgs" / "*.png"), "--prompt_file", str(tmp_path / "prompt.txt")]
+    cli.main(base + ["--output_dir", str(tmp_path / "o1"), "--use_original_filename"])
+    for k, (c, hw) in {"up-level1-repeat2-res-out": (1280, 8), "up-level3-repeat0-vit-block0-self-k": (320, 32)}.items():
+        for n in ("a", "b", "c"):
+            arr = np.load(tmp_path / "o1" / k / f"{n}.npy")
+            assert arr.shape == (c, hw, hw) and arr.dtype == np.float16 and np.isfinite(arr.astype(np.float32)).all()
+    cli.main(base + ["--output_dir", str(tmp_path / "o2"), "--sample_name_first", "--split", "val"])
+    assert sorted(os.listdir(tmp_path / "o2")) == ["val0", "val1", "val2"]
+    assert sorted(os.listdir(tmp_path / "o2" / "val1")) == sorted(k + ".npy" for k in layers)
+    cli.main(base + ["--output_dir", str(tmp_path / "o3"), "--aggregate_output", "--use_original_filename"])
+    agg = np.load(tmp_path / "o3" / "b.npy")
+    assert agg.shape == (1280 + 320, 32, 32)
+    # aggregated == nearest-resize + channel concat of the per-layer files of the same run configuration
+    lo = np.load(tmp_path / "o1" / "up-level1-repeat2-res-out" / "b.npy")
+    assert np.array_equal(agg[:1280, ::4, ::4], lo) and np.array_equal(agg[1280:], np.load(
+        tmp_path / "o1" / "up-level3-repeat0-vit-block0-self-k" / "b.npy"))
