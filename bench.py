@@ -182,6 +182,10 @@ def main():
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # test hook: exercise the multi-rank code path on a 1-GPU box (all ranks on cuda:0, gloo instead of RCCL)
+    share_gpu = os.environ.get("GDF_BENCH_SHARE_GPU", "0") == "1"
+    if share_gpu:
+        local = 0
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
@@ -192,7 +196,10 @@ def main():
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if share_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from components.native import NativeUNet
     import ctypes as C
