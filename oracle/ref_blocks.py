@@ -79,6 +79,163 @@ def _get_activation(name):
     return {"swish": nn.SiLU(), "silu": nn.SiLU(), "mish": nn.Mish(), "gelu": nn.GELU(), "relu": nn.ReLU()}[name.lower()]
 
 
+
+# ---- un-vendored diffusers==0.32.2 classes the Flux files import (transformer_flux.py:34-38,
+# attention_processor.py:141,2331, attention.py:22) — restated from the published algorithm, parameter names as in
+# the diffusers state_dict ---------------------------------------------------------------------------
+class _GELU(nn.Module):
+    """activations.GELU: proj -> F.gelu(approximate)."""
+
+    def __init__(self, dim_in, dim_out, approximate="none", bias=True):
+        super().__init__()
+        self.proj = nn.Linear(dim_in, dim_out, bias=bias)
+        self.approximate = approximate
+
+    def forward(self, hidden_states):
+        return F.gelu(self.proj(hidden_states), approximate=self.approximate)
+
+
+class _RMSNorm(nn.Module):
+    """normalization.RMSNorm (weight only)."""
+
+    def __init__(self, dim, eps, elementwise_affine=True, bias=False):
+        super().__init__()
+        self.eps = eps
+        self.weight = nn.Parameter(torch.ones(dim)) if elementwise_affine else None
+
+    def forward(self, hidden_states):
+        variance = hidden_states.to(torch.float32).pow(2).mean(-1, keepdim=True)
+        hidden_states = hidden_states * torch.rsqrt(variance + self.eps)
+        if self.weight is not None:
+            hidden_states = hidden_states * self.weight
+        return hidden_states
+
+
+class _AdaLayerNormZero(nn.Module):
+    def __init__(self, embedding_dim, num_embeddings=None, norm_type="layer_norm", bias=True):
+        super().__init__()
+        self.silu = nn.SiLU()
+        self.linear = nn.Linear(embedding_dim, 6 * embedding_dim, bias=bias)
+        self.norm = nn.LayerNorm(embedding_dim, elementwise_affine=False, eps=1e-6)
+
+    def forward(self, x, timestep=None, class_labels=None, hidden_dtype=None, emb=None):
+        emb = self.linear(self.silu(emb))
+        shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp = emb.chunk(6, dim=1)
+        x = self.norm(x) * (1 + scale_msa[:, None]) + shift_msa[:, None]
+        return x, gate_msa, shift_mlp, scale_mlp, gate_mlp
+
+
+class _AdaLayerNormZeroSingle(nn.Module):
+    def __init__(self, embedding_dim, norm_type="layer_norm", bias=True):
+        super().__init__()
+        self.silu = nn.SiLU()
+        self.linear = nn.Linear(embedding_dim, 3 * embedding_dim, bias=bias)
+        self.norm = nn.LayerNorm(embedding_dim, elementwise_affine=False, eps=1e-6)
+
+    def forward(self, x, emb=None):
+        emb = self.linear(self.silu(emb))
+        shift_msa, scale_msa, gate_msa = emb.chunk(3, dim=1)
+        x = self.norm(x) * (1 + scale_msa[:, None]) + shift_msa[:, None]
+        return x, gate_msa
+
+
+class _AdaLayerNormContinuous(nn.Module):
+    def __init__(self, embedding_dim, conditioning_embedding_dim, elementwise_affine=True, eps=1e-5, bias=True,
+                 norm_type="layer_norm"):
+        super().__init__()
+        self.silu = nn.SiLU()
+        self.linear = nn.Linear(conditioning_embedding_dim, embedding_dim * 2, bias=bias)
+        self.norm = nn.LayerNorm(embedding_dim, eps, elementwise_affine, bias)
+
+    def forward(self, x, conditioning_embedding):
+        emb = self.linear(self.silu(conditioning_embedding).to(x.dtype))
+        scale, shift = torch.chunk(emb, 2, dim=1)
+        return self.norm(x) * (1 + scale)[:, None, :] + shift[:, None, :]
+
+
+def _get_timestep_embedding(timesteps, dim, flip_sin_to_cos=False, downscale_freq_shift=1.0, max_period=10000):
+    import math
+    half = dim // 2
+    exponent = -math.log(max_period) * torch.arange(half, dtype=torch.float32) / (half - downscale_freq_shift)
+    emb = timesteps[:, None].float() * torch.exp(exponent)[None, :]
+    emb = torch.cat([torch.sin(emb), torch.cos(emb)], dim=-1)
+    if flip_sin_to_cos:
+        emb = torch.cat([emb[:, half:], emb[:, :half]], dim=-1)
+    return emb
+
+
+class _TimestepEmbedding(nn.Module):
+    def __init__(self, in_channels, time_embed_dim):
+        super().__init__()
+        self.linear_1 = nn.Linear(in_channels, time_embed_dim)
+        self.act = nn.SiLU()
+        self.linear_2 = nn.Linear(time_embed_dim, time_embed_dim)
+
+    def forward(self, sample):
+        return self.linear_2(self.act(self.linear_1(sample)))
+
+
+class _PixArtAlphaTextProjection(nn.Module):
+    def __init__(self, in_features, hidden_size, out_features=None, act_fn="silu"):
+        super().__init__()
+        self.linear_1 = nn.Linear(in_features, hidden_size)
+        self.act_1 = nn.SiLU()
+        self.linear_2 = nn.Linear(hidden_size, out_features or hidden_size)
+
+    def forward(self, caption):
+        return self.linear_2(self.act_1(self.linear_1(caption)))
+
+
+class _CombinedTimestepTextProjEmbeddings(nn.Module):
+    def __init__(self, embedding_dim, pooled_projection_dim):
+        super().__init__()
+        self.timestep_embedder = _TimestepEmbedding(256, embedding_dim)
+        self.text_embedder = _PixArtAlphaTextProjection(pooled_projection_dim, embedding_dim, act_fn="silu")
+
+    def forward(self, timestep, pooled_projection):
+        t = self.timestep_embedder(_get_timestep_embedding(timestep, 256, True, 0).to(pooled_projection.dtype))
+        return t + self.text_embedder(pooled_projection)
+
+
+class _CombinedTimestepGuidanceTextProjEmbeddings(nn.Module):
+    def __init__(self, embedding_dim, pooled_projection_dim):
+        super().__init__()
+        self.timestep_embedder = _TimestepEmbedding(256, embedding_dim)
+        self.guidance_embedder = _TimestepEmbedding(256, embedding_dim)
+        self.text_embedder = _PixArtAlphaTextProjection(pooled_projection_dim, embedding_dim, act_fn="silu")
+
+    def forward(self, timestep, guidance, pooled_projection):
+        t = self.timestep_embedder(_get_timestep_embedding(timestep, 256, True, 0).to(pooled_projection.dtype))
+        g = self.guidance_embedder(_get_timestep_embedding(guidance, 256, True, 0).to(pooled_projection.dtype))
+        return t + g + self.text_embedder(pooled_projection)
+
+
+class _FluxPosEmbed(nn.Module):
+    def __init__(self, theta, axes_dim):
+        super().__init__()
+        self.theta = theta
+        self.axes_dim = axes_dim
+
+    def forward(self, ids):
+        cos_out, sin_out = [], []
+        pos = ids.float()
+        for i in range(ids.shape[-1]):
+            d = self.axes_dim[i]
+            freqs = 1.0 / (self.theta ** (torch.arange(0, d, 2, dtype=torch.float64)[: d // 2] / d))
+            ang = torch.outer(pos[:, i].to(torch.float64), freqs)
+            cos_out.append(ang.cos().repeat_interleave(2, dim=1).float())
+            sin_out.append(ang.sin().repeat_interleave(2, dim=1).float())
+        return torch.cat(cos_out, dim=-1), torch.cat(sin_out, dim=-1)
+
+
+def _apply_rotary_emb(x, freqs_cis, use_real=True, use_real_unbind_dim=-1):
+    cos, sin = freqs_cis
+    cos, sin = cos[None, None].to(x.device), sin[None, None].to(x.device)
+    x_real, x_imag = x.reshape(*x.shape[:-1], -1, 2).unbind(-1)
+    x_rotated = torch.stack([-x_imag, x_real], dim=-1).flatten(3)
+    return (x.float() * cos + x_rotated.float() * sin).to(x.dtype)
+
+
 _installed = False
 
 
@@ -115,14 +272,20 @@ def install():
     _mod("diffusers.configuration_utils", register_to_config=_register_to_config,
          ConfigMixin=type("ConfigMixin", (), {}), LegacyConfigMixin=type("LegacyConfigMixin", (), {}))
     _pkg("diffusers.models")
-    _mod("diffusers.models.activations", get_activation=_get_activation, GEGLU=_GEGLU,
-         **{n: _placeholder(n) for n in ("GELU", "ApproximateGELU", "FP32SiLU", "LinearActivation", "SwiGLU")})
-    _mod("diffusers.models.embeddings",
-         **{n: _placeholder(n) for n in ("SinusoidalPositionalEmbedding", "ImagePositionalEmbeddings", "PatchEmbed",
-                                         "PixArtAlphaTextProjection")})
-    _mod("diffusers.models.normalization",
-         **{n: _placeholder(n) for n in ("AdaGroupNorm", "AdaLayerNorm", "AdaLayerNormContinuous", "AdaLayerNormZero",
-                                         "RMSNorm", "SD35AdaLayerNormZeroX", "AdaLayerNormSingle", "FP32LayerNorm", "LpNorm")})
+    _mod("diffusers.models.activations", get_activation=_get_activation, GEGLU=_GEGLU, GELU=_GELU,
+         **{n: _placeholder(n) for n in ("ApproximateGELU", "FP32SiLU", "LinearActivation", "SwiGLU")})
+    _mod("diffusers.models.embeddings", PixArtAlphaTextProjection=_PixArtAlphaTextProjection,
+         CombinedTimestepGuidanceTextProjEmbeddings=_CombinedTimestepGuidanceTextProjEmbeddings,
+         CombinedTimestepTextProjEmbeddings=_CombinedTimestepTextProjEmbeddings, FluxPosEmbed=_FluxPosEmbed,
+         apply_rotary_emb=_apply_rotary_emb,
+         **{n: _placeholder(n) for n in ("SinusoidalPositionalEmbedding", "ImagePositionalEmbeddings", "PatchEmbed")})
+    _mod("diffusers.models.normalization", AdaLayerNormContinuous=_AdaLayerNormContinuous,
+         AdaLayerNormZero=_AdaLayerNormZero, AdaLayerNormZeroSingle=_AdaLayerNormZeroSingle, RMSNorm=_RMSNorm,
+         **{n: _placeholder(n) for n in ("AdaGroupNorm", "AdaLayerNorm", "SD35AdaLayerNormZeroX", "AdaLayerNormSingle",
+                                         "FP32LayerNorm", "LpNorm")})
+    _mix = lambda n: type(n, (), {})
+    _mod("diffusers.loaders", FluxTransformer2DLoadersMixin=_mix("FluxTransformer2DLoadersMixin"),
+         FromOriginalModelMixin=_mix("FromOriginalModelMixin"), PeftAdapterMixin=_mix("PeftAdapterMixin"))
     class _T2DOut:
         def __init__(self, sample=None):
             self.sample = sample
@@ -152,6 +315,7 @@ def install():
     load("diffusers.models.resnet", "diffusers/models/resnet.py")
     load("diffusers.models.attention", "diffusers/models/attention.py")
     load("diffusers.models.transformers.transformer_2d", "diffusers/models/transformers/transformer_2d.py")
+    load("diffusers.models.transformers.transformer_flux", "diffusers/models/transformers/transformer_flux.py")
     load("gdf_ref_feature_extractor", "components/feature_extractor.py")
     # components/attention.py imports names from the installed diffusers package root
     sys.modules["diffusers.models.attention_processor"].__dict__.setdefault("AttnProcessor2_0", None)
@@ -171,6 +335,7 @@ def modules():
         AttnProcessor=m["diffusers.models.attention_processor"].AttnProcessor,
         AttnProcessor2_0=m["diffusers.models.attention_processor"].AttnProcessor2_0,
         Transformer2DModel=m["diffusers.models.transformers.transformer_2d"].Transformer2DModel,
+        FluxTransformer2DModel=m["diffusers.models.transformers.transformer_flux"].FluxTransformer2DModel,
         FeatureStore=m["gdf_ref_feature_extractor"].FeatureStore,
         FeatureGatherer=m["gdf_ref_feature_extractor"].FeatureGatherer,
     )

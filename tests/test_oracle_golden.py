@@ -108,3 +108,34 @@ def test_param_counts():
     n = lambda a: sum(int(np.prod(s)) for s in R.param_shapes(a).values())
     assert n(R.ARCHS["1-5"]) == 859_520_964      # published SD1.5 UNet parameter count
     assert n(R.ARCHS["xl"]) == 2_567_463_684     # published SDXL UNet parameter count
+
+
+# ---- Flux MMDiT: oracle/flux_ref.py vs the reference's transformer_flux.py run ------------
+def test_flux_oracle_matches_reference_golden():
+    from oracle import flux_ref as FR
+    z = np.load(os.path.join(GOLD, "flux_tiny.npz"))
+    meta = ast.literal_eval(str(z["meta"]))
+    arch = meta["arch"]
+    P = FR.synth_params(arch, seed=meta["wseed"])
+    # the fixture pins the (seeded) weights by per-tensor checksums
+    assert np.allclose([float(v.double().sum()) for v in P.values()], z["wsum"], rtol=0, atol=1e-9)
+    assert np.allclose([float(v.double().abs().sum()) for v in P.values()], z["wabs"], rtol=0, atol=1e-9)
+    I = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("in:")}
+    st = FR.Store(None, out_dtype=None)
+    y = FR.flux_forward(P, arch, I["hidden_states"], I["encoder_hidden_states"], I["pooled_projections"], I["timestep"],
+                        I["img_ids"], I["txt_ids"], I.get("guidance"), store=st)
+    assert torch.allclose(y, torch.from_numpy(z["out:y"]), atol=2e-5, rtol=1e-5)
+    hooks = {k[9:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("out:hook:")}
+    assert list(st.feats.keys()) == meta["order"] == FR.hook_ids(arch)
+    for k, v in hooks.items():
+        assert st.feats[k].shape == v.shape, k
+        assert torch.allclose(st.feats[k], v, atol=2e-5, rtol=1e-5), (k, float((st.feats[k] - v).abs().max()))
+
+
+def test_flux_flops_and_param_count():
+    from oracle import flux_ref as FR
+    a = FR.ARCH_FLUX_DEV
+    n = sum(int(np.prod(s)) for s in FR.param_shapes(a).values())
+    assert n == 11_901_408_320                   # published FLUX.1-dev transformer parameter count (11.9 B)
+    tf = FR.flops_per_image(a, 4096, 512) / 1e12
+    assert abs(tf - 74.4) < 0.6, tf
