@@ -69,6 +69,25 @@ SIGNATURES = {
     "gdf_plan_read_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_long), C.POINTER(C.c_double)]),
 }
 
+
+
+class FluxDesc(C.Structure):
+    _fields_ = [("in_channels", C.c_int), ("num_layers", C.c_int), ("num_single_layers", C.c_int),
+                ("attention_head_dim", C.c_int), ("num_attention_heads", C.c_int), ("joint_attention_dim", C.c_int),
+                ("pooled_projection_dim", C.c_int), ("guidance_embeds", C.c_int), ("axes_dims_rope", C.c_int * 3),
+                ("mlp_ratio", C.c_int)]
+
+
+# every symbol declared in include/gdf_flux.h
+SIGNATURES.update({
+    "gdf_flux_model_create": (C.c_int, [C.POINTER(FluxDesc), C.POINTER(C.c_void_p)]),
+    "gdf_flux_plan_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_char_p), C.c_int,
+                                       C.POINTER(PlanOpts), C.POINTER(C.c_void_p)]),
+    "gdf_flux_forward": (C.c_int, [C.c_void_p] + [C.c_void_p] * 7 + [C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gdf_flux_plan_profile": (C.c_int, [C.c_void_p] + [C.c_void_p] * 7 + [C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.POINTER(C.c_float), C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.c_int]),
+})
+
 _lib = None
 
 
@@ -171,41 +190,16 @@ class _Plan:
             pass
 
 
-class NativeUNet:
-    """UNet2DConditionModel replacement running entirely in libgdf.so (hand-written HIP, gfx950).
+class _NativeModel:
+    """Shared surface of the libgdf model wrappers: weights in / hook names out (include/gdf.h model functions)."""
 
-    Call signature mirrors the reference's use at feature/diffusion_feature.py:446-465:
-        unet(latent_model_input, timestep=t, encoder_hidden_states=prompt_embeds,
-             added_cond_kwargs={...}, down_block_additional_residuals=None,
-             mid_block_additional_residual=None, return_dict=False)[0]
-    Hooked activations are delivered to `self.feature_store` (components/feature_extractor.py) in
-    execution order, as (B,C,H,W)-shaped fp16 tensors stored channels-last.
-    """
+    lib = None
+    handle = None
+    device = None
 
-    def __init__(self, cfg, device="cuda", stream_fp32=True, early_exit=False):
-        if not torch.cuda.is_available():
-            raise RuntimeError("NativeUNet needs an MI355X (HIP device); there is no CPU fallback")
-        self.lib = load_library()
-        self.cfg = dict(cfg)
-        self.device = torch.device(device if str(device) != "cuda" else f"cuda:{torch.cuda.current_device()}")
-        self._arch = arch_desc(cfg)
-        h = C.c_void_p()
-        with torch.cuda.device(self.device):
-            _check(self.lib.gdf_model_create(C.byref(self._arch), C.byref(h)), "model_create")
-        self.handle = h
-        self.stream_fp32 = bool(stream_fp32)
-        self.early_exit = bool(early_exit)
-        self.feature_store = None
-        self.shared_ctx = False          # set by FeatureExtractor.extract (it repeats one prompt over the batch)
-        self.extra_hook_ids = []         # hooks FeatureExtractor needs internally (aggregated `attention=` feature)
-        self.last_extra = {}
-        self._plans = {}
-        self.dtype = torch.float16
-        # attributes the reference reads from pipe.unet (diffusion_feature.py:544-547)
-        self.config = types.SimpleNamespace(
-            in_channels=cfg["in_channels"], addition_time_embed_dim=cfg["addition_time_embed_dim"],
-            sample_size=None, cross_attention_dim=cfg["cross_attention_dim"])
-        self.add_embedding = types.SimpleNamespace(linear_1=types.SimpleNamespace(in_features=cfg["add_in_dim"]))
+    def _is_norm(self, name):
+        """True for norm parameters (synthetic init: weight 1 + 0.1 N, bias 0.1 N)."""
+        return False
 
     # ---- nn.Module-like surface used by FeatureExtractor -------------------------------------
     def parameters(self):
@@ -268,7 +262,7 @@ class NativeUNet:
         stream = torch.cuda.current_stream(self.device)
         with torch.cuda.device(self.device):
             for name, shp in self.param_shapes().items():
-                is_norm = ".norm" in name or name.startswith("conv_norm_out")
+                is_norm = self._is_norm(name)
                 t = torch.randn(shp, generator=g, device=self.device, dtype=torch.float32)
                 if name.endswith(".weight") and not is_norm:
                     fan_in = 1
@@ -290,6 +284,54 @@ class NativeUNet:
     def ready(self):
         return bool(self.lib.gdf_model_ready(self.handle))
 
+    def requested_ids(self):
+        fs = self.feature_store
+        if fs is None:
+            return []
+        if fs.accept_all:
+            return self.hook_names()
+        return [k for k, v in fs.to_store.items() if v]
+
+
+class NativeUNet(_NativeModel):
+    """UNet2DConditionModel replacement running entirely in libgdf.so (hand-written HIP, gfx950).
+
+    Call signature mirrors the reference's use at feature/diffusion_feature.py:446-465:
+        unet(latent_model_input, timestep=t, encoder_hidden_states=prompt_embeds,
+             added_cond_kwargs={...}, down_block_additional_residuals=None,
+             mid_block_additional_residual=None, return_dict=False)[0]
+    Hooked activations are delivered to `self.feature_store` (components/feature_extractor.py) in
+    execution order, as (B,C,H,W)-shaped fp16 tensors stored channels-last.
+    """
+
+    def __init__(self, cfg, device="cuda", stream_fp32=True, early_exit=False):
+        if not torch.cuda.is_available():
+            raise RuntimeError("NativeUNet needs an MI355X (HIP device); there is no CPU fallback")
+        self.lib = load_library()
+        self.cfg = dict(cfg)
+        self.device = torch.device(device if str(device) != "cuda" else f"cuda:{torch.cuda.current_device()}")
+        self._arch = arch_desc(cfg)
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _check(self.lib.gdf_model_create(C.byref(self._arch), C.byref(h)), "model_create")
+        self.handle = h
+        self.stream_fp32 = bool(stream_fp32)
+        self.early_exit = bool(early_exit)
+        self.feature_store = None
+        self.shared_ctx = False          # set by FeatureExtractor.extract (it repeats one prompt over the batch)
+        self.extra_hook_ids = []         # hooks FeatureExtractor needs internally (aggregated `attention=` feature)
+        self.last_extra = {}
+        self._plans = {}
+        self.dtype = torch.float16
+        # attributes the reference reads from pipe.unet (diffusion_feature.py:544-547)
+        self.config = types.SimpleNamespace(
+            in_channels=cfg["in_channels"], addition_time_embed_dim=cfg["addition_time_embed_dim"],
+            sample_size=None, cross_attention_dim=cfg["cross_attention_dim"])
+        self.add_embedding = types.SimpleNamespace(linear_1=types.SimpleNamespace(in_features=cfg["add_in_dim"]))
+
+    def _is_norm(self, name):
+        return ".norm" in name or name.startswith("conv_norm_out")
+
     # ---- plans ------------------------------------------------------------------------------------
     def _plan(self, batch, h, w, n_ctx, hook_ids, shared_ctx=False):
         key = (batch, h, w, n_ctx, tuple(hook_ids), self.stream_fp32, self.early_exit, bool(shared_ctx))
@@ -306,14 +348,6 @@ class NativeUNet:
                 self._plans.pop(next(iter(self._plans)))
             self._plans[key] = p
         return p
-
-    def requested_ids(self):
-        fs = self.feature_store
-        if fs is None:
-            return []
-        if fs.accept_all:
-            return self.hook_names()
-        return [k for k, v in fs.to_store.items() if v]
 
     # ---- forward ------------------------------------------------------------------------------------
     def forward_raw(self, sample, timestep, encoder_hidden_states, text_embeds=None, time_ids=None, hook_ids=None,
@@ -392,3 +426,147 @@ class NativeUNet:
         if return_dict:
             return types.SimpleNamespace(sample=noise)
         return (noise,)
+
+
+# --------------------------------------------------------------------------------------------- #
+# MMDiT / Flux (include/gdf_flux.h): FluxTransformer2DModel `config.json` of black-forest-labs/FLUX.1-dev
+# (reference components/models.py:150-169)
+# --------------------------------------------------------------------------------------------- #
+FLUX_CONFIGS = {
+    "flux": dict(in_channels=64, num_layers=19, num_single_layers=38, attention_head_dim=128, num_attention_heads=24,
+                 joint_attention_dim=4096, pooled_projection_dim=768, guidance_embeds=1, axes_dims_rope=(16, 56, 56),
+                 mlp_ratio=4),
+}
+
+
+def flux_desc(cfg):
+    d = FluxDesc()
+    for k in ("in_channels", "num_layers", "num_single_layers", "attention_head_dim", "num_attention_heads",
+              "joint_attention_dim", "pooled_projection_dim"):
+        setattr(d, k, int(cfg[k]))
+    d.guidance_embeds = int(bool(cfg["guidance_embeds"]))
+    d.mlp_ratio = int(cfg.get("mlp_ratio", 4))
+    for i in range(3):
+        d.axes_dims_rope[i] = int(cfg["axes_dims_rope"][i])
+    return d
+
+
+class NativeFluxTransformer(_NativeModel):
+    """FluxTransformer2DModel replacement running entirely in libgdf.so (hand-written HIP, gfx950).
+
+    Call signature mirrors the pipeline's use of `self.transformer(...)` (FluxImg2ImgPipeline, invoked by the reference
+    at feature/diffusion_feature.py:246-254) == FluxTransformer2DModel.forward
+    (feature/diffusers/models/transformers/transformer_flux.py:414-428):
+        transformer(hidden_states=latents, timestep=t/1000, guidance=g, pooled_projections=..., encoder_hidden_states=...,
+                    txt_ids=..., img_ids=..., joint_attention_kwargs=None, return_dict=False)[0]
+    Hooked activations go to `self.feature_store` in execution order as (B, C, h, w) fp16 tensors (channels-last),
+    ids `vit-block{i}-{q,k,v,attn-out,norm-out,ffn-inner,out}` (components/feature_extractor.py:98-123).
+    """
+
+    def __init__(self, cfg, device="cuda", early_exit=False):
+        if not torch.cuda.is_available():
+            raise RuntimeError("NativeFluxTransformer needs an MI355X (HIP device); there is no CPU fallback")
+        self.lib = load_library()
+        self.cfg = dict(cfg)
+        self.device = torch.device(device if str(device) != "cuda" else f"cuda:{torch.cuda.current_device()}")
+        self._desc = flux_desc(cfg)
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _check(self.lib.gdf_flux_model_create(C.byref(self._desc), C.byref(h)), "flux_model_create")
+        self.handle = h
+        self.early_exit = bool(early_exit)
+        self.feature_store = None
+        self._plans = {}
+        self.dtype = torch.float16
+        self.config = types.SimpleNamespace(in_channels=cfg["in_channels"], guidance_embeds=bool(cfg["guidance_embeds"]),
+                                            joint_attention_dim=cfg["joint_attention_dim"],
+                                            pooled_projection_dim=cfg["pooled_projection_dim"])
+
+    def _is_norm(self, name):
+        return ".attn.norm_" in name
+
+    def _plan(self, batch, gh, gw, n_txt, hook_ids):
+        key = (batch, gh, gw, n_txt, tuple(hook_ids), self.early_exit)
+        p = self._plans.get(key)
+        if p is None:
+            ids = (C.c_char_p * max(1, len(hook_ids)))(*[s.encode() for s in hook_ids])
+            opts = PlanOpts(1, int(self.early_exit))
+            ph = C.c_void_p()
+            _check(self.lib.gdf_flux_plan_create(self.handle, batch, gh, gw, n_txt, ids, len(hook_ids), C.byref(opts),
+                                                 C.byref(ph)), "flux_plan_create")
+            p = _Plan(self.lib, ph)
+            if len(self._plans) >= 4:
+                self._plans.pop(next(iter(self._plans)))
+            self._plans[key] = p
+        return p
+
+    def forward_raw(self, hidden_states, encoder_hidden_states, pooled_projections, timestep, img_ids, txt_ids,
+                    guidance=None, hook_ids=None, grid=None, profile=False):
+        """Returns (output (B, S, in_channels) fp16, OrderedDict id -> hook tensor).  `grid` = (h, w) of the packed
+        latent token grid; default: square (the reference's FeatureStore assumes it, feature_extractor.py:46-48)."""
+        dev = self.device
+        B, S, cin = hidden_states.shape
+        if grid is None:
+            g = int(round(S ** 0.5))
+            if g * g != S:
+                raise ValueError(f"{S} image tokens do not form a square grid; pass grid=(h, w)")
+            grid = (g, g)
+        f16 = lambda t: t.to(dev, torch.float16).contiguous()
+        f32 = lambda t: t.to(dev, torch.float32).contiguous()
+        x, enc, pooled = f16(hidden_states), f16(encoder_hidden_states), f16(pooled_projections)
+        t = torch.as_tensor(timestep, device=dev).float().reshape(-1)
+        t = (t.expand(B) if t.numel() == 1 else t).contiguous()
+        gd = None
+        if self.cfg["guidance_embeds"]:
+            if guidance is None:
+                raise ValueError("guidance is required for a guidance-distilled transformer (guidance_embeds)")
+            gd = torch.as_tensor(guidance, device=dev).float().reshape(-1)
+            gd = (gd.expand(B) if gd.numel() == 1 else gd).contiguous()
+        img_ids = f32(img_ids[0] if img_ids.dim() == 3 else img_ids)       # transformer_flux.py:485-496
+        txt_ids = f32(txt_ids[0] if txt_ids.dim() == 3 else txt_ids)
+        T = enc.shape[1]
+        if (cin != self.cfg["in_channels"] or enc.shape != (B, T, self.cfg["joint_attention_dim"])
+                or pooled.shape != (B, self.cfg["pooled_projection_dim"]) or img_ids.shape != (S, 3)
+                or txt_ids.shape != (T, 3)):
+            raise ValueError("flux input shape mismatch")
+        ids = list(hook_ids) if hook_ids is not None else self.requested_ids()
+        plan = self._plan(B, grid[0], grid[1], T, ids)
+        with torch.cuda.device(dev):
+            if plan.workspace is None or plan.workspace.numel() < plan.ws_bytes:
+                plan.workspace = torch.empty(plan.ws_bytes, dtype=torch.uint8, device=dev)
+            hooks = [torch.empty(nbytes // 2, dtype=torch.float16, device=dev) for (_, _, _, nbytes) in plan.hooks]
+            hook_ptrs = (C.c_void_p * max(1, len(hooks)))(*[h.data_ptr() for h in hooks])
+            out = torch.empty(B, S, cin, dtype=torch.float16, device=dev)
+            stream = torch.cuda.current_stream(dev)
+            vp = lambda a: C.c_void_p(a.data_ptr() if a is not None else 0)
+            args = (plan.handle, vp(x), vp(enc), vp(pooled), vp(t), vp(gd), vp(img_ids), vp(txt_ids), hook_ptrs, vp(out),
+                    vp(plan.workspace), C.c_void_p(stream.cuda_stream))
+            prof = None
+            if profile:
+                n = self.lib.gdf_plan_num_ops(plan.handle)
+                ms = (C.c_float * n)(); names = (C.c_char_p * n)(); fl = (C.c_double * n)()
+                if self.lib.gdf_flux_plan_profile(*args, ms, names, fl, n) < 0:
+                    _check(1, "flux_plan_profile")
+                prof = [(names[i].decode(), ms[i], fl[i], self.lib.gdf_plan_op_kernel(plan.handle, i).decode())
+                        for i in range(n)]
+            else:
+                _check(self.lib.gdf_flux_forward(*args), "flux_forward")
+        feats = {}
+        for buf, (hid, shape, stride, _) in zip(hooks, plan.hooks):
+            feats[hid] = torch.as_strided(buf, shape, stride)
+        return (out, feats, prof) if profile else (out, feats)
+
+    def __call__(self, hidden_states, encoder_hidden_states=None, pooled_projections=None, timestep=None, img_ids=None,
+                 txt_ids=None, guidance=None, joint_attention_kwargs=None, controlnet_block_samples=None,
+                 controlnet_single_block_samples=None, return_dict=True, **kwargs):
+        if controlnet_block_samples is not None or controlnet_single_block_samples is not None or joint_attention_kwargs:
+            raise NotImplementedError("ControlNet residuals / IP-adapter kwargs are outside the native hot path")
+        ids = self.requested_ids()
+        out, hooks = self.forward_raw(hidden_states, encoder_hidden_states, pooled_projections, timestep, img_ids, txt_ids,
+                                      guidance=guidance, hook_ids=ids)
+        if self.feature_store is not None:
+            for hid, t in hooks.items():
+                self.feature_store.store(t, hid)
+        if return_dict:
+            return types.SimpleNamespace(sample=out)
+        return (out,)

@@ -47,6 +47,7 @@ const char* gdf_model_hook_name(const gdf_model* m, int i) {
 int gdf_plan_create(gdf_model* m, int batch, int lat_h, int lat_w, int n_ctx, const char* const* hook_ids, int n_hooks,
                     const gdf_plan_opts* opts, gdf_plan** out) {
   if (!m || !out || (n_hooks > 0 && !hook_ids)) { set_error("null argument"); return GDF_ERR_ARG; }
+  if (m->m->kind != 0) { set_error("gdf_plan_create on a Flux model: use gdf_flux_plan_create"); return GDF_ERR_ARG; }
   gdf_plan_opts o{};
   o.stream_fp32 = 1;
   if (opts) o = *opts;
@@ -69,6 +70,48 @@ int gdf_plan_hook_info(const gdf_plan* p, int i, gdf_hook_info* info) {
   for (int k = 0; k < 4; ++k) { info->shape[k] = h.shape[k]; info->stride[k] = h.stride[k]; }
   info->bytes = h.bytes;
   return GDF_OK;
+}
+
+// ---- MMDiT / Flux front end (include/gdf_flux.h) ----
+int gdf_flux_model_create(const gdf_flux_desc* desc, gdf_model** out) {
+  if (!desc || !out) { set_error("null argument"); return GDF_ERR_ARG; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { set_error("no HIP device: libgdf has no CPU fallback"); return GDF_ERR_HIP; }
+  Model* m = flux_model_create(*desc);
+  if (!m) return GDF_ERR_ARG;
+  *out = new gdf_model{m};
+  return GDF_OK;
+}
+int gdf_flux_plan_create(gdf_model* m, int batch, int img_h, int img_w, int n_txt, const char* const* hook_ids, int n_hooks,
+                         const gdf_plan_opts* opts, gdf_plan** out) {
+  if (!m || !out || (n_hooks > 0 && !hook_ids)) { set_error("null argument"); return GDF_ERR_ARG; }
+  gdf_plan_opts o{};
+  o.stream_fp32 = 1;
+  if (opts) o = *opts;
+  gdf_plan* p = new gdf_plan();
+  p->owner = m;
+  p->p.model = m->m;
+  const int rc = flux_plan_build(*m->m, p->p, batch, img_h, img_w, n_txt, hook_ids, n_hooks, o, false);
+  if (rc != GDF_OK) { delete p; return rc; }
+  *out = p;
+  return GDF_OK;
+}
+int gdf_flux_forward(gdf_plan* p, const void* hidden_states, const void* encoder_hidden_states, const void* pooled_projections,
+                     const float* timestep, const float* guidance, const float* img_ids, const float* txt_ids,
+                     void* const* hook_out, void* out, void* workspace, void* stream) {
+  if (!p) { set_error("null plan"); return GDF_ERR_ARG; }
+  return flux_forward(p->p, *p->p.model, hidden_states, encoder_hidden_states, pooled_projections, timestep, guidance, img_ids,
+                      txt_ids, hook_out, out, workspace, (hipStream_t)stream, nullptr, nullptr, nullptr, 0);
+}
+int gdf_flux_plan_profile(gdf_plan* p, const void* hidden_states, const void* encoder_hidden_states,
+                          const void* pooled_projections, const float* timestep, const float* guidance, const float* img_ids,
+                          const float* txt_ids, void* const* hook_out, void* out, void* workspace, void* stream, float* ms,
+                          const char** names, double* flops, int cap) {
+  if (!p || !ms) { set_error("null argument"); return -1; }
+  const int rc = flux_forward(p->p, *p->p.model, hidden_states, encoder_hidden_states, pooled_projections, timestep, guidance,
+                              img_ids, txt_ids, hook_out, out, workspace, (hipStream_t)stream, ms, names, flops, cap);
+  if (rc != GDF_OK) return -1;
+  return (int)p->p.ops.size();
 }
 
 int gdf_forward(gdf_plan* p, const void* latents, const float* timesteps, const void* ctx, const void* add_text_embeds,

@@ -35,6 +35,15 @@ __device__ __forceinline__ float half_sum(float v) {
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
+// token j of sample b -> row of the activation matrix.  seg_T == 0: sample-major rows (b * per_b + j).
+// seg_T > 0 (MMDiT joint attention, Flux): the joint sequence [seg_T text tokens | S_tot - seg_T image tokens] lives
+// region-major in HBM, [all samples' text rows][all samples' image rows], so that the text / image halves of every
+// linear are contiguous row ranges (the reference concatenates per sample: attention_processor.py:2327-2329).
+__device__ __forceinline__ size_t seg_row(int b, int j, int per_b, int seg_T, int B, int S_tot) {
+  if (seg_T == 0) return (size_t)b * per_b + j;
+  return j < seg_T ? (size_t)b * seg_T + j : (size_t)B * seg_T + (size_t)b * (S_tot - seg_T) + (j - seg_T);
+}
+
 template <int D, int QW>
 __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
   constexpr int DQK = (D + 15) / 16 * 16;        // contraction length of QK^T, padded
@@ -68,7 +77,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
   for (int w = 0; w < QW; ++w) {
     q_row[w] = qb * QBLK + wave * QBW + w * 32 + lq;       // query index inside the sequence
     q_ok[w] = q_row[w] < p.Sq;
-    const _Float16* qp = p.q + ((size_t)b * p.Sq + (q_ok[w] ? q_row[w] : 0)) * p.ldq + head * D;
+    const _Float16* qp = p.q + seg_row(b, q_ok[w] ? q_row[w] : 0, p.Sq, p.seg_T, p.B, p.Sq) * p.ldq + head * D;
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
       const int d0 = 16 * s + 8 * lh;
@@ -90,8 +99,8 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
   }
   const float sl2 = p.scale * 1.44269504088896340736f;    // softmax(x*scale) via exp2
 
-  const _Float16* kbase = p.k + (size_t)b * p.kv_bstride * p.ldk + head * D;
-  const _Float16* vbase = p.v + (size_t)b * p.kv_bstride * p.ldv + head * D;
+  const _Float16* kbase = p.k + head * D;
+  const _Float16* vbase = p.v + head * D;
   const int ntiles = (p.Sk + KT - 1) / KT;
 
   f16x8 kreg[NCH], vreg[NCH];
@@ -103,8 +112,9 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
       const int kv = t * KT + row;
       f16x8 kk = {0, 0, 0, 0, 0, 0, 0, 0}, vv = kk;
       if (idx < KT * CPR && kv < p.Sk && ch * 8 < D) {
-        kk = *(const f16x8*)(kbase + (size_t)kv * p.ldk + ch * 8);
-        vv = *(const f16x8*)(vbase + (size_t)kv * p.ldv + ch * 8);
+        const size_t r = seg_row(b, kv, p.kv_bstride, p.seg_T, p.B, p.Sk);
+        kk = *(const f16x8*)(kbase + r * p.ldk + ch * 8);
+        vv = *(const f16x8*)(vbase + r * p.ldv + ch * 8);
       }
       kreg[c] = kk; vreg[c] = vv;
     }
@@ -225,7 +235,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
     const float l_tot = half_sum(l_run[w]);
     const float inv = 1.0f / l_tot;
     if (q_ok[w]) {
-      _Float16* op = p.o + ((size_t)b * p.Sq + q_row[w]) * p.ldo + head * D;
+      _Float16* op = p.o + seg_row(b, q_row[w], p.Sq, p.seg_T, p.B, p.Sq) * p.ldo + head * D;
 #pragma unroll
       for (int db = 0; db < NDB; ++db)
 #pragma unroll
@@ -466,6 +476,7 @@ __global__ __launch_bounds__(256, 2) void attn_map_kernel(const AttnParams p) {
 
 template <int D>
 static hipError_t launch_d(const AttnParams& p, hipStream_t s) {
+  if (p.map && p.seg_T) return hipErrorInvalidValue;     // '-map' hooks of the joint (MMDiT) layout: not built
   if (p.map) {
     const int nqb = (p.Sq + 127) / 128;
     hipLaunchKernelGGL((attn_map_kernel<D>), dim3(p.B * p.heads * nqb), dim3(256), 0, s, p);
@@ -492,6 +503,7 @@ hipError_t launch_attention(const AttnParams& p, hipStream_t s) {
     case 40: return launch_d<40>(p, s);
     case 64: return launch_d<64>(p, s);
     case 80: return launch_d<80>(p, s);
+    case 128: return launch_d<128>(p, s);
     case 160: return launch_d<160>(p, s);
   }
   return hipErrorInvalidValue;

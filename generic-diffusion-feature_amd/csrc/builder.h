@@ -1,0 +1,240 @@
+// Shared host-side builders of libgdf.so: weight-arena layout (WeightBuilder) and the static plan builder base
+// (PlanBuilder: workspace arena with liveness, activation views, hook table, GEMM / hook-copy op emitters).
+// The UNet (model.cpp) and the MMDiT / Flux (flux.cpp) op programs derive from these.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+#include "model.h"
+
+namespace gdf {
+
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// ---- weight arena layout + diffusers parameter-name registration ---------------------------------
+struct WeightBuilder {
+  Model& m;
+  size_t cur = 0;
+  explicit WeightBuilder(Model& mm) : m(mm) {}
+
+  size_t take(size_t bytes) { size_t o = cur; cur = align_up(cur + bytes, 256); return o; }
+
+  void reg(const std::string& name, std::initializer_list<int64_t> shape, int kind, size_t dst, int a0 = 0, int a1 = 0,
+           int a2 = 0) {
+    ParamRec p;
+    p.name = name; p.ndim = (int)shape.size();
+    int i = 0;
+    for (auto s : shape) p.shape[i++] = s;
+    p.kind = kind; p.dst = dst; p.a0 = a0; p.a1 = a1; p.a2 = a2;
+    m.index[name] = (int)m.params.size();
+    m.params.push_back(p);
+  }
+
+  // linear / 1x1 conv into rows [row_off, row_off+n) of a (possibly shared) [ntot][k] matrix
+  void lin_rows(const std::string& n, LinW& w, int rows, int row_off, bool conv1x1, bool bias) {
+    if (conv1x1) reg(n + ".weight", {rows, w.k, 1, 1}, PK_ROWS, w.w, rows, w.k, row_off);
+    else reg(n + ".weight", {rows, w.k}, PK_ROWS, w.w, rows, w.k, row_off);
+    if (bias) reg(n + ".bias", {rows}, PK_VEC_OFF, w.b, rows, row_off);
+  }
+  LinW lin_alloc(int ntot, int k, bool bias) {
+    LinW w; w.n = ntot; w.k = k; w.w = take((size_t)ntot * k * 2); w.b = bias ? take(ntot * 4) : NPOS; w.has_bias = bias;
+    return w;
+  }
+  LinW lin(const std::string& n, int co, int ci, bool bias = true, bool conv1x1 = false) {
+    LinW w = lin_alloc(co, ci, bias);
+    lin_rows(n, w, co, 0, conv1x1, bias);
+    return w;
+  }
+};
+
+struct Arena {   // plan-time first-fit allocator with coalescing free list
+  struct Blk { size_t off, size; };
+  std::vector<Blk> free_;
+  size_t top = 0, peak = 0;
+  size_t alloc(size_t bytes) {
+    bytes = align_up(std::max<size_t>(bytes, 256), 256);
+    for (size_t i = 0; i < free_.size(); ++i)
+      if (free_[i].size >= bytes) {
+        size_t o = free_[i].off;
+        free_[i].off += bytes; free_[i].size -= bytes;
+        if (!free_[i].size) free_.erase(free_.begin() + i);
+        return o;
+      }
+    // extend: if the last free block touches the top, grow it
+    if (!free_.empty() && free_.back().off + free_.back().size == top) {
+      size_t o = free_.back().off;
+      top = o + bytes; free_.pop_back();
+      peak = std::max(peak, top);
+      return o;
+    }
+    size_t o = top; top += bytes; peak = std::max(peak, top);
+    return o;
+  }
+  void release(size_t off, size_t bytes) {
+    bytes = align_up(std::max<size_t>(bytes, 256), 256);
+    Blk b{off, bytes};
+    auto it = std::lower_bound(free_.begin(), free_.end(), b, [](const Blk& x, const Blk& y) { return x.off < y.off; });
+    it = free_.insert(it, b);
+    if (it + 1 != free_.end() && it->off + it->size == (it + 1)->off) { it->size += (it + 1)->size; free_.erase(it + 1); }
+    if (it != free_.begin() && (it - 1)->off + (it - 1)->size == it->off) { (it - 1)->size += it->size; free_.erase(it); }
+  }
+};
+
+// fp16 activation view (+ optional fp32 master of the same logical tensor, contiguous ld = C)
+struct Act {
+  Ref h{}; int ld = 0;        // fp16 [rows][C] with leading dimension ld
+  Ref f{}; bool has_f = false;
+  int C = 0, H = 0, W = 0;
+  size_t h_alloc = NPOS, h_bytes = 0;   // workspace block owned by h (NPOS: lives in a concat buffer / elsewhere)
+  size_t f_alloc = NPOS, f_bytes = 0;
+};
+
+struct PlanBuilder {
+  const Model& m;
+  Plan& P;
+  Arena ar;
+  bool dry;
+  int Bn, n_ctx;
+  bool stop = false;
+  int remaining = 0;
+  const PlanOpts& opt;
+
+  PlanBuilder(const Model& mm, Plan& pp, bool d, const PlanOpts& o) : m(mm), P(pp), dry(d), opt(o) {}
+
+  Ref ws(size_t off) const { return Ref{BUF_WS, off}; }
+  Ref wt(size_t off) const { return Ref{BUF_WT, off}; }
+
+  void op(const char* name, double flops, std::function<hipError_t(const Bind&, hipStream_t)> fn,
+          const char* kernel = nullptr) {
+    if (dry || stop) return;
+    Op o{name, flops, std::move(fn)};
+    const std::string lab = kernel ? kernel : kernel_label(name);
+    size_t li = 0;
+    for (; li < P.labels.size(); ++li) if (P.labels[li] == lab) break;
+    if (li == P.labels.size()) P.labels.push_back(lab);
+    o.label = (int)li;
+    P.ops.push_back(std::move(o));
+  }
+
+  size_t rows(const Act& a) const { return (size_t)Bn * a.H * a.W; }
+
+  Act new_act(int C, int H, int W, bool master) {
+    Act a; a.C = C; a.H = H; a.W = W; a.ld = C;
+    a.h_bytes = (size_t)Bn * H * W * C * 2;
+    a.h_alloc = dry ? 0 : ar.alloc(a.h_bytes);
+    a.h = ws(a.h_alloc);
+    if (master && opt.stream_fp32) add_master(a);
+    return a;
+  }
+  void add_master(Act& a) {
+    a.f_bytes = (size_t)Bn * a.H * a.W * a.C * 4;
+    a.f_alloc = dry ? 0 : ar.alloc(a.f_bytes);
+    a.f = ws(a.f_alloc); a.has_f = true;
+  }
+  // activation whose fp16 image lives inside someone else's buffer (concat slice)
+  Act view_act(Ref h, int ld, int C, int H, int W, bool master) {
+    Act a; a.C = C; a.H = H; a.W = W; a.ld = ld; a.h = h;
+    if (master && opt.stream_fp32) add_master(a);
+    return a;
+  }
+  void free_act(Act& a) {
+    if (dry) return;
+    if (a.h_alloc != NPOS) { ar.release(a.h_alloc, a.h_bytes); a.h_alloc = NPOS; }
+    if (a.f_alloc != NPOS) { ar.release(a.f_alloc, a.f_bytes); a.f_alloc = NPOS; a.has_f = false; }
+  }
+  void free_master(Act& a) {
+    if (dry) return;
+    if (a.f_alloc != NPOS) { ar.release(a.f_alloc, a.f_bytes); a.f_alloc = NPOS; a.has_f = false; }
+  }
+  size_t tmp(size_t bytes) { return dry ? 0 : ar.alloc(bytes); }
+  void untmp(size_t off, size_t bytes) { if (!dry) ar.release(off, bytes); }
+
+  // ---- hooks ------------------------------------------------------------------------------------
+  // returns hook slot (>= 0) if `id` is requested, else -1. Shape is logical (B, C, H, W) stored channels-last.
+  int want(const std::string& id, int C, int H, int W) {
+    if (dry) { P.dry_ids.push_back(id); return -1; }
+    if (stop) return -1;
+    if (!P.requested.count(id)) return -1;
+    HookSlot hs; hs.id = id;
+    hs.shape[0] = Bn; hs.shape[1] = C; hs.shape[2] = H; hs.shape[3] = W;
+    hs.stride[0] = (int64_t)H * W * C; hs.stride[1] = 1; hs.stride[2] = (int64_t)W * C; hs.stride[3] = C;
+    hs.bytes = (size_t)Bn * C * H * W * 2;
+    P.hooks.push_back(hs);
+    return (int)P.hooks.size() - 1;
+  }
+  int want_map(const std::string& id, int heads, int Sq, int Sk) {
+    if (dry) { P.dry_ids.push_back(id); return -1; }
+    if (stop || !P.requested.count(id)) return -1;
+    HookSlot hs; hs.id = id;
+    hs.shape[0] = Bn; hs.shape[1] = heads; hs.shape[2] = Sq; hs.shape[3] = Sk;
+    hs.stride[0] = (int64_t)heads * Sq * Sk; hs.stride[1] = (int64_t)Sq * Sk; hs.stride[2] = Sk; hs.stride[3] = 1;
+    hs.bytes = (size_t)Bn * heads * Sq * Sk * 2;
+    P.hooks.push_back(hs);
+    return (int)P.hooks.size() - 1;
+  }
+  void hook_done() {
+    if (dry) return;
+    if (--remaining == 0 && opt.early_exit) stop = true;
+  }
+  // coalesced hook store: fp16 copy of `rows x C` from (src, ld)
+  void hook_copy(int slot, Ref src, int ld, size_t nrows, int C) {
+    if (slot < 0) return;
+    op("hook_store", 0, [=](const Bind& b, hipStream_t s) {
+      return launch_copy2d((const half_t*)b.p(src), nullptr, ld, (half_t*)b.hook(slot), C, (int)nrows, C, s);
+    });
+    hook_done();
+  }
+  void gather(const std::string& id, const Act& a) { hook_copy(want(id, a.C, a.H, a.W), a.h, a.ld, rows(a), a.C); }
+
+
+  struct Epi {
+    Ref bias{}; bool has_bias = false;
+    Ref rowvec{}; bool has_rv = false; int rps = 1, ldrv = 0;
+    Ref res32{}; bool has_r32 = false; Ref res16{}; bool has_r16 = false; int ldres = 0;
+    Ref out16{}; bool has_o16 = false; int ldo16 = 0;
+    Ref out32{}; bool has_o32 = false; int ldo32 = 0;
+    int aux_slot = -1; int ldaux = 0;
+    int geglu = 0; int bn = 128;
+    int dit = 0, act = 0, rv_mul = 0, rv_seg_rows = 0, rv_rps2 = 0;     // MMDiT epilogue (kernels.h)
+  };
+  void residual_from(Epi& e, const Act& x) {
+    if (x.has_f) { e.res32 = x.f; e.has_r32 = true; e.ldres = x.C; }
+    else { e.res16 = x.h; e.has_r16 = true; e.ldres = x.ld; }
+  }
+  // need_shadow = false: the fp16 image of a stream tensor is not stored when its only consumers read the fp32
+  // master (LayerNorm + the next residual add): saves one 2-byte/element write per residual GEMM
+  void out_to(Epi& e, const Act& y, bool need_shadow = true) {
+    if (need_shadow || !y.has_f) { e.out16 = y.h; e.has_o16 = true; e.ldo16 = y.ld; }
+    if (y.has_f) { e.out32 = y.f; e.has_o32 = true; e.ldo32 = y.C; }
+  }
+  static void fill_epi(GemmParams& g, const Epi& e, const Bind& b) {
+    g.bias = e.has_bias ? (const float*)b.p(e.bias) : nullptr;
+    g.rowvec = e.has_rv ? (const float*)b.p(e.rowvec) : nullptr; g.rows_per_sample = e.rps; g.ldrv = e.ldrv;
+    g.res32 = e.has_r32 ? (const float*)b.p(e.res32) : nullptr;
+    g.res16 = e.has_r16 ? (const half_t*)b.p(e.res16) : nullptr; g.ldres = e.ldres;
+    g.out16 = e.has_o16 ? (half_t*)b.p(e.out16) : nullptr; g.ldo16 = e.ldo16;
+    g.out32 = e.has_o32 ? (float*)b.p(e.out32) : nullptr; g.ldo32 = e.ldo32;
+    g.aux16 = e.aux_slot >= 0 ? (half_t*)b.hook(e.aux_slot) : nullptr; g.ldaux = e.ldaux;
+    g.geglu = e.geglu; g.bn = e.bn;
+    g.dit = e.dit; g.act = e.act; g.rv_mul = e.rv_mul; g.rv_seg_rows = e.rv_seg_rows; g.rv_rps2 = e.rv_rps2;
+  }
+
+  // dense GEMM: A (fp16 [M][K], lda) x W[N][K]
+  void gemm(const char* name, Ref A, int lda, size_t M, const LinW& w, int N, int K, size_t w_off_bytes, const Epi& e0) {
+    Epi e = e0;
+    const Ref W = wt(w.w + w_off_bytes);
+    GemmParams gk{}; gk.M = (int)M; gk.N = N; gk.K = K; gk.mode = A_DENSE; gk.geglu = e.geglu; gk.bn = e.bn; gk.dit = e.dit;
+    op(name, 2.0 * (double)M * N * K, [=](const Bind& b, hipStream_t s) {
+      GemmParams g{};
+      g.A = (const half_t*)b.p(A); g.lda = lda; g.a_bytes = (uint32_t)(((size_t)M - 1) * lda * 2 + (size_t)K * 2);
+      g.M = (int)M; g.N = N; g.K = K; g.mode = A_DENSE;
+      g.Wt = (const half_t*)b.p(W); g.w_bytes = (uint32_t)((size_t)N * K * 2);
+      fill_epi(g, e, b);
+      return launch_gemm(g, s);
+    }, gemm_kernel_name(gk));
+  }
+};
+
+}  // namespace gdf

@@ -1,0 +1,195 @@
+// HBM-bound kernels of the MMDiT (Flux) path for gfx950.
+//
+// Reference ops replaced (paths under /root/reference/feature/diffusers/models; the normalisation / embedding classes
+// are un-vendored diffusers==0.32.2, imported at transformers/transformer_flux.py:34-38 and attention_processor.py:141,2331):
+//   AdaLayerNormZero / AdaLayerNormZeroSingle / AdaLayerNormContinuous `norm(x) * (1 + scale[:, None]) + shift[:, None]`
+//   and the norm2 modulate of FluxTransformerBlock (transformer_flux.py:194-195, 214-215)      -> layernorm_mod_kernel
+//   Attention.norm_q / norm_k / norm_added_q / norm_added_k (RMSNorm per head, attention_processor.py:2300-2303,
+//   2321-2324) + apply_rotary_emb (attention_processor.py:2331-2335)                           -> qk_norm_rope_kernel
+//   FluxPosEmbed (transformer_flux.py:498-499)                                                 -> rope_table_kernel
+// All are streaming kernels: 16 bytes per lane, one pass over the data.
+#include "kernels.h"
+
+namespace gdf {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// one wave per row, the row lives in registers (C <= 64 * 8 * MAXC), exact two-pass statistics
+template <int MAXC>
+__global__ __launch_bounds__(256) void layernorm_mod_kernel(const half_t* x16, const float* x32, int ld, int R, int C,
+                                                            float eps, const float* scale, const float* shift, int ldm,
+                                                            int rps, int seg_rows, int rps2, half_t* y) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= R) return;
+  const int CH = C / 8;
+  float v[MAXC][8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int c = lane + 64 * i;
+    if (c < CH) {
+      if (x32) {
+        const f32x4 a = *(const f32x4*)(x32 + (size_t)row * ld + c * 8), b = *(const f32x4*)(x32 + (size_t)row * ld + c * 8 + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[i][e] = a[e]; v[i][4 + e] = b[e]; }
+      } else {
+        const f16x8 a = *(const f16x8*)(x16 + (size_t)row * ld + c * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[i][e] = (float)a[e];
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += v[i][e];
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+  const float mean = s / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int c = lane + 64 * i;
+    if (c < CH) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mean; q += d * d; }
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) q += __shfl_xor(q, off);
+  const float rstd = rsqrtf(q / (float)C + eps);
+  const int smp = (seg_rows > 0 && row >= seg_rows) ? (row - seg_rows) / rps2 : row / rps;
+  const float* sc = scale + (size_t)smp * ldm;
+  const float* sh = shift + (size_t)smp * ldm;
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int c = lane + 64 * i;
+    if (c < CH) {
+      const f32x4 g0 = *(const f32x4*)(sc + c * 8), g1 = *(const f32x4*)(sc + c * 8 + 4);
+      const f32x4 b0 = *(const f32x4*)(sh + c * 8), b1 = *(const f32x4*)(sh + c * 8 + 4);
+      f16x8 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        o[e] = (_Float16)((v[i][e] - mean) * rstd * (1.0f + g0[e]) + b0[e]);
+        o[4 + e] = (_Float16)((v[i][4 + e] - mean) * rstd * (1.0f + g1[e]) + b1[e]);
+      }
+      *(f16x8*)(y + (size_t)row * C + c * 8) = o;
+    }
+  }
+}
+
+hipError_t launch_layernorm_mod(const half_t* x16, const float* x32, int ld, int R, int C, float eps, const float* scale,
+                                const float* shift, int ldm, int rps, int seg_rows, int rps2, half_t* y, hipStream_t s) {
+  if (C % 8 || C > 64 * 8 * 8 || (ldm & 3) || rps <= 0) return hipErrorInvalidValue;
+  if (R <= 0) return hipSuccess;
+  const int CH = C / 8;
+  dim3 grid((R + 3) / 4), blk(256);
+#define GDF_LNM(N) hipLaunchKernelGGL(layernorm_mod_kernel<N>, grid, blk, 0, s, x16, x32, ld, R, C, eps, scale, shift, ldm, rps, seg_rows, rps2, y)
+  if (CH <= 64) GDF_LNM(1);
+  else if (CH <= 128) GDF_LNM(2);
+  else if (CH <= 256) GDF_LNM(4);
+  else if (CH <= 384) GDF_LNM(6);
+  else GDF_LNM(8);
+#undef GDF_LNM
+  return hipGetLastError();
+}
+
+// 16 lanes per (row, head): 8 halves (= 4 rotary pairs) per lane, D = 128.  q then k of the same (row, head).
+__global__ __launch_bounds__(256) void qk_norm_rope_kernel(half_t* x, int ld, long R, int heads, int q_col, int k_col,
+                                                           const float* wq, const float* wk, float eps,
+                                                           const float* cos_t, const float* sin_t, int pos0, int rps) {
+  constexpr int D = 128;
+  const long g = (long)blockIdx.x * 16 + (threadIdx.x >> 4);     // (row, head) pair
+  if (g >= R * heads) return;
+  const int sub = threadIdx.x & 15;
+  const long row = g / heads;
+  const int head = (int)(g - row * heads);
+  const int pos = pos0 + (int)(row % rps);
+  const f32x4 c0 = *(const f32x4*)(cos_t + (size_t)pos * D + sub * 8), c1 = *(const f32x4*)(cos_t + (size_t)pos * D + sub * 8 + 4);
+  const f32x4 s0 = *(const f32x4*)(sin_t + (size_t)pos * D + sub * 8), s1 = *(const f32x4*)(sin_t + (size_t)pos * D + sub * 8 + 4);
+  float cs[8], sn[8];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { cs[e] = c0[e]; cs[4 + e] = c1[e]; sn[e] = s0[e]; sn[4 + e] = s1[e]; }
+#pragma unroll
+  for (int which = 0; which < 2; ++which) {
+    half_t* px = x + (size_t)row * ld + (which ? k_col : q_col) + head * D + sub * 8;
+    const float* w = (which ? wk : wq) + sub * 8;
+    const f16x8 hv = *(const f16x8*)px;
+    float v[8];
+    float ss = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { v[e] = (float)hv[e]; ss += v[e] * v[e]; }
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) ss += __shfl_xor(ss, off);   // the 16 lanes of this (row, head)
+    const float r = rsqrtf(ss / (float)D + eps);
+    const f32x4 w0 = *(const f32x4*)w, w1 = *(const f32x4*)(w + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[e] *= r * w0[e]; v[4 + e] *= r * w1[e]; }
+    f16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {       // x * cos + stack([-x_imag, x_real]) * sin
+      o[e] = (_Float16)(v[e] * cs[e] - v[e + 1] * sn[e]);
+      o[e + 1] = (_Float16)(v[e + 1] * cs[e + 1] + v[e] * sn[e + 1]);
+    }
+    *(f16x8*)px = o;
+  }
+}
+
+hipError_t launch_qk_norm_rope(half_t* x, int ld, int R, int heads, int D, int q_col, int k_col, const float* wq,
+                               const float* wk, float eps, const float* cos_t, const float* sin_t, int pos0, int rps,
+                               hipStream_t s) {
+  if (D != 128 || (ld & 7) || (q_col & 7) || (k_col & 7) || rps <= 0) return hipErrorInvalidValue;
+  if (R <= 0) return hipSuccess;
+  const long groups = (long)R * heads;
+  hipLaunchKernelGGL(qk_norm_rope_kernel, dim3((unsigned)((groups + 15) / 16)), dim3(256), 0, s, x, ld, (long)R, heads, q_col,
+                     k_col, wq, wk, eps, cos_t, sin_t, pos0, rps);
+  return hipGetLastError();
+}
+
+struct RopeAxes { int n; int dim[4]; int off[4]; int D; };
+
+__global__ void rope_table_kernel(const float* ids, int S, RopeAxes ax, double theta, float* cos_t, float* sin_t, int row0) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int half = ax.D / 2;
+  if (i >= S * half) return;
+  const int r = i / half, pj = i - r * half;        // row, rotary pair index inside the row
+  int a = 0;
+  while (a + 1 < ax.n && 2 * pj >= ax.off[a + 1]) ++a;
+  const int k = (2 * pj - ax.off[a]) / 2;           // pair index inside axis a
+  const double freq = 1.0 / pow(theta, (double)(2 * k) / (double)ax.dim[a]);
+  const double ang = (double)ids[(size_t)r * ax.n + a] * freq;
+  const float c = (float)cos(ang), sn = (float)sin(ang);
+  const size_t o = (size_t)(row0 + r) * ax.D + 2 * pj;
+  cos_t[o] = c; cos_t[o + 1] = c;
+  sin_t[o] = sn; sin_t[o + 1] = sn;
+}
+
+hipError_t launch_rope_table(const float* ids, int S, int n_axes, const int* axes_dim, double theta, float* cos_t,
+                             float* sin_t, int row0, hipStream_t s) {
+  if (n_axes < 1 || n_axes > 4) return hipErrorInvalidValue;
+  RopeAxes ax{};
+  ax.n = n_axes;
+  int off = 0;
+  for (int i = 0; i < n_axes; ++i) {
+    if (axes_dim[i] % 2) return hipErrorInvalidValue;
+    ax.dim[i] = axes_dim[i]; ax.off[i] = off; off += axes_dim[i];
+  }
+  ax.D = off;
+  if (S <= 0) return hipSuccess;
+  const int total = S * (off / 2);
+  hipLaunchKernelGGL(rope_table_kernel, dim3((total + 255) / 256), dim3(256), 0, s, ids, S, ax, theta, cos_t, sin_t, row0);
+  return hipGetLastError();
+}
+
+__global__ void silu_vec_kernel(const float* x, float* out, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { const float v = x[i]; out[i] = v / (1.0f + expf(-v)); }
+}
+
+hipError_t launch_silu_vec(const float* x, float* out, long n, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(silu_vec_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, out, n);
+  return hipGetLastError();
+}
+
+}  // namespace gdf

@@ -64,8 +64,18 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
   return base + idx;
 }
 
-template <int MODE, int BM, int BN, int STAGES, bool GEGLU>
-__global__ __launch_bounds__(BM * 2, 2) void gemm_kernel(const GemmParams p) {
+// tanh-approximate GELU (activations.GELU(approximate="tanh"), Flux FeedForward / proj_mlp):
+// 0.5 x (1 + tanh(u)) = x * sigmoid(2u), u = sqrt(2/pi) (x + 0.044715 x^3): one v_exp_f32 + one v_rcp_f32
+__device__ __forceinline__ float gelu_tanh(float x) {
+  const float u2 = 1.5957691216057308f * (x + 0.044715f * x * x * x);               // 2u
+  return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * u2));
+}
+
+// DIT = true adds the MMDiT epilogue forms (Flux): optional tanh-GELU on (acc + bias), the per-sample
+// row vector applied as a GATE (multiply) instead of an addend, and a two-region row -> sample map (text rows first,
+// image rows second).  It is a compile-time switch so that the UNet kernels keep their code and register budget.
+template <int MODE, int BM, int BN, int STAGES, bool GEGLU, bool DIT>
+__device__ __forceinline__ void gemm_body(const GemmParams& p) {
   constexpr int NW = BM / 32;                    // waves per workgroup (4 or 8)
   // waves along N (the GEGLU form of the 256x320 tile uses 4x2 waves of 64x160: an EVEN number of 16-column fragments,
   // so that every h fragment has its gate fragment in the same lane and register index)
@@ -273,7 +283,8 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_kernel(const GemmParams p) {
   constexpr int FNV = GEGLU ? FN / 2 : FN;             // staged 16-column fragments
   constexpr int WTNV = FNV * 16;                       // staged (= output) columns of this wave tile
   constexpr int SLD = WTNV + 4;                        // padded row length (floats)
-  constexpr int PR = (FM * FN >= 40) ? 16 : 32;        // rows per staging pass (16 for the 160-accumulator tiles: VGPR budget)
+  // rows per staging pass: 16 for the 160-accumulator tiles (VGPR budget) and for 256x256 (8 x 32 x 132 floats would not fit the ring)
+  constexpr int PR = (FM * FN >= 32) ? 16 : 32;
   constexpr int PASSES = WTM / PR;
   constexpr int FPP = FM / PASSES;                     // 16-row fragments per pass
   float* st = (float*)(smem) + wave * (PR * SLD);
@@ -315,6 +326,10 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_kernel(const GemmParams p) {
   // first version branched inside every unrolled iteration: ~800 basic blocks, no overlap between iterations).
   constexpr bool RAGGED = (BN == 16);                    // only the narrow-N variant handles N % 8 != 0 (host-checked)
   const bool rv_in_opnd = p.rowvec && !p.res32;
+  auto sample_of = [&](int row) -> int {                 // row of the per-sample vector table that applies to `row`
+    if (DIT && p.rv_seg_rows > 0 && row >= p.rv_seg_rows) return (row - p.rv_seg_rows) / p.rv_rps2;
+    return row / p.rows_per_sample;
+  };
 #pragma unroll
   for (int ps = 0; ps < PASSES; ++ps) {
     // ---- prefetch this pass's residual / row-vector operands (overlaps the LDS staging below) ----
@@ -342,7 +357,7 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_kernel(const GemmParams p) {
 #pragma unroll
         for (int it = 0; it < NIT; ++it)
           if (okr[it]) {
-            const f32x4* rv = (const f32x4*)(p.rowvec + (size_t)(rowi[it] / p.rows_per_sample) * p.ldrv + col);
+            const f32x4* rv = (const f32x4*)(p.rowvec + (size_t)sample_of(rowi[it]) * p.ldrv + col);
             opnd[it][0] = rv[0]; opnd[it][1] = rv[1];
           }
       } else if (p.res16) {
@@ -373,22 +388,51 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_kernel(const GemmParams p) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) { v[it][e] = x0[e] + bv[e]; v[it][4 + e] = x1[e] + bv[4 + e]; }
     }
+    if (DIT && p.act == 1) {
+#pragma unroll
+      for (int it = 0; it < NIT; ++it)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[it][e] = gelu_tanh(v[it][e]);
+    }
+    const bool aux_early = DIT && p.rv_mul && p.aux16;     // MMDiT `attn-out` hook: the projection BEFORE the gate
+    if (!RAGGED && aux_early) {
+#pragma unroll
+      for (int it = 0; it < NIT; ++it)
+        if (okr[it]) {
+          f16x8 hv;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) hv[e] = (_Float16)v[it][e];
+          *(f16x8*)(p.aux16 + (size_t)rowi[it] * p.ldaux + col) = hv;
+        }
+    }
     if (!RAGGED) {
       if (rv_in_opnd) {
+        if (DIT && p.rv_mul) {
 #pragma unroll
-        for (int it = 0; it < NIT; ++it)
+          for (int it = 0; it < NIT; ++it)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { v[it][e] += opnd[it][0][e]; v[it][4 + e] += opnd[it][1][e]; }
-      } else if (p.rowvec) {                             // (not produced by the plan) temb AND fp32 residual: late load
+            for (int e = 0; e < 4; ++e) { v[it][e] *= opnd[it][0][e]; v[it][4 + e] *= opnd[it][1][e]; }
+        } else {
+#pragma unroll
+          for (int it = 0; it < NIT; ++it)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[it][e] += opnd[it][0][e]; v[it][4 + e] += opnd[it][1][e]; }
+        }
+      } else if (p.rowvec) {                             // row vector AND fp32 residual (MMDiT gate + residual): late load
 #pragma unroll
         for (int it = 0; it < NIT; ++it)
           if (okr[it]) {
-            const f32x4* rv = (const f32x4*)(p.rowvec + (size_t)(rowi[it] / p.rows_per_sample) * p.ldrv + col);
+            const f32x4* rv = (const f32x4*)(p.rowvec + (size_t)sample_of(rowi[it]) * p.ldrv + col);
+            if (DIT && p.rv_mul) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { v[it][e] += rv[0][e]; v[it][4 + e] += rv[1][e]; }
+              for (int e = 0; e < 4; ++e) { v[it][e] *= rv[0][e]; v[it][4 + e] *= rv[1][e]; }
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) { v[it][e] += rv[0][e]; v[it][4 + e] += rv[1][e]; }
+            }
           }
       }
-      if (p.aux16) {
+      if (p.aux16 && !aux_early) {
 #pragma unroll
         for (int it = 0; it < NIT; ++it)
           if (okr[it]) {
@@ -453,13 +497,25 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_kernel(const GemmParams p) {
 }
 
 template <int MODE, int BM, int BN, int STAGES, bool GEGLU>
+__global__ __launch_bounds__(BM * 2, 2) void gemm_kernel(const GemmParams p) {
+  gemm_body<MODE, BM, BN, STAGES, GEGLU, false>(p);
+}
+// dense GEMM with the MMDiT epilogue (tanh-GELU / per-sample gate / two-region sample map)
+template <int BM, int BN, int STAGES>
+__global__ __launch_bounds__(BM * 2, 2) void gemm_dit_kernel(const GemmParams p) {
+  gemm_body<A_DENSE, BM, BN, STAGES, false, true>(p);
+}
+
+template <int MODE, int BM, int BN, int STAGES, bool GEGLU, bool DIT = false>
 static hipError_t launch_t(const GemmParams& p, hipStream_t s) {
   const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
   const int smem = STAGES * (BM * 128 + BN * 128);
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel<MODE, BM, BN, STAGES, GEGLU>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    const void* fn;
+    if constexpr (DIT) fn = (const void*)gemm_dit_kernel<BM, BN, STAGES>;
+    else fn = (const void*)gemm_kernel<MODE, BM, BN, STAGES, GEGLU>;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return e;
     attr_done = true;
   }
@@ -475,7 +531,9 @@ static hipError_t launch_t(const GemmParams& p, hipStream_t s) {
       }
     }
   }
-  hipLaunchKernelGGL((gemm_kernel<MODE, BM, BN, STAGES, GEGLU>), dim3(tiles_m * tiles_n, p.batch > 1 ? p.batch : 1), dim3(BM * 2), smem, s, q);
+  const dim3 grid(tiles_m * tiles_n, p.batch > 1 ? p.batch : 1);
+  if constexpr (DIT) hipLaunchKernelGGL((gemm_dit_kernel<BM, BN, STAGES>), grid, dim3(BM * 2), smem, s, q);
+  else hipLaunchKernelGGL((gemm_kernel<MODE, BM, BN, STAGES, GEGLU>), grid, dim3(BM * 2), smem, s, q);
   return hipGetLastError();
 }
 
@@ -484,6 +542,11 @@ static hipError_t launch_t(const GemmParams& p, hipStream_t s) {
 // multiple of the 512 workgroup slots for the SDXL batch-16 shapes (no tail round).  128x128 serves other N;
 // 256x128 (8 waves, 3-stage ring) wins for very large problems.
 static int pick_variant(const GemmParams& p) {
+  if (p.dit) {   // MMDiT widths are multiples of 256 (3072 = 24 x 128): 256x256 tiles (128 KiB ring, 1 workgroup / CU)
+    const long t256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
+    if (p.variant == 128 || p.variant == 1256) return p.variant;
+    return (p.N % 256 == 0 && t256 >= 128) ? 1256 : 128;
+  }
   if (p.bn == 16) return 16;
   if (p.variant) return p.variant;
   const long tiles256 = (long)((p.M + 255) / 256) * ((p.N + 127) / 128);
@@ -511,7 +574,8 @@ const char* gemm_kernel_name(const GemmParams& p) {
   if (v == 16) bn = 16; else if (v == 160) bn = 160; else if (v == 256) { bm = 256; st = 3; } else if (v == 320) { bm = 256; bn = 320; }
   if (p.mode == A_CONV_SMALLC && v != 160) { bm = 128; bn = 128; st = 2; }
   char tmp[64];
-  snprintf(tmp, sizeof tmp, "gemm_kernel<%d, %d, %d, %d, %s>", p.mode, bm, bn, st, p.geglu ? "true" : "false");
+  if (p.dit) snprintf(tmp, sizeof tmp, "gemm_dit_kernel<%d, %d, 2>", v == 1256 ? 256 : 128, v == 1256 ? 256 : 128);
+  else snprintf(tmp, sizeof tmp, "gemm_kernel<%d, %d, %d, %d, %s>", p.mode, bm, bn, st, p.geglu ? "true" : "false");
   for (int i = 0; i < nb; ++i) if (!strcmp(buf[i], tmp)) return buf[i];
   if (nb < 16) { strcpy(buf[nb], tmp); return buf[nb++]; }
   return "gemm_kernel<...>";
@@ -523,6 +587,11 @@ hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {
   if (p.mode == A_CONV3 && (p.Cin % BK) != 0) return hipErrorInvalidValue;
   const int v = pick_variant(p);
   if (v != 16 && ((p.geglu ? p.N / 2 : p.N) % 8) != 0) return hipErrorInvalidValue;   // ragged N only in the BN = 16 variant
+  if (p.dit) {
+    if (p.mode != A_DENSE || p.geglu || p.batch > 1) return hipErrorInvalidValue;
+    if (v == 1256) return launch_t<A_DENSE, 256, 256, 2, false, true>(p, s);
+    return launch_t<A_DENSE, 128, 128, 2, false, true>(p, s);
+  }
   if (p.geglu) {
     // weight rows / bias interleaved [16 h | 16 gate] (launch_relayout_rows geglu = 16)
     if (p.mode != A_DENSE || (p.N % 32) != 0) return hipErrorInvalidValue;

@@ -55,6 +55,14 @@ struct GemmParams {
   int no_superblock;     // diagnostics: force the linear order
   int no_early_mma;      // diagnostics: disable the opposite-order heads of the two waves sharing a SIMD (256x128 variant)
   int variant;           // 0 = auto; 128 / 160 / 256 force the 128x128, 128x160 or 256x128 tile (diagnostics)
+  // ---- MMDiT epilogue (dit != 0 selects gemm_dit_kernel; dense only) ----
+  //      v = acc + bias;  act == 1: v = gelu_tanh(v);  rowvec: v = rv_mul ? v * rowvec[sample][col] : v + rowvec[sample][col];
+  //      then residual / stores as above.  sample = row / rows_per_sample for row < rv_seg_rows (or rv_seg_rows == 0),
+  //      else (row - rv_seg_rows) / rv_rps2  (joint stream laid out [all text rows][all image rows]).
+  int dit;
+  int act;
+  int rv_mul;
+  int rv_seg_rows, rv_rps2;
 };
 hipError_t launch_gemm(const GemmParams& p, hipStream_t s);
 const char* gemm_kernel_name(const GemmParams& p);   // kernel symbol launch_gemm would pick (only M,N,K,mode,geglu,bn,variant are read)
@@ -72,6 +80,7 @@ struct AttnParams {
   int kv_bstride;        // rows between consecutive samples' K/V (Sk normally; 0 = all samples share one K/V set)
   float scale;
   half_t* map;           // optional: attention probabilities (B, heads, Sq, Sk) fp16 ('-map' hooks)
+  int seg_T;             // > 0: MMDiT joint sequence, region-major rows [B x seg_T text][B x (Sq - seg_T) image] (Sq == Sk)
 };
 hipError_t launch_attention(const AttnParams& p, hipStream_t s);
 
@@ -90,6 +99,21 @@ hipError_t launch_gn_apply(const half_t* x16, const float* x32, int ld, int B, i
 // LayerNorm over the last dim (C), rows x [R][ld]; y contiguous fp16 [R][C]
 hipError_t launch_layernorm(const half_t* x16, const float* x32, int ld, int R, int C, float eps,
                             const float* gamma, const float* beta, half_t* y, hipStream_t s);
+// LayerNorm without affine + adaLN modulation (AdaLayerNormZero / ZeroSingle / Continuous and the norm2 modulate of
+// the MMDiT blocks): y = LN(x, eps) * (1 + scale[s][c]) + shift[s][c]; s = row / rps for row < seg_rows (or
+// seg_rows == 0), else (row - seg_rows) / rps2.  x fp32 (or fp16) [R][ld], y fp16 [R][C], scale/shift fp32 rows of ldm.
+hipError_t launch_layernorm_mod(const half_t* x16, const float* x32, int ld, int R, int C, float eps, const float* scale,
+                                const float* shift, int ldm, int rps, int seg_rows, int rps2, half_t* y, hipStream_t s);
+// RMSNorm(q), RMSNorm(k) per head + rotary embedding, in place on rows [R][ld] fp16: q heads at columns
+// q_col + h*D, k heads at k_col + h*D (D = 128); position of row r = pos0 + r % rps; cos/sin fp32 [pos][D].
+hipError_t launch_qk_norm_rope(half_t* x, int ld, int R, int heads, int D, int q_col, int k_col, const float* wq,
+                               const float* wk, float eps, const float* cos_t, const float* sin_t, int pos0, int rps,
+                               hipStream_t s);
+// FluxPosEmbed: ids fp32 [S][n_axes] -> cos/sin fp32 [S][sum(axes_dim)] (float64 angles, repeat-interleaved pairs)
+hipError_t launch_rope_table(const float* ids, int S, int n_axes, const int* axes_dim, double theta, float* cos_t,
+                             float* sin_t, int row0, hipStream_t s);
+// out[i] = silu(x[i])
+hipError_t launch_silu_vec(const float* x, float* out, long n, hipStream_t s);
 // strided 2-D copy with cast to fp16: dst[r][c] = src[r][c]   (hook stores)
 hipError_t launch_copy2d(const half_t* s16, const float* s32, int lds_, half_t* dst, int ldd, int R, int C,
                          hipStream_t s);
@@ -97,8 +121,9 @@ hipError_t launch_copy2d(const half_t* s16, const float* s32, int lds_, half_t* 
 hipError_t launch_pack_latents(const half_t* x, int B, int Cin, int H, int W, half_t* nhwc8, half_t* hook_nhwc,
                                hipStream_t s);
 // sinusoidal embedding: out[b][off + j] (dim entries, [cos|sin] order = flip_sin_to_cos) of t[b*tstride + ti]
+// tscale multiplies t first (Flux: `timestep * 1000`, transformer_flux.py:472)
 hipError_t launch_sinusoid(const float* t, int B, int n_per_row, int dim, float* out, int ldo, int col_off,
-                           int round_f16, hipStream_t s);
+                           int round_f16, hipStream_t s, float tscale = 1.0f);
 // widen fp16 vector rows into fp32: out[b][col_off + j] = x[b][j]
 hipError_t launch_widen(const half_t* x, int B, int n, float* out, int ldo, int col_off, hipStream_t s);
 // small-M linear in fp32 vectors: out[m][n] = (accum? out : 0) + bias[n] + sum_k act(x[m][k]) * W[n][k]

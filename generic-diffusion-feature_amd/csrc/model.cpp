@@ -18,12 +18,7 @@
 // concatenations of the up path are free: producers store straight into channel slices of a
 // pre-allocated concat buffer.  The residual stream additionally keeps an fp32 master copy
 // (stream_fp32) that only the residual adds in GEMM epilogues read and write.
-#include "model.h"
-
-#include <algorithm>
-#include <cmath>
-#include <cstdio>
-#include <cstring>
+#include "builder.h"
 
 namespace gdf {
 
@@ -31,29 +26,11 @@ thread_local std::string g_err;
 void set_error(const std::string& s) { g_err = s; }
 const char* last_error() { return g_err.c_str(); }
 
-static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
-
 // =====================================================================================================
 // Model: walk the architecture once, lay out the weight arena, register diffusers parameter names
 // =====================================================================================================
-struct ModelBuilder {
-  Model& m;
-  size_t cur = 0;
-  explicit ModelBuilder(Model& mm) : m(mm) {}
-
-  size_t take(size_t bytes) { size_t o = cur; cur = align_up(cur + bytes, 256); return o; }
-
-  void reg(const std::string& name, std::initializer_list<int64_t> shape, int kind, size_t dst, int a0 = 0, int a1 = 0,
-           int a2 = 0) {
-    ParamRec p;
-    p.name = name; p.ndim = (int)shape.size();
-    int i = 0;
-    for (auto s : shape) p.shape[i++] = s;
-    p.kind = kind; p.dst = dst; p.a0 = a0; p.a1 = a1; p.a2 = a2;
-    m.index[name] = (int)m.params.size();
-    m.params.push_back(p);
-  }
-
+struct ModelBuilder : WeightBuilder {
+  explicit ModelBuilder(Model& mm) : WeightBuilder(mm) {}
   NormW norm(const std::string& n, int c) {
     NormW w; w.c = c; w.g = take(c * 4); w.b = take(c * 4);
     reg(n + ".weight", {c}, PK_VEC, w.g); reg(n + ".bias", {c}, PK_VEC, w.b);
@@ -62,21 +39,6 @@ struct ModelBuilder {
   ConvW conv3(const std::string& n, int co, int ci) {
     ConvW w; w.cin = ci; w.cout = co; w.w = take((size_t)co * 9 * ci * 2); w.b = take(co * 4);
     reg(n + ".weight", {co, ci, 3, 3}, PK_CONV3, w.w, co, ci); reg(n + ".bias", {co}, PK_VEC, w.b);
-    return w;
-  }
-  // linear / 1x1 conv into rows [row_off, row_off+n) of a (possibly shared) [ntot][k] matrix
-  void lin_rows(const std::string& n, LinW& w, int rows, int row_off, bool conv1x1, bool bias) {
-    if (conv1x1) reg(n + ".weight", {rows, w.k, 1, 1}, PK_ROWS, w.w, rows, w.k, row_off);
-    else reg(n + ".weight", {rows, w.k}, PK_ROWS, w.w, rows, w.k, row_off);
-    if (bias) reg(n + ".bias", {rows}, PK_VEC_OFF, w.b, rows, row_off);
-  }
-  LinW lin_alloc(int ntot, int k, bool bias) {
-    LinW w; w.n = ntot; w.k = k; w.w = take((size_t)ntot * k * 2); w.b = bias ? take(ntot * 4) : NPOS; w.has_bias = bias;
-    return w;
-  }
-  LinW lin(const std::string& n, int co, int ci, bool bias = true, bool conv1x1 = false) {
-    LinW w = lin_alloc(co, ci, bias);
-    lin_rows(n, w, co, 0, conv1x1, bias);
     return w;
   }
 
@@ -276,146 +238,11 @@ int model_set_param(Model* m, const char* name, const void* src, int dtype, hipS
 // =====================================================================================================
 namespace {
 
-struct Arena {   // plan-time first-fit allocator with coalescing free list
-  struct Blk { size_t off, size; };
-  std::vector<Blk> free_;
-  size_t top = 0, peak = 0;
-  size_t alloc(size_t bytes) {
-    bytes = align_up(std::max<size_t>(bytes, 256), 256);
-    for (size_t i = 0; i < free_.size(); ++i)
-      if (free_[i].size >= bytes) {
-        size_t o = free_[i].off;
-        free_[i].off += bytes; free_[i].size -= bytes;
-        if (!free_[i].size) free_.erase(free_.begin() + i);
-        return o;
-      }
-    // extend: if the last free block touches the top, grow it
-    if (!free_.empty() && free_.back().off + free_.back().size == top) {
-      size_t o = free_.back().off;
-      top = o + bytes; free_.pop_back();
-      peak = std::max(peak, top);
-      return o;
-    }
-    size_t o = top; top += bytes; peak = std::max(peak, top);
-    return o;
-  }
-  void release(size_t off, size_t bytes) {
-    bytes = align_up(std::max<size_t>(bytes, 256), 256);
-    Blk b{off, bytes};
-    auto it = std::lower_bound(free_.begin(), free_.end(), b, [](const Blk& x, const Blk& y) { return x.off < y.off; });
-    it = free_.insert(it, b);
-    if (it + 1 != free_.end() && it->off + it->size == (it + 1)->off) { it->size += (it + 1)->size; free_.erase(it + 1); }
-    if (it != free_.begin() && (it - 1)->off + (it - 1)->size == it->off) { (it - 1)->size += it->size; free_.erase(it); }
-  }
-};
 
-// fp16 activation view (+ optional fp32 master of the same logical tensor, contiguous ld = C)
-struct Act {
-  Ref h{}; int ld = 0;        // fp16 [rows][C] with leading dimension ld
-  Ref f{}; bool has_f = false;
-  int C = 0, H = 0, W = 0;
-  size_t h_alloc = NPOS, h_bytes = 0;   // workspace block owned by h (NPOS: lives in a concat buffer / elsewhere)
-  size_t f_alloc = NPOS, f_bytes = 0;
-};
-
-struct B {   // builder
-  const Model& m;
-  Plan& P;
-  Arena ar;
-  bool dry;
-  int Bn, n_ctx;
-  bool stop = false;
-  int remaining = 0;
-  const PlanOpts& opt;
+struct B : PlanBuilder {   // UNet op program
+  B(const Model& mm, Plan& pp, bool d, const PlanOpts& o) : PlanBuilder(mm, pp, d, o) {}
   Ref temb_all{};     // [B][temb_total] f32
   std::vector<std::pair<size_t, size_t>> kv_bufs;   // per KvGroup: (workspace offset, bytes per block) of the text K/V
-
-  B(const Model& mm, Plan& pp, bool d, const PlanOpts& o) : m(mm), P(pp), dry(d), opt(o) {}
-
-  Ref ws(size_t off) const { return Ref{BUF_WS, off}; }
-  Ref wt(size_t off) const { return Ref{BUF_WT, off}; }
-
-  void op(const char* name, double flops, std::function<hipError_t(const Bind&, hipStream_t)> fn,
-          const char* kernel = nullptr) {
-    if (dry || stop) return;
-    Op o{name, flops, std::move(fn)};
-    const std::string lab = kernel ? kernel : kernel_label(name);
-    size_t li = 0;
-    for (; li < P.labels.size(); ++li) if (P.labels[li] == lab) break;
-    if (li == P.labels.size()) P.labels.push_back(lab);
-    o.label = (int)li;
-    P.ops.push_back(std::move(o));
-  }
-
-  size_t rows(const Act& a) const { return (size_t)Bn * a.H * a.W; }
-
-  Act new_act(int C, int H, int W, bool master) {
-    Act a; a.C = C; a.H = H; a.W = W; a.ld = C;
-    a.h_bytes = (size_t)Bn * H * W * C * 2;
-    a.h_alloc = dry ? 0 : ar.alloc(a.h_bytes);
-    a.h = ws(a.h_alloc);
-    if (master && opt.stream_fp32) add_master(a);
-    return a;
-  }
-  void add_master(Act& a) {
-    a.f_bytes = (size_t)Bn * a.H * a.W * a.C * 4;
-    a.f_alloc = dry ? 0 : ar.alloc(a.f_bytes);
-    a.f = ws(a.f_alloc); a.has_f = true;
-  }
-  // activation whose fp16 image lives inside someone else's buffer (concat slice)
-  Act view_act(Ref h, int ld, int C, int H, int W, bool master) {
-    Act a; a.C = C; a.H = H; a.W = W; a.ld = ld; a.h = h;
-    if (master && opt.stream_fp32) add_master(a);
-    return a;
-  }
-  void free_act(Act& a) {
-    if (dry) return;
-    if (a.h_alloc != NPOS) { ar.release(a.h_alloc, a.h_bytes); a.h_alloc = NPOS; }
-    if (a.f_alloc != NPOS) { ar.release(a.f_alloc, a.f_bytes); a.f_alloc = NPOS; a.has_f = false; }
-  }
-  void free_master(Act& a) {
-    if (dry) return;
-    if (a.f_alloc != NPOS) { ar.release(a.f_alloc, a.f_bytes); a.f_alloc = NPOS; a.has_f = false; }
-  }
-  size_t tmp(size_t bytes) { return dry ? 0 : ar.alloc(bytes); }
-  void untmp(size_t off, size_t bytes) { if (!dry) ar.release(off, bytes); }
-
-  // ---- hooks ------------------------------------------------------------------------------------
-  // returns hook slot (>= 0) if `id` is requested, else -1. Shape is logical (B, C, H, W) stored channels-last.
-  int want(const std::string& id, int C, int H, int W) {
-    if (dry) { P.dry_ids.push_back(id); return -1; }
-    if (stop) return -1;
-    if (!P.requested.count(id)) return -1;
-    HookSlot hs; hs.id = id;
-    hs.shape[0] = Bn; hs.shape[1] = C; hs.shape[2] = H; hs.shape[3] = W;
-    hs.stride[0] = (int64_t)H * W * C; hs.stride[1] = 1; hs.stride[2] = (int64_t)W * C; hs.stride[3] = C;
-    hs.bytes = (size_t)Bn * C * H * W * 2;
-    P.hooks.push_back(hs);
-    return (int)P.hooks.size() - 1;
-  }
-  int want_map(const std::string& id, int heads, int Sq, int Sk) {
-    if (dry) { P.dry_ids.push_back(id); return -1; }
-    if (stop || !P.requested.count(id)) return -1;
-    HookSlot hs; hs.id = id;
-    hs.shape[0] = Bn; hs.shape[1] = heads; hs.shape[2] = Sq; hs.shape[3] = Sk;
-    hs.stride[0] = (int64_t)heads * Sq * Sk; hs.stride[1] = (int64_t)Sq * Sk; hs.stride[2] = Sk; hs.stride[3] = 1;
-    hs.bytes = (size_t)Bn * heads * Sq * Sk * 2;
-    P.hooks.push_back(hs);
-    return (int)P.hooks.size() - 1;
-  }
-  void hook_done() {
-    if (dry) return;
-    if (--remaining == 0 && opt.early_exit) stop = true;
-  }
-  // coalesced hook store: fp16 copy of `rows x C` from (src, ld)
-  void hook_copy(int slot, Ref src, int ld, size_t nrows, int C) {
-    if (slot < 0) return;
-    op("hook_store", 0, [=](const Bind& b, hipStream_t s) {
-      return launch_copy2d((const half_t*)b.p(src), nullptr, ld, (half_t*)b.hook(slot), C, (int)nrows, C, s);
-    });
-    hook_done();
-  }
-  void gather(const std::string& id, const Act& a) { hook_copy(want(id, a.C, a.H, a.W), a.h, a.ld, rows(a), a.C); }
 
   // ---- primitive emitters -----------------------------------------------------------------------
   // GroupNorm (+SiLU) of x -> contiguous fp16 tensor (workspace offset returned)
@@ -438,50 +265,6 @@ struct B {   // builder
     return y;
   }
 
-  struct Epi {
-    Ref bias{}; bool has_bias = false;
-    Ref rowvec{}; bool has_rv = false; int rps = 1, ldrv = 0;
-    Ref res32{}; bool has_r32 = false; Ref res16{}; bool has_r16 = false; int ldres = 0;
-    Ref out16{}; bool has_o16 = false; int ldo16 = 0;
-    Ref out32{}; bool has_o32 = false; int ldo32 = 0;
-    int aux_slot = -1; int ldaux = 0;
-    int geglu = 0; int bn = 128;
-  };
-  void residual_from(Epi& e, const Act& x) {
-    if (x.has_f) { e.res32 = x.f; e.has_r32 = true; e.ldres = x.C; }
-    else { e.res16 = x.h; e.has_r16 = true; e.ldres = x.ld; }
-  }
-  // need_shadow = false: the fp16 image of a stream tensor is not stored when its only consumers read the fp32
-  // master (LayerNorm + the next residual add): saves one 2-byte/element write per residual GEMM
-  void out_to(Epi& e, const Act& y, bool need_shadow = true) {
-    if (need_shadow || !y.has_f) { e.out16 = y.h; e.has_o16 = true; e.ldo16 = y.ld; }
-    if (y.has_f) { e.out32 = y.f; e.has_o32 = true; e.ldo32 = y.C; }
-  }
-  static void fill_epi(GemmParams& g, const Epi& e, const Bind& b) {
-    g.bias = e.has_bias ? (const float*)b.p(e.bias) : nullptr;
-    g.rowvec = e.has_rv ? (const float*)b.p(e.rowvec) : nullptr; g.rows_per_sample = e.rps; g.ldrv = e.ldrv;
-    g.res32 = e.has_r32 ? (const float*)b.p(e.res32) : nullptr;
-    g.res16 = e.has_r16 ? (const half_t*)b.p(e.res16) : nullptr; g.ldres = e.ldres;
-    g.out16 = e.has_o16 ? (half_t*)b.p(e.out16) : nullptr; g.ldo16 = e.ldo16;
-    g.out32 = e.has_o32 ? (float*)b.p(e.out32) : nullptr; g.ldo32 = e.ldo32;
-    g.aux16 = e.aux_slot >= 0 ? (half_t*)b.hook(e.aux_slot) : nullptr; g.ldaux = e.ldaux;
-    g.geglu = e.geglu; g.bn = e.bn;
-  }
-
-  // dense GEMM: A (fp16 [M][K], lda) x W[N][K]
-  void gemm(const char* name, Ref A, int lda, size_t M, const LinW& w, int N, int K, size_t w_off_bytes, const Epi& e0) {
-    Epi e = e0;
-    const Ref W = wt(w.w + w_off_bytes);
-    GemmParams gk{}; gk.M = (int)M; gk.N = N; gk.K = K; gk.mode = A_DENSE; gk.geglu = e.geglu; gk.bn = e.bn;
-    op(name, 2.0 * (double)M * N * K, [=](const Bind& b, hipStream_t s) {
-      GemmParams g{};
-      g.A = (const half_t*)b.p(A); g.lda = lda; g.a_bytes = (uint32_t)(((size_t)M - 1) * lda * 2 + (size_t)K * 2);
-      g.M = (int)M; g.N = N; g.K = K; g.mode = A_DENSE;
-      g.Wt = (const half_t*)b.p(W); g.w_bytes = (uint32_t)((size_t)N * K * 2);
-      fill_epi(g, e, b);
-      return launch_gemm(g, s);
-    }, gemm_kernel_name(gk));
-  }
   // 3x3 conv as implicit GEMM over NHWC `src` (Bn, H, W, ld>=Cin)
   void conv3(const char* name, Ref src, int ld, int Cin, int H, int W, int stride, bool ups, const ConvW& w, const Epi& e0) {
     Epi e = e0;
@@ -919,7 +702,9 @@ const char* kernel_label(const char* n) {
   auto is = [&](const char* x) { return strcmp(n, x) == 0; };
   if (is("conv_in")) return "gemm_kernel<2, 128, 128, 2, false>";
   if (is("attn2_kv")) return "gemm_kernel<0, 128, 128, 2, false>";
-  if (is("attn1") || is("attn2")) return "attn_kernel";
+  if (is("attn1") || is("attn2") || is("joint_attn")) return "attn_kernel";
+  if (is("adaln") || is("adaln_txt") || is("norm_out")) return "layernorm_mod_kernel";
+  if (is("qk_norm_rope")) return "qk_norm_rope_kernel";
   if (is("layernorm")) return "layernorm_kernel";
   if (is("gn_stats")) return "gn_partial_kernel+gn_finalize_kernel";
   if (is("gn_apply") || is("gn_apply_silu")) return "gn_apply_kernel";
@@ -969,6 +754,7 @@ int plan_read_timing(Plan& P, double* ms, long* launches, double* flops) {
 int plan_forward(Plan& P, const Model& m, const void* lat, const float* t, const void* ctx, const void* txt,
                  const float* tid, void* const* hook_out, void* noise, void* ws, hipStream_t s, float* ms,
                  const char** names, double* flops, int cap) {
+  if (m.kind != 0) { set_error("gdf_forward on a Flux model: use gdf_flux_forward"); return GDF_ERR_STATE; }
   if (m.n_set != (int)m.params.size()) { set_error("model weights incomplete"); return GDF_ERR_STATE; }
   Bind b;
   b.base[BUF_WS] = (char*)ws; b.base[BUF_WT] = (char*)m.weights; b.base[BUF_LAT] = (char*)lat; b.base[BUF_T] = (char*)t;
@@ -978,6 +764,10 @@ int plan_forward(Plan& P, const Model& m, const void* lat, const float* t, const
   if (P.hooks.size() && !hook_out) { set_error("hook_out is null"); return GDF_ERR_ARG; }
   if (P.writes_noise && !noise) { set_error("noise_pred buffer required (the plan runs conv_out)"); return GDF_ERR_ARG; }
   b.base[BUF_NOISE] = (char*)noise;
+  return plan_run(P, b, s, ms, names, flops, cap);
+}
+
+int plan_run(Plan& P, const Bind& b, hipStream_t s, float* ms, const char** names, double* flops, int cap) {
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (ms) { hipEventCreate(&e0); hipEventCreate(&e1); }
   int i = 0;

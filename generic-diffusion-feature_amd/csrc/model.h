@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "../../include/gdf.h"
+#include "../../include/gdf_flux.h"
 #include "kernels.h"
 
 namespace gdf {
@@ -36,7 +37,30 @@ struct ParamRec {
 };
 struct TembReg { std::string name; int cout; int off; };
 
+// ---- MMDiT (Flux) weights ------------------------------------------------------------------------
+// mod_*: column offsets (floats) into the per-sample modulation table [B][mod_total] = Linear(silu(temb)) of every
+// AdaLayerNormZero / ZeroSingle / Continuous, stacked into ONE [mod_total][C] matrix (a single launch per forward).
+struct FluxDoubleW {
+  int mod = 0, cmod = 0;                       // norm1.linear (6C: shift,scale,gate msa | shift,scale,gate mlp), norm1_context.linear
+  LinW qkv, cqkv, o, co, ff1, ff2, cff1, cff2; // to_q|k|v fused [3C][C], add_q|k|v_proj fused, to_out.0, to_add_out, ff, ff_context
+  size_t nq = 0, nk = 0, cnq = 0, cnk = 0;     // RMSNorm gains fp32 [D]: norm_q, norm_k, norm_added_q, norm_added_k
+};
+struct FluxSingleW {
+  int mod = 0;                                 // norm.linear (3C: shift, scale, gate)
+  LinW qkv, mlp, out;                          // to_q|k|v fused, proj_mlp, proj_out [C][C + hid]
+  size_t nq = 0, nk = 0;
+};
+struct FluxW {
+  gdf_flux_desc d{};
+  int C = 0, hid = 0, D = 0, mod_total = 0, mod_out = 0;
+  LinW x_emb, ctx_emb, t1, t2, g1, g2, p1, p2, mod_all, proj_out;
+  std::vector<FluxDoubleW> dbl;
+  std::vector<FluxSingleW> sgl;
+};
+
 struct Model {
+  int kind = 0;                                // 0: UNet2DConditionModel, 1: FluxTransformer2DModel
+  FluxW flux;
   GdfArch arch{};
   void* weights = nullptr;
   size_t weight_bytes = 0;
@@ -56,7 +80,9 @@ struct Model {
 };
 
 // ---- plan ----------------------------------------------------------------------------------------
-enum { BUF_WS = 0, BUF_WT, BUF_LAT, BUF_T, BUF_CTX, BUF_TXT, BUF_TID, BUF_NOISE, BUF_COUNT };
+// Flux reuses the slots: LAT = hidden_states, T = timestep, CTX = encoder_hidden_states, TXT = pooled_projections,
+// TID = guidance, NOISE = output; IDS_IMG / IDS_TXT = img_ids / txt_ids
+enum { BUF_WS = 0, BUF_WT, BUF_LAT, BUF_T, BUF_CTX, BUF_TXT, BUF_TID, BUF_NOISE, BUF_IDS_IMG, BUF_IDS_TXT, BUF_COUNT };
 struct Ref { int buf = BUF_WS; size_t off = 0; };
 struct Bind {
   char* base[BUF_COUNT] = {nullptr};
@@ -70,7 +96,7 @@ struct HookSlot { std::string id; int64_t shape[4]; int64_t stride[4]; size_t by
 
 struct Plan {
   const Model* model = nullptr;
-  int batch = 0, H = 0, W = 0, n_ctx = 0;
+  int batch = 0, H = 0, W = 0, n_ctx = 0;    // Flux: H x W = packed-latent token grid, n_ctx = text tokens
   PlanOpts opts{};
   std::vector<Op> ops;
   std::vector<HookSlot> hooks;
@@ -101,5 +127,14 @@ int plan_build(const Model& m, Plan& P, int batch, int H, int W, int n_ctx, cons
 int plan_forward(Plan& P, const Model& m, const void* lat, const float* t, const void* ctx, const void* txt,
                  const float* tid, void* const* hook_out, void* noise, void* ws, hipStream_t s, float* ms,
                  const char** names, double* flops, int cap);
+// executes the op program against an already filled binding table (shared by the UNet and Flux front ends)
+int plan_run(Plan& P, const Bind& b, hipStream_t s, float* ms, const char** names, double* flops, int cap);
+
+Model* flux_model_create(const gdf_flux_desc& d);
+int flux_plan_build(const Model& m, Plan& P, int batch, int img_h, int img_w, int n_txt, const char* const* ids, int n_ids,
+                    const PlanOpts& opts, bool dry);
+int flux_forward(Plan& P, const Model& m, const void* hidden, const void* enc, const void* pooled, const float* timestep,
+                 const float* guidance, const float* img_ids, const float* txt_ids, void* const* hook_out, void* out,
+                 void* ws, hipStream_t s, float* ms, const char** names, double* flops, int cap);
 
 }  // namespace gdf

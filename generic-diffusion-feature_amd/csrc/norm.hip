@@ -281,7 +281,7 @@ hipError_t launch_pack_latents(const half_t* x, int B, int Cin, int H, int W, ha
 
 // diffusers get_timestep_embedding(flip_sin_to_cos=True, downscale_freq_shift=0): [cos | sin]
 __global__ void sinusoid_kernel(const float* t, int n_per_row, int dim, float* out, int ldo, int col_off, int round_f16,
-                                int total) {
+                                int total, float tscale) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   const int half = dim / 2;
@@ -290,17 +290,17 @@ __global__ void sinusoid_kernel(const float* t, int n_per_row, int dim, float* o
   const int b = i / (dim * n_per_row);
   const int f = j < half ? j : j - half;
   const float freq = expf(-9.210340371976184f * (float)f / (float)half);   // ln(10000)
-  const float arg = t[b * n_per_row + ti] * freq;
+  const float arg = t[b * n_per_row + ti] * tscale * freq;
   float v = j < half ? cosf(arg) : sinf(arg);
   if (round_f16) v = (float)(_Float16)v;
   out[(size_t)b * ldo + col_off + ti * dim + j] = v;
 }
 
 hipError_t launch_sinusoid(const float* t, int B, int n_per_row, int dim, float* out, int ldo, int col_off,
-                           int round_f16, hipStream_t s) {
+                           int round_f16, hipStream_t s, float tscale) {
   const int total = B * n_per_row * dim;
   hipLaunchKernelGGL(sinusoid_kernel, dim3((total + 255) / 256), dim3(256), 0, s, t, n_per_row, dim, out, ldo, col_off,
-                     round_f16, total);
+                     round_f16, total, tscale);
   return hipGetLastError();
 }
 

@@ -1,0 +1,72 @@
+/* gdf_flux.h — C ABI of the MMDiT (Flux) hot path of libgdf.so (BASELINE config 5).
+ *
+ * What it replaces in the reference (paths relative to /root/reference/feature):
+ *   - FluxTransformer2DModel.forward                       diffusers/models/transformers/transformer_flux.py:414-603
+ *     (FluxTransformerBlock :167-226, FluxSingleTransformerBlock :86-112, FluxAttnProcessor2_0
+ *      diffusers/models/attention_processor.py:2266-2362, FeedForward diffusers/models/attention.py:1249-1258)
+ *     — the denoiser call inside `self.pipe(image=..., prompt=..., strength=t/1000, guidance_scale=1)`,
+ *     diffusion_feature.py:246-254
+ *   - the side effects of every `feature_gatherer.gather(...)` in those files (FeatureStore.store,
+ *     components/feature_extractor.py:31-76) with the flux id scheme of components/feature_extractor.py:98-123:
+ *       vit-block{i}-{q,k,v,attn-out,norm-out,ffn-inner,out}   i <  num_layers          (double blocks)
+ *       vit-block{i}-{q,k,v,attn-out,out}                      i >= num_layers          (single blocks)
+ *
+ * Handles (gdf_model / gdf_plan) and every model / plan query, hook-info, workspace and timing function are the ones
+ * of gdf.h; only creation and the forward call differ.  Same conventions: plain C, int status (0 = ok), caller owns
+ * all device buffers, asynchronous on the stream passed in.  Arithmetic: fp16 MFMA operands, fp32 accumulate, fp32
+ * residual stream (the reference runs bfloat16: same operand width, 3 fewer mantissa bits; hooks are fp16 in both,
+ * components/feature_extractor.py:59-60).
+ */
+#ifndef GDF_FLUX_H
+#define GDF_FLUX_H
+#include <stddef.h>
+#include <stdint.h>
+
+#include "gdf.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* FluxTransformer2DModel hyper-parameters (transformer/config.json of black-forest-labs/FLUX.1-dev,
+ * components/models.py:150-169; registered at transformer_flux.py:247-259). */
+typedef struct gdf_flux_desc {
+  int in_channels;              /* 64  (packed 2x2 latent patches x 16 channels) */
+  int num_layers;               /* 19  double (MMDiT) blocks */
+  int num_single_layers;        /* 38  single blocks */
+  int attention_head_dim;       /* 128 (must be 128: sum of axes_dims_rope) */
+  int num_attention_heads;      /* 24 */
+  int joint_attention_dim;      /* 4096 (T5 width) */
+  int pooled_projection_dim;    /* 768  (CLIP pooled width) */
+  int guidance_embeds;          /* 1 (FLUX.1-dev), 0 (schnell) */
+  int axes_dims_rope[3];        /* 16, 56, 56 */
+  int mlp_ratio;                /* 4 */
+} gdf_flux_desc;
+
+int gdf_flux_model_create(const gdf_flux_desc* desc, gdf_model** out);
+
+/* Static op program for `batch` samples of img_h x img_w image tokens (packed latent grid: 64 x 64 at 1024^2) and
+ * n_txt text tokens (512).  Hook tensors are logical (B, C, img_h, img_w) stored channels-last, as in gdf.h. */
+int gdf_flux_plan_create(gdf_model* m, int batch, int img_h, int img_w, int n_txt, const char* const* hook_ids,
+                         int n_hooks, const gdf_plan_opts* opts, gdf_plan** out);
+
+/* One transformer forward.  hidden_states (B, img_h*img_w, in_channels) fp16; encoder_hidden_states
+ * (B, n_txt, joint_attention_dim) fp16; pooled_projections (B, pooled_projection_dim) fp16; timestep (B) fp32 in
+ * [0,1] (the model multiplies by 1000, transformer_flux.py:472); guidance (B) fp32 or NULL when !guidance_embeds;
+ * img_ids (img_h*img_w, 3) fp32, txt_ids (n_txt, 3) fp32; out (B, img_h*img_w, in_channels) fp16 or NULL with
+ * early_exit. */
+int gdf_flux_forward(gdf_plan* p, const void* hidden_states, const void* encoder_hidden_states,
+                     const void* pooled_projections, const float* timestep, const float* guidance,
+                     const float* img_ids, const float* txt_ids, void* const* hook_out, void* out, void* workspace,
+                     void* stream);
+
+/* Per-op timing (diagnostics; synchronises). Same contract as gdf_plan_profile. */
+int gdf_flux_plan_profile(gdf_plan* p, const void* hidden_states, const void* encoder_hidden_states,
+                          const void* pooled_projections, const float* timestep, const float* guidance,
+                          const float* img_ids, const float* txt_ids, void* const* hook_out, void* out, void* workspace,
+                          void* stream, float* ms, const char** names, double* flops, int cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GDF_FLUX_H */

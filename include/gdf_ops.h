@@ -54,6 +54,31 @@ int gdf_op_copy2d(const void* s16, const float* s32, int lds, void* dst, int ldd
 int gdf_op_relayout_conv3(const void* w_oihw_f16, void* dst, int O, int I, void* stream);
 int gdf_op_relayout_geglu(const void* w_f16, const float* bias, void* w_dst, float* bias_dst, int R, int K, int group /*16*/, void* stream);
 
+/* ---- MMDiT (Flux) kernels (reference files cited in csrc/dit.hip, gdf_flux.h) ---- */
+
+/* Dense GEMM with the MMDiT epilogue: v = A W^T + bias; act=1: tanh-GELU; vec != NULL: v = vec_mul ? v * vec[s] : v + vec[s]
+ * (s = row / rps for row < seg_rows or seg_rows == 0, else (row - seg_rows) / rps2; vec fp32 rows of ldvec);
+ * aux16 (optional) receives fp16(v) BEFORE the gate; then + res32, stores out16 / out32.
+ * Replaces nn.Linear + gate/residual arithmetic of transformer_flux.py:95-106, 191-218. */
+int gdf_op_gemm_dit(const void* A, int lda, const void* W, const float* bias, int act, const float* vec, int ldvec, int vec_mul,
+                    int rps, int seg_rows, int rps2, const float* res32, int ldres, void* aux16, int ldaux, void* out16,
+                    int ldo16, float* out32, int ldo32, int M, int N, int K, int variant, void* stream);
+
+/* y = LayerNorm(x, eps, no affine) * (1 + scale[s]) + shift[s]  (AdaLayerNormZero & co.); x fp32 [R][ld], y fp16 [R][C]. */
+int gdf_op_layernorm_mod(const float* x32, int ld, int R, int C, float eps, const float* scale, const float* shift, int ldm,
+                         int rps, int seg_rows, int rps2, void* y, void* stream);
+
+/* In place RMSNorm(q), RMSNorm(k) per head (D = 128) + rotary embedding on fp16 rows [R][ld]; position = pos0 + r % rps. */
+int gdf_op_qk_norm_rope(void* x, int ld, int R, int heads, int q_col, int k_col, const float* wq, const float* wk, float eps,
+                        const float* cos_t, const float* sin_t, int pos0, int rps, void* stream);
+
+/* FluxPosEmbed: ids fp32 [S][3] -> cos/sin fp32 [S][axes0+axes1+axes2] written at row offset row0. */
+int gdf_op_rope_table(const float* ids, int S, int a0, int a1, int a2, float* cos_t, float* sin_t, int row0, void* stream);
+
+/* Joint attention over [T text | S image] tokens per sample, rows region-major [B*T text rows][B*S image rows]. */
+int gdf_op_attention_joint(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* o, int ldo, int B,
+                           int heads, int T, int S, int D, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

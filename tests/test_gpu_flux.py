@@ -1,0 +1,185 @@
+"""GPU parity of the MMDiT (Flux) path through the C ABI (include/gdf_flux.h, gdf_ops.h):
+kernels vs fp32 PyTorch, whole tiny-Flux forward with every hook vs the CPU oracle (oracle/flux_ref.py), and the
+committed reference golden (tests/golden/flux_tiny.npz, produced by the reference's own transformer_flux.py).
+
+Stated tolerance: relative L2 error per hooked tensor <= 3e-3 (fp16 MFMA operands, fp32 accumulate / stream)."""
+import ast
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import rel_l2
+from oracle import flux_ref as FR
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+TOL = 3e-3
+
+
+def _ops():
+    from ops_binding import P, lib, ok, stream
+    return lib(), P, ok, stream
+
+
+def _region_major(x_txt, x_img):
+    """(B,T,C), (B,S,C) -> [B*T + B*S][C]"""
+    return torch.cat([x_txt.reshape(-1, x_txt.shape[-1]), x_img.reshape(-1, x_img.shape[-1])], 0).contiguous()
+
+
+@pytest.mark.parametrize("M,N,K,variant", [(300, 256, 192, 128), (1024, 512, 256, 1256), (700, 768, 1280, 1256), (520, 64, 256, 128)])
+@pytest.mark.parametrize("mode", ["plain", "gelu", "gate_res", "gate_res_seg"])
+def test_gemm_dit(M, N, K, variant, mode):
+    L, P, ok, stream = _ops()
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    A = torch.randn(M, K, device="cuda", generator=g).half()
+    W = (torch.randn(N, K, device="cuda", generator=g) * K ** -0.5).half()
+    bias = torch.randn(N, device="cuda", generator=g)
+    ref = A.float() @ W.float().t() + bias
+    o16 = torch.empty(M, N, device="cuda", dtype=torch.half)
+    if mode == "plain":
+        ok(L.gdf_op_gemm_dit(P(A), K, P(W), P(bias), 0, None, 0, 0, 1, 0, 1, None, 0, None, 0, P(o16), N, None, 0, M, N, K, variant, stream()), L)
+        got = o16
+    elif mode == "gelu":
+        ok(L.gdf_op_gemm_dit(P(A), K, P(W), P(bias), 1, None, 0, 0, 1, 0, 1, None, 0, None, 0, P(o16), N, None, 0, M, N, K, variant, stream()), L)
+        ref = torch.nn.functional.gelu(ref, approximate="tanh")
+        got = o16
+    else:
+        seg = mode.endswith("seg")
+        rps, seg_rows, rps2 = (50, 200, 100) if seg else (100, 0, 1)
+        rows = torch.arange(M, device="cuda")
+        smp = torch.where(rows < seg_rows, rows // rps, (rows - seg_rows) // rps2) if seg else rows // rps
+        nb = int(smp.max()) + 1
+        vec = torch.randn(nb, N + 8, device="cuda", generator=g)
+        res = torch.randn(M, N, device="cuda", generator=g)
+        aux = torch.empty(M, N, device="cuda", dtype=torch.half)
+        o32 = res.clone()
+        ok(L.gdf_op_gemm_dit(P(A), K, P(W), P(bias), 0, P(vec), N + 8, 1, rps, seg_rows, rps2, P(o32), N, P(aux), N, None, 0,
+                             P(o32), N, M, N, K, variant, stream()), L)
+        assert rel_l2(aux, ref) < 1e-3                    # pre-gate projection (`attn-out` hook)
+        ref = res + vec[smp, :N] * ref
+        got = o32
+    torch.cuda.synchronize()
+    assert rel_l2(got, ref) < 1e-3, (mode, rel_l2(got, ref))
+
+
+@pytest.mark.parametrize("C", [256, 1024, 3072])
+def test_layernorm_mod(C):
+    L, P, ok, stream = _ops()
+    T, S, B = 8, 24, 3
+    R = B * (T + S)
+    x = torch.randn(R, C, device="cuda") * 3 + 0.5
+    mod = torch.randn(B, 2 * C + 16, device="cuda")
+    y = torch.empty(R, C, device="cuda", dtype=torch.half)
+    ok(L.gdf_op_layernorm_mod(P(x), C, R, C, 1e-6, P(mod[:, C:]), P(mod), mod.shape[1], T, B * T, S, P(y), stream()), L)
+    rows = torch.arange(R, device="cuda")
+    smp = torch.where(rows < B * T, rows // T, (rows - B * T) // S)
+    ref = torch.nn.functional.layer_norm(x, (C,), eps=1e-6) * (1 + mod[smp, C:2 * C]) + mod[smp, :C]
+    assert rel_l2(y, ref) < 1e-3
+
+
+def test_rope_table_and_qk_norm_rope():
+    L, P, ok, stream = _ops()
+    T, gh = 8, 4
+    S = gh * gh
+    ids = torch.cat([torch.zeros(T, 3), FR.latent_image_ids(gh, gh)], 0).cuda()
+    cos = torch.empty(T + S, 128, device="cuda"); sin = torch.empty_like(cos)
+    ok(L.gdf_op_rope_table(P(ids[:T].contiguous()), T, 16, 56, 56, P(cos), P(sin), 0, stream()), L)
+    ok(L.gdf_op_rope_table(P(ids[T:].contiguous()), S, 16, 56, 56, P(cos), P(sin), T, stream()), L)
+    rc, rs = FR.rope_freqs(ids.cpu(), (16, 56, 56))
+    assert torch.allclose(cos.cpu(), rc, atol=1e-6) and torch.allclose(sin.cpu(), rs, atol=1e-6)
+    B, heads, C = 2, 3, 384
+    x = torch.randn(B * S, 3 * C, device="cuda").half()
+    wq = 1 + 0.1 * torch.randn(128, device="cuda"); wk = 1 + 0.1 * torch.randn(128, device="cuda")
+    y = x.clone()
+    ok(L.gdf_op_qk_norm_rope(P(y), 3 * C, B * S, heads, 0, C, P(wq), P(wk), 1e-6, P(cos), P(sin), T, S, stream()), L)
+    xf = x.float().cpu().view(B, S, 3, heads, 128)
+    for which, w in ((0, wq), (1, wk)):
+        t = xf[:, :, which].permute(0, 2, 1, 3)                       # B, heads, S, D
+        ref = FR.apply_rope(FR.rms_norm(t, w.cpu()), rc[T:], rs[T:]).permute(0, 2, 1, 3).reshape(B * S, C)
+        assert rel_l2(y[:, which * C:(which + 1) * C], ref) < 1e-3
+    assert torch.equal(y[:, 2 * C:], x[:, 2 * C:])                    # v untouched
+
+
+@pytest.mark.parametrize("B,heads,T,S", [(2, 2, 64, 256), (1, 3, 40, 100), (2, 1, 8, 16)])
+def test_joint_attention(B, heads, T, S):
+    L, P, ok, stream = _ops()
+    D, C = 128, heads * 128
+    g = torch.Generator(device="cuda").manual_seed(7)
+    qkv_t = torch.randn(B, T, 3 * C, device="cuda", generator=g).half()
+    qkv_i = torch.randn(B, S, 3 * C, device="cuda", generator=g).half()
+    buf = _region_major(qkv_t, qkv_i)
+    o = torch.zeros(B * (T + S), C, device="cuda", dtype=torch.half)
+    base = buf.data_ptr()
+    import ctypes
+    ptr = lambda col: ctypes.c_void_p(base + col * 2)
+    ok(L.gdf_op_attention_joint(ptr(0), 3 * C, ptr(C), 3 * C, ptr(2 * C), 3 * C, P(o), C, B, heads, T, S, D, stream()), L)
+    j = torch.cat([qkv_t, qkv_i], 1).float()                          # per-sample joint sequence (B, T+S, 3C)
+    q, k, v = [j[..., i * C:(i + 1) * C].view(B, T + S, heads, D).transpose(1, 2) for i in range(3)]
+    ref = torch.nn.functional.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(B, T + S, C)
+    got = torch.cat([o[:B * T].view(B, T, C), o[B * T:].view(B, S, C)], 1)
+    assert rel_l2(got, ref) < 2e-3
+
+
+def _run_native(arch, P, I, ids, grid):
+    from components.native import NativeFluxTransformer
+    cfg = dict(arch)
+    net = NativeFluxTransformer(cfg, device="cuda:0")
+    net.load_state_dict({k: v.half() for k, v in P.items()})
+    assert net.ready()
+    out, hooks = net.forward_raw(I["hidden_states"].cuda(), I["encoder_hidden_states"].cuda(), I["pooled_projections"].cuda(),
+                                 I["timestep"].cuda(), I["img_ids"].cuda(), I["txt_ids"].cuda(),
+                                 guidance=I["guidance"].cuda() if I.get("guidance") is not None else None, hook_ids=ids,
+                                 grid=(grid, grid))
+    torch.cuda.synchronize()
+    return net, out, hooks
+
+
+def test_flux_tiny_all_hooks_vs_oracle():
+    arch = FR.tiny_arch()
+    P = FR.synth_params(arch, seed=0)
+    I = FR.synth_inputs(arch, batch=2, grid=8, n_txt=24, seed=1, same_prompt=False)
+    st = FR.Store(None)
+    y = FR.flux_forward(P, arch, I["hidden_states"], I["encoder_hidden_states"], I["pooled_projections"], I["timestep"],
+                        I["img_ids"], I["txt_ids"], I["guidance"], store=st)
+    net, out, hooks = _run_native(arch, P, I, FR.hook_ids(arch), 8)
+    assert net.hook_names() == FR.hook_ids(arch)
+    assert list(hooks.keys()) == list(st.feats.keys())
+    worst = rel_l2(out, y)
+    assert worst < TOL, ("output", worst)
+    for k, ref in st.feats.items():
+        assert hooks[k].shape == ref.shape and hooks[k].dtype == torch.float16, k
+        e = rel_l2(hooks[k], ref)
+        worst = max(worst, e)
+        assert e < TOL, (k, e)
+    print("flux tiny: worst rel L2", worst)
+
+
+def test_flux_matches_reference_golden():
+    """tests/golden/flux_tiny.npz = outputs of the reference's own FluxTransformer2DModel (gen_golden_flux.py)."""
+    z = np.load(os.path.join(GOLD, "flux_tiny.npz"))
+    meta = ast.literal_eval(str(z["meta"]))
+    arch = meta["arch"]
+    P = FR.synth_params(arch, seed=meta["wseed"])
+    I = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("in:")}
+    net, out, hooks = _run_native(arch, P, I, meta["order"], 4)
+    assert list(hooks.keys()) == meta["order"]
+    assert rel_l2(out, torch.from_numpy(z["out:y"])) < TOL
+    for k in meta["order"]:
+        e = rel_l2(hooks[k], torch.from_numpy(z["out:hook:" + k]))
+        assert e < TOL, (k, e)
+
+
+def test_flux_subset_early_exit_and_unknown_ids():
+    arch = FR.tiny_arch(num_layers=1, num_single_layers=2)
+    P = FR.synth_params(arch, seed=2)
+    I = FR.synth_inputs(arch, batch=1, grid=4, n_txt=8, seed=3)
+    ids = ["vit-block1-attn-out", "vit-block0-ffn-inner", "not-a-layer"]
+    st = FR.Store({k: True for k in ids})
+    FR.flux_forward(P, arch, I["hidden_states"], I["encoder_hidden_states"], I["pooled_projections"], I["timestep"],
+                    I["img_ids"], I["txt_ids"], I["guidance"], store=st)
+    net, out, hooks = _run_native(arch, P, I, ids, 4)
+    assert list(hooks.keys()) == list(st.feats.keys()) == ["vit-block0-ffn-inner", "vit-block1-attn-out"]
+    for k, ref in st.feats.items():
+        assert rel_l2(hooks[k], ref) < TOL, k
