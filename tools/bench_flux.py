@@ -1,0 +1,154 @@
+#!/usr/bin/env python3
+"""BASELINE.json configs[4]: Flux.1-dev MMDiT 1024x1024 (4096 image + 512 text tokens), batch 8, one MI355X.
+
+    python tools/bench_flux.py [--batch 8] [--steps 3] [--warmup 1] [--hooks practical|all|none] [--profile-ops]
+                               [--layers 19 --single-layers 38]   (smaller stacks for quick checks)
+
+A step = one FluxTransformer2DModel forward over `--batch` synthetic packed latents resident in HBM, hooks written
+to HBM.  Prints ONE JSON line in bench.py's schema (metric images/s, roofline of the dominant kernel measured live
+with HIP events, cpu_baseline = oracle/flux_ref.py on a bounded sample).  The reference has no flux layer config
+(feature/configs holds none), so `practical` = block outputs + attention queries at four depths.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "generic-diffusion-feature_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+
+MFMA_PEAK_TFLOPS = 2500.0
+
+
+def cpu_baseline(cfg, n_img, n_txt, fl_full, budget_s=25.0):
+    from oracle import flux_ref as FR
+    arch = dict(FR.ARCH_FLUX_DEV)
+    arch.update(num_layers=1, num_single_layers=2)              # bounded sample: 1 double + 2 single blocks, full widths
+    cores = os.cpu_count() or 1
+    threads = min(cores, 32)
+    torch.set_num_threads(threads)
+    shapes = FR.param_shapes(arch)
+    big = max(int(torch.tensor(s).prod()) for s in shapes.values())
+    buf = torch.empty(big).fill_(0.01)
+    P = {k: buf[:int(torch.tensor(s).prod())].view(s) for k, s in shapes.items()}
+    g, t = 32, 128                                              # 1024 image + 128 text tokens
+    I = FR.synth_inputs(arch, 1, g, t, seed=1)
+    t0 = time.time()
+    with torch.no_grad():
+        FR.flux_forward(P, arch, I["hidden_states"], I["encoder_hidden_states"], I["pooled_projections"], I["timestep"],
+                        I["img_ids"], I["txt_ids"], I["guidance"])
+    dt = time.time() - t0
+    fl_s = FR.flops_per_image(arch, g * g, t)
+    per_img = dt * fl_full / fl_s
+    return dict(value=round(1.0 / per_img, 6), unit="images/s", cores=threads, kind="port",
+                sample=f"oracle/flux_ref.py fp32, 1 double + 2 single blocks at full width on 1024+128 tokens: {dt:.1f} s on "
+                       f"{threads} threads (of {cores} host CPUs), scaled by the algorithmic FLOP ratio {fl_full / fl_s:.0f}x")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--grid", type=int, default=64, help="packed latent grid (64 = 1024x1024 image)")
+    ap.add_argument("--txt", type=int, default=512)
+    ap.add_argument("--layers", type=int, default=19)
+    ap.add_argument("--single-layers", type=int, default=38)
+    ap.add_argument("--hooks", default="practical", choices=("practical", "all", "none"))
+    ap.add_argument("--profile-ops", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+    if not torch.cuda.is_available():
+        sys.exit("needs an MI355X (no CPU fallback for the measured path)")
+    from components.native import FLUX_CONFIGS, NativeFluxTransformer
+    from oracle.flux_ref import flops_per_image, latent_image_ids        # FLOP model + id helper only (not measured)
+    dev = torch.device("cuda:0")
+    cfg = dict(FLUX_CONFIGS["flux"]); cfg.update(num_layers=args.layers, num_single_layers=args.single_layers)
+    net = NativeFluxTransformer(cfg, device=dev)
+    t0 = time.time()
+    net.init_synthetic(seed=0)
+    torch.cuda.synchronize()
+    t_w = time.time() - t0
+    B, S, T = args.batch, args.grid * args.grid, args.txt
+    g = torch.Generator(device=dev).manual_seed(1)
+    x = torch.randn(B, S, cfg["in_channels"], generator=g, device=dev).half()
+    enc = torch.randn(1, T, cfg["joint_attention_dim"], generator=g, device=dev).half().expand(B, -1, -1).contiguous()
+    pooled = torch.randn(1, cfg["pooled_projection_dim"], generator=g, device=dev).half().expand(B, -1).contiguous()
+    ts = torch.full((B,), 0.1, device=dev); gd = torch.full((B,), 1.0, device=dev)
+    img_ids = latent_image_ids(args.grid, args.grid).to(dev); txt_ids = torch.zeros(T, 3, device=dev)
+    names = net.hook_names()
+    nl = args.layers + args.single_layers
+    if args.hooks == "all":
+        ids = names
+    elif args.hooks == "none":
+        ids = []
+    else:
+        picks = sorted({min(nl - 1, max(0, int(nl * f))) for f in (0.2, 0.4, 0.6, 0.8)})
+        ids = [f"vit-block{i}-out" for i in picks] + [f"vit-block{i}-q" for i in picks]
+    step = lambda **kw: net.forward_raw(x, enc, pooled, ts, img_ids, txt_ids, guidance=gd, hook_ids=ids,
+                                        grid=(args.grid, args.grid), **kw)
+    for _ in range(max(1, args.warmup)):
+        out = step()
+    torch.cuda.synchronize()
+    _, _, prof = step(profile=True)
+    plan = net._plan(B, args.grid, args.grid, T, ids)
+    lib = net.lib
+    by = {}
+    for name, ms, fl, lab in prof:
+        d = by.setdefault(lab, [0.0, 0.0, 0]); d[0] += ms; d[1] += fl; d[2] += 1
+    dominant = max(by, key=lambda k: by[k][0])
+    assert lib.gdf_plan_set_timing(plan.handle, dominant.encode()) == 0
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ms_tot = C.c_double(); launches = C.c_long(); fl_tot = C.c_double()
+    lib.gdf_plan_read_timing(plan.handle, C.byref(ms_tot), C.byref(launches), C.byref(fl_tot))
+    lib.gdf_plan_set_timing(plan.handle, None)
+    assert torch.isfinite(out[0].float()).all()
+    hook_bytes = sum(v.numel() * 2 for v in out[1].values())
+    from oracle.flux_ref import ARCH_FLUX_DEV
+    arch = dict(ARCH_FLUX_DEV); arch.update(num_layers=args.layers, num_single_layers=args.single_layers)
+    fl_img = flops_per_image(arch, S, T)
+    ips = B * args.steps / dt
+    achieved = (fl_tot.value / 1e12) / (ms_tot.value / 1e3) if ms_tot.value > 0 else 0.0
+    tot = sum(v[0] for v in by.values())
+    res = {"metric": "images/sec feature-extract, Flux.1-dev MMDiT 1024^2 single forward", "value": round(ips, 3),
+           "unit": "images/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(1e3 * dt / args.steps, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f16", "data": "synthetic",
+           "config": {"workload": f"Flux MMDiT ({args.layers} double + {args.single_layers} single blocks, 24 heads x 128), "
+                                  f"{S}+{T} tokens, batch {B}, hooks={args.hooks} ({len(out[1])} ids, "
+                                  f"{hook_bytes / B / 1e6:.1f} MB/img)",
+                      "tflop_per_image": round(fl_img / 1e12, 2), "model_tflops_per_s": round(ips * fl_img / 1e12, 1),
+                      "weights_gb": round(lib.gdf_model_weight_bytes(net.handle) / 1e9, 2), "weights_init_s": round(t_w, 1),
+                      "workspace_gb": round(plan.ws_bytes / 1e9, 2),
+                      "arithmetic": "fp16 MFMA operands, fp32 accumulate, fp32 residual stream (reference: bf16)"},
+           "roofline": {"bound": "mfma", "kernel": dominant, "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                        "launches": int(launches.value), "avg_launch_ms": round(ms_tot.value / max(1, launches.value), 4),
+                        "share_of_step_time": round(by[dominant][0] / tot, 3)},
+           "kernel_time_share": {k: round(v[0] / tot, 3) for k, v in sorted(by.items(), key=lambda kv: -kv[1][0])[:8]},
+           "kernel_tflops": {k: round(v[1] / 1e9 / v[0], 1) for k, v in by.items() if v[1] > 0 and v[0] > 0}}
+    if args.profile_ops:
+        rows = {}
+        for name, ms, f_, _k in prof:
+            r = rows.setdefault(name, [0.0, 0.0, 0]); r[0] += ms; r[1] += f_; r[2] += 1
+        for name, r in sorted(rows.items(), key=lambda kv: -kv[1][0]):
+            print(f"# {name:18s} n={r[2]:4d} {r[0]:9.3f} ms  {r[1] / 1e9 / max(r[0], 1e-9):8.1f} TFLOP/s", file=sys.stderr)
+    if not args.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline(cfg, S, T, fl_img)
+        res["config"]["gpu_over_cpu"] = round(ips / res["cpu_baseline"]["value"], 1)
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()
