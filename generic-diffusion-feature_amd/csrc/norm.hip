@@ -362,9 +362,86 @@ __global__ __launch_bounds__(256) void small_linear_kernel(const float* x, int l
   }
 }
 
+// Wide version (N large: the stacked adaLN modulation linear of the MMDiT, N = 1.06 M columns, 6.5 GB of weights):
+// HBM-streaming bound.  x (<= 8 rows x K fp32, activation already applied) is staged ONCE per workgroup in LDS instead
+// of being re-read from L2 by every wave (the column-per-wave kernel above moved 104 GB through L2 for this op: 43 ms);
+// every wave owns 4 output columns per step (4 independent 16-byte weight streams in flight per lane).
+__global__ __launch_bounds__(256) void small_linear_wide_kernel(const float* x, int ldx, int M, int K, const half_t* Wt,
+                                                                const float* bias, int N, int silu_in, int accumulate,
+                                                                float* out, int ldo, int cols_per_block) {
+  extern __shared__ float xs[];                       // [8][K]
+  for (int i = threadIdx.x; i < 8 * K; i += 256) {
+    const int m = i / K, k = i - m * K;
+    float v = (m < M) ? x[(size_t)m * ldx + k] : 0.f;
+    if (silu_in) v = v / (1.0f + expf(-v));
+    xs[i] = v;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n_beg = blockIdx.x * cols_per_block, n_end = min(N, n_beg + cols_per_block);
+  for (int n0 = n_beg + wave * 4; n0 < n_end; n0 += 16) {
+    float acc[4][8];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int m = 0; m < 8; ++m) acc[c][m] = 0.f;
+    for (int k = lane * 8; k < K; k += 512) {
+      f16x8 wv[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int n = min(n0 + c, N - 1);
+        wv[c] = *(const f16x8*)(Wt + (size_t)n * K + k);
+      }
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
+        const f32x4 a = *(const f32x4*)(xs + m * K + k), b = *(const f32x4*)(xs + m * K + k + 4);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[c][m] += a[e] * (float)wv[c][e] + b[e] * (float)wv[c][4 + e];
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) acc[c][m] += __shfl_xor(acc[c][m], off);
+      }
+    if (lane < 32) {                                  // lane -> (column c, row m)
+      const int c = lane >> 3, m = lane & 7;
+      const int n = n0 + c;
+      if (n < n_end && m < M) {
+        float v = 0.f;
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+          for (int mm = 0; mm < 8; ++mm) if (cc == c && mm == m) v = acc[cc][mm];
+        v += bias ? bias[n] : 0.f;
+        float* op = out + (size_t)m * ldo + n;
+        if (accumulate) v += *op;
+        *op = v;
+      }
+    }
+  }
+}
+
 hipError_t launch_small_linear(const float* x, int ldx, int M, int K, const half_t* Wt, const float* bias, int N,
                                int silu_in, int accumulate, float* out, int ldo, hipStream_t s) {
   if (K % 8) return hipErrorInvalidValue;
+  if (N >= 65536 && M <= 8 && (size_t)K * 32 <= 128 * 1024) {
+    static bool attr_done = false;
+    if (!attr_done) {
+      hipError_t e = hipFuncSetAttribute((const void*)small_linear_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+      if (e != hipSuccess) return e;
+      attr_done = true;
+    }
+    const int cpb = 512;                               // 32 steps of 16 columns per workgroup: x staging amortised
+    hipLaunchKernelGGL(small_linear_wide_kernel, dim3((N + cpb - 1) / cpb), dim3(256), (size_t)K * 32, s, x, ldx, M, K, Wt, bias,
+                       N, silu_in, accumulate, out, ldo, cpb);
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL(small_linear_kernel, dim3((N + 3) / 4), dim3(256), 0, s, x, ldx, M, K, Wt, bias, N, silu_in,
                      accumulate, out, ldo);
   return hipGetLastError();

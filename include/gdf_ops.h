@@ -54,6 +54,12 @@ int gdf_op_copy2d(const void* s16, const float* s32, int lds, void* dst, int ldd
 int gdf_op_relayout_conv3(const void* w_oihw_f16, void* dst, int O, int I, void* stream);
 int gdf_op_relayout_geglu(const void* w_f16, const float* bias, void* w_dst, float* bias_dst, int R, int K, int group /*16*/, void* stream);
 
+/* out[m][n] = (accumulate ? out : 0) + bias[n] + sum_k act(x[m][k]) W[n][k]; x fp32 [M][ldx] (M small), W fp16 [N][K], out fp32.
+ * The time / text / adaLN-modulation embedding linears (unet_2d_condition.py:1142-1162, resnet.py:343-346; MMDiT adaLN
+ * `linear(silu(temb))`, stacked over all blocks: N = 1.06 M columns -> LDS-staged wide kernel).                          */
+int gdf_op_small_linear(const float* x, int ldx, int M, int K, const void* W, const float* bias, int N, int silu_in,
+                        int accumulate, float* out, int ldo, void* stream);
+
 /* ---- MMDiT (Flux) kernels (reference files cited in csrc/dit.hip, gdf_flux.h) ---- */
 
 /* Dense GEMM with the MMDiT epilogue: v = A W^T + bias; act=1: tanh-GELU; vec != NULL: v = vec_mul ? v * vec[s] : v + vec[s]

@@ -64,6 +64,22 @@ def test_gemm_dit(M, N, K, variant, mode):
     assert rel_l2(got, ref) < 1e-3, (mode, rel_l2(got, ref))
 
 
+@pytest.mark.parametrize("M,K,N,silu,acc", [(8, 3072, 70000, 0, 0), (3, 512, 65536 + 37, 1, 1), (8, 256, 1000, 1, 0), (2, 3072, 4096, 0, 1)])
+def test_small_linear_both_kernels(M, K, N, silu, acc):
+    """N >= 65536 takes the LDS-staged wide kernel (stacked adaLN modulation), smaller N the column-per-wave kernel."""
+    L, P, ok, stream = _ops()
+    g = torch.Generator(device="cuda").manual_seed(N)
+    x = torch.randn(M, K + 8, device="cuda", generator=g)
+    W = (torch.randn(N, K, device="cuda", generator=g) * K ** -0.5).half()
+    bias = torch.randn(N, device="cuda", generator=g)
+    out0 = torch.randn(M, N, device="cuda", generator=g)
+    out = out0.clone()
+    ok(L.gdf_op_small_linear(P(x), K + 8, M, K, P(W), P(bias), N, silu, acc, P(out), N, stream()), L)
+    xin = x[:, :K]
+    ref = (torch.nn.functional.silu(xin) if silu else xin).double() @ W.double().t() + bias.double() + (out0.double() if acc else 0)
+    assert rel_l2(out, ref) < 1e-5
+
+
 @pytest.mark.parametrize("C", [256, 1024, 3072])
 def test_layernorm_mod(C):
     L, P, ok, stream = _ops()
