@@ -49,17 +49,21 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
   constexpr int DQK = (D + 15) / 16 * 16;        // contraction length of QK^T, padded
   constexpr int DV = (D + 31) / 32 * 32;         // output rows of O^T, padded
   constexpr int DP = DV;                         // data halves per LDS row (DV >= DQK)
-  constexpr int LDR = DP + 8;                    // LDS row stride in halves (+16 B: conflict-free b128 reads)
+  constexpr int LDR = DP + 8;                    // K row stride in halves (+16 B: conflict-free b128 fragment reads)
+  // V row stride: the transposed fragment read (ds_read_b64_tr_b16) touches 4 rows x 64 B per half-wave, so the row
+  // stride must be an odd multiple of 64 B (PMC: with the K stride half of all LDS cycles were bank conflicts)
+  constexpr int LDV = (DP % 64 == 32) ? DP : DP + 32;
   constexpr int CPR = DP / 8;                    // 16-B chunks per row
   constexpr int NCH = (KT * CPR + 255) / 256;    // chunks per thread per tile
   constexpr int NS = DQK / 16;                   // k-steps of QK^T
   constexpr int NDB = DV / 32;                   // 32-row blocks of O^T
   constexpr int QBW = 32 * QW;                   // query rows per wave
   constexpr int QBLK = 4 * QBW;                  // query rows per workgroup
+  constexpr bool PADDED = (DP != D);             // head dims 40 / 80: zero-filled pad chunks
 
   // double-buffered K / V tiles: one barrier per tile
   __shared__ __attribute__((aligned(16))) _Float16 sK[2][KT * LDR];
-  __shared__ __attribute__((aligned(16))) _Float16 sV[2][KT * LDR];
+  __shared__ __attribute__((aligned(16))) _Float16 sV[2][KT * LDV];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nqb = (p.Sq + QBLK - 1) / QBLK;
@@ -99,9 +103,17 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
   }
   const float sl2 = p.scale * 1.44269504088896340736f;    // softmax(x*scale) via exp2
 
+  // ---- K / V tile loads: global -> registers -> LDS.  Key kv of sample b lives in row kv + (kv < T ? c0 : c1)
+  // (sample-major: c0 = c1 = b * kv_bstride; joint MMDiT layout: text rows first, see seg_row).  All address
+  // arithmetic is 32-bit and scalar-based (uniform base pointer + per-lane unsigned element offset: the first
+  // version spent ~150 of its 330 VALU instructions per tile on 64-bit address math and was VALU bound).
   const _Float16* kbase = p.k + head * D;
   const _Float16* vbase = p.v + head * D;
   const int ntiles = (p.Sk + KT - 1) / KT;
+  const int segT = p.seg_T > 0 ? p.seg_T : 0x7fffffff;
+  const uint32_t c0 = p.seg_T > 0 ? (uint32_t)b * (uint32_t)p.seg_T : (uint32_t)b * (uint32_t)p.kv_bstride;
+  const uint32_t c1 = p.seg_T > 0 ? (uint32_t)p.B * (uint32_t)p.seg_T + (uint32_t)b * (uint32_t)(p.Sk - p.seg_T) - (uint32_t)p.seg_T : c0;
+  const uint32_t ldk = (uint32_t)p.ldk, ldv = (uint32_t)p.ldv;
 
   f16x8 kreg[NCH], vreg[NCH];
   auto gload = [&](int t) {
@@ -109,12 +121,15 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
     for (int c = 0; c < NCH; ++c) {
       const int idx = tid + c * 256;
       const int row = idx / CPR, ch = idx - row * CPR;
-      const int kv = t * KT + row;
+      int kv = t * KT + row;
+      kv = min(kv, p.Sk - 1);                    // tail rows re-read the last key: their scores are masked to -inf below
+      const uint32_t r = (uint32_t)kv + (kv < segT ? c0 : c1);
       f16x8 kk = {0, 0, 0, 0, 0, 0, 0, 0}, vv = kk;
-      if (idx < KT * CPR && kv < p.Sk && ch * 8 < D) {
-        const size_t r = seg_row(b, kv, p.kv_bstride, p.seg_T, p.B, p.Sk);
-        kk = *(const f16x8*)(kbase + r * p.ldk + ch * 8);
-        vv = *(const f16x8*)(vbase + r * p.ldv + ch * 8);
+      if ((KT * CPR) % 256 == 0 || idx < KT * CPR) {
+        if (!PADDED || ch * 8 < D) {
+          kk = *(const f16x8*)(kbase + (r * ldk + (uint32_t)(ch * 8)));
+          vv = *(const f16x8*)(vbase + (r * ldv + (uint32_t)(ch * 8)));
+        }
       }
       kreg[c] = kk; vreg[c] = vv;
     }
@@ -124,9 +139,9 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
     for (int c = 0; c < NCH; ++c) {
       const int idx = tid + c * 256;
       const int row = idx / CPR, ch = idx - row * CPR;
-      if (idx < KT * CPR) {
+      if ((KT * CPR) % 256 == 0 || idx < KT * CPR) {
         *(f16x8*)(&sK[buf][row * LDR + ch * 8]) = kreg[c];
-        *(f16x8*)(&sV[buf][row * LDR + ch * 8]) = vreg[c];
+        *(f16x8*)(&sV[buf][row * LDV + ch * 8]) = vreg[c];
       }
     }
   };
@@ -142,9 +157,9 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
     // ---- S^T = K Q^T : two 32-key blocks; every K fragment feeds QW query blocks ----
     f32x16 s[QW][2];
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
+    for (int st = 0; st < NS; ++st) {
 #pragma unroll
-      for (int st = 0; st < NS; ++st) {
+      for (int kb = 0; kb < 2; ++kb) {           // the two key blocks alternate: no back-to-back dependent MFMAs
         const f16x8 kf = *(const f16x8*)(cK + (kb * 32 + lq) * LDR + 16 * st + 8 * lh);
 #pragma unroll
         for (int w = 0; w < QW; ++w) {
@@ -177,9 +192,10 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[w][kb][r]);
-      mx = half_max(mx);
-      const float m_new = fmaxf(m_run[w], mx * sl2);
-      const float alpha = __builtin_amdgcn_exp2f(m_run[w] - m_new);   // raw v_exp_f32; first tile: exp2(-inf) = 0
+      mx = half_max(mx) * sl2;
+      // lazy rescale: the running max only moves when the new one exceeds it by more than 2^8 (probabilities then stay
+      // <= 256 in fp16 and the fp32 accumulators never need the per-tile alpha multiply after the first tiles)
+      const float m_new = (mx > m_run[w] + 8.0f) ? mx : m_run[w];
       float psum = 0.f;
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
@@ -194,13 +210,15 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
           pf[w][kb * 2 + (r >> 3)][r & 7] = h2[0];
           pf[w][kb * 2 + (r >> 3)][(r & 7) + 1] = h2[1];
         }
-      l_run[w] = l_run[w] * alpha + psum;
-      if (m_new != m_run[w]) {                            // the running max rarely grows after the first tiles
+      if (m_new != m_run[w]) {
+        const float alpha = __builtin_amdgcn_exp2f(m_run[w] - m_new);   // raw v_exp_f32; first tile: exp2(-inf) = 0
+        l_run[w] *= alpha;
 #pragma unroll
         for (int i = 0; i < NDB; ++i)
 #pragma unroll
           for (int r = 0; r < 16; ++r) o[w][i][r] *= alpha;
       }
+      l_run[w] += psum;
       m_run[w] = m_new;
     }
 
@@ -211,10 +229,10 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
       for (int db = 0; db < NDB; ++db) {
         // V^T fragment: lane (d = db*32 + lq, lh) needs V[16 s4 + 4 lh + {0..3}][d] and V[16 s4 + 8 + 4 lh + {0..3}][d]
         const int i16 = lane & 15;
-        const int c0 = db * 32 + 16 * ((lane >> 4) & 1) + (i16 & 3) * 4;
+        const int c0v = db * 32 + 16 * ((lane >> 4) & 1) + (i16 & 3) * 4;
         const int r0 = 16 * s4 + 4 * lh + (i16 >> 2);
-        const fp16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((LDS_AS fp16x4_t*)(cV + r0 * LDR + c0));
-        const fp16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((LDS_AS fp16x4_t*)(cV + (r0 + 8) * LDR + c0));
+        const fp16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((LDS_AS fp16x4_t*)(cV + r0 * LDV + c0v));
+        const fp16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((LDS_AS fp16x4_t*)(cV + (r0 + 8) * LDV + c0v));
         union { fp16x4_t q[2]; f16x8 h; } vf;            // pure register re-interpretation, no conversion
         vf.q[0] = lo; vf.q[1] = hi;
 #pragma unroll
