@@ -125,14 +125,33 @@ def unet_layer_ids(cfg, include_dropped=False):
     return ids
 
 
+def flux_layer_ids(cfg):
+    """Every hook id of a Flux MMDiT in execution order: the flux branch of the reference's prepare_feature_extractor
+    (:98-123) combined with the gather sites (transformer_flux.py:107-108,196-207; attention_processor.py:2280-2291,
+    2355-2361; attention.py:1255-1257).  Single blocks continue the double-block numbering."""
+    ids = []
+    for i in range(cfg["num_layers"]):
+        b = f"vit-block{i}"
+        ids += [f"{b}-q", f"{b}-k", f"{b}-v", f"{b}-attn-out", f"{b}-norm-out", f"{b}-ffn-inner", f"{b}-out"]
+    for j in range(cfg["num_single_layers"]):
+        b = f"vit-block{cfg['num_layers'] + j}"
+        ids += [f"{b}-q", f"{b}-k", f"{b}-v", f"{b}-attn-out", f"{b}-out"]
+    return ids
+
+
 def prepare_feature_extractor(version, pipe, config, resize_ratio, train_unet):
     """Same signature as the reference (:92).  `config`: JSON path, dict, or None/{} (= accept all)."""
     if isinstance(config, str):
         with open(config, 'r') as f:
             config = json.load(f)
     feature_store = FeatureStore(config, resize_ratio, train_unet)
-    if version == 'flux' or hasattr(pipe, 'transformer'):
-        raise NotImplementedError("DiT / Flux denoisers are a later row of the hot-path scope table (SURVEY.md §8f)")
+    if version == 'flux':                          # reference :98-123
+        if not hasattr(pipe.transformer, 'forward_raw'):
+            raise NotImplementedError("pipe.transformer is not the native MMDiT (components.native.NativeFluxTransformer)")
+        pipe.transformer.feature_store = feature_store
+        return feature_store
+    if hasattr(pipe, 'transformer') and not hasattr(pipe, 'unet'):
+        raise NotImplementedError("PixArt / Hunyuan DiT denoisers are not on the native hot path (SURVEY.md §8f rank 4)")
     pipe.unet.feature_store = feature_store       # the native UNet delivers hook tensors here
     return feature_store
 

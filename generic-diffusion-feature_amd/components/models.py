@@ -15,7 +15,7 @@ import types
 
 import torch
 
-from .native import ARCH_CONFIGS, NativeUNet, config_from_diffusers
+from .native import ARCH_CONFIGS, FLUX_CONFIGS, NativeFluxTransformer, NativeUNet, config_from_diffusers
 
 # version -> (HF repo id, pipeline class name) exactly as the reference selects them (models.py:18-70)
 _HF = {
@@ -23,7 +23,7 @@ _HF = {
     "xl": ("stabilityai/stable-diffusion-xl-base-1.0", "StableDiffusionXLImg2ImgPipeline"),
     "pgv2": ("playgroundai/playground-v2-1024px-aesthetic", "StableDiffusionXLImg2ImgPipeline"),
 }
-_LATER = ("2-1", "pixart-sigma", "pixart-sigma-512", "pixart-alpha", "flux", "if", "hunyuan")
+_LATER = ("2-1", "pixart-sigma", "pixart-sigma-512", "pixart-alpha", "if", "hunyuan")
 
 
 def _parse_dtype(dtype):
@@ -128,6 +128,88 @@ class SyntheticPipe:
         return self.scheduler.add_noise(lat, noise, timestep).to(dtype)
 
 
+class SyntheticFluxPipe:
+    """Offline stand-in for diffusers' FluxImg2ImgPipeline as the reference drives it
+    (`pipe(image=..., prompt=..., strength=t/1000, guidance_scale=1)`, diffusion_feature.py:246-254): true-architecture
+    MMDiT (NativeFluxTransformer, seeded random weights) + deterministic stand-ins for the T5/CLIP encoders and the
+    16-channel VAE, flow-matching sigmas, 2x2 latent packing and the img2img strength -> timestep rule."""
+
+    num_inference_steps = 28                      # FluxImg2ImgPipeline.__call__ default
+
+    def __init__(self, device, seed=0, cfg=None, n_txt=512):
+        self.device = device
+        self._cfg = dict(cfg or FLUX_CONFIGS["flux"])
+        self.n_txt = n_txt
+        self.transformer = NativeFluxTransformer(self._cfg, device=device).init_synthetic(seed)
+        self.unet = self.transformer               # reference models.py:169 `pipe.unet = pipe.transformer`
+        empty = types.SimpleNamespace(parameters=lambda: iter(()), to=lambda *a, **k: None)
+        self.vae = types.SimpleNamespace(parameters=lambda: iter(()), config=types.SimpleNamespace(scaling_factor=0.3611, shift_factor=0.1159))
+        self.text_encoder = empty
+        self.text_encoder_2 = empty
+        self.scheduler = types.SimpleNamespace()
+        self.image_processor = types.SimpleNamespace(preprocess=SyntheticPipe._preprocess.__get__(self))
+
+    def _embeds(self, text, shape):
+        seed = int.from_bytes(hashlib.sha256(text.encode()).digest()[:4], "little")
+        return torch.randn(shape, generator=torch.Generator().manual_seed(seed)).to(self.device, torch.float16)
+
+    def __call__(self, image=None, prompt=None, strength=0.6, guidance_scale=7.0, num_inference_steps=None, **kw):
+        dev = self.device
+        imgs = image if isinstance(image, (list, tuple)) else [image]
+        x = torch.cat([self.image_processor.preprocess(i) for i in imgs], 0).to(dev, torch.float32)
+        B = x.shape[0]
+        prompts = prompt if isinstance(prompt, (list, tuple)) else [prompt] * B
+        enc = torch.cat([self._embeds(p, (1, self.n_txt, self._cfg["joint_attention_dim"])) for p in prompts], 0)
+        pooled = torch.cat([self._embeds("pool:" + p, (1, self._cfg["pooled_projection_dim"])) for p in prompts], 0)
+        # synthetic 16-channel 'VAE encode' (8x8 average pooling + fixed channel mix), then 2x2 packing -> (B, S, 64)
+        lat = torch.nn.functional.avg_pool2d(x, 8)
+        mix = torch.linspace(-1.0, 1.0, 48, device=dev).reshape(16, 3)
+        lat = torch.einsum("oc,bchw->bohw", mix, lat) * 2.0
+        Bc, Cc, H, W = lat.shape
+        gh, gw = H // 2, W // 2
+        pack = lambda z: z.view(Bc, Cc, gh, 2, gw, 2).permute(0, 2, 4, 1, 3, 5).reshape(Bc, gh * gw, Cc * 4)
+        # img2img schedule: sigmas 1 .. 1/N, the last int(N * strength) steps are run (get_timesteps)
+        N = num_inference_steps or self.num_inference_steps
+        sigmas = torch.linspace(1.0, 1.0 / N, N).tolist() + [0.0]
+        init = min(N * strength, N)
+        t_start = int(max(N - init, 0))
+        if N - t_start < 1:
+            raise ValueError(f"After adjusting the num_inference_steps by strength parameter: {strength}, the number of "
+                             f"pipeline steps is {N - t_start} which is < 1 and not appropriate for this pipeline.")
+        noise = torch.randn(lat.shape, generator=torch.Generator(device=dev).manual_seed(1234), device=dev)
+        s0 = sigmas[t_start]
+        z = pack((1.0 - s0) * lat + s0 * noise)                      # FlowMatchEulerDiscreteScheduler.scale_noise
+        img_ids = torch.zeros(gh, gw, 3, device=dev)
+        img_ids[..., 1] = torch.arange(gh, device=dev)[:, None]; img_ids[..., 2] = torch.arange(gw, device=dev)[None, :]
+        img_ids = img_ids.reshape(gh * gw, 3)
+        txt_ids = torch.zeros(self.n_txt, 3, device=dev)
+        guidance = torch.full((B,), float(guidance_scale), device=dev) if self._cfg["guidance_embeds"] else None
+        for i in range(t_start, N):
+            t = torch.full((B,), sigmas[i], device=dev)               # the pipeline passes timestep / 1000 = sigma
+            out = self.transformer.forward_raw(z, enc, pooled, t, img_ids, txt_ids, guidance=guidance,
+                                               hook_ids=self.transformer.requested_ids(), grid=(gh, gw))
+            v, hooks = out
+            if self.transformer.feature_store is not None:
+                for hid, tens in hooks.items():
+                    self.transformer.feature_store.store(tens, hid)
+            z = (z.float() + (sigmas[i + 1] - sigmas[i]) * v.float()).half()
+        return types.SimpleNamespace(images=None, latents=z)
+
+
+def _native_flux_from_diffusers(pipe, device):
+    """Swap pipe.transformer (diffusers FluxTransformer2DModel, bf16) for the native MMDiT with the same weights."""
+    c = pipe.transformer.config
+    cfg = dict(in_channels=c.in_channels, num_layers=c.num_layers, num_single_layers=c.num_single_layers,
+               attention_head_dim=c.attention_head_dim, num_attention_heads=c.num_attention_heads,
+               joint_attention_dim=c.joint_attention_dim, pooled_projection_dim=c.pooled_projection_dim,
+               guidance_embeds=int(bool(c.guidance_embeds)), axes_dims_rope=tuple(c.axes_dims_rope), mlp_ratio=4)
+    net = NativeFluxTransformer(cfg, device=device)
+    net.load_state_dict(pipe.transformer.state_dict())
+    pipe.transformer = net
+    pipe.unet = net
+    return pipe
+
+
 def _native_from_diffusers(pipe, device):
     """Swap pipe.unet (diffusers UNet2DConditionModel) for the native implementation with the same weights."""
     unet = NativeUNet(config_from_diffusers(pipe.unet.config), device=device)
@@ -140,9 +222,23 @@ def get_diffusion_model(version, dtype, offline_lora=None, offline_lora_filename
     dt = _parse_dtype(dtype)
     if version in _LATER:
         raise NotImplementedError(f"version '{version}' is not on the native hot path yet (SURVEY.md §8f / Appendix D)")
+    synthetic = os.environ.get("GDF_SYNTHETIC_WEIGHTS", "0") not in ("", "0")
+    if version == "flux":                                         # reference models.py:150-170 (bf16 pipeline, fp16 hooks)
+        if synthetic:
+            return SyntheticFluxPipe(device, seed=int(os.environ.get("GDF_SYNTHETIC_SEED", "0")))
+        try:
+            import diffusers
+        except ImportError as e:
+            raise RuntimeError("diffusers is not installed and GDF_SYNTHETIC_WEIGHTS is not set (see INTEGRATION.md)") from e
+        pipe = diffusers.FluxImg2ImgPipeline.from_pretrained('black-forest-labs/FLUX.1-dev', torch_dtype=torch.bfloat16,
+                                                             use_safetensors=True)
+        if offline_lora:
+            pipe.load_lora_weights(offline_lora, weight_name=offline_lora_filename)
+            pipe.fuse_lora()
+        return _native_flux_from_diffusers(pipe.to(device), device)
     if version not in _HF:
         raise NotImplementedError                                 # reference models.py:173-174
-    if os.environ.get("GDF_SYNTHETIC_WEIGHTS", "0") not in ("", "0"):
+    if synthetic:
         return SyntheticPipe(version, device, seed=int(os.environ.get("GDF_SYNTHETIC_SEED", "0")))
     try:
         import diffusers

@@ -22,7 +22,7 @@ from components.feature_extractor import (ATTENTION_CATEGORIES, aggregate_attent
 class FeatureExtractor(nn.Module):
     def __init__(self,
                  layer,            # filename of the layer json, a pre-loaded dict, or None (= all layers)
-                 version,          # '1-5', 'xl', 'pgv2'
+                 version,          # '1-5', 'xl', 'pgv2', 'flux'
                  device,
                  dtype='float16',
                  img_size=1024,    # 512 for 1-5, 1024 otherwise
@@ -56,6 +56,8 @@ class FeatureExtractor(nn.Module):
         self.pipe = pipe
         self.control_pipe = None
         self.attention_store = None
+        if attention and version == 'flux':
+            raise NotImplementedError("aggregated attention maps of the MMDiT (FluxAttnStoreProcessor) are not native yet")
         self.scheduler_backup = copy.deepcopy(self.pipe.scheduler)
         self.version = version
         self.img_size = img_size
@@ -65,7 +67,7 @@ class FeatureExtractor(nn.Module):
 
         # freeze whatever torch modules the front-end carries (reference :98-111)
         to_disable = [self.pipe.vae, self.pipe.text_encoder, self.pipe.unet]
-        if version in ['xl', 'pgv2']:
+        if version in ['xl', 'pgv2', 'flux']:
             to_disable.append(self.pipe.text_encoder_2)
         for m in to_disable:
             for p in m.parameters():
@@ -115,6 +117,10 @@ class FeatureExtractor(nn.Module):
             raise NotImplementedError("only the single-timestep path is native (SURVEY.md §2 #1)")
         self.feature_store.reset()
         device = self.device
+        if self.version == 'flux':                                                       # reference :246-254
+            self.pipe(image=[i.resize((self.img_size, self.img_size)).convert("RGB") for i in image],
+                      prompt=prompts, strength=t / 1000, guidance_scale=1)
+            return self.feature_store.stored_feats
 
         prompt_embeds, _neg, pooled, _negp = prompts
         prompt_embeds = prompt_embeds.repeat(batch_size, 1, 1)                           # reference :272

@@ -199,3 +199,25 @@ def test_flux_subset_early_exit_and_unknown_ids():
     assert list(hooks.keys()) == list(st.feats.keys()) == ["vit-block0-ffn-inner", "vit-block1-attn-out"]
     for k, ref in st.feats.items():
         assert rel_l2(hooks[k], ref) < TOL, k
+
+
+def test_feature_extractor_api_flux_synthetic():
+    """FeatureExtractor(version='flux').extract -> pipe(image, prompt, strength=t/1000, guidance_scale=1)
+    (reference diffusion_feature.py:246-254) on the synthetic front end with a tiny MMDiT."""
+    import numpy as np
+    from PIL import Image
+    import diffusion_feature
+    from components.feature_extractor import flux_layer_ids
+    from components.models import SyntheticFluxPipe
+    arch = FR.tiny_arch(num_layers=2, num_single_layers=2)
+    pipe = SyntheticFluxPipe("cuda:0", seed=0, cfg=arch, n_txt=16)
+    assert pipe.transformer.hook_names() == flux_layer_ids(arch) == FR.hook_ids(arch)
+    layer = {"vit-block0-out": True, "vit-block1-q": True, "vit-block3-out": True, "vit-block2-attn-out": True, "nope": True}
+    df = diffusion_feature.FeatureExtractor(layer=layer, version='flux', img_size=128, device='cuda:0', external_model=pipe)
+    img = Image.fromarray((np.random.RandomState(0).rand(90, 70, 3) * 255).astype(np.uint8))
+    feats = df.extract("a photo of a cat", batch_size=2, image=[img, img], t=100)     # strength 0.1 -> 2 of 28 steps
+    assert list(feats.keys()) == ["vit-block0-out", "vit-block1-q", "vit-block2-attn-out", "vit-block3-out"]
+    for v in feats.values():
+        assert v.shape == (2, 256, 8, 8) and v.dtype == torch.float16 and v.is_cuda and torch.isfinite(v.float()).all()
+    f1 = df.extract("x", batch_size=1, image=[img], t=10)                                # strength 0.01 -> the last step only
+    assert list(f1.keys()) == list(feats.keys()) and f1["vit-block0-out"].shape == (1, 256, 8, 8)

@@ -101,7 +101,7 @@ def test_model_registry_error_behaviour(monkeypatch):
     with pytest.raises(NotImplementedError):
         models.get_diffusion_model("no-such-version", "float16")     # reference models.py:173-174
     with pytest.raises(NotImplementedError):
-        models.get_diffusion_model("flux", "float16")
+        models.get_diffusion_model("pixart-sigma", "float16")            # not on the native hot path
     monkeypatch.delenv("GDF_SYNTHETIC_WEIGHTS", raising=False)
     with pytest.raises(RuntimeError):
         models.get_diffusion_model("1-5", "float16")                 # no diffusers, no synthetic opt-in: loud failure
@@ -150,3 +150,18 @@ def test_attention_map_id_selection():
     # AttentionStore(img/32, img/16) keeps 16x16 and 32x32 grids: up-level1 (16^2) and up-level2 (32^2); mid is 8x8 -> dropped
     assert ids["mid_self"] == []
     assert ids["up_cross"] == [f"up-level{l}-repeat{r}-vit-block0-cross-map" for l in (1, 2) for r in range(3)]
+
+
+def test_flux_layer_ids_match_oracle_and_reference_golden():
+    """flux id scheme (reference components/feature_extractor.py:98-123): host list == oracle == order recorded from the
+    reference's own run in tests/golden/flux_tiny.npz."""
+    import ast
+    import numpy as np
+    from components.feature_extractor import flux_layer_ids
+    from components.native import FLUX_CONFIGS
+    from oracle import flux_ref as FR
+    z = np.load(os.path.join(GOLD, "flux_tiny.npz"))
+    meta = ast.literal_eval(str(z["meta"]))
+    assert flux_layer_ids(meta["arch"]) == meta["order"] == FR.hook_ids(meta["arch"])
+    ids = flux_layer_ids(FLUX_CONFIGS["flux"])
+    assert len(ids) == 19 * 7 + 38 * 5 and ids[0] == "vit-block0-q" and ids[-1] == "vit-block56-out"
