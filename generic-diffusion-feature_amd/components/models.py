@@ -15,7 +15,8 @@ import types
 
 import torch
 
-from .native import ARCH_CONFIGS, FLUX_CONFIGS, NativeFluxTransformer, NativeUNet, config_from_diffusers
+from .native import (ARCH_CONFIGS, FLUX_CONFIGS, VAE_CONFIGS, NativeFluxTransformer, NativeUNet, NativeVAEEncoder,
+                     config_from_diffusers)
 
 # version -> (HF repo id, pipeline class name) exactly as the reference selects them (models.py:18-70)
 _HF = {
@@ -58,10 +59,43 @@ class _Scheduler:
         return x / (self._sigma(t) ** 2 + 1) ** 0.5
 
     def add_noise(self, x, noise, t):
+        a, b = self.noise_scalars(t)
+        return a * x + b * noise
+
+    def noise_scalars(self, t):
+        """(noise_a, noise_b) with add_noise(x, n, t) = a x + b n."""
         ac = float(self.alphas_cumprod[int(t.flatten()[0])])
         if self.euler:
-            return x + noise * self._sigma(t)
-        return ac ** 0.5 * x + (1 - ac) ** 0.5 * noise
+            return 1.0, self._sigma(t)
+        return ac ** 0.5, (1 - ac) ** 0.5
+
+
+def scheduler_noise_scalars(scheduler, timestep):
+    """(a, b) such that scheduler.add_noise(x, noise, timestep) == a * x + b * noise, for the scheduler families the
+    reference uses (PNDM / DDPM-style `alphas_cumprod` for 1-5, EulerDiscrete `sigmas` for 2-1 / xl: models.py:26,38,51)."""
+    if hasattr(scheduler, "noise_scalars"):
+        return scheduler.noise_scalars(timestep)
+    t = timestep.flatten()[0]
+    if hasattr(scheduler, "sigmas") and hasattr(scheduler, "index_for_timestep"):
+        sigma = float(scheduler.sigmas[scheduler.index_for_timestep(t)])
+        return 1.0, sigma
+    ac = float(scheduler.alphas_cumprod[int(t)])
+    return ac ** 0.5, (1 - ac) ** 0.5
+
+
+def native_prepare_latents(pipe, image, timestep, batch_size, num_images_per_prompt, dtype, device, generator=None):
+    """Drop-in for `StableDiffusion(XL)Img2ImgPipeline.prepare_latents` as the reference calls it
+    (feature/diffusion_feature.py:371-380): VAE encode -> latent_dist.sample -> * scaling_factor -> scheduler.add_noise,
+    executed by libgdf.so (include/gdf_vae.h); the random tensors come from torch exactly where the pipeline draws them."""
+    enc = pipe.native_vae
+    f = 1 << (len(enc.cfg["block_out_channels"]) - 1)
+    B, _, H, W = image.shape
+    shape = (B, enc.cfg["latent_channels"], H // f, W // f)
+    eps = torch.randn(shape, generator=generator, device=device, dtype=torch.float32)
+    noise = torch.randn(shape, generator=generator, device=device, dtype=torch.float32)
+    a, b = scheduler_noise_scalars(pipe.scheduler, timestep)
+    lat = enc.encode(image, eps=eps, noise=noise, scaling_factor=float(pipe.vae.config.scaling_factor), noise_a=a, noise_b=b)
+    return lat.to(dtype)
 
 
 class SyntheticPipe:
@@ -73,7 +107,10 @@ class SyntheticPipe:
         self.device = device
         self.unet = NativeUNet(cfg, device=device, stream_fp32=stream_fp32).init_synthetic(seed)
         empty = types.SimpleNamespace(parameters=lambda: iter(()), to=lambda *a, **k: None)
-        self.vae = types.SimpleNamespace(parameters=lambda: iter(()), config=types.SimpleNamespace(scaling_factor=0.13025))
+        self.vae = types.SimpleNamespace(parameters=lambda: iter(()), config=types.SimpleNamespace(
+            scaling_factor=0.13025 if cfg["addition_embed_text_time"] else 0.18215))
+        # true-architecture AutoencoderKL encoder (seeded random weights) in libgdf.so: the step before the hot path
+        self.native_vae = NativeVAEEncoder(VAE_CONFIGS["sd"], device=device).init_synthetic(seed + 1)
         self.text_encoder = empty
         if cfg["addition_embed_text_time"]:
             pooled = cfg["add_in_dim"] - 6 * cfg["addition_time_embed_dim"]
@@ -118,14 +155,9 @@ class SyntheticPipe:
         return ts, num_inference_steps - t_start
 
     def prepare_latents(self, image, timestep, batch_size, num_images_per_prompt, dtype, device, generator=None):
-        """Synthetic 'VAE encode': 8x8 average pooling + a fixed 3->4 channel mix, then scheduler noise."""
-        x = image.to(device, torch.float32)
-        x = torch.nn.functional.avg_pool2d(x, 8)
-        mix = torch.tensor([[0.6, 0.3, 0.1], [-0.2, 0.5, 0.4], [0.3, -0.4, 0.5], [0.2, 0.2, -0.6]], device=device)
-        lat = torch.einsum("oc,bchw->bohw", mix, x) * 4.0
-        g = torch.Generator(device=device).manual_seed(1234)
-        noise = torch.randn(lat.shape, generator=g, device=device)
-        return self.scheduler.add_noise(lat, noise, timestep).to(dtype)
+        """prepare_latents of the img2img pipelines on the native VAE encoder (random-weight AutoencoderKL offline)."""
+        g = generator or torch.Generator(device=device).manual_seed(1234)
+        return native_prepare_latents(self, image.to(device), timestep, batch_size, num_images_per_prompt, dtype, device, g)
 
 
 class SyntheticFluxPipe:
@@ -215,6 +247,16 @@ def _native_from_diffusers(pipe, device):
     unet = NativeUNet(config_from_diffusers(pipe.unet.config), device=device)
     unet.load_state_dict(pipe.unet.state_dict())
     pipe.unet = unet
+    # the step before the hot path: VAE encode + sample + noise-add in libgdf.so as well.
+    # GDF_NATIVE_VAE=0 keeps diffusers' prepare_latents (e.g. the original SDXL VAE, whose activations need fp32).
+    if os.environ.get("GDF_NATIVE_VAE", "1") not in ("", "0"):
+        vc = pipe.vae.config
+        enc = NativeVAEEncoder(dict(in_channels=vc.in_channels, latent_channels=vc.latent_channels,
+                                    block_out_channels=tuple(vc.block_out_channels), layers_per_block=vc.layers_per_block,
+                                    use_quant_conv=int(getattr(vc, "use_quant_conv", True))), device=device)
+        enc.load_vae_state_dict(pipe.vae.state_dict())
+        pipe.native_vae = enc
+        pipe.prepare_latents = types.MethodType(native_prepare_latents, pipe)
     return pipe
 
 

@@ -78,6 +78,22 @@ class FluxDesc(C.Structure):
                 ("mlp_ratio", C.c_int)]
 
 
+class VaeDesc(C.Structure):
+    _fields_ = [("in_channels", C.c_int), ("latent_channels", C.c_int), ("n_levels", C.c_int),
+                ("block_out_channels", C.c_int * MAX_LEVELS), ("layers_per_block", C.c_int), ("use_quant_conv", C.c_int)]
+
+
+# every symbol declared in include/gdf_vae.h
+SIGNATURES.update({
+    "gdf_vae_model_create": (C.c_int, [C.POINTER(VaeDesc), C.POINTER(C.c_void_p)]),
+    "gdf_vae_plan_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "gdf_vae_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float,
+                                 C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gdf_vae_plan_profile": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_char_p),
+                                       C.POINTER(C.c_double), C.c_int]),
+})
+
 # every symbol declared in include/gdf_flux.h
 SIGNATURES.update({
     "gdf_flux_model_create": (C.c_int, [C.POINTER(FluxDesc), C.POINTER(C.c_void_p)]),
@@ -570,3 +586,89 @@ class NativeFluxTransformer(_NativeModel):
         if return_dict:
             return types.SimpleNamespace(sample=out)
         return (out,)
+
+
+# --------------------------------------------------------------------------------------------- #
+# VAE encoder + sampling + noise-add (include/gdf_vae.h): the step before the hot path
+# --------------------------------------------------------------------------------------------- #
+VAE_CONFIGS = {"sd": dict(in_channels=3, latent_channels=4, block_out_channels=(128, 256, 512, 512), layers_per_block=2,
+                          use_quant_conv=1)}
+
+
+class NativeVAEEncoder(_NativeModel):
+    """AutoencoderKL encoder half + `latent_dist.sample()` + scaling + `scheduler.add_noise` + `scale_model_input` in
+    libgdf.so — what `pipe.prepare_latents(...)` / `scheduler.scale_model_input` do at the reference's
+    feature/diffusion_feature.py:371-380, :405-406.  Weights: `vae.state_dict()` entries "encoder.*" and "quant_conv.*"."""
+
+    def __init__(self, cfg=None, device="cuda"):
+        if not torch.cuda.is_available():
+            raise RuntimeError("NativeVAEEncoder needs an MI355X (HIP device); there is no CPU fallback")
+        self.lib = load_library()
+        self.cfg = dict(cfg or VAE_CONFIGS["sd"])
+        self.device = torch.device(device if str(device) != "cuda" else f"cuda:{torch.cuda.current_device()}")
+        d = VaeDesc()
+        d.in_channels, d.latent_channels = self.cfg["in_channels"], self.cfg["latent_channels"]
+        d.n_levels = len(self.cfg["block_out_channels"])
+        for i, c in enumerate(self.cfg["block_out_channels"]):
+            d.block_out_channels[i] = c
+        d.layers_per_block = self.cfg["layers_per_block"]
+        d.use_quant_conv = int(bool(self.cfg.get("use_quant_conv", 1)))
+        self._desc = d
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _check(self.lib.gdf_vae_model_create(C.byref(d), C.byref(h)), "vae_model_create")
+        self.handle = h
+        self._plans = {}
+        self.feature_store = None
+
+    def _is_norm(self, name):
+        return "norm" in name
+
+    def load_vae_state_dict(self, sd):
+        """Accepts a full `AutoencoderKL.state_dict()`: only the encoder / quant_conv entries are used."""
+        return self.load_state_dict({k: v for k, v in sd.items() if k.startswith("encoder.") or k.startswith("quant_conv.")})
+
+    def _plan(self, batch, h, w):
+        key = (batch, h, w)
+        p = self._plans.get(key)
+        if p is None:
+            ph = C.c_void_p()
+            _check(self.lib.gdf_vae_plan_create(self.handle, batch, h, w, C.byref(ph)), "vae_plan_create")
+            p = _Plan(self.lib, ph)
+            if len(self._plans) >= 4:
+                self._plans.pop(next(iter(self._plans)))
+            self._plans[key] = p
+        return p
+
+    def encode(self, image, eps=None, noise=None, scaling_factor=0.18215, noise_a=1.0, noise_b=0.0, input_scale=1.0,
+               profile=False):
+        """image (B,3,H,W) in [-1,1]; eps / noise (B,L,H/f,W/f) or None, f = 2^(levels-1) (8 for the SD VAEs).
+        Returns (B,L,H/f,W/f) fp16: input_scale * (noise_a * scaling_factor * (mean + std * eps) + noise_b * noise)."""
+        dev = self.device
+        B, _, H, W = image.shape
+        f = 1 << (len(self.cfg["block_out_channels"]) - 1)
+        x = image.to(dev, torch.float16).contiguous()
+        L = self.cfg["latent_channels"]
+        f16 = lambda t: None if t is None else t.to(dev, torch.float16).contiguous()
+        eps, noise = f16(eps), f16(noise)
+        for t in (eps, noise):
+            if t is not None and tuple(t.shape) != (B, L, H // f, W // f):
+                raise ValueError("eps / noise must have the latent shape (B, L, H/f, W/f)")
+        plan = self._plan(B, H, W)
+        with torch.cuda.device(dev):
+            if plan.workspace is None or plan.workspace.numel() < plan.ws_bytes:
+                plan.workspace = torch.empty(plan.ws_bytes, dtype=torch.uint8, device=dev)
+            out = torch.empty(B, L, H // f, W // f, dtype=torch.float16, device=dev)
+            stream = torch.cuda.current_stream(dev)
+            vp = lambda a: C.c_void_p(a.data_ptr() if a is not None else 0)
+            args = (plan.handle, vp(x), vp(eps), vp(noise), float(scaling_factor), float(noise_a), float(noise_b),
+                    float(input_scale), vp(out), vp(plan.workspace), C.c_void_p(stream.cuda_stream))
+            if profile:
+                n = self.lib.gdf_plan_num_ops(plan.handle)
+                ms = (C.c_float * n)(); names = (C.c_char_p * n)(); fl = (C.c_double * n)()
+                if self.lib.gdf_vae_plan_profile(*args, ms, names, fl, n) < 0:
+                    _check(1, "vae_plan_profile")
+                return out, [(names[i].decode(), ms[i], fl[i], self.lib.gdf_plan_op_kernel(plan.handle, i).decode())
+                             for i in range(n)]
+            _check(self.lib.gdf_vae_encode(*args), "vae_encode")
+        return out

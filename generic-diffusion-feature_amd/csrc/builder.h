@@ -42,6 +42,17 @@ struct WeightBuilder {
     LinW w; w.n = ntot; w.k = k; w.w = take((size_t)ntot * k * 2); w.b = bias ? take(ntot * 4) : NPOS; w.has_bias = bias;
     return w;
   }
+  NormW norm(const std::string& n, int c) {
+    NormW w; w.c = c; w.g = take(c * 4); w.b = take(c * 4);
+    reg(n + ".weight", {c}, PK_VEC, w.g); reg(n + ".bias", {c}, PK_VEC, w.b);
+    return w;
+  }
+  ConvW conv3(const std::string& n, int co, int ci) {
+    ConvW w; w.cin = ci; w.cout = co; w.w = take((size_t)co * 9 * ci * 2); w.b = take(co * 4);
+    reg(n + ".weight", {co, ci, 3, 3}, PK_CONV3, w.w, co, ci); reg(n + ".bias", {co}, PK_VEC, w.b);
+    return w;
+  }
+
   LinW lin(const std::string& n, int co, int ci, bool bias = true, bool conv1x1 = false) {
     LinW w = lin_alloc(co, ci, bias);
     lin_rows(n, w, co, 0, conv1x1, bias);
@@ -198,6 +209,7 @@ struct PlanBuilder {
     int aux_slot = -1; int ldaux = 0;
     int geglu = 0; int bn = 128;
     int dit = 0, act = 0, rv_mul = 0, rv_seg_rows = 0, rv_rps2 = 0;     // MMDiT epilogue (kernels.h)
+    int pad0 = 0;                                                         // conv3: 1 = pad right / bottom only
   };
   void residual_from(Epi& e, const Act& x) {
     if (x.has_f) { e.res32 = x.f; e.has_r32 = true; e.ldres = x.C; }
@@ -235,6 +247,93 @@ struct PlanBuilder {
       return launch_gemm(g, s);
     }, gemm_kernel_name(gk));
   }
+
+  Ref temb_all{};     // [B][temb_total] f32: every resnet's time_emb_proj(silu(emb)) (UNet only)
+
+  // ---- primitive emitters -----------------------------------------------------------------------
+  // GroupNorm (+SiLU) of x -> contiguous fp16 tensor (workspace offset returned)
+  size_t groupnorm(const Act& x, const NormW& w, float eps, bool silu) {
+    const size_t n = rows(x);
+    const size_t y = tmp(n * x.C * 2);
+    const size_t part_b = gn_partial_floats(Bn, x.H * x.W, x.C) * 4, ab_b = (size_t)Bn * x.C * 8;
+    const size_t part = tmp(part_b), ab = tmp(ab_b);
+    const Ref xh = x.h; const int ld = x.ld, C = x.C, HW = x.H * x.W, Bq = Bn;
+    const Ref g = wt(w.g), bt = wt(w.b);
+    op("gn_stats", 0, [=](const Bind& b, hipStream_t s) {
+      return launch_gn_stats((const half_t*)b.p(xh), nullptr, ld, Bq, HW, C, 32, eps, (const float*)b.p(g),
+                             (const float*)b.p(bt), (float*)b.ws(part), (float*)b.ws(ab), s);
+    });
+    op(silu ? "gn_apply_silu" : "gn_apply", 0, [=](const Bind& b, hipStream_t s) {
+      return launch_gn_apply((const half_t*)b.p(xh), nullptr, ld, Bq, HW, C, (const float*)b.ws(ab), silu ? 1 : 0,
+                             (half_t*)b.ws(y), s);
+    });
+    untmp(part, part_b); untmp(ab, ab_b);
+    return y;
+  }
+
+  // 3x3 conv as implicit GEMM over NHWC `src` (Bn, H, W, ld>=Cin)
+  void conv3(const char* name, Ref src, int ld, int Cin, int H, int W, int stride, bool ups, const ConvW& w, const Epi& e0) {
+    Epi e = e0;
+    const int IH = ups ? 2 * H : H, IW = ups ? 2 * W : W;
+    const int OH = (IH + 2 - 3) / stride + 1, OW = (IW + 2 - 3) / stride + 1;
+    const size_t M = (size_t)Bn * OH * OW;
+    const Ref Wr = wt(w.w);
+    const int N = w.cout, Bq = Bn;
+    GemmParams gk{}; gk.M = (int)M; gk.N = N; gk.K = 9 * Cin; gk.mode = A_CONV3; gk.bn = e.bn;
+    op(name, 2.0 * (double)M * N * 9 * Cin, [=](const Bind& b, hipStream_t s) {
+      GemmParams g{};
+      g.A = (const half_t*)b.p(src); g.lda = ld;
+      g.a_bytes = (uint32_t)(((size_t)Bq * H * W - 1) * ld * 2 + (size_t)Cin * 2);
+      g.M = (int)M; g.N = N; g.K = 9 * Cin; g.mode = A_CONV3; g.H = H; g.W = W; g.OH = OH; g.OW = OW;
+      g.stride = stride; g.ups = ups ? 1 : 0; g.Cin = Cin; g.pad0 = e.pad0;
+      g.Wt = (const half_t*)b.p(Wr); g.w_bytes = (uint32_t)((size_t)N * 9 * Cin * 2);
+      fill_epi(g, e, b);
+      return launch_gemm(g, s);
+    }, gemm_kernel_name(gk));
+  }
+
+  // ---- ResnetBlock2D ------------------------------------------------------------------------------
+  // x -> y (y.h destination prepared by the caller)
+  void resnet(const std::string& id, const ResnetW& w, const Act& x, Act& y) {
+    if (stop) return;
+    const size_t n = rows(x);
+    const int HW = x.H * x.W;
+    const size_t n1 = groupnorm(x, w.n1, w.eps, true);
+    const size_t h1_b = n * w.cout * 2;
+    Act h1 = new_act(w.cout, x.H, x.W, false);
+    {
+      Epi e; e.bias = wt(w.c1.b); e.has_bias = true;
+      if (w.has_temb) {                                                                    // resnet.py:343-350
+        e.rowvec = Ref{temb_all.buf, temb_all.off + (size_t)w.temb_off * 4}; e.has_rv = true; e.rps = HW; e.ldrv = m.temb_total;
+      }
+      out_to(e, h1);
+      conv3("res_conv1", ws(n1), x.C, x.C, x.H, x.W, 1, false, w.c1, e);
+    }
+    untmp(n1, n * x.C * 2);
+    const size_t n2 = groupnorm(h1, w.n2, w.eps, true);
+    free_act(h1);
+    (void)h1_b;
+    // shortcut: 1x1 conv of x into an fp32 residual buffer
+    size_t sc = NPOS; const size_t sc_b = n * w.cout * 4;
+    if (w.has_sc) {
+      sc = tmp(sc_b);
+      Epi e; e.bias = wt(w.sc.b); e.has_bias = true; e.out32 = ws(sc); e.has_o32 = true; e.ldo32 = w.cout;
+      gemm("res_shortcut", x.h, x.ld, n, w.sc, w.cout, x.C, 0, e);
+    }
+    {
+      Epi e; e.bias = wt(w.c2.b); e.has_bias = true;
+      e.aux_slot = want(id + "-res-increment", w.cout, x.H, x.W); e.ldaux = w.cout;      // resnet.py:371-372
+      if (w.has_sc) { e.res32 = ws(sc); e.has_r32 = true; e.ldres = w.cout; }
+      else residual_from(e, x);
+      out_to(e, y);
+      conv3("res_conv2", ws(n2), w.cout, w.cout, x.H, x.W, 1, false, w.c2, e);
+      if (e.aux_slot >= 0) hook_done();
+    }
+    untmp(n2, n * w.cout * 2);
+    if (w.has_sc) untmp(sc, sc_b);
+    gather(id + "-res-out", y);                                                           // resnet.py:376-377
+  }
+
 };
 
 }  // namespace gdf

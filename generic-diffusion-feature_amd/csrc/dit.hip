@@ -181,6 +181,103 @@ hipError_t launch_rope_table(const float* ids, int S, int n_axes, const int* axe
   return hipGetLastError();
 }
 
+// one workgroup per row; the row is held in registers as packed halves (n <= 256 * 8 * 8 = 16384 per pass, looped beyond)
+__global__ __launch_bounds__(256) void softmax_rows_kernel(half_t* x, int ld, int n, float scale) {
+  __shared__ float red[8];
+  half_t* row = x + (size_t)blockIdx.x * ld;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float sl2 = scale * 1.44269504088896340736f;
+  constexpr int MAXV = 8;                                // f16x8 vectors per thread kept in registers
+  f16x8 v[MAXV];
+  const int nvec = n / 8;                                // host guarantees n % 8 == 0 and n <= 256 * 8 * MAXV
+  float mx = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = tid + i * 256;
+    if (c < nvec) {
+      v[i] = *(const f16x8*)(row + c * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) mx = fmaxf(mx, (float)v[i][e]);
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) * sl2;
+  float sum = 0.f;
+  float ev[MAXV][8];
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = tid + i * 256;
+    if (c < nvec) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { ev[i][e] = __builtin_amdgcn_exp2f((float)v[i][e] * sl2 - mx); sum += ev[i][e]; }
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+  if (lane == 0) red[4 + wave] = sum;
+  __syncthreads();
+  const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = tid + i * 256;
+    if (c < nvec) {
+      f16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (_Float16)(ev[i][e] * inv);
+      *(f16x8*)(row + c * 8) = o;
+    }
+  }
+}
+
+hipError_t launch_softmax_rows(half_t* x, int ld, int R, int n, float scale, hipStream_t s) {
+  if ((n & 7) || (ld & 7) || n > 256 * 8 * 8) return hipErrorInvalidValue;
+  if (R <= 0) return hipSuccess;
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3(R), dim3(256), 0, s, x, ld, n, scale);
+  return hipGetLastError();
+}
+
+__global__ void vae_finish_kernel(const float* h, int HW, int L, const half_t* wq, const float* bq, const half_t* eps,
+                                  const half_t* noise, float scaling, float na, float nb, float in_scale, half_t* out, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;      // (b, pixel)
+  if (i >= total) return;
+  const long b = i / HW;
+  const int pix = (int)(i - b * HW);
+  float m[16], hv[16];
+  const int L2 = 2 * L;
+  for (int c = 0; c < L2; ++c) hv[c] = h[(size_t)i * L2 + c];
+  for (int o = 0; o < L2; ++o) {
+    if (wq) {
+      float a = bq[o];
+      for (int c = 0; c < L2; ++c) a += (float)wq[o * L2 + c] * hv[c];
+      m[o] = a;
+    } else {
+      m[o] = hv[o];
+    }
+  }
+  for (int c = 0; c < L; ++c) {
+    const size_t oi = ((size_t)b * L + c) * HW + pix;
+    float z = m[c];
+    if (eps) z += expf(0.5f * fminf(fmaxf(m[L + c], -30.0f), 20.0f)) * (float)eps[oi];
+    float lat = scaling * z;
+    if (noise) lat = na * lat + nb * (float)noise[oi];
+    out[oi] = (_Float16)(in_scale * lat);
+  }
+}
+
+hipError_t launch_vae_finish(const float* h, int B, int HW, int L, const half_t* wq, const float* bq, const half_t* eps,
+                             const half_t* noise, float scaling, float noise_a, float noise_b, float in_scale, half_t* out,
+                             hipStream_t s) {
+  if (L < 1 || L > 8) return hipErrorInvalidValue;
+  const long total = (long)B * HW;
+  if (total <= 0) return hipSuccess;
+  hipLaunchKernelGGL(vae_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, h, HW, L, wq, bq, eps, noise,
+                     scaling, noise_a, noise_b, in_scale, out, total);
+  return hipGetLastError();
+}
+
 __global__ void silu_vec_kernel(const float* x, float* out, long n) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) { const float v = x[i]; out[i] = v / (1.0f + expf(-v)); }

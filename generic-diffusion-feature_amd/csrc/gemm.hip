@@ -138,8 +138,8 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
       const int rem = m - n * hw;
       const int oy = rem / p.OW, ox = rem - oy * p.OW;
       a_off[j] = (uint32_t)(n * p.H * p.W);           // pixel index base of sample n
-      a_oy[j] = (m < p.M) ? oy * p.stride - 1 : -(1 << 20);
-      a_ox[j] = ox * p.stride - 1;
+      a_oy[j] = (m < p.M) ? oy * p.stride - 1 + p.pad0 : -(1 << 20);   // pad0 = 1: no top / left padding (VAE downsample)
+      a_ox[j] = ox * p.stride - 1 + p.pad0;
     }
   }
   uint32_t b_off[B_PER_WAVE];

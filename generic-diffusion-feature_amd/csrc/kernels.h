@@ -24,6 +24,7 @@ struct GemmParams {
   int OH, OW;            // output spatial size (conv)
   int stride;            // 1 or 2 (conv)
   int ups;               // 1: source is nearest-upsampled x2 before the conv (Upsample2D fused)
+  int pad0;              // 0: zero padding 1 on every side; 1: pad right / bottom only (F.pad (0,1,0,1), Downsample2D padding=0)
   int Cin;
   // ---- B operand: weights [N][K] fp16, K contiguous (conv: K index = tap*Cin + c)
   const half_t* Wt;
@@ -112,6 +113,14 @@ hipError_t launch_qk_norm_rope(half_t* x, int ld, int R, int heads, int D, int q
 // FluxPosEmbed: ids fp32 [S][n_axes] -> cos/sin fp32 [S][sum(axes_dim)] (float64 angles, repeat-interleaved pairs)
 hipError_t launch_rope_table(const float* ids, int S, int n_axes, const int* axes_dim, double theta, float* cos_t,
                              float* sin_t, int row0, hipStream_t s);
+// in-place row softmax of fp16 scores: x[r][0..n) = softmax(scale * x[r][0..n)) (fp32 math), rows of ld halves
+hipError_t launch_softmax_rows(half_t* x, int ld, int R, int n, float scale, hipStream_t s);
+// VAE tail: moments = quant_conv(h) (1x1, [2L][2L] fp16 weights, fp32 bias; wq == NULL: identity), mean / logvar split,
+// logvar clamp(-30, 20), z = mean + exp(0.5 logvar) * eps (eps == NULL: mode), lat = scaling * z,
+// out = in_scale * (noise_a * lat + noise_b * noise) (noise == NULL: no noise) -> NCHW fp16 (B, L, H, W).  h: fp32 [B*HW][2L].
+hipError_t launch_vae_finish(const float* h, int B, int HW, int L, const half_t* wq, const float* bq, const half_t* eps,
+                             const half_t* noise, float scaling, float noise_a, float noise_b, float in_scale, half_t* out,
+                             hipStream_t s);
 // out[i] = silu(x[i])
 hipError_t launch_silu_vec(const float* x, float* out, long n, hipStream_t s);
 // strided 2-D copy with cast to fp16: dst[r][c] = src[r][c]   (hook stores)

@@ -8,6 +8,7 @@
 
 #include "../../include/gdf.h"
 #include "../../include/gdf_flux.h"
+#include "../../include/gdf_vae.h"
 #include "kernels.h"
 
 namespace gdf {
@@ -23,7 +24,8 @@ const char* last_error();
 struct NormW { size_t g = 0, b = 0; int c = 0; };                               // fp32 gamma / beta
 struct ConvW { size_t w = 0, b = 0; int cin = 0, cout = 0; };                    // fp16 [cout][9][cin], fp32 bias
 struct LinW { size_t w = 0, b = NPOS; int n = 0, k = 0; bool has_bias = false; };  // fp16 [n][k], fp32 bias
-struct ResnetW { NormW n1, n2; ConvW c1, c2; LinW sc; bool has_sc = false; int cin = 0, cout = 0, temb_off = 0; };
+struct ResnetW { NormW n1, n2; ConvW c1, c2; LinW sc; bool has_sc = false; int cin = 0, cout = 0, temb_off = 0;
+                 bool has_temb = true; float eps = 1e-5f; };   // VAE resnets: temb_channels=None, eps 1e-6
 struct BlockW { NormW ln1, ln2, ln3; LinW qkv, o1, q2, kv2, o2, ff1, ff2; int kv_group = 0, kv_index = 0; };
 // text K/V projection weights of all transformer blocks with the same width live contiguously: one grouped GEMM per width
 struct KvGroup { int C = 0, count = 0, next = 0; size_t base = 0, stride = 0; };
@@ -58,9 +60,21 @@ struct FluxW {
   std::vector<FluxSingleW> sgl;
 };
 
+// ---- VAE encoder weights ---------------------------------------------------------------------------
+struct VaeW {
+  gdf_vae_desc d{};
+  ConvW conv_in, conv_out;
+  std::vector<std::vector<ResnetW>> down;      // [level][layer]
+  std::vector<ConvW> downsamplers;             // level < L-1
+  ResnetW mid0, mid1;
+  NormW attn_gn, norm_out;
+  LinW q, k, v, o, quant;
+};
+
 struct Model {
-  int kind = 0;                                // 0: UNet2DConditionModel, 1: FluxTransformer2DModel
+  int kind = 0;                                // 0: UNet2DConditionModel, 1: FluxTransformer2DModel, 2: AutoencoderKL encoder
   FluxW flux;
+  VaeW vae;
   GdfArch arch{};
   void* weights = nullptr;
   size_t weight_bytes = 0;
@@ -87,6 +101,7 @@ struct Ref { int buf = BUF_WS; size_t off = 0; };
 struct Bind {
   char* base[BUF_COUNT] = {nullptr};
   void* const* hooks = nullptr;
+  float f[8] = {0, 0, 0, 0, 0, 0, 0, 0};     // run-time scalars (VAE: scaling_factor, noise_a, noise_b, input_scale)
   void* p(const Ref& r) const { return base[r.buf] + r.off; }
   void* ws(size_t off) const { return base[BUF_WS] + off; }
   void* hook(int slot) const { return hooks[slot]; }
@@ -96,6 +111,7 @@ struct HookSlot { std::string id; int64_t shape[4]; int64_t stride[4]; size_t by
 
 struct Plan {
   const Model* model = nullptr;
+  int chunk = 0;                              // VAE: images per pass (the plan is built for `chunk`, forward loops)
   int batch = 0, H = 0, W = 0, n_ctx = 0;    // Flux: H x W = packed-latent token grid, n_ctx = text tokens
   PlanOpts opts{};
   std::vector<Op> ops;
@@ -129,6 +145,12 @@ int plan_forward(Plan& P, const Model& m, const void* lat, const float* t, const
                  const char** names, double* flops, int cap);
 // executes the op program against an already filled binding table (shared by the UNet and Flux front ends)
 int plan_run(Plan& P, const Bind& b, hipStream_t s, float* ms, const char** names, double* flops, int cap);
+
+// ---- VAE encoder front end (include/gdf_vae.h) ----
+Model* vae_model_create(const gdf_vae_desc& d);
+int vae_plan_build(const Model& m, Plan& P, int batch, int img_h, int img_w, bool dry);
+int vae_encode(Plan& P, const Model& m, const void* image, const void* eps, const void* noise, float scaling, float noise_a,
+               float noise_b, float in_scale, void* out, void* ws, hipStream_t s, float* ms, const char** names, double* flops, int cap);
 
 Model* flux_model_create(const gdf_flux_desc& d);
 int flux_plan_build(const Model& m, Plan& P, int batch, int img_h, int img_w, int n_txt, const char* const* ids, int n_ids,

@@ -106,6 +106,10 @@ int gdf_op_small_linear(const float* x, int ldx, int M, int K, const void* W, co
   return fin(launch_small_linear(x, ldx, M, K, (const half_t*)W, bias, N, silu_in, accumulate, out, ldo, (hipStream_t)stream), "small_linear");
 }
 
+int gdf_op_softmax_rows(void* x, int ld, int R, int n, float scale, void* stream) {
+  return fin(launch_softmax_rows((half_t*)x, ld, R, n, scale, (hipStream_t)stream), "softmax_rows");
+}
+
 int gdf_op_gemm_dit(const void* A, int lda, const void* W, const float* bias, int act, const float* vec, int ldvec, int vec_mul,
                     int rps, int seg_rows, int rps2, const float* res32, int ldres, void* aux16, int ldaux, void* out16,
                     int ldo16, float* out32, int ldo32, int M, int N, int K, int variant, void* stream) {

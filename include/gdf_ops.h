@@ -60,6 +60,10 @@ int gdf_op_relayout_geglu(const void* w_f16, const float* bias, void* w_dst, flo
 int gdf_op_small_linear(const float* x, int ldx, int M, int K, const void* W, const float* bias, int N, int silu_in,
                         int accumulate, float* out, int ldo, void* stream);
 
+/* in-place row softmax of fp16 scores: x[r][0..n) = softmax(scale * x[r][0..n)) with fp32 math (VAE mid-block attention,
+ * attention_processor.py:3311-3313 run as explicit GEMMs; n <= 16384, n % 8 == 0). */
+int gdf_op_softmax_rows(void* x, int ld, int R, int n, float scale, void* stream);
+
 /* ---- MMDiT (Flux) kernels (reference files cited in csrc/dit.hip, gdf_flux.h) ---- */
 
 /* Dense GEMM with the MMDiT epilogue: v = A W^T + bias; act=1: tanh-GELU; vec != NULL: v = vec_mul ? v * vec[s] : v + vec[s]

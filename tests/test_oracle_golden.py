@@ -139,3 +139,26 @@ def test_flux_flops_and_param_count():
     assert n == 11_901_408_320                   # published FLUX.1-dev transformer parameter count (11.9 B)
     tf = FR.flops_per_image(a, 4096, 512) / 1e12
     assert abs(tf - 74.4) < 0.6, tf
+
+
+# ---- VAE encoder blocks: oracle/vae_ref.py vs the reference's resnet / downsample / attention ----
+def test_vae_blocks_match_reference_golden():
+    from oracle import vae_ref as VR
+    for name in ("vae_resnet_same", "vae_resnet_shortcut"):
+        W, I, O, _ = load(name)
+        y = VR.resnet_block({"r." + k: v for k, v in W.items()}, "r", I["x"])
+        assert torch.allclose(y, O["y"], atol=2e-5, rtol=1e-5), name
+    W, I, O, _ = load("vae_downsample_pad0")
+    assert torch.allclose(VR.downsample_pad0({"d." + k: v for k, v in W.items()}, "d", I["x"]), O["y"], atol=2e-5, rtol=1e-5)
+    W, I, O, _ = load("vae_mid_attention")
+    assert torch.allclose(VR.mid_attention({"a." + k: v for k, v in W.items()}, "a", I["x"]), O["y"], atol=2e-5, rtol=1e-5)
+
+
+def test_vae_param_count_and_shapes():
+    from oracle import vae_ref as VR
+    n = sum(int(np.prod(s)) for s in VR.param_shapes(VR.ARCH_SD_VAE).values())
+    assert n == 34_163_664            # encoder (34,163,592) + quant_conv (72) of the SD / SDXL AutoencoderKL
+    P = VR.synth_params(VR.tiny_arch(), seed=0)
+    img = torch.randn(1, 3, 32, 32, generator=torch.Generator().manual_seed(0))
+    mean, logvar = VR.encoder_moments(P, VR.tiny_arch(), img)
+    assert mean.shape == (1, 4, 8, 8) and logvar.shape == (1, 4, 8, 8)
