@@ -308,6 +308,37 @@ def main():
                                   for k, v in sorted(by_label.items(), key=lambda kv: -kv[1][0])[:8]},
             "kernel_tflops": {k: round(v[1] / 1e9 / v[0], 1) for k, v in by_label.items() if v[1] > 0 and v[0] > 0},
         }
+        # ---- the rooflines BASELINE.json's north_star names, from the synchronising per-op pass (one forward) ----
+        # attention-MFMA: self-attention QK^T + PV FLOPs / time of those launches; conv: 3x3 conv FLOPs / time (MFMA) and the
+        # ResBlock activation bytes of SURVEY.md §8d (2 Cin + 3 Cout per pixel, fp16) / time of all ResBlock ops (HBM);
+        # hook writes: bytes of the hooks stored by copy2d_kernel / its time.
+        grp = {}
+        for name, ms, f_, _k in prof:
+            g_ = grp.setdefault(name, [0.0, 0.0]); g_[0] += ms; g_[1] += f_
+        def tsum(names):
+            return sum(grp[n][0] for n in names if n in grp), sum(grp[n][1] for n in names if n in grp)
+        a_ms, a_fl = tsum(["attn1"])
+        c_ms, c_fl = tsum(["res_conv1", "res_conv2", "upsample", "downsample"])
+        r_ms, _ = tsum(["res_conv1", "res_conv2", "res_shortcut", "gn_stats", "gn_apply_silu"])
+        res_bytes = B * (610.8e6 if args.version == "xl" and lat == 128 else 152.9e6 if args.version == "1-5" and lat == 64 else 0.0)
+        h_ms, _ = tsum(["hook_store"])
+        copied = sum(v.numel() * 2 for k, v in out[1].items() if not (k.endswith("res-increment") or k.endswith("-map")))
+        res["rooflines"] = {
+            "attention_mfma": {"kernel": "attn_kernel", "achieved": round(a_fl / 1e9 / max(a_ms, 1e-9), 1), "peak": MFMA_PEAK_TFLOPS,
+                               "unit": "TFLOP/s", "frac": round(a_fl / 1e9 / max(a_ms, 1e-9) / MFMA_PEAK_TFLOPS, 4),
+                               "ms_per_step": round(a_ms, 3)},
+            "conv_mfma": {"achieved": round(c_fl / 1e9 / max(c_ms, 1e-9), 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                          "frac": round(c_fl / 1e9 / max(c_ms, 1e-9) / MFMA_PEAK_TFLOPS, 4), "ms_per_step": round(c_ms, 3)},
+            "conv_hbm": {"achieved": round(res_bytes / 1e6 / max(r_ms, 1e-9), 1) if res_bytes else None, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(res_bytes / 1e6 / max(r_ms, 1e-9) / HBM_PEAK_GBS, 4) if res_bytes else None,
+                         "note": "ResBlock activation bytes (2 Cin + 3 Cout per pixel, fp16) / time of conv + GroupNorm + shortcut ops: "
+                                 "the fused block is MFMA-bound, so this fraction is far below 1 by construction",
+                         "ms_per_step": round(r_ms, 3)},
+            "hook_writes": {"kernel": "copy2d_kernel", "achieved": round(2 * copied / 1e6 / max(h_ms, 1e-9), 1) if h_ms > 0 else None,
+                            "peak": HBM_PEAK_GBS, "unit": "GB/s (read + write)",
+                            "frac": round(2 * copied / 1e6 / max(h_ms, 1e-9) / HBM_PEAK_GBS, 4) if h_ms > 0 else None,
+                            "bytes_per_step": copied, "ms_per_step": round(h_ms, 4)},
+        }
         if args.profile_ops:
             rows = {}
             for name, ms, f_, _k in prof:
