@@ -176,10 +176,10 @@ class _TimestepEmbedding(nn.Module):
 
 
 class _PixArtAlphaTextProjection(nn.Module):
-    def __init__(self, in_features, hidden_size, out_features=None, act_fn="silu"):
+    def __init__(self, in_features, hidden_size, out_features=None, act_fn="gelu_tanh"):
         super().__init__()
         self.linear_1 = nn.Linear(in_features, hidden_size)
-        self.act_1 = nn.SiLU()
+        self.act_1 = {"gelu_tanh": nn.GELU(approximate="tanh"), "silu": nn.SiLU()}[act_fn]
         self.linear_2 = nn.Linear(hidden_size, out_features or hidden_size)
 
     def forward(self, caption):
@@ -208,6 +208,79 @@ class _CombinedTimestepGuidanceTextProjEmbeddings(nn.Module):
         t = self.timestep_embedder(_get_timestep_embedding(timestep, 256, True, 0).to(pooled_projection.dtype))
         g = self.guidance_embedder(_get_timestep_embedding(guidance, 256, True, 0).to(pooled_projection.dtype))
         return t + g + self.text_embedder(pooled_projection)
+
+
+def _get_1d_sincos_pos_embed_from_grid(embed_dim, pos):
+    import numpy as np
+    omega = np.arange(embed_dim // 2, dtype=np.float64)
+    omega /= embed_dim / 2.0
+    omega = 1.0 / 10000 ** omega
+    out = np.einsum("m,d->md", pos.reshape(-1), omega)
+    return np.concatenate([np.sin(out), np.cos(out)], axis=1)
+
+
+def _get_2d_sincos_pos_embed(embed_dim, grid_size, base_size=16, interpolation_scale=1.0):
+    import numpy as np
+    if isinstance(grid_size, int):
+        grid_size = (grid_size, grid_size)
+    grid_h = np.arange(grid_size[0], dtype=np.float32) / (grid_size[0] / base_size) / interpolation_scale
+    grid_w = np.arange(grid_size[1], dtype=np.float32) / (grid_size[1] / base_size) / interpolation_scale
+    grid = np.meshgrid(grid_w, grid_h)  # here w goes first
+    grid = np.stack(grid, axis=0)
+    grid = grid.reshape([2, 1, grid_size[1], grid_size[0]])
+    emb_h = _get_1d_sincos_pos_embed_from_grid(embed_dim // 2, grid[0])
+    emb_w = _get_1d_sincos_pos_embed_from_grid(embed_dim // 2, grid[1])
+    return np.concatenate([emb_h, emb_w], axis=1)
+
+
+class _PatchEmbed(nn.Module):
+    """embeddings.PatchEmbed (sincos positional table, no layer norm)."""
+
+    def __init__(self, height=224, width=224, patch_size=16, in_channels=3, embed_dim=768, layer_norm=False, flatten=True,
+                 bias=True, interpolation_scale=1, pos_embed_type="sincos", pos_embed_max_size=None):
+        super().__init__()
+        self.proj = nn.Conv2d(in_channels, embed_dim, kernel_size=(patch_size, patch_size), stride=patch_size, bias=bias)
+        self.patch_size = patch_size
+        self.height, self.width = height // patch_size, width // patch_size
+        self.base_size = height // patch_size
+        self.interpolation_scale = interpolation_scale
+        num_patches = (height // patch_size) * (width // patch_size)
+        pe = _get_2d_sincos_pos_embed(embed_dim, int(num_patches ** 0.5), base_size=self.base_size,
+                                      interpolation_scale=interpolation_scale)
+        self.register_buffer("pos_embed", torch.from_numpy(pe).float().unsqueeze(0), persistent=False)
+
+    def forward(self, latent):
+        height, width = latent.shape[-2] // self.patch_size, latent.shape[-1] // self.patch_size
+        latent = self.proj(latent).flatten(2).transpose(1, 2)
+        if self.height != height or self.width != width:
+            pe = _get_2d_sincos_pos_embed(self.pos_embed.shape[-1], (height, width), base_size=self.base_size,
+                                          interpolation_scale=self.interpolation_scale)
+            pos_embed = torch.from_numpy(pe).float().unsqueeze(0)
+        else:
+            pos_embed = self.pos_embed
+        return (latent + pos_embed).to(latent.dtype)
+
+
+class _PixArtAlphaCombinedTimestepSizeEmbeddings(nn.Module):
+    def __init__(self, embedding_dim, size_emb_dim, use_additional_conditions=False):
+        super().__init__()
+        assert not use_additional_conditions, "scaffolding covers use_additional_conditions=False (resolution=None call site)"
+        self.timestep_embedder = _TimestepEmbedding(256, embedding_dim)
+
+    def forward(self, timestep, resolution=None, aspect_ratio=None, batch_size=None, hidden_dtype=None):
+        return self.timestep_embedder(_get_timestep_embedding(timestep, 256, True, 0).to(hidden_dtype))
+
+
+class _AdaLayerNormSingle(nn.Module):
+    def __init__(self, embedding_dim, use_additional_conditions=False):
+        super().__init__()
+        self.emb = _PixArtAlphaCombinedTimestepSizeEmbeddings(embedding_dim, embedding_dim // 3, use_additional_conditions)
+        self.silu = nn.SiLU()
+        self.linear = nn.Linear(embedding_dim, 6 * embedding_dim, bias=True)
+
+    def forward(self, timestep, added_cond_kwargs=None, batch_size=None, hidden_dtype=None):
+        embedded_timestep = self.emb(timestep, **(added_cond_kwargs or {}), batch_size=batch_size, hidden_dtype=hidden_dtype)
+        return self.linear(self.silu(embedded_timestep)), embedded_timestep
 
 
 class _FluxPosEmbed(nn.Module):
@@ -277,12 +350,12 @@ def install():
     _mod("diffusers.models.embeddings", PixArtAlphaTextProjection=_PixArtAlphaTextProjection,
          CombinedTimestepGuidanceTextProjEmbeddings=_CombinedTimestepGuidanceTextProjEmbeddings,
          CombinedTimestepTextProjEmbeddings=_CombinedTimestepTextProjEmbeddings, FluxPosEmbed=_FluxPosEmbed,
-         apply_rotary_emb=_apply_rotary_emb,
-         **{n: _placeholder(n) for n in ("SinusoidalPositionalEmbedding", "ImagePositionalEmbeddings", "PatchEmbed")})
+         apply_rotary_emb=_apply_rotary_emb, PatchEmbed=_PatchEmbed,
+         **{n: _placeholder(n) for n in ("SinusoidalPositionalEmbedding", "ImagePositionalEmbeddings")})
     _mod("diffusers.models.normalization", AdaLayerNormContinuous=_AdaLayerNormContinuous,
          AdaLayerNormZero=_AdaLayerNormZero, AdaLayerNormZeroSingle=_AdaLayerNormZeroSingle, RMSNorm=_RMSNorm,
-         **{n: _placeholder(n) for n in ("AdaGroupNorm", "AdaLayerNorm", "SD35AdaLayerNormZeroX", "AdaLayerNormSingle",
-                                         "FP32LayerNorm", "LpNorm")})
+         AdaLayerNormSingle=_AdaLayerNormSingle,
+         **{n: _placeholder(n) for n in ("AdaGroupNorm", "AdaLayerNorm", "SD35AdaLayerNormZeroX", "FP32LayerNorm", "LpNorm")})
     _mix = lambda n: type(n, (), {})
     _mod("diffusers.loaders", FluxTransformer2DLoadersMixin=_mix("FluxTransformer2DLoadersMixin"),
          FromOriginalModelMixin=_mix("FromOriginalModelMixin"), PeftAdapterMixin=_mix("PeftAdapterMixin"))

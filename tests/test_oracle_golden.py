@@ -162,3 +162,30 @@ def test_vae_param_count_and_shapes():
     img = torch.randn(1, 3, 32, 32, generator=torch.Generator().manual_seed(0))
     mean, logvar = VR.encoder_moments(P, VR.tiny_arch(), img)
     assert mean.shape == (1, 4, 8, 8) and logvar.shape == (1, 4, 8, 8)
+
+
+# ---- PixArt DiT: oracle/pixart_ref.py vs the reference's Transformer2DModel run ----------------
+def test_pixart_oracle_matches_reference_golden():
+    from oracle import pixart_ref as PR
+    z = np.load(os.path.join(GOLD, "pixart_tiny.npz"))
+    meta = ast.literal_eval(str(z["meta"]))
+    arch = meta["arch"]
+    P = PR.synth_params(arch, seed=meta["wseed"])
+    assert np.allclose([float(v.double().sum()) for v in P.values()], z["wsum"], rtol=0, atol=1e-9)
+    assert np.allclose([float(v.double().abs().sum()) for v in P.values()], z["wabs"], rtol=0, atol=1e-9)
+    I = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("in:")}
+    st = PR.Store(None, out_dtype=None)
+    y = PR.pixart_forward(P, arch, I["hidden_states"], I["encoder_hidden_states"], I["timestep"], I["encoder_attention_mask"], st)
+    assert torch.allclose(y, torch.from_numpy(z["out:y"]), atol=2e-5, rtol=1e-5)
+    assert list(st.feats.keys()) == meta["order"] == PR.hook_ids(arch)
+    for k in meta["order"]:
+        v = torch.from_numpy(z["out:hook:" + k])
+        assert st.feats[k].shape == v.shape and torch.allclose(st.feats[k], v, atol=2e-5, rtol=1e-5), k
+
+
+def test_pixart_param_count():
+    from oracle import pixart_ref as PR
+    n = sum(int(np.prod(s)) for s in PR.param_shapes(PR.ARCH_PIXART_SIGMA).values())
+    assert abs(n - 610.9e6) < 1.0e6, n          # PixArt-Sigma-XL-2: ~0.6 B parameters
+    tf = PR.flops_per_image(PR.ARCH_PIXART_SIGMA, 4096, 300) / 1e12
+    assert abs(tf - 6.63) < 0.4, tf
