@@ -139,6 +139,19 @@ def flux_layer_ids(cfg):
     return ids
 
 
+def dit_layer_ids(cfg, include_dropped=False):
+    """Hook ids of a PixArt DiT in execution order (reference prepare_feature_extractor :250-286 + gather sites in
+    attention.py:589-590,1255-1257 and attention_processor.py:3291-3294; cross-k / cross-v are dropped by the store)."""
+    ids = []
+    for i in range(cfg["num_layers"]):
+        b = f"vit-block{i}"
+        ids += [f"{b}-self-q", f"{b}-self-k", f"{b}-self-v", f"{b}-cross-q"]
+        if include_dropped:
+            ids += [f"{b}-cross-k", f"{b}-cross-v"]
+        ids += [f"{b}-ffn-inner", f"{b}-out"]
+    return ids
+
+
 def prepare_feature_extractor(version, pipe, config, resize_ratio, train_unet):
     """Same signature as the reference (:92).  `config`: JSON path, dict, or None/{} (= accept all)."""
     if isinstance(config, str):
@@ -150,8 +163,11 @@ def prepare_feature_extractor(version, pipe, config, resize_ratio, train_unet):
             raise NotImplementedError("pipe.transformer is not the native MMDiT (components.native.NativeFluxTransformer)")
         pipe.transformer.feature_store = feature_store
         return feature_store
-    if hasattr(pipe, 'transformer') and not hasattr(pipe, 'unet'):
-        raise NotImplementedError("PixArt / Hunyuan DiT denoisers are not on the native hot path (SURVEY.md §8f rank 4)")
+    if hasattr(pipe, 'transformer'):               # DiT branch of the reference (:250-286): PixArt alpha / sigma
+        if not hasattr(pipe.transformer, 'forward_raw'):
+            raise NotImplementedError("pipe.transformer is not a native DiT (components.native.NativePixArtTransformer)")
+        pipe.transformer.feature_store = feature_store
+        return feature_store
     pipe.unet.feature_store = feature_store       # the native UNet delivers hook tensors here
     return feature_store
 

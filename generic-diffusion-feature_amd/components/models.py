@@ -15,8 +15,8 @@ import types
 
 import torch
 
-from .native import (ARCH_CONFIGS, FLUX_CONFIGS, VAE_CONFIGS, NativeFluxTransformer, NativeUNet, NativeVAEEncoder,
-                     config_from_diffusers)
+from .native import (ARCH_CONFIGS, FLUX_CONFIGS, PIXART_CONFIGS, VAE_CONFIGS, NativeFluxTransformer, NativePixArtTransformer,
+                     NativeUNet, NativeVAEEncoder, config_from_diffusers)
 
 # version -> (HF repo id, pipeline class name) exactly as the reference selects them (models.py:18-70)
 _HF = {
@@ -24,7 +24,7 @@ _HF = {
     "xl": ("stabilityai/stable-diffusion-xl-base-1.0", "StableDiffusionXLImg2ImgPipeline"),
     "pgv2": ("playgroundai/playground-v2-1024px-aesthetic", "StableDiffusionXLImg2ImgPipeline"),
 }
-_LATER = ("2-1", "pixart-sigma", "pixart-sigma-512", "pixart-alpha", "if", "hunyuan")
+_LATER = ("2-1", "pixart-alpha", "if", "hunyuan")       # pixart-alpha-1024 needs the resolution micro-conditioning
 
 
 def _parse_dtype(dtype):
@@ -160,6 +160,35 @@ class SyntheticPipe:
         return native_prepare_latents(self, image.to(device), timestep, batch_size, num_images_per_prompt, dtype, device, g)
 
 
+class SyntheticPixartPipe(SyntheticPipe):
+    """Offline stand-in for diffusers' PixArtSigmaPipeline as FeatureExtractor uses it: true-architecture DiT
+    (NativePixArtTransformer, seeded random weights), native VAE encoder, stand-in T5 embeddings with a ragged mask."""
+
+    def __init__(self, version, device, seed=0, cfg=None, n_txt=300):
+        cfg = dict(cfg or PIXART_CONFIGS[version])
+        self.version = version
+        self.device = device
+        self._pcfg = cfg
+        self.n_txt = n_txt
+        self.transformer = NativePixArtTransformer(cfg, device=device).init_synthetic(seed)
+        self.unet = self.transformer               # reference models.py:91 `pipe.unet = pipe.transformer`
+        empty = types.SimpleNamespace(parameters=lambda: iter(()), to=lambda *a, **k: None)
+        self.vae = types.SimpleNamespace(parameters=lambda: iter(()), config=types.SimpleNamespace(scaling_factor=0.13025))
+        self.native_vae = NativeVAEEncoder(VAE_CONFIGS["sd"], device=device).init_synthetic(seed + 1)
+        self.text_encoder = empty
+        self.scheduler = _Scheduler(euler=False)
+        self.config = types.SimpleNamespace(requires_aesthetics_score=False)
+        self.image_processor = types.SimpleNamespace(preprocess=self._preprocess)
+
+    def encode_prompt(self, prompt, device=None, num_images_per_prompt=1, negative_prompt='',
+                      do_classifier_free_guidance=True, **kw):
+        """(prompt_embeds, prompt_attention_mask, negative_prompt_embeds, negative_prompt_attention_mask) — PixArt order."""
+        cc = self._pcfg["caption_channels"]
+        n_valid = max(1, min(self.n_txt, len(prompt.split()) + 2))
+        mask = (torch.arange(self.n_txt, device=self.device)[None] < n_valid).to(torch.int64)
+        return self._embeds(prompt, (1, self.n_txt, cc)), mask, self._embeds("neg:", (1, self.n_txt, cc)), torch.ones_like(mask)
+
+
 class SyntheticFluxPipe:
     """Offline stand-in for diffusers' FluxImg2ImgPipeline as the reference drives it
     (`pipe(image=..., prompt=..., strength=t/1000, guidance_scale=1)`, diffusion_feature.py:246-254): true-architecture
@@ -278,6 +307,19 @@ def get_diffusion_model(version, dtype, offline_lora=None, offline_lora_filename
             pipe.load_lora_weights(offline_lora, weight_name=offline_lora_filename)
             pipe.fuse_lora()
         return _native_flux_from_diffusers(pipe.to(device), device)
+    if version in PIXART_CONFIGS:                                 # reference models.py:72-111 (PixArtSigmaPipeline)
+        if synthetic:
+            return SyntheticPixartPipe(version, device, seed=int(os.environ.get("GDF_SYNTHETIC_SEED", "0")))
+        try:
+            import diffusers
+        except ImportError as e:
+            raise RuntimeError("diffusers is not installed and GDF_SYNTHETIC_WEIGHTS is not set (see INTEGRATION.md)") from e
+        repo = "PixArt-alpha/PixArt-Sigma-XL-2-1024-MS" if version == "pixart-sigma" else "PixArt-alpha/PixArt-Sigma-XL-2-512-MS"
+        pipe = diffusers.PixArtSigmaPipeline.from_pretrained(repo, torch_dtype=dt, use_safetensors=True).to(device)
+        net = NativePixArtTransformer(PIXART_CONFIGS[version], device=device)
+        net.load_state_dict({k: v for k, v in pipe.transformer.state_dict().items() if k != "pos_embed.pos_embed"})
+        pipe.transformer = pipe.unet = net
+        return pipe
     if version not in _HF:
         raise NotImplementedError                                 # reference models.py:173-174
     if synthetic:

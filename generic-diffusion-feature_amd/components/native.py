@@ -94,6 +94,21 @@ SIGNATURES.update({
                                        C.POINTER(C.c_double), C.c_int]),
 })
 
+class PixartDesc(C.Structure):
+    _fields_ = [(k, C.c_int) for k in ("num_attention_heads", "attention_head_dim", "in_channels", "out_channels", "num_layers",
+                                       "patch_size", "sample_size", "caption_channels", "interpolation_scale")]
+
+
+# every symbol declared in include/gdf_pixart.h
+SIGNATURES.update({
+    "gdf_pixart_model_create": (C.c_int, [C.POINTER(PixartDesc), C.POINTER(C.c_void_p)]),
+    "gdf_pixart_plan_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_char_p), C.c_int,
+                                         C.POINTER(PlanOpts), C.POINTER(C.c_void_p)]),
+    "gdf_pixart_forward": (C.c_int, [C.c_void_p] * 5 + [C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gdf_pixart_plan_profile": (C.c_int, [C.c_void_p] * 5 + [C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.POINTER(C.c_float), C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.c_int]),
+})
+
 # every symbol declared in include/gdf_flux.h
 SIGNATURES.update({
     "gdf_flux_model_create": (C.c_int, [C.POINTER(FluxDesc), C.POINTER(C.c_void_p)]),
@@ -672,3 +687,143 @@ class NativeVAEEncoder(_NativeModel):
                              for i in range(n)]
             _check(self.lib.gdf_vae_encode(*args), "vae_encode")
         return out
+
+
+# --------------------------------------------------------------------------------------------- #
+# PixArt DiT (include/gdf_pixart.h): Transformer2DModel `config.json` of PixArt-alpha/PixArt-Sigma-XL-2-1024-MS
+# (reference components/models.py:72-111)
+# --------------------------------------------------------------------------------------------- #
+PIXART_CONFIGS = {
+    "pixart-sigma": dict(num_attention_heads=16, attention_head_dim=72, in_channels=4, out_channels=8, num_layers=28,
+                         patch_size=2, sample_size=128, caption_channels=4096, interpolation_scale=2),
+    "pixart-sigma-512": dict(num_attention_heads=16, attention_head_dim=72, in_channels=4, out_channels=8, num_layers=28,
+                             patch_size=2, sample_size=64, caption_channels=4096, interpolation_scale=1),
+}
+
+
+class NativePixArtTransformer(_NativeModel):
+    """Transformer2DModel (PixArt, ada_norm_single) replacement running entirely in libgdf.so.
+
+    Call signature mirrors the reference's use at feature/diffusion_feature.py:466-474:
+        transformer(latent_model_input, encoder_hidden_states=prompt_embeds, encoder_attention_mask=prompt_attention_mask,
+                    timestep=t, return_dict=False, added_cond_kwargs={'resolution': None, 'aspect_ratio': None})[0]
+    Hook ids `vit-block{i}-{self-q,self-k,self-v,cross-q,ffn-inner,out}` (components/feature_extractor.py:250-286)."""
+
+    def __init__(self, cfg, device="cuda", early_exit=False):
+        if not torch.cuda.is_available():
+            raise RuntimeError("NativePixArtTransformer needs an MI355X (HIP device); there is no CPU fallback")
+        self.lib = load_library()
+        self.cfg = dict(cfg)
+        self.device = torch.device(device if str(device) != "cuda" else f"cuda:{torch.cuda.current_device()}")
+        d = PixartDesc()
+        for k, _ in PixartDesc._fields_:
+            setattr(d, k, int(cfg[k]))
+        self._desc = d
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _check(self.lib.gdf_pixart_model_create(C.byref(d), C.byref(h)), "pixart_model_create")
+        self.handle = h
+        self.early_exit = bool(early_exit)
+        self.feature_store = None
+        self._plans = {}
+        self.dtype = torch.float16
+        self.config = types.SimpleNamespace(in_channels=cfg["in_channels"], sample_size=cfg["sample_size"],
+                                            out_channels=cfg["out_channels"])
+
+    def init_synthetic(self, seed=0, **kw):
+        """Linear weights ~ N(0, 1/fan_in), biases 0.05 N, scale_shift_table ~ N(0, 1/C) (transformer_2d.py:304)."""
+        g = torch.Generator(device=self.device).manual_seed(seed)
+        stream = torch.cuda.current_stream(self.device)
+        c = self.cfg["num_attention_heads"] * self.cfg["attention_head_dim"]
+        with torch.cuda.device(self.device):
+            for name, shp in self.param_shapes().items():
+                t = torch.randn(shp, generator=g, device=self.device, dtype=torch.float32)
+                if name.endswith("scale_shift_table"):
+                    t.mul_(c ** -0.5)
+                elif name.endswith(".weight"):
+                    fan = 1
+                    for s_ in shp[1:]:
+                        fan *= s_
+                    t.mul_(fan ** -0.5)
+                else:
+                    t.mul_(0.05)
+                t = t.half()
+                _check(self.lib.gdf_model_set_param(self.handle, name.encode(), C.c_void_p(t.data_ptr()), GDF_F16,
+                                                    C.c_void_p(stream.cuda_stream)), f"set_param({name})")
+                stream.synchronize()
+        return self
+
+    def _plan(self, batch, h, w, n_txt, hook_ids):
+        key = (batch, h, w, n_txt, tuple(hook_ids), self.early_exit)
+        p = self._plans.get(key)
+        if p is None:
+            ids = (C.c_char_p * max(1, len(hook_ids)))(*[s.encode() for s in hook_ids])
+            opts = PlanOpts(1, int(self.early_exit))
+            ph = C.c_void_p()
+            _check(self.lib.gdf_pixart_plan_create(self.handle, batch, h, w, n_txt, ids, len(hook_ids), C.byref(opts),
+                                                   C.byref(ph)), "pixart_plan_create")
+            p = _Plan(self.lib, ph)
+            if len(self._plans) >= 4:
+                self._plans.pop(next(iter(self._plans)))
+            self._plans[key] = p
+        return p
+
+    def forward_raw(self, hidden_states, encoder_hidden_states, timestep, encoder_attention_mask=None, hook_ids=None,
+                    profile=False):
+        """Returns (output (B, out_channels, H, W) fp16, OrderedDict id -> hook tensor)."""
+        dev = self.device
+        B, cin, H, W = hidden_states.shape
+        x = hidden_states.to(dev, torch.float16).contiguous()
+        enc = encoder_hidden_states.to(dev, torch.float16).contiguous()
+        t = torch.as_tensor(timestep, device=dev).float().reshape(-1)
+        t = (t.expand(B) if t.numel() == 1 else t).contiguous()
+        T = enc.shape[1]
+        if cin != self.cfg["in_channels"] or enc.shape != (B, T, self.cfg["caption_channels"]):
+            raise ValueError("pixart input shape mismatch")
+        lens = None
+        if encoder_attention_mask is not None:
+            m = encoder_attention_mask.to(dev).reshape(B, T) > 0.5
+            lens = m.sum(1).to(torch.int32)
+            if not torch.equal(m, torch.arange(T, device=dev)[None] < lens[:, None]):
+                raise NotImplementedError("encoder_attention_mask must keep a leading prefix of the caption tokens")
+            lens = lens.contiguous()
+        ids = list(hook_ids) if hook_ids is not None else self.requested_ids()
+        plan = self._plan(B, H, W, T, ids)
+        with torch.cuda.device(dev):
+            if plan.workspace is None or plan.workspace.numel() < plan.ws_bytes:
+                plan.workspace = torch.empty(plan.ws_bytes, dtype=torch.uint8, device=dev)
+            hooks = [torch.empty(nbytes // 2, dtype=torch.float16, device=dev) for (_, _, _, nbytes) in plan.hooks]
+            hook_ptrs = (C.c_void_p * max(1, len(hooks)))(*[h.data_ptr() for h in hooks])
+            out = torch.empty(B, self.cfg["out_channels"], H, W, dtype=torch.float16, device=dev)
+            stream = torch.cuda.current_stream(dev)
+            vp = lambda a: C.c_void_p(a.data_ptr() if a is not None else 0)
+            args = (plan.handle, vp(x), vp(t), vp(enc), vp(lens), hook_ptrs, vp(out), vp(plan.workspace),
+                    C.c_void_p(stream.cuda_stream))
+            prof = None
+            if profile:
+                n = self.lib.gdf_plan_num_ops(plan.handle)
+                ms = (C.c_float * n)(); names = (C.c_char_p * n)(); fl = (C.c_double * n)()
+                if self.lib.gdf_pixart_plan_profile(*args, ms, names, fl, n) < 0:
+                    _check(1, "pixart_plan_profile")
+                prof = [(names[i].decode(), ms[i], fl[i], self.lib.gdf_plan_op_kernel(plan.handle, i).decode())
+                        for i in range(n)]
+            else:
+                _check(self.lib.gdf_pixart_forward(*args), "pixart_forward")
+        feats = {}
+        for buf, (hid, shape, stride, _) in zip(hooks, plan.hooks):
+            feats[hid] = torch.as_strided(buf, shape, stride)
+        return (out, feats, prof) if profile else (out, feats)
+
+    def __call__(self, hidden_states, encoder_hidden_states=None, timestep=None, added_cond_kwargs=None,
+                 encoder_attention_mask=None, return_dict=True, **kwargs):
+        akw = added_cond_kwargs or {}
+        if akw.get("resolution") is not None or akw.get("aspect_ratio") is not None:
+            raise NotImplementedError("PixArt-alpha micro-conditioning (use_additional_conditions) is not native")
+        out, hooks = self.forward_raw(hidden_states, encoder_hidden_states, timestep, encoder_attention_mask,
+                                      hook_ids=self.requested_ids())
+        if self.feature_store is not None:
+            for hid, tens in hooks.items():
+                self.feature_store.store(tens, hid)
+        if return_dict:
+            return types.SimpleNamespace(sample=out)
+        return (out,)

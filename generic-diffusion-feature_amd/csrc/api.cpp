@@ -72,6 +72,46 @@ int gdf_plan_hook_info(const gdf_plan* p, int i, gdf_hook_info* info) {
   return GDF_OK;
 }
 
+// ---- PixArt DiT front end (include/gdf_pixart.h) ----
+int gdf_pixart_model_create(const gdf_pixart_desc* desc, gdf_model** out) {
+  if (!desc || !out) { set_error("null argument"); return GDF_ERR_ARG; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { set_error("no HIP device: libgdf has no CPU fallback"); return GDF_ERR_HIP; }
+  Model* m = pixart_model_create(*desc);
+  if (!m) return GDF_ERR_ARG;
+  *out = new gdf_model{m};
+  return GDF_OK;
+}
+int gdf_pixart_plan_create(gdf_model* m, int batch, int lat_h, int lat_w, int n_txt, const char* const* hook_ids, int n_hooks,
+                           const gdf_plan_opts* opts, gdf_plan** out) {
+  if (!m || !out || (n_hooks > 0 && !hook_ids)) { set_error("null argument"); return GDF_ERR_ARG; }
+  gdf_plan_opts o{};
+  o.stream_fp32 = 1;
+  if (opts) o = *opts;
+  gdf_plan* p = new gdf_plan();
+  p->owner = m;
+  p->p.model = m->m;
+  const int rc = pixart_plan_build(*m->m, p->p, batch, lat_h, lat_w, n_txt, hook_ids, n_hooks, o, false);
+  if (rc != GDF_OK) { delete p; return rc; }
+  *out = p;
+  return GDF_OK;
+}
+int gdf_pixart_forward(gdf_plan* p, const void* latents, const float* timestep, const void* encoder_hidden_states,
+                       const int* text_lens, void* const* hook_out, void* out, void* workspace, void* stream) {
+  if (!p) { set_error("null plan"); return GDF_ERR_ARG; }
+  return pixart_forward(p->p, *p->p.model, latents, timestep, encoder_hidden_states, text_lens, hook_out, out, workspace,
+                        (hipStream_t)stream, nullptr, nullptr, nullptr, 0);
+}
+int gdf_pixart_plan_profile(gdf_plan* p, const void* latents, const float* timestep, const void* encoder_hidden_states,
+                            const int* text_lens, void* const* hook_out, void* out, void* workspace, void* stream, float* ms,
+                            const char** names, double* flops, int cap) {
+  if (!p || !ms) { set_error("null argument"); return -1; }
+  const int rc = pixart_forward(p->p, *p->p.model, latents, timestep, encoder_hidden_states, text_lens, hook_out, out, workspace,
+                                (hipStream_t)stream, ms, names, flops, cap);
+  if (rc != GDF_OK) return -1;
+  return (int)p->p.ops.size();
+}
+
 // ---- VAE encoder front end (include/gdf_vae.h) ----
 int gdf_vae_model_create(const gdf_vae_desc* desc, gdf_model** out) {
   if (!desc || !out) { set_error("null argument"); return GDF_ERR_ARG; }

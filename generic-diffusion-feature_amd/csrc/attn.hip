@@ -109,7 +109,10 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
   // version spent ~150 of its 330 VALU instructions per tile on 64-bit address math and was VALU bound).
   const _Float16* kbase = p.k + head * D;
   const _Float16* vbase = p.v + head * D;
-  const int ntiles = (p.Sk + KT - 1) / KT;
+  // per-sample key count (PixArt cross attention: the text mask keeps a prefix of the Sk caption tokens; the reference adds
+  // -10000 to the masked scores, transformer_2d.py:397-399, whose softmax weight is exactly 0 in fp32)
+  const int Sk = p.kv_len ? max(1, min(p.kv_len[b], p.Sk)) : p.Sk;
+  const int ntiles = (Sk + KT - 1) / KT;
   const int segT = p.seg_T > 0 ? p.seg_T : 0x7fffffff;
   const uint32_t c0 = p.seg_T > 0 ? (uint32_t)b * (uint32_t)p.seg_T : (uint32_t)b * (uint32_t)p.kv_bstride;
   const uint32_t c1 = p.seg_T > 0 ? (uint32_t)p.B * (uint32_t)p.seg_T + (uint32_t)b * (uint32_t)(p.Sk - p.seg_T) - (uint32_t)p.seg_T : c0;
@@ -122,7 +125,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
       const int idx = tid + c * 256;
       const int row = idx / CPR, ch = idx - row * CPR;
       int kv = t * KT + row;
-      kv = min(kv, p.Sk - 1);                    // tail rows re-read the last key: their scores are masked to -inf below
+      kv = min(kv, Sk - 1);                    // tail rows re-read the last key: their scores are masked to -inf below
       const uint32_t r = (uint32_t)kv + (kv < segT ? c0 : c1);
       f16x8 kk = {0, 0, 0, 0, 0, 0, 0, 0}, vv = kk;
       if ((KT * CPR) % 256 == 0 || idx < KT * CPR) {
@@ -173,7 +176,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
       }
     }
     // ---- mask the tail tile, online softmax (per-lane query column) ----
-    if ((t + 1) * KT > p.Sk) {
+    if ((t + 1) * KT > Sk) {
 #pragma unroll
       for (int w = 0; w < QW; ++w)
 #pragma unroll
@@ -181,7 +184,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int kv = t * KT + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            if (kv >= p.Sk) s[w][kb][r] = -INFINITY;
+            if (kv >= Sk) s[w][kb][r] = -INFINITY;
           }
     }
     f16x8 pf[QW][4];
@@ -494,7 +497,7 @@ __global__ __launch_bounds__(256, 2) void attn_map_kernel(const AttnParams p) {
 
 template <int D>
 static hipError_t launch_d(const AttnParams& p, hipStream_t s) {
-  if (p.map && p.seg_T) return hipErrorInvalidValue;     // '-map' hooks of the joint (MMDiT) layout: not built
+  if (p.map && (p.seg_T || p.kv_len)) return hipErrorInvalidValue;     // '-map' hooks of the MMDiT / masked layouts: not built
   if (p.map) {
     const int nqb = (p.Sq + 127) / 128;
     hipLaunchKernelGGL((attn_map_kernel<D>), dim3(p.B * p.heads * nqb), dim3(256), 0, s, p);
@@ -520,6 +523,7 @@ hipError_t launch_attention(const AttnParams& p, hipStream_t s) {
     case 32: return launch_d<32>(p, s);
     case 40: return launch_d<40>(p, s);
     case 64: return launch_d<64>(p, s);
+    case 72: return launch_d<72>(p, s);
     case 80: return launch_d<80>(p, s);
     case 128: return launch_d<128>(p, s);
     case 160: return launch_d<160>(p, s);

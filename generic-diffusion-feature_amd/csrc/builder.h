@@ -210,6 +210,7 @@ struct PlanBuilder {
     int geglu = 0; int bn = 128;
     int dit = 0, act = 0, rv_mul = 0, rv_seg_rows = 0, rv_rps2 = 0;     // MMDiT epilogue (kernels.h)
     int pad0 = 0;                                                         // conv3: 1 = pad right / bottom only
+    int rv_tok = 0;                                                       // row vector indexed by token (row % rps)
   };
   void residual_from(Epi& e, const Act& x) {
     if (x.has_f) { e.res32 = x.f; e.has_r32 = true; e.ldres = x.C; }
@@ -230,7 +231,7 @@ struct PlanBuilder {
     g.out32 = e.has_o32 ? (float*)b.p(e.out32) : nullptr; g.ldo32 = e.ldo32;
     g.aux16 = e.aux_slot >= 0 ? (half_t*)b.hook(e.aux_slot) : nullptr; g.ldaux = e.ldaux;
     g.geglu = e.geglu; g.bn = e.bn;
-    g.dit = e.dit; g.act = e.act; g.rv_mul = e.rv_mul; g.rv_seg_rows = e.rv_seg_rows; g.rv_rps2 = e.rv_rps2;
+    g.dit = e.dit; g.act = e.act; g.rv_mul = e.rv_mul; g.rv_seg_rows = e.rv_seg_rows; g.rv_rps2 = e.rv_rps2; g.rv_tok = e.rv_tok;
   }
 
   // dense GEMM: A (fp16 [M][K], lda) x W[N][K]

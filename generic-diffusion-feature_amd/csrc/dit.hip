@@ -278,6 +278,107 @@ hipError_t launch_vae_finish(const float* h, int B, int HW, int L, const half_t*
   return hipGetLastError();
 }
 
+__global__ void sincos_pos_embed_kernel(float* out, int C, int gh, int gw, float sh, float sw) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int S = gh * gw;
+  if (i >= S * C) return;
+  const int tok = i / C, c = i - tok * C;
+  // diffusers: grid = np.meshgrid(grid_w, grid_h) reshaped [2,1,gw,gh] and flattened; grid[0] (x coordinates) feeds the
+  // first half of the channels.  Flat index m of the (gw, gh)-shaped view == m of the (gh, gw) meshgrid array.
+  const int y = tok / gw, x = tok - y * gw;
+  const int half = C / 2, quarter = C / 4;
+  const int cc = c < half ? c : c - half;
+  const double pos = c < half ? (double)((float)x * sw) : (double)((float)y * sh);
+  const int k = cc < quarter ? cc : cc - quarter;
+  const double omega = 1.0 / pow(10000.0, (double)k / (double)quarter);
+  const double a = pos * omega;
+  out[i] = (float)(cc < quarter ? sin(a) : cos(a));
+}
+
+hipError_t launch_sincos_pos_embed(float* out, int C, int gh, int gw, int base_size, float interpolation_scale, hipStream_t s) {
+  if (C % 4) return hipErrorInvalidValue;
+  // grid_h = arange(gh) / (gh / base_size) / interpolation_scale (float32 arithmetic in numpy)
+  const float sh = 1.0f / ((float)gh / (float)base_size) / interpolation_scale;
+  const float sw = 1.0f / ((float)gw / (float)base_size) / interpolation_scale;
+  const int total = gh * gw * C;
+  hipLaunchKernelGGL(sincos_pos_embed_kernel, dim3((total + 255) / 256), dim3(256), 0, s, out, C, gh, gw, sh, sw);
+  return hipGetLastError();
+}
+
+__global__ void add_table_kernel(const float* table, const float* vec, int ldvec, int period, long n, float* out, long ldo) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int b = blockIdx.y;
+  out[(size_t)b * ldo + i] = table[i] + vec[(size_t)b * ldvec + (int)(i % period)];
+}
+
+hipError_t launch_add_table(const float* table, const float* vec, int ldvec, int period, int B, long n, float* out, long ldo,
+                            hipStream_t s) {
+  if (n <= 0 || B <= 0) return hipSuccess;
+  hipLaunchKernelGGL(add_table_kernel, dim3((unsigned)((n + 255) / 256), B), dim3(256), 0, s, table, vec, ldvec, period, n, out, ldo);
+  return hipGetLastError();
+}
+
+__global__ void patchify_kernel(const half_t* x, int Cin, int H, int W, int p, int kpad, half_t* out, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;      // (row, col)
+  if (i >= total) return;
+  const long row = i / kpad;
+  const int col = (int)(i - row * kpad);
+  const int gh = H / p, gw = W / p;
+  const long b = row / (gh * gw);
+  const int t = (int)(row - b * gh * gw), ty = t / gw, tx = t - ty * gw;
+  _Float16 v = (_Float16)0.f;
+  if (col < Cin * p * p) {
+    const int c = col / (p * p), r = col - c * p * p, py = r / p, px = r - py * p;
+    v = x[(((size_t)b * Cin + c) * H + (ty * p + py)) * W + tx * p + px];
+  }
+  out[i] = v;
+}
+
+hipError_t launch_patchify(const half_t* x, int B, int Cin, int H, int W, int p, int kpad, half_t* out, hipStream_t s) {
+  if (p < 1 || H % p || W % p || Cin * p * p > kpad) return hipErrorInvalidValue;
+  const long total = (long)B * (H / p) * (W / p) * kpad;
+  hipLaunchKernelGGL(patchify_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, Cin, H, W, p, kpad, out, total);
+  return hipGetLastError();
+}
+
+__global__ void unpatchify_kernel(const half_t* x, int Cout, int gh, int gw, int p, half_t* out, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;      // output element (b, c, y, x)
+  if (i >= total) return;
+  const int W = gw * p, H = gh * p;
+  const int xx = (int)(i % W);
+  const int yy = (int)((i / W) % H);
+  const int c = (int)((i / ((long)W * H)) % Cout);
+  const long b = i / ((long)W * H * Cout);
+  const int ty = yy / p, py = yy - ty * p, tx = xx / p, px = xx - tx * p;
+  out[i] = x[((size_t)b * gh * gw + (size_t)ty * gw + tx) * (p * p * Cout) + (py * p + px) * Cout + c];
+}
+
+hipError_t launch_unpatchify(const half_t* x, int B, int Cout, int gh, int gw, int p, half_t* out, hipStream_t s) {
+  const long total = (long)B * Cout * gh * p * gw * p;
+  if (total <= 0) return hipSuccess;
+  hipLaunchKernelGGL(unpatchify_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, Cout, gh, gw, p, out, total);
+  return hipGetLastError();
+}
+
+__global__ void relayout_rows_padk_kernel(const void* src, int f32, half_t* dst, int ksrc, int kdst, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const long r = i / kdst;
+  const int k = (int)(i - r * kdst);
+  float v = 0.f;
+  if (k < ksrc) v = f32 ? ((const float*)src)[r * ksrc + k] : (float)((const half_t*)src)[r * ksrc + k];
+  dst[i] = (_Float16)v;
+}
+
+hipError_t launch_relayout_rows_padk(const void* src, int src_f32, half_t* dst, int R, int ksrc, int kdst, hipStream_t s) {
+  const long total = (long)R * kdst;
+  if (total <= 0) return hipSuccess;
+  hipLaunchKernelGGL(relayout_rows_padk_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, src_f32, dst, ksrc,
+                     kdst, total);
+  return hipGetLastError();
+}
+
 __global__ void silu_vec_kernel(const float* x, float* out, long n) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) { const float v = x[i]; out[i] = v / (1.0f + expf(-v)); }

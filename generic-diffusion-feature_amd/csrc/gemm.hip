@@ -328,6 +328,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
   const bool rv_in_opnd = p.rowvec && !p.res32;
   auto sample_of = [&](int row) -> int {                 // row of the per-sample vector table that applies to `row`
     if (DIT && p.rv_seg_rows > 0 && row >= p.rv_seg_rows) return (row - p.rv_seg_rows) / p.rv_rps2;
+    if (DIT && p.rv_tok) return row % p.rows_per_sample;
     return row / p.rows_per_sample;
   };
 #pragma unroll
@@ -544,8 +545,9 @@ static hipError_t launch_t(const GemmParams& p, hipStream_t s) {
 static int pick_variant(const GemmParams& p) {
   if (p.dit) {   // MMDiT widths are multiples of 256 (3072 = 24 x 128): 256x256 tiles (128 KiB ring, 1 workgroup / CU)
     const long t256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
-    if (p.variant == 128 || p.variant == 1256) return p.variant;
-    return (p.N % 256 == 0 && t256 >= 128) ? 1256 : 128;
+    if (p.variant == 128 || p.variant == 1256 || p.variant == 2128) return p.variant;
+    if (p.N % 256 == 0 && t256 >= 128) return 1256;
+    return (p.N % 128 == 0 && (long)((p.M + 255) / 256) * (p.N / 128) >= 256) ? 2128 : 128;   // PixArt: C = 1152 = 9 x 128
   }
   if (p.bn == 16) return 16;
   if (p.variant) return p.variant;
@@ -574,7 +576,7 @@ const char* gemm_kernel_name(const GemmParams& p) {
   if (v == 16) bn = 16; else if (v == 160) bn = 160; else if (v == 256) { bm = 256; st = 3; } else if (v == 320) { bm = 256; bn = 320; }
   if (p.mode == A_CONV_SMALLC && v != 160) { bm = 128; bn = 128; st = 2; }
   char tmp[64];
-  if (p.dit) snprintf(tmp, sizeof tmp, "gemm_dit_kernel<%d, %d, 2>", v == 1256 ? 256 : 128, v == 1256 ? 256 : 128);
+  if (p.dit) snprintf(tmp, sizeof tmp, "gemm_dit_kernel<%d, %d, %d>", v == 128 ? 128 : 256, v == 1256 ? 256 : 128, v == 2128 ? 3 : 2);
   else snprintf(tmp, sizeof tmp, "gemm_kernel<%d, %d, %d, %d, %s>", p.mode, bm, bn, st, p.geglu ? "true" : "false");
   for (int i = 0; i < nb; ++i) if (!strcmp(buf[i], tmp)) return buf[i];
   if (nb < 16) { strcpy(buf[nb], tmp); return buf[nb++]; }
@@ -590,6 +592,7 @@ hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {
   if (p.dit) {
     if (p.mode != A_DENSE || p.geglu || p.batch > 1) return hipErrorInvalidValue;
     if (v == 1256) return launch_t<A_DENSE, 256, 256, 2, false, true>(p, s);
+    if (v == 2128) return launch_t<A_DENSE, 256, 128, 3, false, true>(p, s);
     return launch_t<A_DENSE, 128, 128, 2, false, true>(p, s);
   }
   if (p.geglu) {

@@ -64,6 +64,7 @@ struct GemmParams {
   int act;
   int rv_mul;
   int rv_seg_rows, rv_rps2;
+  int rv_tok;            // 1: the row vector is per TOKEN (row % rows_per_sample), e.g. the PatchEmbed positional table
 };
 hipError_t launch_gemm(const GemmParams& p, hipStream_t s);
 const char* gemm_kernel_name(const GemmParams& p);   // kernel symbol launch_gemm would pick (only M,N,K,mode,geglu,bn,variant are read)
@@ -81,6 +82,7 @@ struct AttnParams {
   int kv_bstride;        // rows between consecutive samples' K/V (Sk normally; 0 = all samples share one K/V set)
   float scale;
   half_t* map;           // optional: attention probabilities (B, heads, Sq, Sk) fp16 ('-map' hooks)
+  const int* kv_len;     // optional [B]: keys [kv_len[b], Sk) of sample b are masked out (prefix text mask)
   int seg_T;             // > 0: MMDiT joint sequence, region-major rows [B x seg_T text][B x (Sq - seg_T) image] (Sq == Sk)
 };
 hipError_t launch_attention(const AttnParams& p, hipStream_t s);
@@ -121,6 +123,17 @@ hipError_t launch_softmax_rows(half_t* x, int ld, int R, int n, float scale, hip
 hipError_t launch_vae_finish(const float* h, int B, int HW, int L, const half_t* wq, const float* bq, const half_t* eps,
                              const half_t* noise, float scaling, float noise_a, float noise_b, float in_scale, half_t* out,
                              hipStream_t s);
+// PatchEmbed positional table (embeddings.get_2d_sincos_pos_embed as PatchEmbed calls it): out fp32 [gh*gw][C]
+hipError_t launch_sincos_pos_embed(float* out, int C, int gh, int gw, int base_size, float interpolation_scale, hipStream_t s);
+// out[b][i] = table[i] + vec[b][i % period]   (ada_norm_single: scale_shift_table + timestep embedding, all blocks at once)
+hipError_t launch_add_table(const float* table, const float* vec, int ldvec, int period, int B, long n, float* out, long ldo,
+                            hipStream_t s);
+// latents NCHW fp16 (B,Cin,H,W) -> patch rows [B*(H/p)*(W/p)][kpad] fp16, column = (c*p + py)*p + px (Conv2d weight order), zero padded
+hipError_t launch_patchify(const half_t* x, int B, int Cin, int H, int W, int p, int kpad, half_t* out, hipStream_t s);
+// token rows [B*gh*gw][p*p*Cout] fp16 -> NCHW fp16 (B,Cout,gh*p,gw*p)  (transformer_2d.py:563-570 einsum nhwpqc->nchpwq)
+hipError_t launch_unpatchify(const half_t* x, int B, int Cout, int gh, int gw, int p, half_t* out, hipStream_t s);
+// dst[r][0..kdst) = src[r][0..ksrc) zero padded (weights whose K is not a multiple of 64: the 2x2 patch conv)
+hipError_t launch_relayout_rows_padk(const void* src, int src_f32, half_t* dst, int R, int ksrc, int kdst, hipStream_t s);
 // out[i] = silu(x[i])
 hipError_t launch_silu_vec(const float* x, float* out, long n, hipStream_t s);
 // strided 2-D copy with cast to fp16: dst[r][c] = src[r][c]   (hook stores)

@@ -214,6 +214,7 @@ int model_set_param(Model* m, const char* name, const void* src, int dtype, hipS
     case PK_CONV3: e = launch_relayout_conv(src, f32, (half_t*)(base + p.dst), p.a0, p.a1, 9, p.a1, 9, s); break;
     case PK_CONV_IN: e = launch_relayout_conv(src, f32, (half_t*)(base + p.dst), p.a0, p.a1, 9, 8, 16, s); break;
     case PK_ROWS: e = launch_relayout_rows(src, f32, (half_t*)(base + p.dst), p.a0, p.a1, p.a2, 0, s); break;
+    case PK_ROWS_PADK: e = launch_relayout_rows_padk(src, f32, (half_t*)(base + p.dst), p.a0, p.a1, p.a2, s); break;
     case PK_ROWS_GEGLU: e = launch_relayout_rows(src, f32, (half_t*)(base + p.dst), p.a0, p.a1, 0, geglu_group(p.a0), s); break;
     default: set_error("bad param kind"); return GDF_ERR_STATE;
   }

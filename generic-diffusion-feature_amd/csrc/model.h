@@ -9,6 +9,7 @@
 #include "../../include/gdf.h"
 #include "../../include/gdf_flux.h"
 #include "../../include/gdf_vae.h"
+#include "../../include/gdf_pixart.h"
 #include "kernels.h"
 
 namespace gdf {
@@ -32,7 +33,7 @@ struct KvGroup { int C = 0, count = 0, next = 0; size_t base = 0, stride = 0; };
 struct VitW { NormW gn; LinW pin, pout; std::vector<BlockW> blocks; int c = 0, heads = 0; };
 struct LevelW { std::vector<ResnetW> res; std::vector<VitW> vit; std::vector<int> skip_c; bool has_sampler = false; ConvW sampler; };
 
-enum ParamKind { PK_VEC, PK_VEC_OFF, PK_VEC_GEGLU, PK_CONV3, PK_CONV_IN, PK_ROWS, PK_ROWS_GEGLU };
+enum ParamKind { PK_VEC, PK_VEC_OFF, PK_VEC_GEGLU, PK_CONV3, PK_CONV_IN, PK_ROWS, PK_ROWS_GEGLU, PK_ROWS_PADK };
 struct ParamRec {
   std::string name; int ndim = 0; int64_t shape[4] = {0, 0, 0, 0};
   int kind = 0; size_t dst = 0; int a0 = 0, a1 = 0, a2 = 0; bool set = false;
@@ -60,6 +61,16 @@ struct FluxW {
   std::vector<FluxSingleW> sgl;
 };
 
+// ---- PixArt DiT weights -----------------------------------------------------------------------------
+struct PixartBlockW { LinW qkv, o1, q2, kv2, o2, ff1, ff2; int table = 0; };   // table: float offset of scale_shift_table (6C)
+struct PixartW {
+  gdf_pixart_desc d{};
+  int C = 0, kpad = 0;
+  LinW patch, t1, t2, ada, cap1, cap2, proj_out;
+  size_t tables = 0;                           // fp32 [num_layers * 6C + 2C]: every block's scale_shift_table, then the final one
+  std::vector<PixartBlockW> blocks;
+};
+
 // ---- VAE encoder weights ---------------------------------------------------------------------------
 struct VaeW {
   gdf_vae_desc d{};
@@ -75,6 +86,7 @@ struct Model {
   int kind = 0;                                // 0: UNet2DConditionModel, 1: FluxTransformer2DModel, 2: AutoencoderKL encoder
   FluxW flux;
   VaeW vae;
+  PixartW pix;                                 // kind 3
   GdfArch arch{};
   void* weights = nullptr;
   size_t weight_bytes = 0;
@@ -151,6 +163,13 @@ Model* vae_model_create(const gdf_vae_desc& d);
 int vae_plan_build(const Model& m, Plan& P, int batch, int img_h, int img_w, bool dry);
 int vae_encode(Plan& P, const Model& m, const void* image, const void* eps, const void* noise, float scaling, float noise_a,
                float noise_b, float in_scale, void* out, void* ws, hipStream_t s, float* ms, const char** names, double* flops, int cap);
+
+// ---- PixArt DiT front end (include/gdf_pixart.h) ----
+Model* pixart_model_create(const gdf_pixart_desc& d);
+int pixart_plan_build(const Model& m, Plan& P, int batch, int lat_h, int lat_w, int n_txt, const char* const* ids, int n_ids,
+                      const PlanOpts& opts, bool dry);
+int pixart_forward(Plan& P, const Model& m, const void* latents, const float* timestep, const void* enc, const int* text_lens,
+                   void* const* hook_out, void* out, void* ws, hipStream_t s, float* ms, const char** names, double* flops, int cap);
 
 Model* flux_model_create(const gdf_flux_desc& d);
 int flux_plan_build(const Model& m, Plan& P, int batch, int img_h, int img_w, int n_txt, const char* const* ids, int n_ids,

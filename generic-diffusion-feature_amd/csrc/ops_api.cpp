@@ -110,6 +110,10 @@ int gdf_op_softmax_rows(void* x, int ld, int R, int n, float scale, void* stream
   return fin(launch_softmax_rows((half_t*)x, ld, R, n, scale, (hipStream_t)stream), "softmax_rows");
 }
 
+int gdf_op_sincos_pos_embed(float* out, int C, int gh, int gw, int base_size, float interpolation_scale, void* stream) {
+  return fin(launch_sincos_pos_embed(out, C, gh, gw, base_size, interpolation_scale, (hipStream_t)stream), "sincos_pos_embed");
+}
+
 int gdf_op_gemm_dit(const void* A, int lda, const void* W, const float* bias, int act, const float* vec, int ldvec, int vec_mul,
                     int rps, int seg_rows, int rps2, const float* res32, int ldres, void* aux16, int ldaux, void* out16,
                     int ldo16, float* out32, int ldo32, int M, int N, int K, int variant, void* stream) {

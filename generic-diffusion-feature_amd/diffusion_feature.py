@@ -22,7 +22,7 @@ from components.feature_extractor import (ATTENTION_CATEGORIES, aggregate_attent
 class FeatureExtractor(nn.Module):
     def __init__(self,
                  layer,            # filename of the layer json, a pre-loaded dict, or None (= all layers)
-                 version,          # '1-5', 'xl', 'pgv2', 'flux'
+                 version,          # '1-5', 'xl', 'pgv2', 'flux', 'pixart-sigma', 'pixart-sigma-512'
                  device,
                  dtype='float16',
                  img_size=1024,    # 512 for 1-5, 1024 otherwise
@@ -92,7 +92,9 @@ class FeatureExtractor(nn.Module):
             prompts = prompt_str
         ret = self.pipe.encode_prompt(prompt=prompts, device=self.device, num_images_per_prompt=1,
                                       negative_prompt='', do_classifier_free_guidance=True)
-        if self.version in ('xl', 'pgv2'):
+        if self.version in ('xl', 'pgv2') or self.version.startswith('pixart'):
+            # SDXL: (embeds, negative, pooled, negative_pooled); PixArt: (embeds, mask, negative, negative_mask) — the
+            # reference returns the pipeline's 4-tuple as is (diffusion_feature.py:182-206)
             prompt_embeds, negative_prompt_embeds, pooled, negative_pooled = ret
         else:
             prompt_embeds, negative_prompt_embeds = ret
@@ -122,10 +124,18 @@ class FeatureExtractor(nn.Module):
                       prompt=prompts, strength=t / 1000, guidance_scale=1)
             return self.feature_store.stored_feats
 
-        prompt_embeds, _neg, pooled, _negp = prompts
-        prompt_embeds = prompt_embeds.repeat(batch_size, 1, 1)                           # reference :272
-        if pooled is not None:
-            pooled = pooled.repeat(batch_size, 1, 1).squeeze(1)                          # :275
+        is_dit = self.version.startswith('pixart')
+        if is_dit:                                                                       # reference :277-283
+            prompt_embeds, prompt_attention_mask, _neg, _negm = prompts
+            if prompt_embeds.shape[0] == 1 and batch_size > 1:
+                prompt_embeds = prompt_embeds.repeat(batch_size, 1, 1)
+                prompt_attention_mask = prompt_attention_mask.repeat(batch_size, 1)
+            pooled = None
+        else:
+            prompt_embeds, _neg, pooled, _negp = prompts
+            prompt_embeds = prompt_embeds.repeat(batch_size, 1, 1)                       # reference :272
+            if pooled is not None:
+                pooled = pooled.repeat(batch_size, 1, 1).squeeze(1)                      # :275
 
         # timestep selection through the scheduler, as the reference does (:288-295)
         self.pipe.scheduler = copy.deepcopy(self.scheduler_backup)
@@ -161,6 +171,11 @@ class FeatureExtractor(nn.Module):
                                          self.img_size // 32, self.img_size // 16)
             self.pipe.unet.extra_hook_ids = [i for ids in attn_ids.values() for i in ids]
 
+        if is_dit:                                                                       # reference :466-474
+            self.pipe.transformer(latent_model_input, encoder_hidden_states=prompt_embeds.to(device),
+                                  encoder_attention_mask=prompt_attention_mask.to(device), timestep=t, return_dict=False,
+                                  added_cond_kwargs={'resolution': None, 'aspect_ratio': None})
+            return self.feature_store.stored_feats
         # ---- the hot path: native UNet forward, hooks written by the kernels (:445-465) ----
         if hasattr(self.pipe.unet, 'shared_ctx'):
             self.pipe.unet.shared_ctx = True      # prompt_embeds.repeat(batch_size, 1, 1) above: one prompt for the whole batch

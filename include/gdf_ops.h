@@ -64,6 +64,9 @@ int gdf_op_small_linear(const float* x, int ldx, int M, int K, const void* W, co
  * attention_processor.py:3311-3313 run as explicit GEMMs; n <= 16384, n % 8 == 0). */
 int gdf_op_softmax_rows(void* x, int ld, int R, int n, float scale, void* stream);
 
+/* PatchEmbed positional table (PixArt): out fp32 [gh*gw][C] = get_2d_sincos_pos_embed(C, (gh, gw), base_size, interpolation_scale). */
+int gdf_op_sincos_pos_embed(float* out, int C, int gh, int gw, int base_size, float interpolation_scale, void* stream);
+
 /* ---- MMDiT (Flux) kernels (reference files cited in csrc/dit.hip, gdf_flux.h) ---- */
 
 /* Dense GEMM with the MMDiT epilogue: v = A W^T + bias; act=1: tanh-GELU; vec != NULL: v = vec_mul ? v * vec[s] : v + vec[s]

@@ -34,7 +34,8 @@ ARCH_PIXART_SIGMA = dict(num_attention_heads=16, attention_head_dim=72, in_chann
                          patch_size=2, sample_size=128, caption_channels=4096, interpolation_scale=2)
 
 
-def tiny_arch(heads=2, num_layers=2, caption_channels=128, sample_size=16):
+def tiny_arch(heads=8, num_layers=2, caption_channels=128, sample_size=16):
+    """heads x 72 must be a multiple of 64 for the native GEMMs (K tiles): 8 heads -> inner dim 576."""
     a = dict(ARCH_PIXART_SIGMA)
     a.update(num_attention_heads=heads, num_layers=num_layers, caption_channels=caption_channels, sample_size=sample_size,
              interpolation_scale=max(sample_size // 64, 1))

@@ -5,7 +5,7 @@
 Runs the reference's Transformer2DModel (feature/diffusers/models/transformers/transformer_2d.py, patched-input +
 ada_norm_single branch) with its BasicTransformerBlock / FeedForward (attention.py), Attention + AttnProcessor2_0
 (attention_processor.py) and FeatureStore / FeatureGatherer, wired with the DiT ids of
-components/feature_extractor.py:268-286, on a tiny DiT (2 blocks, 2 heads x 72) with a ragged text mask.  Un-vendored
+components/feature_extractor.py:268-286, on a tiny DiT (2 blocks, 8 heads x 72) with a ragged text mask.  Un-vendored
 classes (PatchEmbed, AdaLayerNormSingle, PixArtAlphaTextProjection, GELU) come from the scaffolding in
 oracle/ref_blocks.py.  Fixture = inputs, per-tensor weight checksums (weights = synth_params seed 5), output, every hook."""
 import os

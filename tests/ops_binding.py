@@ -21,6 +21,7 @@ OPS = {
     "gdf_op_copy2d": (ci, [vp, vp, ci, vp, ci, ci, ci, vp]),
     "gdf_op_relayout_conv3": (ci, [vp, vp, ci, ci, vp]),
     "gdf_op_relayout_geglu": (ci, [vp, vp, vp, vp, ci, ci, ci, vp]),
+    "gdf_op_sincos_pos_embed": (ci, [vp, ci, ci, ci, ci, fp, vp]),
     "gdf_op_softmax_rows": (ci, [vp, ci, ci, ci, fp, vp]),
     "gdf_op_small_linear": (ci, [vp, ci, ci, ci, vp, vp, ci, ci, ci, vp, ci, vp]),
     "gdf_op_gemm_dit": (ci, [vp, ci, vp, vp, ci, vp, ci, ci, ci, ci, ci, vp, ci, vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, vp]),

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     import __graft_entry__ as G
     G.build()                                              # hipcc cross-compiles gfx950 without a GPU
     lib = ctypes.CDLL(G.LIB)
-    names = _declared("gdf.h") + _declared("gdf_ops.h") + _declared("gdf_flux.h") + _declared("gdf_vae.h")
+    names = _declared("gdf.h") + _declared("gdf_ops.h") + _declared("gdf_flux.h") + _declared("gdf_vae.h") + _declared("gdf_pixart.h")
     assert len(names) >= 40
     for n in names:
         assert hasattr(lib, n), n
@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_binding_covers_header():
     from components import native
-    assert sorted(native.SIGNATURES) == sorted(set(_declared("gdf.h") + _declared("gdf_flux.h") + _declared("gdf_vae.h")))
+    assert sorted(native.SIGNATURES) == sorted(set(_declared("gdf.h") + _declared("gdf_flux.h") + _declared("gdf_vae.h") + _declared("gdf_pixart.h")))
 
 
 def test_native_path_fails_loudly_without_gpu():
