@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Full-size parity check: the TRUE SDXL (or SD1.5) UNet, batch 1, seeded synthetic weights, native HIP path vs the fp32 CPU
+oracle (oracle/unet_ref.py — checker only) on a set of hooks spread over the depth of the network.  Prints the relative L2
+error per hook (the north-star target is 1e-3; the stated test tolerance 3e-3).
+    python tools/parity_full.py [--version xl] [--lat 128] [--threads 32]"""
+import argparse, json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "generic-diffusion-feature_amd"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+import torch
+from oracle import unet_ref as R
+from components.native import NativeUNet
+from helpers import cfg_from_oracle_arch, rel_l2
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--version", default="xl"); ap.add_argument("--lat", type=int, default=0); ap.add_argument("--threads", type=int, default=32)
+a = ap.parse_args()
+torch.set_num_threads(min(a.threads, os.cpu_count() or 1))
+arch = R.ARCHS[a.version]
+lat = a.lat or (128 if a.version == "xl" else 64)
+t0 = time.time(); P = R.synth_params(arch, seed=0); t_w = time.time() - t0
+I = R.synth_inputs(arch, 1, lat, seed=1)
+allids = R.stored_hook_ids(arch)
+pick = [i for i in allids if i.endswith("-vit-out") or i.endswith("res-out") or i.endswith("sampler-out")]
+pick = pick[:: max(1, len(pick) // 14)] + ["unet-out"]
+if a.version == "xl":
+    pick += ["up-level0-repeat0-vit-block7-out", "up-level0-repeat0-vit-block5-out", "up-level1-repeat0-vit-block0-cross-q",
+             "up-level1-repeat0-vit-block0-out"]
+pick = [i for i in allids if i in set(pick)]
+st = R.Store({k: True for k in pick})
+t0 = time.time()
+with torch.no_grad():
+    R.unet_forward(P, arch, I["sample"], I["timestep"], I["ctx"], I.get("text_embeds"), I.get("time_ids"), store=st)
+t_cpu = time.time() - t0
+unet = NativeUNet(cfg_from_oracle_arch(arch), device="cuda:0")
+unet.load_state_dict({k: v.half() for k, v in P.items()})
+cu = lambda k: I[k].cuda() if I.get(k) is not None else None
+_, hooks = unet.forward_raw(cu("sample"), cu("timestep"), cu("ctx"), cu("text_embeds"), cu("time_ids"), hook_ids=pick)
+torch.cuda.synchronize()
+errs = {k: rel_l2(hooks[k], st.feats[k]) for k in st.feats}
+print(json.dumps(dict(version=a.version, latent=lat, weights_s=round(t_w, 1), cpu_forward_s=round(t_cpu, 1),
+                      worst=max(errs.values()), median=sorted(errs.values())[len(errs) // 2])))
+for k, e in errs.items():
+    print(f"# {k:44s} {e:.2e}")
