@@ -221,3 +221,24 @@ def test_feature_extractor_api_flux_synthetic():
         assert v.shape == (2, 256, 8, 8) and v.dtype == torch.float16 and v.is_cuda and torch.isfinite(v.float()).all()
     f1 = df.extract("x", batch_size=1, image=[img], t=10)                                # strength 0.01 -> the last step only
     assert list(f1.keys()) == list(feats.keys()) and f1["vit-block0-out"].shape == (1, 256, 8, 8)
+
+
+def test_flux_early_exit_matches_full_run():
+    from components.native import NativeFluxTransformer
+    arch = FR.tiny_arch(num_layers=2, num_single_layers=3)
+    P = FR.synth_params(arch, seed=4)
+    I = FR.synth_inputs(arch, batch=2, grid=4, n_txt=8, seed=5)
+    ids = ["vit-block1-ffn-inner", "vit-block2-q", "vit-block3-attn-out"]
+    outs = []
+    for ee in (False, True):
+        net = NativeFluxTransformer(arch, device="cuda:0", early_exit=ee)
+        net.load_state_dict({k: v.half() for k, v in P.items()})
+        _, hooks = net.forward_raw(I["hidden_states"].cuda(), I["encoder_hidden_states"].cuda(), I["pooled_projections"].cuda(),
+                                   I["timestep"].cuda(), I["img_ids"].cuda(), I["txt_ids"].cuda(), guidance=I["guidance"].cuda(),
+                                   hook_ids=ids, grid=(4, 4))
+        torch.cuda.synchronize()
+        outs.append((hooks, net.lib.gdf_plan_num_ops(net._plan(2, 4, 4, 8, ids).handle)))
+    (full, n_full), (early, n_early) = outs
+    assert list(full.keys()) == list(early.keys()) == ids and n_early < n_full
+    for k in ids:
+        assert torch.equal(full[k], early[k]), k

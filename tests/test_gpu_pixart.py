@@ -86,3 +86,23 @@ def test_feature_extractor_api_pixart_synthetic():
     assert feats["vit-block1-out"].shape == (2, 576, 8, 8) and feats["vit-block1-ffn-inner"].shape == (2, 2304, 8, 8)
     for v in feats.values():
         assert v.dtype == torch.float16 and v.is_cuda and torch.isfinite(v.float()).all()
+
+
+def test_pixart_early_exit_and_no_mask():
+    from components.native import NativePixArtTransformer
+    arch = PR.tiny_arch(heads=8, num_layers=3)
+    P = PR.synth_params(arch, seed=2)
+    I = PR.synth_inputs(arch, 2, 8, 16, seed=3)                      # all caption tokens valid
+    st = PR.Store({"vit-block1-cross-q": True, "vit-block0-out": True})
+    PR.pixart_forward(P, arch, I["hidden_states"], I["encoder_hidden_states"], I["timestep"], None, st)
+    outs = {}
+    for ee in (False, True):
+        net = NativePixArtTransformer(arch, device="cuda:0", early_exit=ee)
+        net.load_state_dict({k: v.half() for k, v in P.items()})
+        _, hooks = net.forward_raw(I["hidden_states"].cuda(), I["encoder_hidden_states"].cuda(), I["timestep"].cuda(), None,
+                                   hook_ids=list(st.feats.keys()))
+        torch.cuda.synchronize()
+        outs[ee] = hooks
+    assert list(outs[True].keys()) == list(st.feats.keys())
+    for k, ref in st.feats.items():
+        assert torch.equal(outs[True][k], outs[False][k]) and rel_l2(outs[True][k], ref) < TOL, k
