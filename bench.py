@@ -339,6 +339,29 @@ def main():
                             "frac": round(2 * copied / 1e6 / max(h_ms, 1e-9) / HBM_PEAK_GBS, 4) if h_ms > 0 else None,
                             "bytes_per_step": copied, "ms_per_step": round(h_ms, 4)},
         }
+        # ---- hipGraph leg (extra, N = 1): the same K steps replayed as ONE hipGraphLaunch each on a side stream (gdf.h
+        # gdf_plan_set_graph).  `value` above stays the eagerly launched, event-instrumented region the contract asks for;
+        # this shows the launch-bound host cost (process CPU time per step) the graph path removes.
+        if world == 1:
+            side = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    o2 = step()
+                torch.cuda.synchronize()
+                c0 = time.process_time(); t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    o2 = step()
+                c1 = time.process_time()
+                torch.cuda.synchronize(); dt2 = time.perf_counter() - t1
+            c2 = time.process_time()
+            for _ in range(args.steps):
+                o2 = step()
+            c3 = time.process_time()
+            torch.cuda.synchronize()
+            res["hipgraph"] = {"value": round(B * args.steps / dt2, 3), "unit": "images/s",
+                               "host_cpu_ms_per_step": round((c1 - c0) / args.steps * 1e3, 2),
+                               "eager_host_cpu_ms_per_step": round((c3 - c2) / args.steps * 1e3, 2),
+                               "ops_per_step": lib.gdf_plan_num_ops(plan.handle)}
         if args.profile_ops:
             rows = {}
             for name, ms, f_, _k in prof:

@@ -62,6 +62,8 @@ SIGNATURES = {
     "gdf_plan_profile": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.POINTER(C.c_float), C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.c_int]),
+    "gdf_plan_set_graph": (C.c_int, [C.c_void_p, C.c_int]),
+    "gdf_plan_graph_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_long), C.POINTER(C.c_long)]),
     "gdf_plan_op_kernel": (C.c_char_p, [C.c_void_p, C.c_int]),
     "gdf_plan_num_kernel_labels": (C.c_int, [C.c_void_p]),
     "gdf_plan_kernel_label": (C.c_char_p, [C.c_void_p, C.c_int]),
@@ -206,6 +208,8 @@ def config_from_diffusers(uc):
 class _Plan:
     def __init__(self, lib, handle):
         self.lib, self.handle = lib, handle
+        if os.environ.get("GDF_HIP_GRAPH", "1") not in ("", "0"):      # hipGraph replay on non-default streams (gdf.h)
+            lib.gdf_plan_set_graph(handle, 1)
         self.ws_bytes = lib.gdf_plan_workspace_bytes(handle)
         self.hooks = []
         for i in range(lib.gdf_plan_hook_count(handle)):

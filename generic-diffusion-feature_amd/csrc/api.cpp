@@ -214,6 +214,17 @@ int gdf_plan_num_kernel_labels(const gdf_plan* p) { return p ? (int)p->p.labels.
 const char* gdf_plan_kernel_label(const gdf_plan* p, int i) {
   return (p && i >= 0 && i < (int)p->p.labels.size()) ? p->p.labels[i].c_str() : nullptr;
 }
+int gdf_plan_set_graph(gdf_plan* p, int enable) {
+  if (!p) { set_error("null plan"); return GDF_ERR_ARG; }
+  p->p.graph_mode = enable ? 1 : 0;
+  return GDF_OK;
+}
+int gdf_plan_graph_stats(const gdf_plan* p, long* captures, long* launches) {
+  if (!p) { set_error("null plan"); return GDF_ERR_ARG; }
+  if (captures) *captures = p->p.graph_captures;
+  if (launches) *launches = p->p.graph_launches;
+  return GDF_OK;
+}
 int gdf_plan_set_timing(gdf_plan* p, const char* kernel_label) {
   if (!p) { set_error("null plan"); return GDF_ERR_ARG; }
   return plan_set_timing(p->p, kernel_label);

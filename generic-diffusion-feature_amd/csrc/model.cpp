@@ -621,6 +621,7 @@ const char* kernel_label(const char* n) {
 
 Plan::~Plan() {
   for (auto& v : ev) for (auto e : v) hipEventDestroy(e);
+  for (auto& g : graphs) { if (g.exec) hipGraphExecDestroy(g.exec); if (g.graph) hipGraphDestroy(g.graph); }
 }
 
 static void timing_collect(Plan& P, int set) {
@@ -674,7 +675,63 @@ int plan_forward(Plan& P, const Model& m, const void* lat, const float* t, const
   return plan_run(P, b, s, ms, names, flops, cap);
 }
 
+static int run_ops_eager(Plan& P, const Bind& b, hipStream_t s) {
+  for (auto& op : P.ops) {
+    hipError_t e = op.fn(b, s);
+    if (e != hipSuccess) { set_error(std::string("op '") + op.name + "' failed: " + hipGetErrorString(e)); return GDF_ERR_HIP; }
+  }
+  return GDF_OK;
+}
+
+// hipGraph path: the op program is captured once per distinct binding table on the caller's (non-default) stream and
+// replayed with one hipGraphLaunch; ~2400 kernel launches per SDXL forward become one host call.
+static int run_ops_graph(Plan& P, const Bind& b, hipStream_t s) {
+  const size_t nh = P.hooks.size();
+  for (auto& g : P.graphs) {
+    bool same = memcmp(g.key.base, b.base, sizeof b.base) == 0 && memcmp(g.key.f, b.f, sizeof b.f) == 0 && g.hook_ptrs.size() == nh;
+    for (size_t i = 0; same && i < nh; ++i) same = g.hook_ptrs[i] == b.hooks[i];
+    if (same) {
+      g.stamp = ++P.graph_clock; ++P.graph_launches;
+      if (hipGraphLaunch(g.exec, s) != hipSuccess) { set_error("hipGraphLaunch failed"); return GDF_ERR_HIP; }
+      return GDF_OK;
+    }
+  }
+  Plan::GraphEntry g;
+  g.key = b; g.key.hooks = nullptr;
+  for (size_t i = 0; i < nh; ++i) g.hook_ptrs.push_back(b.hooks[i]);
+  if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+    (void)hipGetLastError();
+    return run_ops_eager(P, b, s);                       // e.g. the legacy default stream cannot be captured
+  }
+  const int rc = run_ops_eager(P, b, s);
+  hipError_t e = hipStreamEndCapture(s, &g.graph);
+  if (rc != GDF_OK || e != hipSuccess || !g.graph) {
+    if (g.graph) hipGraphDestroy(g.graph);
+    if (rc == GDF_OK) set_error("hipStreamEndCapture failed");
+    return rc != GDF_OK ? rc : GDF_ERR_HIP;
+  }
+  if (hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0) != hipSuccess) {
+    hipGraphDestroy(g.graph); set_error("hipGraphInstantiate failed"); return GDF_ERR_HIP;
+  }
+  ++P.graph_captures;
+  if (P.graphs.size() >= 4) {                            // evict the least recently used entry
+    size_t lru = 0;
+    for (size_t i = 1; i < P.graphs.size(); ++i) if (P.graphs[i].stamp < P.graphs[lru].stamp) lru = i;
+    hipGraphExecDestroy(P.graphs[lru].exec); hipGraphDestroy(P.graphs[lru].graph);
+    P.graphs.erase(P.graphs.begin() + lru);
+  }
+  g.stamp = ++P.graph_clock; ++P.graph_launches;
+  P.graphs.push_back(g);
+  if (hipGraphLaunch(P.graphs.back().exec, s) != hipSuccess) { set_error("hipGraphLaunch failed"); return GDF_ERR_HIP; }
+  return GDF_OK;
+}
+
 int plan_run(Plan& P, const Bind& b, hipStream_t s, float* ms, const char** names, double* flops, int cap) {
+  if (P.graph_mode && !ms && P.timing_label < 0 && s != nullptr) {
+    if (!P.warmed) { P.warmed = true; return run_ops_eager(P, b, s); }
+    return run_ops_graph(P, b, s);
+  }
+  P.warmed = true;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (ms) { hipEventCreate(&e0); hipEventCreate(&e1); }
   int i = 0;

@@ -141,6 +141,13 @@ struct Plan {
   bool ev_used[EV_RING] = {false, false, false, false};
   int ev_next = 0;
   double t_ms = 0, t_flops = 0; long t_launches = 0;
+  // hipGraph replay of the op program (gdf_plan_set_graph): one captured + instantiated graph per distinct binding table
+  // (the op program is static, only the caller's buffer addresses vary), small LRU
+  struct GraphEntry { Bind key; std::vector<void*> hook_ptrs; hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; long stamp = 0; };
+  int graph_mode = 0;
+  bool warmed = false;                        // first forward runs eagerly (lazy one-time kernel attribute setup)
+  long graph_clock = 0, graph_launches = 0, graph_captures = 0;
+  std::vector<GraphEntry> graphs;
   ~Plan();
 };
 const char* kernel_label(const char* opname);

@@ -112,6 +112,13 @@ int gdf_forward(gdf_plan* p, const void* latents, const float* timesteps, const 
                 const void* add_text_embeds, const float* add_time_ids,
                 void* const* hook_out, void* noise_pred, void* workspace, void* stream);
 
+/* hipGraph replay: with enable != 0 every forward on a NON-default stream is served by one hipGraphLaunch of the plan's op
+ * program, captured once per distinct set of buffer addresses (workspace, inputs, hooks, outputs; LRU of 4) after one eager
+ * warm-up forward.  Calls on the legacy default stream, profiled calls and calls with live kernel timing run eagerly.
+ * Applies to UNet, Flux, PixArt and VAE plans alike. */
+int gdf_plan_set_graph(gdf_plan* p, int enable);
+int gdf_plan_graph_stats(const gdf_plan* p, long* captures, long* launches);
+
 /* Per-op timing of the last plan (diagnostics; synchronises the stream). Fills up to cap entries
  * with milliseconds per op, returns the op count. names[i] points into plan-owned storage. */
 int gdf_plan_profile(gdf_plan* p, const void* latents, const float* timesteps, const void* ctx,
