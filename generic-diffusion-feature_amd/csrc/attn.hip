@@ -284,7 +284,17 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
 // the scores, normalises, feeds O^T += V^T P^T and writes the probability tile: each wave transposes its
 // 32 x 64 tile through LDS so that the global stores are 16 B per lane, 128 contiguous bytes per query row.
 // -------------------------------------------------------------------------------------------------
-template <int D>
+// Workgroup barrier that only orders LDS traffic.  __syncthreads() carries a release fence, i.e. `s_waitcnt vmcnt(0)`:
+// inside the map kernel that made every key tile wait for the round trip of the probability stores just issued
+// (PMC: 54 % of wave cycles parked in s_waitcnt).  The K/V staging only needs the ds_writes to have landed.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// FULL = Sq % 128 == 0 and Sk % 64 == 0 (every SD / SDXL level): no bounds predicates in the loops, so the probability
+// stores are straight-line code and the compiler's waitcnt insertion can count them (with the predicated form every loop
+// iteration started with `s_waitcnt vmcnt(0)`, i.e. waited for the store round trip of the previous tile).
+template <int D, bool FULL>
 __global__ __launch_bounds__(256, 2) void attn_map_kernel(const AttnParams p) {
   constexpr int DQK = (D + 15) / 16 * 16;
   constexpr int DV = (D + 31) / 32 * 32;
@@ -335,7 +345,7 @@ __global__ __launch_bounds__(256, 2) void attn_map_kernel(const AttnParams p) {
       const int row = idx / CPR, ch = idx - row * CPR;
       const int kv = t * KT + row;
       f16x8 kk = {0, 0, 0, 0, 0, 0, 0, 0}, vv = kk;
-      if (idx < KT * CPR && kv < p.Sk && ch * 8 < D) {
+      if (((KT * CPR) % 256 == 0 || idx < KT * CPR) && (FULL || kv < p.Sk) && ch * 8 < D) {
         kk = *(const f16x8*)(kbase + (size_t)kv * p.ldk + ch * 8);
         if (with_v) vv = *(const f16x8*)(vbase + (size_t)kv * p.ldv + ch * 8);
       }
@@ -366,7 +376,7 @@ __global__ __launch_bounds__(256, 2) void attn_map_kernel(const AttnParams p) {
           s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[st], s[kb], 0, 0, 0);
         }
       }
-    if ((t + 1) * KT > p.Sk) {
+    if (!FULL && (t + 1) * KT > p.Sk) {
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -380,7 +390,7 @@ __global__ __launch_bounds__(256, 2) void attn_map_kernel(const AttnParams p) {
   // ---------------- pass A: row max and row sum ----------------
   float m_run = -INFINITY, l_run = 0.f;
   gload(0, false); lstore(0, false);
-  __syncthreads();
+  lds_barrier();
   if (ntiles > 1) gload(1, false);
   for (int t = 0; t < ntiles; ++t) {
     f32x16 s[2];
@@ -400,7 +410,7 @@ __global__ __launch_bounds__(256, 2) void attn_map_kernel(const AttnParams p) {
     l_run = l_run * __builtin_amdgcn_exp2f(m_run - m_new) + psum;
     m_run = m_new;
     if (t + 1 < ntiles) lstore((t + 1) & 1, false);
-    __syncthreads();
+    lds_barrier();
     if (t + 2 < ntiles) gload(t + 2, false);
   }
   const float inv_l = 1.0f / half_sum(l_run);
@@ -415,9 +425,12 @@ __global__ __launch_bounds__(256, 2) void attn_map_kernel(const AttnParams p) {
   _Float16* mbase = p.map + (((size_t)b * p.heads + head) * p.Sq) * p.Sk;
   const bool vec_ok = (p.Sk & 7) == 0;            // 16-byte aligned probability rows
   gload(0, true); lstore(0, true);
-  __syncthreads();
-  if (ntiles > 1) gload(1, true);
+  lds_barrier();
   for (int t = 0; t < ntiles; ++t) {
+    // K/V of tile t+1 are requested at the top and staged at the bottom of the SAME iteration: no load is pending across
+    // the loop edge, so the only wait on the probability stores is the one the hardware needs (with loads carried over the
+    // back edge the compiler started every iteration with `s_waitcnt vmcnt(0)`, i.e. after the previous tile's stores)
+    if (t + 1 < ntiles) gload(t + 1, true);
     const _Float16* cV = sV[t & 1];
     f32x16 s[2];
     scores(sK[t & 1], t, s);
@@ -450,7 +463,9 @@ __global__ __launch_bounds__(256, 2) void attn_map_kernel(const AttnParams p) {
     for (int it = 0; it < 4; ++it) {
       const int row = it * 8 + (lane >> 3), ch = lane & 7;
       const int q = q0 + row, kv = t * KT + ch * 8;
-      if (q < p.Sq && kv < p.Sk) {
+      if (FULL) {
+        *(f16x8*)(mbase + (size_t)q * p.Sk + kv) = *(const f16x8*)(sPw + row * PLD + ch * 8);
+      } else if (q < p.Sq && kv < p.Sk) {
         const f16x8 v8 = *(const f16x8*)(sPw + row * PLD + ch * 8);
         _Float16* dst = mbase + (size_t)q * p.Sk + kv;
         if (vec_ok) {
@@ -475,8 +490,7 @@ __global__ __launch_bounds__(256, 2) void attn_map_kernel(const AttnParams p) {
         o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf.h, pf[s4], o[db], 0, 0, 0);
       }
     if (t + 1 < ntiles) lstore((t + 1) & 1, true);
-    __syncthreads();
-    if (t + 2 < ntiles) gload(t + 2, true);
+    lds_barrier();
   }
   if (q_ok) {
     _Float16* op = p.o + ((size_t)b * p.Sq + q_row) * p.ldo + head * D;
@@ -500,7 +514,8 @@ static hipError_t launch_d(const AttnParams& p, hipStream_t s) {
   if (p.map && (p.seg_T || p.kv_len)) return hipErrorInvalidValue;     // '-map' hooks of the MMDiT / masked layouts: not built
   if (p.map) {
     const int nqb = (p.Sq + 127) / 128;
-    hipLaunchKernelGGL((attn_map_kernel<D>), dim3(p.B * p.heads * nqb), dim3(256), 0, s, p);
+    if (p.Sq % 128 == 0 && p.Sk % KT == 0) hipLaunchKernelGGL((attn_map_kernel<D, true>), dim3(p.B * p.heads * nqb), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((attn_map_kernel<D, false>), dim3(p.B * p.heads * nqb), dim3(256), 0, s, p);
   } else {
     // 64 query rows per wave (every K / V fragment feeds two MFMAs) when the sequence is long and the
     // accumulators fit (D <= 64); 32 rows per wave otherwise
