@@ -239,6 +239,7 @@ struct PlanBuilder {
     Epi e = e0;
     const Ref W = wt(w.w + w_off_bytes);
     GemmParams gk{}; gk.M = (int)M; gk.N = N; gk.K = K; gk.mode = A_DENSE; gk.geglu = e.geglu; gk.bn = e.bn; gk.dit = e.dit;
+    gk.res32 = e.has_r32 ? (const float*)1 : nullptr;      // tile selection looks at the epilogue form (never dereferenced)
     op(name, 2.0 * (double)M * N * K, [=](const Bind& b, hipStream_t s) {
       GemmParams g{};
       g.A = (const half_t*)b.p(A); g.lda = lda; g.a_bytes = (uint32_t)(((size_t)M - 1) * lda * 2 + (size_t)K * 2);

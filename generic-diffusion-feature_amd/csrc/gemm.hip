@@ -561,6 +561,10 @@ static int pick_variant(const GemmParams& p) {
     if (p.N % 320 == 0 && p.K >= 5760 && tiles320 >= 128) return 320;     // 1070-1236 TFLOP/s
     return (p.N % 160 == 0) ? 160 : 128;                                   // 1000-1107
   }
+  // short-K GEMMs with the fp32 residual epilogue (attention out-projections: 10 B/element of epilogue traffic against
+  // 20 K-tiles of MFMA work) fill the chip in ONE round of 256x320 tiles, so main loop and epilogue traffic never overlap;
+  // 128x160 tiles run 2 workgroups per CU and 2+ rounds (80 vs 89 us at 16384 x 1280 x 1280)
+  if (p.res32 && p.K <= 1536 && p.N % 160 == 0 && tiles320 <= 512) return 160;
   if (p.N % 320 == 0 && tiles320 >= 128) return 320;                       // qkv 1049, ff_out 1009, attn2_q 1046, shortcut 1044
   if (p.N % 160 == 0 && p.K >= 1024) return 160;
   if ((long)p.M * p.N >= (1L << 26) && tiles256 >= 512) return 256;        // short-K, large MxN (qkv @ C=640): 712 vs 642
