@@ -139,7 +139,8 @@ def main(argv=None):
     with open(args.prompt_file, 'r') as f:
         prompt_text = f.read()
     print('prompt:', prompt_text)
-    prompts = df.encode_prompt(prompt_text)
+    # reference extract_feature.py:81-82: flux / hunyuan pipelines take the raw prompt text
+    prompts = prompt_text if args.version in ('flux', 'hunyuan') else df.encode_prompt(prompt_text)
 
     writer = HostWriter(args)
     with torch.no_grad():
