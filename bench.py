@@ -172,7 +172,8 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=16, help="images per GPU per step")
-    ap.add_argument("--version", default="xl", choices=("xl", "1-5"))
+    ap.add_argument("--version", default="xl", choices=("xl", "1-5", "flux"),
+                    help="xl = BASELINE headline (configs[2]); 1-5 = configs[1]; flux = configs[4] (single GPU, tools/bench_flux.py)")
     ap.add_argument("--img", type=int, default=0, help="image size (default 1024 for xl, 512 for 1-5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fp16-stream", action="store_true", help="disable the fp32 master of the residual stream")
@@ -180,6 +181,12 @@ def main():
     ap.add_argument("--profile-ops", action="store_true", help="print a per-op time table (extra synchronising pass)")
     args = ap.parse_args()
 
+    if args.version == "flux":                    # BASELINE configs[4]: same JSON schema, single GPU (tools/bench_flux.py)
+        sys.argv = [sys.argv[0], "--steps", str(args.steps), "--warmup", str(args.warmup)] + \
+                   (["--batch", str(args.batch)] if args.batch != 16 else []) + (["--no-cpu-baseline"] if args.no_cpu_baseline else [])
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_flux
+        return bench_flux.main()
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     # test hook: exercise the multi-rank code path on a 1-GPU box (all ranks on cuda:0, gloo instead of RCCL)
