@@ -559,7 +559,8 @@ static int pick_variant(const GemmParams& p) {
   }
   if (p.mode != A_DENSE) {                                                 // convs (K = 9 Cin is long)
     if (p.N % 320 == 0 && p.K >= 5760 && tiles320 >= 128) return 320;     // 1070-1236 TFLOP/s
-    return (p.N % 160 == 0) ? 160 : 128;                                   // 1000-1107
+    if (p.N % 160 == 0) return 160;                                        // 1000-1107
+    return (p.N <= 128 && p.M >= (1 << 20)) ? 256 : 128;                   // VAE level-0 convs (N = 128, 4 M pixels): 797 vs 697
   }
   // short-K GEMMs with the fp32 residual epilogue (attention out-projections: 10 B/element of epilogue traffic against
   // 20 K-tiles of MFMA work) fill the chip in ONE round of 256x320 tiles, so main loop and epilogue traffic never overlap;
