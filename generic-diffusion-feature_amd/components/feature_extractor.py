@@ -128,14 +128,16 @@ def unet_layer_ids(cfg, include_dropped=False):
 def flux_layer_ids(cfg):
     """Every hook id of a Flux MMDiT in execution order: the flux branch of the reference's prepare_feature_extractor
     (:98-123) combined with the gather sites (transformer_flux.py:107-108,196-207; attention_processor.py:2280-2291,
-    2355-2361; attention.py:1255-1257).  Single blocks continue the double-block numbering."""
+    2355-2361; attention.py:1255-1257; the `*-map` ids come from the eager FluxAttnStoreProcessor, components/attention.py:
+    493-502, which the reference installs as soon as one map id is requested).  Single blocks continue the numbering."""
     ids = []
     for i in range(cfg["num_layers"]):
         b = f"vit-block{i}"
-        ids += [f"{b}-q", f"{b}-k", f"{b}-v", f"{b}-attn-out", f"{b}-norm-out", f"{b}-ffn-inner", f"{b}-out"]
+        ids += [f"{b}-q", f"{b}-k", f"{b}-v", f"{b}-cross-map", f"{b}-self-map", f"{b}-attn-out", f"{b}-norm-out",
+                f"{b}-ffn-inner", f"{b}-out"]
     for j in range(cfg["num_single_layers"]):
         b = f"vit-block{cfg['num_layers'] + j}"
-        ids += [f"{b}-q", f"{b}-k", f"{b}-v", f"{b}-attn-out", f"{b}-out"]
+        ids += [f"{b}-q", f"{b}-k", f"{b}-v", f"{b}-cross-map", f"{b}-self-map", f"{b}-attn-out", f"{b}-out"]
     return ids
 
 

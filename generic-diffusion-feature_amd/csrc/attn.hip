@@ -323,7 +323,7 @@ __global__ __launch_bounds__(256, 2) void attn_map_kernel(const AttnParams p) {
 
   f16x8 qf[NS];
   {
-    const _Float16* qp = p.q + ((size_t)b * p.Sq + (q_ok ? q_row : 0)) * p.ldq + head * D;
+    const _Float16* qp = p.q + seg_row(b, q_ok ? q_row : 0, p.Sq, p.seg_T, p.B, p.Sq) * p.ldq + head * D;
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
       const int d0 = 16 * s + 8 * lh;
@@ -333,8 +333,8 @@ __global__ __launch_bounds__(256, 2) void attn_map_kernel(const AttnParams p) {
     }
   }
   const float sl2 = p.scale * 1.44269504088896340736f;
-  const _Float16* kbase = p.k + (size_t)b * p.kv_bstride * p.ldk + head * D;
-  const _Float16* vbase = p.v + (size_t)b * p.kv_bstride * p.ldv + head * D;
+  const _Float16* kbase = p.k + head * D;
+  const _Float16* vbase = p.v + head * D;
   const int ntiles = (p.Sk + KT - 1) / KT;
 
   f16x8 kreg[NCH], vreg[NCH];
@@ -346,8 +346,9 @@ __global__ __launch_bounds__(256, 2) void attn_map_kernel(const AttnParams p) {
       const int kv = t * KT + row;
       f16x8 kk = {0, 0, 0, 0, 0, 0, 0, 0}, vv = kk;
       if (((KT * CPR) % 256 == 0 || idx < KT * CPR) && (FULL || kv < p.Sk) && ch * 8 < D) {
-        kk = *(const f16x8*)(kbase + (size_t)kv * p.ldk + ch * 8);
-        if (with_v) vv = *(const f16x8*)(vbase + (size_t)kv * p.ldv + ch * 8);
+        const size_t r = seg_row(b, kv, p.kv_bstride, p.seg_T, p.B, p.Sk);
+        kk = *(const f16x8*)(kbase + r * p.ldk + ch * 8);
+        if (with_v) vv = *(const f16x8*)(vbase + r * p.ldv + ch * 8);
       }
       kreg[c] = kk; vreg[c] = vv;
     }
@@ -422,8 +423,13 @@ __global__ __launch_bounds__(256, 2) void attn_map_kernel(const AttnParams p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
   _Float16* sPw = sP[wave];
-  _Float16* mbase = p.map + (((size_t)b * p.heads + head) * p.Sq) * p.Sk;
-  const bool vec_ok = (p.Sk & 7) == 0;            // 16-byte aligned probability rows
+  // sample-major: map = (B, heads, Sq, Sk).  MMDiT joint layout (seg_T = T > 0, FluxAttnStoreProcessor,
+  // components/attention.py:493-502): only the image queries are kept, split by key into
+  //   map  = `self-map`  (B, heads, Sq - T, Sk - T)      map2 = `cross-map` (B, heads, Sq - T, T)      (either may be NULL)
+  const int T = p.seg_T, Si = p.Sq - T;
+  _Float16* mbase = p.map ? p.map + (((size_t)b * p.heads + head) * (T ? Si : p.Sq)) * (T ? Si : p.Sk) : nullptr;
+  _Float16* m2base = (T && p.map2) ? p.map2 + (((size_t)b * p.heads + head) * Si) * T : nullptr;
+  const bool vec_ok = T ? (((T | Si) & 7) == 0) : ((p.Sk & 7) == 0);            // 16-byte aligned probability rows
   gload(0, true); lstore(0, true);
   lds_barrier();
   for (int t = 0; t < ntiles; ++t) {
@@ -463,15 +469,26 @@ __global__ __launch_bounds__(256, 2) void attn_map_kernel(const AttnParams p) {
     for (int it = 0; it < 4; ++it) {
       const int row = it * 8 + (lane >> 3), ch = lane & 7;
       const int q = q0 + row, kv = t * KT + ch * 8;
-      if (FULL) {
-        *(f16x8*)(mbase + (size_t)q * p.Sk + kv) = *(const f16x8*)(sPw + row * PLD + ch * 8);
-      } else if (q < p.Sq && kv < p.Sk) {
+      if (T == 0) {
+        if (FULL) {
+          *(f16x8*)(mbase + (size_t)q * p.Sk + kv) = *(const f16x8*)(sPw + row * PLD + ch * 8);
+        } else if (q < p.Sq && kv < p.Sk) {
+          const f16x8 v8 = *(const f16x8*)(sPw + row * PLD + ch * 8);
+          _Float16* dst = mbase + (size_t)q * p.Sk + kv;
+          if (vec_ok) {
+            *(f16x8*)dst = v8;
+          } else {
+            for (int e = 0; e < 8; ++e) if (kv + e < p.Sk) dst[e] = v8[e];
+          }
+        }
+      } else if (q >= T && q < p.Sq && kv < p.Sk) {          // T % 8 == 0 (host-checked): an 8-key chunk never straddles T
         const f16x8 v8 = *(const f16x8*)(sPw + row * PLD + ch * 8);
-        _Float16* dst = mbase + (size_t)q * p.Sk + kv;
-        if (vec_ok) {
-          *(f16x8*)dst = v8;
-        } else {
-          for (int e = 0; e < 8; ++e) if (kv + e < p.Sk) dst[e] = v8[e];
+        _Float16* dst = (kv < T) ? (m2base ? m2base + (size_t)(q - T) * T + kv : nullptr)
+                                 : (mbase ? mbase + (size_t)(q - T) * Si + (kv - T) : nullptr);
+        if (dst) {
+          const int lim = (kv < T) ? T : p.Sk;
+          if (vec_ok && kv + 8 <= lim) *(f16x8*)dst = v8;
+          else for (int e = 0; e < 8; ++e) if (kv + e < lim) dst[e] = v8[e];
         }
       }
     }
@@ -493,7 +510,7 @@ __global__ __launch_bounds__(256, 2) void attn_map_kernel(const AttnParams p) {
     lds_barrier();
   }
   if (q_ok) {
-    _Float16* op = p.o + ((size_t)b * p.Sq + q_row) * p.ldo + head * D;
+    _Float16* op = p.o + seg_row(b, q_row, p.Sq, p.seg_T, p.B, p.Sq) * p.ldo + head * D;
 #pragma unroll
     for (int db = 0; db < NDB; ++db)
 #pragma unroll
@@ -511,10 +528,12 @@ __global__ __launch_bounds__(256, 2) void attn_map_kernel(const AttnParams p) {
 
 template <int D>
 static hipError_t launch_d(const AttnParams& p, hipStream_t s) {
-  if (p.map && (p.seg_T || p.kv_len)) return hipErrorInvalidValue;     // '-map' hooks of the MMDiT / masked layouts: not built
-  if (p.map) {
+  const bool maps = p.map || p.map2;
+  if (maps && p.kv_len) return hipErrorInvalidValue;                    // '-map' hooks of the masked (PixArt) layout: not built
+  if (maps && p.seg_T && (p.seg_T & 7)) return hipErrorInvalidValue;    // an 8-key chunk must not straddle the text / image boundary
+  if (maps) {
     const int nqb = (p.Sq + 127) / 128;
-    if (p.Sq % 128 == 0 && p.Sk % KT == 0) hipLaunchKernelGGL((attn_map_kernel<D, true>), dim3(p.B * p.heads * nqb), dim3(256), 0, s, p);
+    if (p.Sq % 128 == 0 && p.Sk % KT == 0 && !p.seg_T) hipLaunchKernelGGL((attn_map_kernel<D, true>), dim3(p.B * p.heads * nqb), dim3(256), 0, s, p);
     else hipLaunchKernelGGL((attn_map_kernel<D, false>), dim3(p.B * p.heads * nqb), dim3(256), 0, s, p);
   } else {
     // 64 query rows per wave (every K / V fragment feeds two MFMAs) when the sequence is long and the

@@ -123,7 +123,9 @@ struct FB : PlanBuilder {   // Flux op program
                                  (const float*)b.p(cs), (const float*)b.p(sn), pos0, rps, s);
     });
   }
-  void joint_attention(size_t qkv, Ref o, int ldo) {
+  // cross_slot / self_slot: hook slots of `cross-map` (B, heads, S, T) / `self-map` (B, heads, S, S) or -1
+  // (FluxAttnStoreProcessor, components/attention.py:493-502: image queries only, split by key)
+  void joint_attention(size_t qkv, Ref o, int ldo, int cross_slot = -1, int self_slot = -1) {
     const int C = f.C, D = f.D, heads = C / D, Bq = Bn, Sj = T + S, Tq = T;
     const Ref q = ws(qkv), k = ws(qkv + (size_t)C * 2), v = ws(qkv + (size_t)2 * C * 2);
     op("joint_attn", 4.0 * (double)Bn * heads * Sj * (double)Sj * D, [=](const Bind& b, hipStream_t s) {
@@ -131,9 +133,19 @@ struct FB : PlanBuilder {   // Flux op program
       a.q = (const half_t*)b.p(q); a.ldq = 3 * C; a.k = (const half_t*)b.p(k); a.ldk = 3 * C;
       a.v = (const half_t*)b.p(v); a.ldv = 3 * C; a.o = (half_t*)b.p(o); a.ldo = ldo;
       a.B = Bq; a.heads = heads; a.Sq = Sj; a.Sk = Sj; a.D = D; a.scale = 1.0f / sqrtf((float)D);
-      a.kv_bstride = Sj; a.seg_T = Tq; a.map = nullptr;
+      a.kv_bstride = Sj; a.seg_T = Tq;
+      a.map = self_slot >= 0 ? (half_t*)b.hook(self_slot) : nullptr;
+      a.map2 = cross_slot >= 0 ? (half_t*)b.hook(cross_slot) : nullptr;
       return launch_attention(a, s);
     });
+    if (cross_slot >= 0) hook_done();
+    if (self_slot >= 0) hook_done();
+  }
+  // ids are emitted in the reference's gather order: cross-map, then self-map
+  void map_slots(const std::string& bid, int& cross_slot, int& self_slot) {
+    const int heads = f.C / f.D;
+    cross_slot = want_map(bid + "-cross-map", heads, S, T);
+    self_slot = want_map(bid + "-self-map", heads, S, S);
   }
   Epi plain(const LinW& w) { Epi e; e.dit = 1; e.bias = wt(w.b); e.has_bias = w.has_bias; return e; }
   // stream[r0..] += gate * (A W^T + bias)
@@ -246,7 +258,9 @@ struct FB : PlanBuilder {   // Flux op program
       qk_norm_rope(qkv, 0, nt, w.cnq, w.cnk, 0, T);                                  // norm_added_q/k, text positions
       qk_norm_rope(qkv, nt, ns, w.nq, w.nk, T, S);                                   // norm_q/k, image positions
       const size_t ao = tmp(ln_b);
-      joint_attention(qkv, ws(ao), C);
+      int mc = -1, ms = -1;
+      map_slots(bid, mc, ms);
+      joint_attention(qkv, ws(ao), C, mc, ms);
       untmp(qkv, qkv_b);
       { Epi e = gated(w.o, nt, w.mod + 2 * C, S);                                    // hidden += gate_msa * to_out(attn)
         e.aux_slot = want(bid + "-attn-out", C, gh, gw); e.ldaux = C;                // :2355-2356 (pre-gate projection)
@@ -299,7 +313,9 @@ struct FB : PlanBuilder {   // Flux op program
       if (stop) { untmp(qkv, qkv_b); untmp(cat, nr * CK * 2); break; }
       qk_norm_rope(qkv, 0, nt, w.nq, w.nk, 0, T);
       qk_norm_rope(qkv, nt, ns, w.nq, w.nk, T, S);
-      joint_attention(qkv, ws(cat), CK);                                             // cat([attn_output, mlp], 2) in place (:103)
+      int mc = -1, ms = -1;
+      map_slots(bid, mc, ms);
+      joint_attention(qkv, ws(cat), CK, mc, ms);                                     // cat([attn_output, mlp], 2) in place (:103)
       untmp(qkv, qkv_b);
       hook_rows16(bid + "-attn-out", ws(cat + nt * CK * 2), CK, C);                  // :2360-2361
       { Epi e = gated(w.out, 0, w.mod + 2 * C, T, nt, S); gemm("proj_out", ws(cat), CK, nr, w.out, C, CK, 0, e); }   // :104-106
@@ -350,6 +366,8 @@ int flux_plan_build(const Model& m, Plan& P, int batch, int img_h, int img_w, in
                     const PlanOpts& opts, bool dry) {
   if (m.kind != 1) { set_error("not a Flux model"); return GDF_ERR_ARG; }
   if (batch < 1 || img_h < 1 || img_w < 1 || n_txt < 1) { set_error("batch, token grid and n_txt must be positive"); return GDF_ERR_ARG; }
+  for (int i = 0; i < n_ids; ++i)
+    if (ids[i] && strstr(ids[i], "-map") && (n_txt % 8)) { set_error("'-map' hooks need n_txt % 8 == 0"); return GDF_ERR_UNSUPPORTED; }
   const size_t rows = (size_t)batch * ((size_t)img_h * img_w + n_txt);
   if (rows * (size_t)(m.flux.C + m.flux.hid) * 2 >= (1ull << 31)) {      // 32-bit buffer offsets of the GEMM A operand
     set_error("batch * tokens too large for 32-bit buffer offsets; split the batch"); return GDF_ERR_UNSUPPORTED;

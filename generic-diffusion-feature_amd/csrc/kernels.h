@@ -81,7 +81,8 @@ struct AttnParams {
   int B, heads, Sq, Sk, D;
   int kv_bstride;        // rows between consecutive samples' K/V (Sk normally; 0 = all samples share one K/V set)
   float scale;
-  half_t* map;           // optional: attention probabilities (B, heads, Sq, Sk) fp16 ('-map' hooks)
+  half_t* map;           // optional: attention probabilities (B, heads, Sq, Sk) fp16 ('-map' hooks); seg_T > 0: `self-map`
+  half_t* map2;          // seg_T > 0 only: `cross-map` (B, heads, Sq - seg_T, seg_T) (image queries x text keys)
   const int* kv_len;     // optional [B]: keys [kv_len[b], Sk) of sample b are masked out (prefix text mask)
   int seg_T;             // > 0: MMDiT joint sequence, region-major rows [B x seg_T text][B x (Sq - seg_T) image] (Sq == Sk)
 };

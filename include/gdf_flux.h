@@ -8,8 +8,10 @@
  *     diffusion_feature.py:246-254
  *   - the side effects of every `feature_gatherer.gather(...)` in those files (FeatureStore.store,
  *     components/feature_extractor.py:31-76) with the flux id scheme of components/feature_extractor.py:98-123:
- *       vit-block{i}-{q,k,v,attn-out,norm-out,ffn-inner,out}   i <  num_layers          (double blocks)
- *       vit-block{i}-{q,k,v,attn-out,out}                      i >= num_layers          (single blocks)
+ *       vit-block{i}-{q,k,v,cross-map,self-map,attn-out,norm-out,ffn-inner,out}   i <  num_layers   (double blocks)
+ *       vit-block{i}-{q,k,v,cross-map,self-map,attn-out,out}                      i >= num_layers   (single blocks)
+ *     `cross-map` (B, heads, S_img, n_txt) / `self-map` (B, heads, S_img, S_img): softmax probabilities of the image queries
+ *     (FluxAttnStoreProcessor, components/attention.py:404-527), contiguous fp16; they need n_txt % 8 == 0.
  *
  * Handles (gdf_model / gdf_plan) and every model / plan query, hook-info, workspace and timing function are the ones
  * of gdf.h; only creation and the forward call differ.  Same conventions: plain C, int status (0 = ok), caller owns

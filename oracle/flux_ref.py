@@ -184,8 +184,10 @@ def time_text_embed(P, arch, timestep, guidance, pooled):
 # --------------------------------------------------------------------------- #
 # in-tree blocks
 # --------------------------------------------------------------------------- #
-def flux_attention(P, pfx, arch, x, enc, cos, sin, store, mid, text_len):
-    """FluxAttnProcessor2_0.__call__ (attention_processor.py:2266-2362)."""
+def flux_attention(P, pfx, arch, x, enc, cos, sin, store, mid, text_len, want_map=False):
+    """FluxAttnProcessor2_0.__call__ (attention_processor.py:2266-2362); with want_map the eager FluxAttnStoreProcessor
+    (components/attention.py:404-527): softmax(q k^T / sqrt(d)) materialised, hooks `cross-map` = probs[:, :, T:, :T] and
+    `self-map` = probs[:, :, T:, T:] (image queries only), in that order, before the output projections (:493-502)."""
     heads = arch["num_attention_heads"]
     b = x.shape[0]
     q = _lin(P, pfx + ".to_q", x); k = _lin(P, pfx + ".to_k", x); v = _lin(P, pfx + ".to_v", x)
@@ -204,7 +206,14 @@ def flux_attention(P, pfx, arch, x, enc, cos, sin, store, mid, text_len):
         eq = rms_norm(eq, P[pfx + ".norm_added_q.weight"]); ek = rms_norm(ek, P[pfx + ".norm_added_k.weight"])
         q = torch.cat([eq, q], dim=2); k = torch.cat([ek, k], dim=2); v = torch.cat([ev, v], dim=2)   # :2327-2329
     q = apply_rope(q, cos, sin); k = apply_rope(k, cos, sin)             # :2331-2335
-    o = F.scaled_dot_product_attention(q, k, v)                           # :2337-2339
+    if want_map:
+        tl = enc.shape[1] if enc is not None else text_len
+        probs = torch.softmax(torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(d), dim=-1)   # components/attention.py:265-292
+        store.gather(mid, probs[:, :, tl:, :tl], "cross-map")
+        store.gather(mid, probs[:, :, tl:, tl:], "self-map")
+        o = torch.matmul(probs, v)
+    else:
+        o = F.scaled_dot_product_attention(q, k, v)                       # :2337-2339
     o = o.transpose(1, 2).reshape(b, -1, heads * d)
     if enc is not None:
         n_enc = enc.shape[1]
@@ -225,7 +234,7 @@ def feed_forward(P, pfx, x, store=None, mid=None):
     return _lin(P, pfx + ".net.2", h)
 
 
-def double_block(P, i, arch, x, enc, temb, cos, sin, store):
+def double_block(P, i, arch, x, enc, temb, cos, sin, store, want_map=False):
     """FluxTransformerBlock.forward (transformer_flux.py:167-226)."""
     p = f"transformer_blocks.{i}"; mid = f"vit-block{i}"
     mod = _lin(P, p + ".norm1.linear", F.silu(temb))                      # AdaLayerNormZero
@@ -234,7 +243,7 @@ def double_block(P, i, arch, x, enc, temb, cos, sin, store):
     cmod = _lin(P, p + ".norm1_context.linear", F.silu(temb))
     csh_a, csc_a, cg_a, csh_m, csc_m, cg_m = cmod.chunk(6, dim=1)
     ne = layer_norm(enc) * (1 + csc_a[:, None]) + csh_a[:, None]
-    ao, eo = flux_attention(P, p + ".attn", arch, nx, ne, cos, sin, store, mid, None)
+    ao, eo = flux_attention(P, p + ".attn", arch, nx, ne, cos, sin, store, mid, None, want_map)
     x = x + g_a[:, None] * ao                                             # :191-192
     nx = layer_norm(x) * (1 + sc_m[:, None]) + sh_m[:, None]             # :194-195
     store.gather(mid, nx, "norm-out")                                     # :196-197
@@ -247,7 +256,7 @@ def double_block(P, i, arch, x, enc, temb, cos, sin, store):
     return enc, x
 
 
-def single_block(P, i, idx, arch, x, temb, cos, sin, store, text_len):
+def single_block(P, i, idx, arch, x, temb, cos, sin, store, text_len, want_map=False):
     """FluxSingleTransformerBlock.forward (transformer_flux.py:86-112); `idx` continues the double-block numbering
     (components/feature_extractor.py:112-122)."""
     p = f"single_transformer_blocks.{i}"; mid = f"vit-block{idx}"
@@ -255,7 +264,7 @@ def single_block(P, i, idx, arch, x, temb, cos, sin, store, text_len):
     sh, sc, gate = mod.chunk(3, dim=1)
     nx = layer_norm(x) * (1 + sc[:, None]) + sh[:, None]
     mlp = F.gelu(_lin(P, p + ".proj_mlp", nx), approximate="tanh")       # :95
-    ao = flux_attention(P, p + ".attn", arch, nx, None, cos, sin, store, mid, text_len)
+    ao = flux_attention(P, p + ".attn", arch, nx, None, cos, sin, store, mid, text_len, want_map)
     h = gate[:, None] * _lin(P, p + ".proj_out", torch.cat([ao, mlp], dim=2))   # :103-105
     x = x + h
     store.gather(mid, x[:, text_len:], "out")                             # :107-108
@@ -263,9 +272,13 @@ def single_block(P, i, idx, arch, x, temb, cos, sin, store, text_len):
 
 
 def flux_forward(P, arch, hidden_states, encoder_hidden_states, pooled_projections, timestep, img_ids, txt_ids,
-                 guidance=None, store=None):
-    """FluxTransformer2DModel.forward (transformer_flux.py:414-603). Returns (B, S, in_channels)."""
+                 guidance=None, store=None, want_map=None):
+    """FluxTransformer2DModel.forward (transformer_flux.py:414-603). Returns (B, S, in_channels).
+    want_map=None follows the reference: any requested '*map*' id (or accept-all) swaps in the eager processor
+    (diffusion_feature.py:72-77)."""
     store = store if store is not None else Store({"__none__": True})
+    if want_map is None:
+        want_map = store.accept_all or any("map" in k and v for k, v in store.to_store.items())
     x = _lin(P, "x_embedder", hidden_states)                              # :470
     t = timestep.float() * 1000                                           # :472
     g = guidance.float() * 1000 if guidance is not None else None
@@ -273,11 +286,11 @@ def flux_forward(P, arch, hidden_states, encoder_hidden_states, pooled_projectio
     enc = _lin(P, "context_embedder", encoder_hidden_states)              # :483
     cos, sin = rope_freqs(torch.cat([txt_ids, img_ids], dim=0), arch["axes_dims_rope"])   # :498-499
     for i in range(arch["num_layers"]):
-        enc, x = double_block(P, i, arch, x, enc, temb, cos, sin, store)
+        enc, x = double_block(P, i, arch, x, enc, temb, cos, sin, store, want_map)
     text_len = enc.shape[1]
     x = torch.cat([enc, x], dim=1)                                        # :549
     for i in range(arch["num_single_layers"]):
-        x = single_block(P, i, arch["num_layers"] + i, arch, x, temb, cos, sin, store, text_len)
+        x = single_block(P, i, arch["num_layers"] + i, arch, x, temb, cos, sin, store, text_len, want_map)
     x = x[:, text_len:]                                                   # :591
     mod = _lin(P, "norm_out.linear", F.silu(temb))                        # AdaLayerNormContinuous: scale, shift
     scale, shift = mod.chunk(2, dim=1)
@@ -285,15 +298,17 @@ def flux_forward(P, arch, hidden_states, encoder_hidden_states, pooled_projectio
     return _lin(P, "proj_out", x)                                         # :594
 
 
-def hook_ids(arch):
-    """Every gather() id in execution order (== what an accept-all FeatureStore keeps; nothing is dropped)."""
+def hook_ids(arch, maps=False):
+    """Every gather() id in execution order; maps=True adds the eager processor's `cross-map` / `self-map`
+    (what an accept-all FeatureStore keeps: the reference then installs FluxAttnStoreProcessor, diffusion_feature.py:72-77)."""
     ids = []
+    mp = lambda b: [b + "-cross-map", b + "-self-map"] if maps else []
     for i in range(arch["num_layers"]):
         b = f"vit-block{i}"
-        ids += [b + "-q", b + "-k", b + "-v", b + "-attn-out", b + "-norm-out", b + "-ffn-inner", b + "-out"]
+        ids += [b + "-q", b + "-k", b + "-v"] + mp(b) + [b + "-attn-out", b + "-norm-out", b + "-ffn-inner", b + "-out"]
     for j in range(arch["num_single_layers"]):
         b = f"vit-block{arch['num_layers'] + j}"
-        ids += [b + "-q", b + "-k", b + "-v", b + "-attn-out", b + "-out"]
+        ids += [b + "-q", b + "-k", b + "-v"] + mp(b) + [b + "-attn-out", b + "-out"]
     return ids
 
 

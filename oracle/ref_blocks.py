@@ -415,6 +415,12 @@ def modules():
     return ns
 
 
+def flux_attn_store_processor():
+    """components/attention.py::FluxAttnStoreProcessor (the eager MMDiT processor behind `self-map` / `cross-map`)."""
+    attn_store_processor()
+    return sys.modules["gdf_ref_attention"].FluxAttnStoreProcessor
+
+
 def attn_store_processor():
     """components/attention.py::AttnStoreProcessor (the eager '-map' processor)."""
     install()

@@ -156,11 +156,12 @@ def test_flux_tiny_all_hooks_vs_oracle():
     arch = FR.tiny_arch()
     P = FR.synth_params(arch, seed=0)
     I = FR.synth_inputs(arch, batch=2, grid=8, n_txt=24, seed=1, same_prompt=False)
-    st = FR.Store(None)
+    st = FR.Store(None)                                    # accept-all: the eager processor with `*-map` hooks, like the reference
     y = FR.flux_forward(P, arch, I["hidden_states"], I["encoder_hidden_states"], I["pooled_projections"], I["timestep"],
                         I["img_ids"], I["txt_ids"], I["guidance"], store=st)
-    net, out, hooks = _run_native(arch, P, I, FR.hook_ids(arch), 8)
-    assert net.hook_names() == FR.hook_ids(arch)
+    net, out, hooks = _run_native(arch, P, I, FR.hook_ids(arch, maps=True), 8)
+    assert net.hook_names() == FR.hook_ids(arch, maps=True)
+    assert hooks["vit-block0-cross-map"].shape == (2, 2, 64, 24) and hooks["vit-block3-self-map"].shape == (2, 2, 64, 64)
     assert list(hooks.keys()) == list(st.feats.keys())
     worst = rel_l2(out, y)
     assert worst < TOL, ("output", worst)
@@ -173,7 +174,8 @@ def test_flux_tiny_all_hooks_vs_oracle():
 
 
 def test_flux_matches_reference_golden():
-    """tests/golden/flux_tiny.npz = outputs of the reference's own FluxTransformer2DModel (gen_golden_flux.py)."""
+    """tests/golden/flux_tiny.npz = outputs of the reference's own FluxTransformer2DModel (gen_golden_flux.py);
+    flux_tiny_maps.npz = the same model on the reference's FluxAttnStoreProcessor (`cross-map` / `self-map` hooks)."""
     z = np.load(os.path.join(GOLD, "flux_tiny.npz"))
     meta = ast.literal_eval(str(z["meta"]))
     arch = meta["arch"]
@@ -185,6 +187,15 @@ def test_flux_matches_reference_golden():
     for k in meta["order"]:
         e = rel_l2(hooks[k], torch.from_numpy(z["out:hook:" + k]))
         assert e < TOL, (k, e)
+    zm = np.load(os.path.join(GOLD, "flux_tiny_maps.npz"))
+    mm = ast.literal_eval(str(zm["meta"]))
+    net, out, hooks = _run_native(arch, P, I, mm["order"], 4)
+    assert list(hooks.keys()) == mm["order"] == net.hook_names()
+    assert rel_l2(out, torch.from_numpy(zm["out:y"])) < TOL
+    for k in mm["order"]:
+        if k.endswith("-map"):
+            ref = torch.from_numpy(zm["out:hook:" + k])
+            assert hooks[k].shape == ref.shape and rel_l2(hooks[k], ref) < TOL, (k, rel_l2(hooks[k], ref))
 
 
 def test_flux_subset_early_exit_and_unknown_ids():
@@ -211,7 +222,7 @@ def test_feature_extractor_api_flux_synthetic():
     from components.models import SyntheticFluxPipe
     arch = FR.tiny_arch(num_layers=2, num_single_layers=2)
     pipe = SyntheticFluxPipe("cuda:0", seed=0, cfg=arch, n_txt=16)
-    assert pipe.transformer.hook_names() == flux_layer_ids(arch) == FR.hook_ids(arch)
+    assert pipe.transformer.hook_names() == flux_layer_ids(arch) == FR.hook_ids(arch, maps=True)
     layer = {"vit-block0-out": True, "vit-block1-q": True, "vit-block3-out": True, "vit-block2-attn-out": True, "nope": True}
     df = diffusion_feature.FeatureExtractor(layer=layer, version='flux', img_size=128, device='cuda:0', external_model=pipe)
     img = Image.fromarray((np.random.RandomState(0).rand(90, 70, 3) * 255).astype(np.uint8))

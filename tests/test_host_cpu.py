@@ -101,7 +101,7 @@ def test_model_registry_error_behaviour(monkeypatch):
     with pytest.raises(NotImplementedError):
         models.get_diffusion_model("no-such-version", "float16")     # reference models.py:173-174
     with pytest.raises(NotImplementedError):
-        models.get_diffusion_model("pixart-sigma", "float16")            # not on the native hot path
+        models.get_diffusion_model("pixart-alpha", "float16")            # alpha-1024 micro-conditioning: not native
     monkeypatch.delenv("GDF_SYNTHETIC_WEIGHTS", raising=False)
     with pytest.raises(RuntimeError):
         models.get_diffusion_model("1-5", "float16")                 # no diffusers, no synthetic opt-in: loud failure
@@ -162,6 +162,8 @@ def test_flux_layer_ids_match_oracle_and_reference_golden():
     from oracle import flux_ref as FR
     z = np.load(os.path.join(GOLD, "flux_tiny.npz"))
     meta = ast.literal_eval(str(z["meta"]))
-    assert flux_layer_ids(meta["arch"]) == meta["order"] == FR.hook_ids(meta["arch"])
+    assert [i for i in flux_layer_ids(meta["arch"]) if not i.endswith("-map")] == meta["order"] == FR.hook_ids(meta["arch"])
+    zm = np.load(os.path.join(GOLD, "flux_tiny_maps.npz"))          # the reference on its FluxAttnStoreProcessor
+    assert flux_layer_ids(meta["arch"]) == ast.literal_eval(str(zm["meta"]))["order"] == FR.hook_ids(meta["arch"], maps=True)
     ids = flux_layer_ids(FLUX_CONFIGS["flux"])
-    assert len(ids) == 19 * 7 + 38 * 5 and ids[0] == "vit-block0-q" and ids[-1] == "vit-block56-out"
+    assert len(ids) == 19 * 9 + 38 * 7 and ids[0] == "vit-block0-q" and ids[-1] == "vit-block56-out"

@@ -123,13 +123,32 @@ def test_flux_oracle_matches_reference_golden():
     I = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("in:")}
     st = FR.Store(None, out_dtype=None)
     y = FR.flux_forward(P, arch, I["hidden_states"], I["encoder_hidden_states"], I["pooled_projections"], I["timestep"],
-                        I["img_ids"], I["txt_ids"], I.get("guidance"), store=st)
+                        I["img_ids"], I["txt_ids"], I.get("guidance"), store=st, want_map=False)
     assert torch.allclose(y, torch.from_numpy(z["out:y"]), atol=2e-5, rtol=1e-5)
     hooks = {k[9:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("out:hook:")}
     assert list(st.feats.keys()) == meta["order"] == FR.hook_ids(arch)
     for k, v in hooks.items():
         assert st.feats[k].shape == v.shape, k
         assert torch.allclose(st.feats[k], v, atol=2e-5, rtol=1e-5), (k, float((st.feats[k] - v).abs().max()))
+
+
+def test_flux_oracle_maps_match_reference_store_processor():
+    """flux_tiny_maps.npz: the reference model on FluxAttnStoreProcessor (components/attention.py:404-527)."""
+    from oracle import flux_ref as FR
+    z = np.load(os.path.join(GOLD, "flux_tiny.npz")); zm = np.load(os.path.join(GOLD, "flux_tiny_maps.npz"))
+    meta = ast.literal_eval(str(zm["meta"]))
+    arch = meta["arch"]
+    P = FR.synth_params(arch, seed=meta["wseed"])
+    I = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("in:")}
+    st = FR.Store(None, out_dtype=None)                     # accept-all -> eager processor, like diffusion_feature.py:72-77
+    y = FR.flux_forward(P, arch, I["hidden_states"], I["encoder_hidden_states"], I["pooled_projections"], I["timestep"],
+                        I["img_ids"], I["txt_ids"], I.get("guidance"), store=st)
+    assert list(st.feats.keys()) == meta["order"] == FR.hook_ids(arch, maps=True)
+    assert torch.allclose(y, torch.from_numpy(zm["out:y"]), atol=2e-5, rtol=1e-5)
+    for k in meta["order"]:
+        if k.endswith("-map"):
+            v = torch.from_numpy(zm["out:hook:" + k])
+            assert st.feats[k].shape == v.shape and torch.allclose(st.feats[k], v, atol=2e-5, rtol=1e-5), k
 
 
 def test_flux_flops_and_param_count():

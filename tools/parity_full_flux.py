@@ -24,7 +24,7 @@ st = FR.Store(None)
 t0 = time.time()
 with torch.no_grad():
     y = FR.flux_forward(P, arch, I["hidden_states"], I["encoder_hidden_states"], I["pooled_projections"], I["timestep"],
-                        I["img_ids"], I["txt_ids"], I["guidance"], store=st)
+                        I["img_ids"], I["txt_ids"], I["guidance"], store=st, want_map=False)
 t_cpu = time.time() - t0
 net = NativeFluxTransformer(arch, device="cuda:0")
 net.load_state_dict({k: v.half() for k, v in P.items()})
