@@ -147,10 +147,10 @@ def dit_layer_ids(cfg, include_dropped=False):
     ids = []
     for i in range(cfg["num_layers"]):
         b = f"vit-block{i}"
-        ids += [f"{b}-self-q", f"{b}-self-k", f"{b}-self-v", f"{b}-cross-q"]
+        ids += [f"{b}-self-q", f"{b}-self-k", f"{b}-self-v", f"{b}-self-map", f"{b}-cross-q"]
         if include_dropped:
             ids += [f"{b}-cross-k", f"{b}-cross-v"]
-        ids += [f"{b}-ffn-inner", f"{b}-out"]
+        ids += [f"{b}-cross-map", f"{b}-ffn-inner", f"{b}-out"]
     return ids
 
 

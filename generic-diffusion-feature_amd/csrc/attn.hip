@@ -336,6 +336,8 @@ __global__ __launch_bounds__(256, 2) void attn_map_kernel(const AttnParams p) {
   const _Float16* kbase = p.k + head * D;
   const _Float16* vbase = p.v + head * D;
   const int ntiles = (p.Sk + KT - 1) / KT;
+  // keys [Skv, Sk) are masked (PixArt caption mask, AttnParams.kv_len): probability 0, still written to the map
+  const int Skv = p.kv_len ? max(1, min(p.kv_len[b], p.Sk)) : p.Sk;
 
   f16x8 kreg[NCH], vreg[NCH];
   auto gload = [&](int t, bool with_v) {
@@ -377,13 +379,13 @@ __global__ __launch_bounds__(256, 2) void attn_map_kernel(const AttnParams p) {
           s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[st], s[kb], 0, 0, 0);
         }
       }
-    if (!FULL && (t + 1) * KT > p.Sk) {
+    if (!FULL && (t + 1) * KT > Skv) {
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int kv = t * KT + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          if (kv >= p.Sk) s[kb][r] = -INFINITY;
+          if (kv >= Skv) s[kb][r] = -INFINITY;
         }
     }
   };
@@ -529,11 +531,10 @@ __global__ __launch_bounds__(256, 2) void attn_map_kernel(const AttnParams p) {
 template <int D>
 static hipError_t launch_d(const AttnParams& p, hipStream_t s) {
   const bool maps = p.map || p.map2;
-  if (maps && p.kv_len) return hipErrorInvalidValue;                    // '-map' hooks of the masked (PixArt) layout: not built
   if (maps && p.seg_T && (p.seg_T & 7)) return hipErrorInvalidValue;    // an 8-key chunk must not straddle the text / image boundary
   if (maps) {
     const int nqb = (p.Sq + 127) / 128;
-    if (p.Sq % 128 == 0 && p.Sk % KT == 0 && !p.seg_T) hipLaunchKernelGGL((attn_map_kernel<D, true>), dim3(p.B * p.heads * nqb), dim3(256), 0, s, p);
+    if (p.Sq % 128 == 0 && p.Sk % KT == 0 && !p.seg_T && !p.kv_len) hipLaunchKernelGGL((attn_map_kernel<D, true>), dim3(p.B * p.heads * nqb), dim3(256), 0, s, p);
     else hipLaunchKernelGGL((attn_map_kernel<D, false>), dim3(p.B * p.heads * nqb), dim3(256), 0, s, p);
   } else {
     // 64 query rows per wave (every K / V fragment feeds two MFMAs) when the sequence is long and the

@@ -92,7 +92,7 @@ struct XB : PlanBuilder {   // PixArt op program
     });
   }
   void hook16(const std::string& id, Ref src, int ld, int C) { hook_copy(want(id, C, gh, gw), src, ld, (size_t)Bn * S, C); }
-  void attention(const char* name, Ref q, int ldq, Ref k, Ref v, int ldkv, Ref o, int Sk, bool masked) {
+  void attention(const char* name, Ref q, int ldq, Ref k, Ref v, int ldkv, Ref o, int Sk, bool masked, int map_slot = -1) {
     const int C = x.C, D = x.d.attention_head_dim, heads = x.d.num_attention_heads, Bq = Bn, Sq = S;
     op(name, 4.0 * (double)Bn * heads * Sq * (double)Sk * D, [=](const Bind& b, hipStream_t s) {
       AttnParams a{};
@@ -100,8 +100,10 @@ struct XB : PlanBuilder {   // PixArt op program
       a.o = (half_t*)b.p(o); a.ldo = C; a.B = Bq; a.heads = heads; a.Sq = Sq; a.Sk = Sk; a.D = D; a.kv_bstride = Sk;
       a.scale = 1.0f / sqrtf((float)D);
       a.kv_len = masked ? (const int*)b.base[BUF_TID] : nullptr;
+      a.map = map_slot >= 0 ? (half_t*)b.hook(map_slot) : nullptr;          // AttnStoreProcessor `map` hook (B, heads, S, Sk)
       return launch_attention(a, s);
     });
+    if (map_slot >= 0) hook_done();
   }
 
   void build(int H, int W) {
@@ -177,7 +179,8 @@ struct XB : PlanBuilder {   // PixArt op program
       hook16(bid + "-self-v", ws(qkv + (size_t)2 * C * 2), 3 * C, C);
       if (stop) { untmp(qkv, n * 3 * C * 2); break; }
       size_t ao = tmp(nb);
-      attention("attn1", ws(qkv), 3 * C, ws(qkv + (size_t)C * 2), ws(qkv + (size_t)2 * C * 2), 3 * C, ws(ao), S, false);
+      attention("attn1", ws(qkv), 3 * C, ws(qkv + (size_t)C * 2), ws(qkv + (size_t)2 * C * 2), 3 * C, ws(ao), S, false,
+                want_map(bid + "-self-map", x.d.num_attention_heads, S, S));        // components/attention.py:238-244
       untmp(qkv, n * 3 * C * 2);
       { Epi e = resid(w.o1, t0 + 2 * C, true); gemm("attn1_out", ws(ao), C, n, w.o1, C, C, 0, e); }   // gate_msa; fp16 shadow for attn2
       untmp(ao, nb);
@@ -187,7 +190,8 @@ struct XB : PlanBuilder {   // PixArt op program
       hook16(bid + "-cross-q", ws(q2), C, C);
       { Epi e = plain(w.kv2); e.out16 = ws(kv); e.has_o16 = true; e.ldo16 = 2 * C; gemm("attn2_kv", ws(enc), C, nt, w.kv2, 2 * C, C, 0, e); }
       ao = tmp(nb);
-      attention("attn2", ws(q2), C, ws(kv), ws(kv + (size_t)C * 2), 2 * C, ws(ao), T, true);
+      attention("attn2", ws(q2), C, ws(kv), ws(kv + (size_t)C * 2), 2 * C, ws(ao), T, true,
+                want_map(bid + "-cross-map", x.d.num_attention_heads, S, T));
       untmp(q2, nb); untmp(kv, nt * 2 * C * 2);
       { Epi e = resid(w.o2, -1, false); gemm("attn2_out", ws(ao), C, n, w.o2, C, C, 0, e); }
       untmp(ao, nb);

@@ -9,7 +9,9 @@
  *      :496-516, :540-575; BasicTransformerBlock.forward (ada_norm_single)  diffusers/models/attention.py:498-592;
  *      Attention + AttnProcessor2_0  diffusers/models/attention_processor.py:3244-3331; FeedForward  attention.py:1249-1258
  *   and every `gather` side effect with the DiT id scheme of components/feature_extractor.py:250-286:
- *      vit-block{i}-{self-q, self-k, self-v, cross-q, ffn-inner, out}     (cross-k / cross-v are dropped by the store, :38-39)
+ *      vit-block{i}-{self-q, self-k, self-v, self-map, cross-q, cross-map, ffn-inner, out}
+ *      (cross-k / cross-v are dropped by the store, :38-39; self-map (B, heads, S, S) / cross-map (B, heads, S, n_txt) are the
+ *      softmax probabilities of AttnStoreProcessor, components/attention.py, masked caption keys hold exact zeros)
  *
  * Handles, model / plan queries, hook info, workspace and timing functions are those of gdf.h.  Parameter names are the
  * `Transformer2DModel.state_dict()` names ("pos_embed.proj.*", "adaln_single.*", "caption_projection.*",

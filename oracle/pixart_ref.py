@@ -121,8 +121,9 @@ def sincos_pos_embed(embed_dim, grid_h, grid_w, base_size, interpolation_scale):
     return torch.from_numpy(emb).float()
 
 
-def attention(P, pfx, x, enc, heads, bias_mask, store, mid):
-    """Attention + AttnProcessor2_0 with biases and an additive (B,1,K) mask (attention_processor.py:3244-3331)."""
+def attention(P, pfx, x, enc, heads, bias_mask, store, mid, want_map=False):
+    """Attention + AttnProcessor2_0 with biases and an additive (B,1,K) mask (attention_processor.py:3244-3331); with
+    want_map the eager AttnStoreProcessor (components/attention.py:176-263): softmax(q k^T * scale + mask) -> hook `map`."""
     src = x if enc is None else enc
     q = _lin(P, pfx + ".to_q", x); k = _lin(P, pfx + ".to_k", src); v = _lin(P, pfx + ".to_v", src)
     store.gather(mid, q, "q"); store.gather(mid, k, "k"); store.gather(mid, v, "v")          # :3291-3294
@@ -130,19 +131,25 @@ def attention(P, pfx, x, enc, heads, bias_mask, store, mid):
     d = c // heads
     sp = lambda t: t.view(b, -1, heads, d).transpose(1, 2)
     m = None if bias_mask is None else bias_mask[:, None]                                 # (B,1,1,K) broadcast over heads
+    if want_map:
+        sc = torch.matmul(sp(q), sp(k).transpose(-1, -2)) * d ** -0.5
+        probs = torch.softmax(sc if m is None else sc + m, dim=-1)
+        store.gather(mid, probs, "map")                                                   # components/attention.py:238-244
+        o = torch.matmul(probs, sp(v))
+        return _lin(P, pfx + ".to_out.0", o.transpose(1, 2).reshape(b, s, c))
     o = F.scaled_dot_product_attention(sp(q), sp(k), sp(v), attn_mask=m)
     return _lin(P, pfx + ".to_out.0", o.transpose(1, 2).reshape(b, s, c))
 
 
-def block(P, i, arch, x, enc, tvec, enc_bias, store):
+def block(P, i, arch, x, enc, tvec, enc_bias, store, want_map=False):
     """BasicTransformerBlock.forward, ada_norm_single (attention.py:498-592)."""
     b = f"transformer_blocks.{i}"; mid = f"vit-block{i}"
     heads = arch["num_attention_heads"]; B = x.shape[0]
     mod = P[b + ".scale_shift_table"][None] + tvec.reshape(B, 6, -1)                      # :498-503
     sh_a, sc_a, g_a, sh_m, sc_m, g_m = mod.chunk(6, dim=1)
     n = F.layer_norm(x, (x.shape[-1],), None, None, 1e-6) * (1 + sc_a) + sh_a
-    x = g_a * attention(P, b + ".attn1", n, None, heads, None, store, mid + "-self") + x   # :514-526
-    x = attention(P, b + ".attn2", x, enc, heads, enc_bias, store, mid + "-cross") + x     # :541-558 (no norm2, no gate)
+    x = g_a * attention(P, b + ".attn1", n, None, heads, None, store, mid + "-self", want_map) + x   # :514-526
+    x = attention(P, b + ".attn2", x, enc, heads, enc_bias, store, mid + "-cross", want_map) + x     # :541-558 (no norm2, no gate)
     n = F.layer_norm(x, (x.shape[-1],), None, None, 1e-6) * (1 + sc_m) + sh_m             # :570-573
     h = F.gelu(_lin(P, b + ".ff.net.0.proj", n), approximate="tanh")
     store.gather(mid + "-ffn", h, "inner")                                                # :1255-1257
@@ -151,9 +158,13 @@ def block(P, i, arch, x, enc, tvec, enc_bias, store):
     return x
 
 
-def pixart_forward(P, arch, hidden_states, encoder_hidden_states, timestep, encoder_attention_mask=None, store=None):
-    """Transformer2DModel.forward, patched inputs + ada_norm_single (transformer_2d.py:404-475). Returns (B, out, H, W)."""
+def pixart_forward(P, arch, hidden_states, encoder_hidden_states, timestep, encoder_attention_mask=None, store=None,
+                   want_map=None):
+    """Transformer2DModel.forward, patched inputs + ada_norm_single (transformer_2d.py:404-475). Returns (B, out, H, W).
+    want_map=None follows the reference: a requested '*map*' id (or accept-all) installs the eager processor everywhere."""
     store = store if store is not None else Store({"__none__": True})
+    if want_map is None:
+        want_map = store.accept_all or any("map" in k and v for k, v in store.to_store.items())
     C = inner_dim(arch); p = arch["patch_size"]
     B, _, H, W = hidden_states.shape
     enc_bias = None
@@ -169,7 +180,7 @@ def pixart_forward(P, arch, hidden_states, encoder_hidden_states, timestep, enco
     enc = _lin(P, "caption_projection.linear_2",
                F.gelu(_lin(P, "caption_projection.linear_1", encoder_hidden_states.float()), approximate="tanh"))
     for i in range(arch["num_layers"]):
-        x = block(P, i, arch, x, enc, tvec, enc_bias, store)
+        x = block(P, i, arch, x, enc, tvec, enc_bias, store, want_map)
     shift, scale = (P["scale_shift_table"][None] + emb[:, None]).chunk(2, dim=1)          # :552-556
     x = F.layer_norm(x, (C,), None, None, 1e-6) * (1 + scale) + shift
     x = _lin(P, "proj_out", x)
@@ -178,14 +189,14 @@ def pixart_forward(P, arch, hidden_states, encoder_hidden_states, timestep, enco
     return torch.einsum("nhwpqc->nchpwq", x).reshape(B, oc, gh * p, gw * p)
 
 
-def hook_ids(arch, include_dropped=False):
+def hook_ids(arch, include_dropped=False, maps=False):
     ids = []
     for i in range(arch["num_layers"]):
         b = f"vit-block{i}"
-        ids += [b + "-self-q", b + "-self-k", b + "-self-v", b + "-cross-q"]
+        ids += [b + "-self-q", b + "-self-k", b + "-self-v"] + ([b + "-self-map"] if maps else []) + [b + "-cross-q"]
         if include_dropped:
             ids += [b + "-cross-k", b + "-cross-v"]
-        ids += [b + "-ffn-inner", b + "-out"]
+        ids += ([b + "-cross-map"] if maps else []) + [b + "-ffn-inner", b + "-out"]
     return ids
 
 

@@ -57,12 +57,44 @@ def main():
     np.savez_compressed(path, **arrs)
     print("pixart_tiny ->", os.path.getsize(path) // 1024, "KiB;", len(store.stored_feats), "hooks")
     st = PR.Store(None, out_dtype=None)
-    y2 = PR.pixart_forward(P, arch, I["hidden_states"], I["encoder_hidden_states"], I["timestep"], I["encoder_attention_mask"], st)
+    y2 = PR.pixart_forward(P, arch, I["hidden_states"], I["encoder_hidden_states"], I["timestep"], I["encoder_attention_mask"], st,
+                           want_map=False)
     assert list(st.feats.keys()) == list(store.stored_feats.keys()), (list(st.feats.keys()), list(store.stored_feats.keys()))
     worst = float((y2 - y).abs().max())
     for k in st.feats:
         worst = max(worst, float((st.feats[k].float() - store.stored_feats[k].float()).abs().max()))
     print("oracle vs reference: max abs diff", worst)
+    assert worst < 2e-4, worst
+
+    # ---- second fixture: every attention on the reference's eager AttnStoreProcessor (components/attention.py:176-263,
+    # installed for DiTs by register_attention_store, :582-590) -> `self-map` / `cross-map` hooks with the ragged mask
+    Proc = RB.attn_store_processor()
+    store = m.FeatureStore({}, 1, True)
+    for i, bb in enumerate(model.transformer_blocks):
+        bb.feature_gatherer = G(f"vit-block{i}", store)
+        bb.attn1.feature_gatherer = G(f"vit-block{i}-self", store)
+        bb.attn2.feature_gatherer = G(f"vit-block{i}-cross", store)
+        bb.ff.feature_gatherer = G(f"vit-block{i}-ffn", store)
+        bb.attn1.processor = Proc(attnstore=None, place_in_unet="up")
+        bb.attn2.processor = Proc(attnstore=None, place_in_unet="up")
+    ym = model(I["hidden_states"], encoder_hidden_states=I["encoder_hidden_states"], timestep=I["timestep"],
+               encoder_attention_mask=I["encoder_attention_mask"], added_cond_kwargs={"resolution": None, "aspect_ratio": None},
+               return_dict=False)[0]
+    arrs = {"out:y": ym.float().numpy()}
+    for k, v in store.stored_feats.items():
+        if k.endswith("-map"):
+            arrs["out:hook:" + k] = v.detach().float().numpy()
+    arrs["meta"] = np.array(repr(dict(arch=arch, wseed=5, order=list(store.stored_feats.keys()))))
+    path = os.path.join(HERE, "pixart_tiny_maps.npz")
+    np.savez_compressed(path, **arrs)
+    print("pixart_tiny_maps ->", os.path.getsize(path) // 1024, "KiB")
+    st = PR.Store(None, out_dtype=None)
+    y3 = PR.pixart_forward(P, arch, I["hidden_states"], I["encoder_hidden_states"], I["timestep"], I["encoder_attention_mask"], st)
+    assert list(st.feats.keys()) == list(store.stored_feats.keys()) == PR.hook_ids(arch, maps=True), list(store.stored_feats.keys())
+    worst = float((y3 - ym).abs().max())
+    for k in st.feats:
+        worst = max(worst, float((st.feats[k].float() - store.stored_feats[k].float()).abs().max()))
+    print("oracle (maps) vs reference: max abs diff", worst)
     assert worst < 2e-4, worst
 
 

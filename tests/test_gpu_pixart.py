@@ -43,10 +43,11 @@ def test_pixart_tiny_all_hooks_vs_oracle(heads, lat, n_txt, valid):
     arch = PR.tiny_arch(heads=heads)
     P = PR.synth_params(arch, seed=0)
     I = PR.synth_inputs(arch, 2, lat, n_txt, seed=1, valid=valid)
-    st = PR.Store(None)
+    st = PR.Store(None)                                   # accept-all: eager processor incl. `*-map` hooks, like the reference
     y = PR.pixart_forward(P, arch, I["hidden_states"], I["encoder_hidden_states"], I["timestep"], I["encoder_attention_mask"], st)
-    net, out, hooks = _run(arch, P, I, PR.hook_ids(arch))
-    assert net.hook_names() == PR.hook_ids(arch) and list(hooks.keys()) == list(st.feats.keys())
+    net, out, hooks = _run(arch, P, I, PR.hook_ids(arch, maps=True))
+    assert net.hook_names() == PR.hook_ids(arch, maps=True) and list(hooks.keys()) == list(st.feats.keys())
+    assert hooks["vit-block0-cross-map"].shape == (2, heads, (lat // 2) ** 2, n_txt)
     assert out.shape == y.shape and rel_l2(out, y) < TOL, rel_l2(out, y)
     for k, ref in st.feats.items():
         assert hooks[k].shape == ref.shape and hooks[k].dtype == torch.float16, k
@@ -64,6 +65,14 @@ def test_pixart_matches_reference_golden():
     assert rel_l2(out, torch.from_numpy(z["out:y"])) < TOL
     for k in meta["order"]:
         assert rel_l2(hooks[k], torch.from_numpy(z["out:hook:" + k])) < TOL, k
+    zm = np.load(os.path.join(GOLD, "pixart_tiny_maps.npz"))          # the reference on its AttnStoreProcessor (ragged mask)
+    mm = ast.literal_eval(str(zm["meta"]))
+    net, out, hooks = _run(arch, P, I, mm["order"])
+    assert list(hooks.keys()) == mm["order"] == net.hook_names()
+    for k in mm["order"]:
+        if k.endswith("-map"):
+            ref = torch.from_numpy(zm["out:hook:" + k])
+            assert hooks[k].shape == ref.shape and rel_l2(hooks[k], ref) < TOL, (k, rel_l2(hooks[k], ref))
 
 
 def test_feature_extractor_api_pixart_synthetic():
@@ -76,7 +85,7 @@ def test_feature_extractor_api_pixart_synthetic():
     from components.models import SyntheticPixartPipe
     arch = PR.tiny_arch(heads=8, num_layers=2, sample_size=16)
     pipe = SyntheticPixartPipe("pixart-sigma", "cuda:0", seed=0, cfg=arch, n_txt=20)
-    assert pipe.transformer.hook_names() == dit_layer_ids(arch) == PR.hook_ids(arch)
+    assert pipe.transformer.hook_names() == dit_layer_ids(arch) == PR.hook_ids(arch, maps=True)
     layer = {"vit-block1-out": True, "vit-block0-cross-q": True, "vit-block1-ffn-inner": True, "vit-block0-cross-k": True}
     df = diffusion_feature.FeatureExtractor(layer=layer, version='pixart-sigma', img_size=128, device='cuda:0', external_model=pipe)
     prompt = df.encode_prompt('a photo of a cat')
@@ -94,7 +103,7 @@ def test_pixart_early_exit_and_no_mask():
     P = PR.synth_params(arch, seed=2)
     I = PR.synth_inputs(arch, 2, 8, 16, seed=3)                      # all caption tokens valid
     st = PR.Store({"vit-block1-cross-q": True, "vit-block0-out": True})
-    PR.pixart_forward(P, arch, I["hidden_states"], I["encoder_hidden_states"], I["timestep"], None, st)
+    PR.pixart_forward(P, arch, I["hidden_states"], I["encoder_hidden_states"], I["timestep"], None, st, want_map=False)
     outs = {}
     for ee in (False, True):
         net = NativePixArtTransformer(arch, device="cuda:0", early_exit=ee)

@@ -194,12 +194,31 @@ def test_pixart_oracle_matches_reference_golden():
     assert np.allclose([float(v.double().abs().sum()) for v in P.values()], z["wabs"], rtol=0, atol=1e-9)
     I = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("in:")}
     st = PR.Store(None, out_dtype=None)
-    y = PR.pixart_forward(P, arch, I["hidden_states"], I["encoder_hidden_states"], I["timestep"], I["encoder_attention_mask"], st)
+    y = PR.pixart_forward(P, arch, I["hidden_states"], I["encoder_hidden_states"], I["timestep"], I["encoder_attention_mask"], st,
+                          want_map=False)
     assert torch.allclose(y, torch.from_numpy(z["out:y"]), atol=2e-5, rtol=1e-5)
     assert list(st.feats.keys()) == meta["order"] == PR.hook_ids(arch)
     for k in meta["order"]:
         v = torch.from_numpy(z["out:hook:" + k])
         assert st.feats[k].shape == v.shape and torch.allclose(st.feats[k], v, atol=2e-5, rtol=1e-5), k
+
+
+def test_pixart_oracle_maps_match_reference_store_processor():
+    """pixart_tiny_maps.npz: the reference DiT on its eager AttnStoreProcessor with the ragged caption mask."""
+    from oracle import pixart_ref as PR
+    z = np.load(os.path.join(GOLD, "pixart_tiny.npz")); zm = np.load(os.path.join(GOLD, "pixart_tiny_maps.npz"))
+    meta = ast.literal_eval(str(zm["meta"]))
+    arch = meta["arch"]
+    P = PR.synth_params(arch, seed=meta["wseed"])
+    I = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("in:")}
+    st = PR.Store(None, out_dtype=None)
+    y = PR.pixart_forward(P, arch, I["hidden_states"], I["encoder_hidden_states"], I["timestep"], I["encoder_attention_mask"], st)
+    assert list(st.feats.keys()) == meta["order"] == PR.hook_ids(arch, maps=True)
+    assert torch.allclose(y, torch.from_numpy(zm["out:y"]), atol=2e-5, rtol=1e-5)
+    for k in meta["order"]:
+        if k.endswith("-map"):
+            v = torch.from_numpy(zm["out:hook:" + k])
+            assert st.feats[k].shape == v.shape and torch.allclose(st.feats[k], v, atol=2e-5, rtol=1e-5), k
 
 
 def test_pixart_param_count():
