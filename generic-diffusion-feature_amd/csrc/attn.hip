@@ -13,6 +13,7 @@
 //     `ds_read_b64_tr_b16` from a row-major V tile.
 //   * head dims 40/64/80/160 (SD1.5: 40,80,160; SDXL: 64) are zero-padded to MFMA granularity in LDS.
 #include "kernels.h"
+#include <type_traits>
 
 namespace gdf {
 
@@ -284,6 +285,12 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
 // the scores, normalises, feeds O^T += V^T P^T and writes the probability tile: each wave transposes its
 // 32 x 64 tile through LDS so that the global stores are 16 B per lane, 128 contiguous bytes per query row.
 // -------------------------------------------------------------------------------------------------
+// a wave-uniform pointer the compiler could not prove uniform, moved into an SGPR pair
+__device__ __forceinline__ const _Float16* uniform_ptr(const _Float16* ptr) {
+  const uint64_t a = (uint64_t)ptr;
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+  return (const _Float16*)(((uint64_t)hi << 32) | lo);
+}
 // Workgroup barrier that only orders LDS traffic.  __syncthreads() carries a release fence, i.e. `s_waitcnt vmcnt(0)`:
 // inside the map kernel that made every key tile wait for the round trip of the probability stores just issued
 // (PMC: 54 % of wave cycles parked in s_waitcnt).  The K/V staging only needs the ds_writes to have landed.
@@ -291,22 +298,31 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-// FULL = Sq % 128 == 0 and Sk % 64 == 0 (every SD / SDXL level): no bounds predicates in the loops, so the probability
-// stores are straight-line code and the compiler's waitcnt insertion can count them (with the predicated form every loop
-// iteration started with `s_waitcnt vmcnt(0)`, i.e. waited for the store round trip of the previous tile).
-template <int D, bool FULL>
-__global__ __launch_bounds__(256, 2) void attn_map_kernel(const AttnParams p) {
+// FULL = Sq % 128 == 0 and Sk % 64 == 0, sample-major, no key mask (every SD / SDXL level): no bounds predicates in the
+// loops and unconditional tile loads (with the predicated form every loop iteration started with `s_waitcnt vmcnt(0)`,
+// i.e. waited for the store round trip of the previous tile).
+// OCC  = workgroups per CU the LDS / VGPR budget is cut for (3 for D <= 48: K rows trimmed to DQK columns).
+// LW   = a fifth wave does nothing but move K/V tiles HBM -> LDS (see the loader block below); FULL, D <= 48, Sk % 128 == 0.
+// SD1.5 level 0 (8 heads x 40, 4096^2 map, B = 8) on MI355X: 1.225 ms -> 0.92..0.97 ms (unconditional loads + K/V staged
+// before the stores 1.10, 3 workgroups/CU 1.03, staggered key-tile order 0.99, loader wave 0.95); with the stores
+// compiled out the kernel takes 0.63 ms, a pure 128-byte-strip store of the same tensor 0.39 ms
+// (tools/micro/strip_store.hip, 5.1-5.5 TB/s): the remaining gap is issue latency of the two-pass softmax (PMC: VALU busy
+// 33 %, MFMA 16 % of SIMD time), not HBM.
+template <int D, bool FULL, int OCC, bool LW>
+__global__ __launch_bounds__(LW ? 320 : 256, OCC) void attn_map_kernel(const AttnParams p) {
+  static_assert(!LW || FULL, "the loader-wave variant has no bounds predicates");
   constexpr int DQK = (D + 15) / 16 * 16;
   constexpr int DV = (D + 31) / 32 * 32;
   constexpr int DP = DV;
   constexpr int LDR = DP + 8;
+  constexpr int LDK = OCC > 2 ? DQK + 8 : LDR;    // K rows only hold the DQK columns the score MFMAs read
   constexpr int CPR = DP / 8;
   constexpr int NCH = (KT * CPR + 255) / 256;
   constexpr int NS = DQK / 16;
   constexpr int NDB = DV / 32;
   constexpr int PLD = KT + 8;                     // staging row stride (halves) of the probability tile
 
-  __shared__ __attribute__((aligned(16))) _Float16 sK[2][KT * LDR];
+  __shared__ __attribute__((aligned(16))) _Float16 sK[2][KT * LDK];
   __shared__ __attribute__((aligned(16))) _Float16 sV[2][KT * LDR];
   __shared__ __attribute__((aligned(16))) _Float16 sP[4][32 * PLD];
 
@@ -322,7 +338,7 @@ __global__ __launch_bounds__(256, 2) void attn_map_kernel(const AttnParams p) {
   const bool q_ok = q_row < p.Sq;
 
   f16x8 qf[NS];
-  {
+  if (!(LW && wave == 4)) {        // (the loader wave must not have a compiler-tracked load in flight next to its asm loads)
     const _Float16* qp = p.q + seg_row(b, q_ok ? q_row : 0, p.Sq, p.seg_T, p.B, p.Sq) * p.ldq + head * D;
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
@@ -340,19 +356,37 @@ __global__ __launch_bounds__(256, 2) void attn_map_kernel(const AttnParams p) {
   const int Skv = p.kv_len ? max(1, min(p.kv_len[b], p.Sk)) : p.Sk;
 
   f16x8 kreg[NCH], vreg[NCH];
+  constexpr int CHV = (D + 7) / 8;                 // 16-byte chunks of a K / V row that hold data
+  if (FULL) {
+    // FULL: the zero padding of the staged rows (columns [D, DP)) is written once; the tile loads are unconditional
+    // (pad lanes re-read the last data chunk and drop it), so no load sits under a lane predicate or behind a zero-fill
+    // of its destination registers — both made the compiler start every key tile with `s_waitcnt vmcnt(0)`
+    const f16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = tid; i < 2 * KT * LDK / 8; i += 256) *(f16x8*)(&sK[0][i * 8]) = z8;
+    for (int i = tid; i < 2 * KT * LDR / 8; i += 256) *(f16x8*)(&sV[0][i * 8]) = z8;
+    __syncthreads();
+  }
+  const _Float16* kfull = kbase + (size_t)b * p.kv_bstride * p.ldk;
+  const _Float16* vfull = vbase + (size_t)b * p.kv_bstride * p.ldv;
   auto gload = [&](int t, bool with_v) {
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       const int idx = tid + c * 256;
       const int row = idx / CPR, ch = idx - row * CPR;
       const int kv = t * KT + row;
-      f16x8 kk = {0, 0, 0, 0, 0, 0, 0, 0}, vv = kk;
-      if (((KT * CPR) % 256 == 0 || idx < KT * CPR) && (FULL || kv < p.Sk) && ch * 8 < D) {
-        const size_t r = seg_row(b, kv, p.kv_bstride, p.seg_T, p.B, p.Sk);
-        kk = *(const f16x8*)(kbase + r * p.ldk + ch * 8);
-        if (with_v) vv = *(const f16x8*)(vbase + r * p.ldv + ch * 8);
+      if (FULL) {
+        const int che = ch < CHV ? ch : CHV - 1;
+        kreg[c] = *(const f16x8*)(kfull + (size_t)kv * p.ldk + che * 8);
+        if (with_v) vreg[c] = *(const f16x8*)(vfull + (size_t)kv * p.ldv + che * 8);
+      } else {
+        f16x8 kk = {0, 0, 0, 0, 0, 0, 0, 0}, vv = kk;
+        if (((KT * CPR) % 256 == 0 || idx < KT * CPR) && kv < p.Sk && ch * 8 < D) {
+          const size_t r = seg_row(b, kv, p.kv_bstride, p.seg_T, p.B, p.Sk);
+          kk = *(const f16x8*)(kbase + r * p.ldk + ch * 8);
+          if (with_v) vv = *(const f16x8*)(vbase + r * p.ldv + ch * 8);
+        }
+        kreg[c] = kk; vreg[c] = vv;
       }
-      kreg[c] = kk; vreg[c] = vv;
     }
   };
   auto lstore = [&](int buf, bool with_v) {
@@ -360,8 +394,13 @@ __global__ __launch_bounds__(256, 2) void attn_map_kernel(const AttnParams p) {
     for (int c = 0; c < NCH; ++c) {
       const int idx = tid + c * 256;
       const int row = idx / CPR, ch = idx - row * CPR;
-      if (idx < KT * CPR) {
-        *(f16x8*)(&sK[buf][row * LDR + ch * 8]) = kreg[c];
+      if (FULL) {
+        if (ch < CHV) {
+          *(f16x8*)(&sK[buf][row * LDK + ch * 8]) = kreg[c];
+          if (with_v) *(f16x8*)(&sV[buf][row * LDR + ch * 8]) = vreg[c];
+        }
+      } else if (idx < KT * CPR) {
+        if (ch * 8 < DQK) *(f16x8*)(&sK[buf][row * LDK + ch * 8]) = kreg[c];
         if (with_v) *(f16x8*)(&sV[buf][row * LDR + ch * 8]) = vreg[c];
       }
     }
@@ -371,7 +410,7 @@ __global__ __launch_bounds__(256, 2) void attn_map_kernel(const AttnParams p) {
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int st = 0; st < NS; ++st) {
-        const f16x8 kf = *(const f16x8*)(cK + (kb * 32 + lq) * LDR + 16 * st + 8 * lh);
+        const f16x8 kf = *(const f16x8*)(cK + (kb * 32 + lq) * LDK + 16 * st + 8 * lh);
         if (st == 0) {
           const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
           s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[st], z, 0, 0, 0);
@@ -390,11 +429,103 @@ __global__ __launch_bounds__(256, 2) void attn_map_kernel(const AttnParams p) {
     }
   };
 
+  // every workgroup walks the key tiles of pass B from its own starting tile (wrapping): at any instant the resident
+  // workgroups then write different 128-byte columns of their rows instead of the same one (HBM channel spread)
+  const int t0 = (int)((blockIdx.x * 37u) % (unsigned)ntiles);
+  auto tile_of = [&](int t) { int x = t + t0; return x >= ntiles ? x - ntiles : x; };
+
+  // ---------------- LW: wave 4 only moves K / V tiles HBM -> LDS ----------------
+  // `vmcnt` is one counter for loads and stores, and the compiler has to assume stores retire out of order with loads: in a
+  // wave that does both, every wait for a K/V tile is also a wait for the probability stores issued before it (store round
+  // trip per key tile).  With the loads in a wave of their own the four compute waves only ever have stores in flight and
+  // never wait on the counter inside the loops.  Step i of 2 * ntiles (pass A then pass B) lives in buffer i & 1; the
+  // loader runs two steps ahead in registers and one step ahead in LDS; every wave meets at one barrier per step.
+  if constexpr (LW) if (wave == 4) {
+    constexpr int NLC = KT * CHV / 64;
+    static_assert((KT * CHV) % 64 == 0, "whole wave loads");
+    const int nsteps = 2 * ntiles;
+    f16x8 ak[NLC], av[NLC], bk[NLC], bv[NLC];
+    // The loads are inline asm with hand-counted waits: for loads carried over a loop back edge the compiler's own
+    // waitcnt insertion falls back to `vmcnt(0)`, which would also wait for the tile just requested.  Loads retire in order,
+    // so "all but the N youngest have landed" is exact; the "+v" ties keep every use of a register after its wait.
+    auto gld = [&](const _Float16* base, uint32_t off) {      // uniform 64-bit tile base (SGPR pair) + per-lane byte offset
+      f16x8 r;
+      // s_nop: the base may have just been written by v_readfirstlane (VALU-writes-SGPR -> VMEM-reads-it needs 5 wait states,
+      // and the hazard recogniser does not look inside inline asm)
+      asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(r) : "v"(off), "s"(base) : "memory");
+      return r;
+    };
+    uint32_t offk[NLC], offv[NLC];                            // byte offsets inside a tile: the same for every step
+#pragma unroll
+    for (int c = 0; c < NLC; ++c) {
+      const int idx = lane + c * 64;
+      const int row = idx / CHV, ch = idx - row * CHV;
+      offk[c] = (uint32_t)(row * p.ldk + ch * 8) * 2u;
+      offv[c] = (uint32_t)(row * p.ldv + ch * 8) * 2u;
+    }
+    auto ld = [&](int step, auto with_v, f16x8 (&rk)[NLC], f16x8 (&rv)[NLC]) {
+      const int tile = decltype(with_v)::value ? tile_of(step - ntiles) : step;    // V travels in pass B only
+      const _Float16* kt = uniform_ptr(kfull + (size_t)tile * KT * p.ldk);
+      const _Float16* vt = uniform_ptr(vfull + (size_t)tile * KT * p.ldv);
+#pragma unroll
+      for (int c = 0; c < NLC; ++c) {
+        rk[c] = gld(kt, offk[c]);
+        if constexpr (decltype(with_v)::value) rv[c] = gld(vt, offv[c]);
+      }
+    };
+    // wait until at most `younger` loads are in flight, then stage the tile
+    auto st = [&](int step, auto with_v, auto younger, f16x8 (&rk)[NLC], f16x8 (&rv)[NLC]) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(decltype(younger)::value) : "memory");
+#pragma unroll
+      for (int c = 0; c < NLC; ++c) {
+        asm volatile("" : "+v"(rk[c]));
+        if constexpr (decltype(with_v)::value) asm volatile("" : "+v"(rv[c]));
+      }
+#pragma unroll
+      for (int c = 0; c < NLC; ++c) {
+        const int idx = lane + c * 64;
+        const int row = idx / CHV, ch = idx - row * CHV;
+        *(f16x8*)(&sK[step & 1][row * LDK + ch * 8]) = rk[c];
+        if constexpr (decltype(with_v)::value) *(f16x8*)(&sV[step & 1][row * LDR + ch * 8]) = rv[c];
+      }
+    };
+    constexpr std::false_type K_{};
+    constexpr std::true_type KV_{};
+    constexpr std::integral_constant<int, 0> N0{};
+    constexpr std::integral_constant<int, NLC> NK{};          // loads of one K tile
+    constexpr std::integral_constant<int, 2 * NLC> NKV{};     // loads of one K + V tile
+    // straight-line pairs of steps; ntiles is even (host-checked)
+    ld(0, K_, ak, av); st(0, K_, N0, ak, av);
+    lds_barrier();
+    ld(1, K_, bk, bv);
+    int i = 0;
+    for (; i + 2 < ntiles; i += 2) {                          // pass A
+      ld(i + 2, K_, ak, av); st(i + 1, K_, NK, bk, bv);
+      lds_barrier();                                          // end of step i
+      ld(i + 3, K_, bk, bv); st(i + 2, K_, NK, ak, av);
+      lds_barrier();                                          // end of step i + 1
+    }
+    ld(i + 2, KV_, ak, av); st(i + 1, K_, NKV, bk, bv);       // pass A -> pass B
+    lds_barrier();
+    ld(i + 3, KV_, bk, bv); st(i + 2, KV_, NKV, ak, av);
+    lds_barrier();
+    for (i += 2; i + 2 < nsteps; i += 2) {                    // pass B
+      ld(i + 2, KV_, ak, av); st(i + 1, KV_, NKV, bk, bv);
+      lds_barrier();
+      ld(i + 3, KV_, bk, bv); st(i + 2, KV_, NKV, ak, av);
+      lds_barrier();
+    }
+    st(i + 1, KV_, N0, bk, bv);
+    lds_barrier();
+    lds_barrier();
+    return;
+  }
+
   // ---------------- pass A: row max and row sum ----------------
   float m_run = -INFINITY, l_run = 0.f;
-  gload(0, false); lstore(0, false);
+  if (!LW) { gload(0, false); lstore(0, false); }
   lds_barrier();
-  if (ntiles > 1) gload(1, false);
+  if (!LW && ntiles > 1) gload(1, false);
   for (int t = 0; t < ntiles; ++t) {
     f32x16 s[2];
     scores(sK[t & 1], t, s);
@@ -412,11 +543,11 @@ __global__ __launch_bounds__(256, 2) void attn_map_kernel(const AttnParams p) {
       for (int r = 0; r < 16; ++r) psum += __builtin_amdgcn_exp2f(s[kb][r] * sl2 - m_new);
     l_run = l_run * __builtin_amdgcn_exp2f(m_run - m_new) + psum;
     m_run = m_new;
-    if (t + 1 < ntiles) lstore((t + 1) & 1, false);
+    if (!LW && t + 1 < ntiles) lstore((t + 1) & 1, false);
     lds_barrier();
-    if (t + 2 < ntiles) gload(t + 2, false);
+    if (!LW && t + 2 < ntiles) gload(t + 2, false);
   }
-  const float inv_l = 1.0f / half_sum(l_run);
+  const float m_fin = m_run + __builtin_amdgcn_logf(half_sum(l_run));   // p = 2^(s - m - log2 l)   (v_log_f32 is log2)
 
   // ---------------- pass B: probabilities -> HBM, O^T += V^T P^T ----------------
   f32x16 o[NDB];
@@ -428,33 +559,41 @@ __global__ __launch_bounds__(256, 2) void attn_map_kernel(const AttnParams p) {
   // sample-major: map = (B, heads, Sq, Sk).  MMDiT joint layout (seg_T = T > 0, FluxAttnStoreProcessor,
   // components/attention.py:493-502): only the image queries are kept, split by key into
   //   map  = `self-map`  (B, heads, Sq - T, Sk - T)      map2 = `cross-map` (B, heads, Sq - T, T)      (either may be NULL)
-  const int T = p.seg_T, Si = p.Sq - T;
+  const int T = FULL ? 0 : p.seg_T, Si = p.Sq - T;
   _Float16* mbase = p.map ? p.map + (((size_t)b * p.heads + head) * (T ? Si : p.Sq)) * (T ? Si : p.Sk) : nullptr;
   _Float16* m2base = (T && p.map2) ? p.map2 + (((size_t)b * p.heads + head) * Si) * T : nullptr;
   const bool vec_ok = T ? (((T | Si) & 7) == 0) : ((p.Sk & 7) == 0);            // 16-byte aligned probability rows
-  gload(0, true); lstore(0, true);
-  lds_barrier();
+  const int bofs = LW ? (ntiles & 1) : 0;          // LW: pass B continues the step numbering of pass A
+  if (!LW) {
+    gload(tile_of(0), true); lstore(0, true);
+    lds_barrier();
+  }
   for (int t = 0; t < ntiles; ++t) {
+    const int tt = tile_of(t);
+    const int cb = (t + bofs) & 1;
     // K/V of tile t+1 are requested at the top and staged at the bottom of the SAME iteration: no load is pending across
     // the loop edge, so the only wait on the probability stores is the one the hardware needs (with loads carried over the
     // back edge the compiler started every iteration with `s_waitcnt vmcnt(0)`, i.e. after the previous tile's stores)
-    if (t + 1 < ntiles) gload(t + 1, true);
-    const _Float16* cV = sV[t & 1];
+    if (!LW && t + 1 < ntiles) gload(tile_of(t + 1), true);
+    const _Float16* cV = sV[cb];
     f32x16 s[2];
-    scores(sK[t & 1], t, s);
+    scores(sK[cb], tt, s);
     f16x8 pf[4];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {
-        const float e0 = __builtin_amdgcn_exp2f(s[kb][r] * sl2 - m_run) * inv_l;
-        const float e1 = __builtin_amdgcn_exp2f(s[kb][r + 1] * sl2 - m_run) * inv_l;
+        const float e0 = __builtin_amdgcn_exp2f(s[kb][r] * sl2 - m_fin);      // 1 / l folded into the exponent
+        const float e1 = __builtin_amdgcn_exp2f(s[kb][r + 1] * sl2 - m_fin);
         typedef float f32x2 __attribute__((ext_vector_type(2)));
         typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
         const f16x2 h2 = __builtin_convertvector(f32x2{e0, e1}, f16x2);
         pf[kb * 2 + (r >> 3)][r & 7] = h2[0];
         pf[kb * 2 + (r >> 3)][(r & 7) + 1] = h2[1];
       }
+    // stage K/V of tile t+1 BEFORE this tile's probability stores are issued: the wait for the loads then sits behind the
+    // stores of tile t-1 only (a whole iteration old), not behind the ones about to be issued
+    if (!LW && t + 1 < ntiles) lstore((t + 1) & 1, true);
     // transpose the 32 x 64 probability tile through this wave's LDS slab: lane (q = lq, lh) owns keys
     // kb*32 + 8*g + 4*lh + {0..3}  (g = r >> 2)  ->  row q, 4 consecutive halves
 #pragma unroll
@@ -470,7 +609,7 @@ __global__ __launch_bounds__(256, 2) void attn_map_kernel(const AttnParams p) {
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       const int row = it * 8 + (lane >> 3), ch = lane & 7;
-      const int q = q0 + row, kv = t * KT + ch * 8;
+      const int q = q0 + row, kv = tt * KT + ch * 8;
       if (T == 0) {
         if (FULL) {
           *(f16x8*)(mbase + (size_t)q * p.Sk + kv) = *(const f16x8*)(sPw + row * PLD + ch * 8);
@@ -508,7 +647,6 @@ __global__ __launch_bounds__(256, 2) void attn_map_kernel(const AttnParams p) {
         vf.q[0] = lo; vf.q[1] = hi;
         o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf.h, pf[s4], o[db], 0, 0, 0);
       }
-    if (t + 1 < ntiles) lstore((t + 1) & 1, true);
     lds_barrier();
   }
   if (q_ok) {
@@ -534,8 +672,13 @@ static hipError_t launch_d(const AttnParams& p, hipStream_t s) {
   if (maps && p.seg_T && (p.seg_T & 7)) return hipErrorInvalidValue;    // an 8-key chunk must not straddle the text / image boundary
   if (maps) {
     const int nqb = (p.Sq + 127) / 128;
-    if (p.Sq % 128 == 0 && p.Sk % KT == 0 && !p.seg_T && !p.kv_len) hipLaunchKernelGGL((attn_map_kernel<D, true>), dim3(p.B * p.heads * nqb), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((attn_map_kernel<D, false>), dim3(p.B * p.heads * nqb), dim3(256), 0, s, p);
+    constexpr bool can3 = D <= 48;   // K trimmed to DQK columns: 3 workgroups per CU fit the 160 KiB of LDS
+    constexpr bool canlw = D <= 48;  // loader-wave variant (two K+V tiles of staging registers must fit 128 VGPRs)
+    const dim3 grid(p.B * p.heads * nqb);
+    if (p.Sq % 128 == 0 && p.Sk % KT == 0 && !p.seg_T && !p.kv_len) {
+      if (canlw && p.Sk % (2 * KT) == 0) hipLaunchKernelGGL((attn_map_kernel<D, true, can3 ? 3 : 2, canlw>), grid, dim3(320), 0, s, p);
+      else hipLaunchKernelGGL((attn_map_kernel<D, true, can3 ? 3 : 2, false>), grid, dim3(256), 0, s, p);
+    } else hipLaunchKernelGGL((attn_map_kernel<D, false, 2, false>), grid, dim3(256), 0, s, p);
   } else {
     // 64 query rows per wave (every K / V fragment feeds two MFMAs) when the sequence is long and the
     // accumulators fit (D <= 64); 32 rows per wave otherwise

@@ -52,7 +52,12 @@ def bench_gemm():
                                           flags, stream()), L)
             ms = timeit(fn)
             out.append(f"{ms:8.4f} {2.0 * M * N * K / ms / 1e9:8.1f}")
-        print(f"{name:14s} {M:6d} {N:6d} {K:5d} 128x128 {out[0]}  128x160 {out[1]}  256x128 {out[2]}  256x320 {out[3]}")
+        # library yardstick (hipBLASLt through torch.matmul, plain fp16 GEMM without our epilogue) — not a product path
+        Wt = W.t().contiguous(); lib16 = torch.empty(M, N, device=dev, dtype=torch.half)
+        ms_nt = timeit(lambda: torch.matmul(A, W.t(), out=lib16)); ms_nn = timeit(lambda: torch.matmul(A, Wt, out=lib16))
+        ms_l = min(ms_nt, ms_nn)
+        print(f"{name:14s} {M:6d} {N:6d} {K:5d} 128x128 {out[0]}  128x160 {out[1]}  256x128 {out[2]}  256x320 {out[3]}"
+              f"  hipBLASLt {ms_l:8.4f} {2.0 * M * N * K / ms_l / 1e9:8.1f}")
 
 
 def bench_conv():

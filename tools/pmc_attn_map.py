@@ -5,7 +5,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from ops_binding import P, lib, ok, stream
 L = lib()
-B, h, S, D = int(sys.argv[1]) if len(sys.argv) > 1 else 8, 8, 4096, 40
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+h = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+D = int(sys.argv[3]) if len(sys.argv) > 3 else 40
+S = int(sys.argv[4]) if len(sys.argv) > 4 else 4096
 C = h * D
 qkv = torch.randn(B * S, 3 * C, device="cuda").half(); o = torch.empty(B * S, C, device="cuda", dtype=torch.half)
 m = torch.empty(B, h, S, S, device="cuda", dtype=torch.half)
@@ -15,4 +18,4 @@ for _ in range(2): f()
 torch.cuda.synchronize(); e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True); e0.record()
 for _ in range(3): f()
 e1.record(); torch.cuda.synchronize(); ms = e0.elapsed_time(e1) / 3
-print(f"map attention B={B}: {ms:.3f} ms, map write {m.numel() * 2 / ms / 1e9:.2f} TB/s, {4.0 * B * h * S * S * D / ms / 1e9:.0f} TFLOP/s (single-pass count)")
+print(f"map attention B={B} h={h} D={D} S={S}: {ms:.3f} ms, map write {m.numel() * 2 / ms / 1e9:.2f} TB/s, {4.0 * B * h * S * S * D / ms / 1e9:.0f} TFLOP/s (single-pass count)")
