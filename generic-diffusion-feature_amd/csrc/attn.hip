@@ -682,6 +682,7 @@ static hipError_t launch_d(const AttnParams& p, hipStream_t s) {
   } else {
     // 64 query rows per wave (every K / V fragment feeds two MFMAs) when the sequence is long and the
     // accumulators fit (D <= 64); 32 rows per wave otherwise
+    // (D = 128 with 64 rows per wave needs all 512 registers, one wave per SIMD: measured 822 vs 886 TFLOP/s on the Flux joint shape)
     constexpr bool can2 = D <= 64;
     if (can2 && p.Sq >= 512) {
       const int nqb = (p.Sq + 255) / 256;
