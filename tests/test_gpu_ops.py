@@ -136,7 +136,12 @@ def test_conv_in():
 
 @pytest.mark.parametrize("B,heads,Sq,Sk,D", [(1, 2, 64, 64, 64), (2, 2, 36, 36, 32), (2, 3, 200, 77, 64),
                                               (1, 4, 256, 256, 40), (1, 2, 130, 77, 80), (1, 1, 64, 200, 160),
-                                              (1, 2, 1024, 1024, 64)])
+                                              (1, 2, 1024, 1024, 64),
+                                              # map-kernel variants: loader wave at its minimum of two key tiles (D = 32) and with
+                                              # ragged batches of steps (D = 40, 6 tiles); FULL without loader wave (Sk % 128 != 0,
+                                              # D = 64 / 80)
+                                              (1, 2, 128, 128, 32), (2, 2, 384, 384, 40), (2, 2, 384, 192, 40),
+                                              (1, 2, 256, 512, 64), (1, 2, 128, 320, 80)])
 def test_attention(B, heads, Sq, Sk, D):
     L = lib()
     C = heads * D
@@ -151,7 +156,7 @@ def test_attention(B, heads, Sq, Sk, D):
     ok(L.gdf_op_attention(P(qd), C, P(kd), C, P(vd), C, P(o), C, B, heads, Sq, Sk, D, None, stream()), L)
     torch.cuda.synchronize()
     assert rel(o, ref) < 2e-3
-    if Sq * Sk <= 256 * 256:
+    if Sq * Sk <= 512 * 512:
         o2 = torch.zeros_like(o); mp = torch.zeros(B, heads, Sq, Sk, dtype=torch.half, device="cuda")
         ok(L.gdf_op_attention(P(qd), C, P(kd), C, P(vd), C, P(o2), C, B, heads, Sq, Sk, D, P(mp), stream()), L)
         torch.cuda.synchronize()
