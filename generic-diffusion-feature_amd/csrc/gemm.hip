@@ -23,6 +23,7 @@
 //   * Epilogue is staged per wave through LDS so every global store / residual load is a full
 //     16-byte-per-lane, 128-byte-per-row access.
 #include "kernels.h"
+#include <type_traits>
 #include <cstdio>
 #include <cstring>
 
@@ -91,7 +92,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
   constexpr int B_INSTR = BN / 8;                // 1-KiB wave-instructions per B tile
   constexpr int B_PER_WAVE = (B_INSTR + NW - 1) / NW;
   constexpr int LPT = A_PER_WAVE + B_PER_WAVE;   // DMA instructions per wave per K-tile (uniform when BN == 128)
-  static_assert(STAGES == 2 || (STAGES == 3 && B_INSTR % NW == 0), "3-stage ring needs a uniform per-wave load count");
+  static_assert(STAGES == 2 || STAGES == 8 || (STAGES == 3 && B_INSTR % NW == 0), "3-stage ring needs a uniform per-wave load count");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -235,7 +236,108 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
   constexpr bool EARLY_OK = (NW == 8) && (FM * FN <= 16);
   const bool early_mma = EARLY_OK && !p.no_early_mma && (wave >= 4);
 
-  if (STAGES == 2) {
+  if constexpr (STAGES == 8) {
+    // ---- 8-phase schedule (256x256 dense tile, 2 K-tile buffers of 64 KiB) ----
+    // The two waves of a SIMD (w, w + 4) belong to two groups that run ONE BARRIER apart: while one group multiplies a
+    // quadrant of its 64x128 wave tile (16 MFMAs under s_setprio 1) the other reads its next fragments from LDS and issues
+    // its share of the next half-tile DMA, then they swap (2 barriers per phase, 4 phases per K-tile).  The MFMA pipe of
+    // every SIMD therefore always has a wave that is multiplying.  DMA runs 1.5 K-tiles ahead in 16-KiB half-tiles
+    // (A rows 0-127 / 128-255, B rows likewise; every wave issues 2 of a half-tile's 16 instructions), the one counted wait
+    // per K-tile leaves three half-tiles in flight:
+    //   K-tile T (buffer T & 1)   phase 1: read A (all 64 rows) + B cols 0-63     stage B-hi of T+1      MFMA (A0,B0)
+    //                             phase 2:                                        stage A-lo of T+2      MFMA (A1,B0)
+    //                             phase 3: read B cols 64-127, retire the reads   stage A-hi of T+2      MFMA (A1,B1)
+    //                             phase 4: wait vmcnt(6) = tile T+1 has landed    stage B-lo of T+2      MFMA (A0,B1)
+    // Slot lifetimes (why each staging is safe): A slots are last read in phase 1 (A-lo by group 0 only, A-hi by group 1
+    // only), B slots in phase 3 with the reads retired (lgkmcnt) BEFORE the reader's next barrier; a slot is restaged by
+    // a wave that has passed a barrier the last reader arrived at after retiring its reads.  Tiles >= nk are staged too
+    // (garbage or zeros, never read) so that the wait count is the same in every iteration.
+    static_assert(MODE == A_DENSE && BM == 256 && BN == 256 && FM == 4 && FN == 8, "8-phase schedule: 256x256 dense tile");
+    uint32_t ha[2][2], hb[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int r = h * 128 + (wave * 2 + j) * 8 + lrow;
+        ha[h][j] = (m0 + r < p.M) ? (uint32_t)(m0 + r) * (uint32_t)p.lda * 2u + (uint32_t)chunk * 16u : OOB;
+        hb[h][j] = (n0 + r < p.N) ? (uint32_t)(n0 + r) * (uint32_t)p.K * 2u + (uint32_t)chunk * 16u : OOB;
+      }
+    auto stage = [&](int kt, int buf, auto which) {            // which: 0 A-lo, 1 A-hi, 2 B-lo, 3 B-hi
+      constexpr int W = decltype(which)::value;
+      char* base = smem + buf * STAGE + (W >= 2 ? A_TILE : 0) + (W & 1) * 16384 + wave * 2048;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) glds16(W < 2 ? rsA : rsB, base + j * 1024, (W < 2 ? ha[W & 1][j] : hb[W & 1][j]) + (uint32_t)kt * 128u);
+    };
+    constexpr std::integral_constant<int, 0> ALO{};
+    constexpr std::integral_constant<int, 1> AHI{};
+    constexpr std::integral_constant<int, 2> BLO{};
+    constexpr std::integral_constant<int, 3> BHI{};
+    f16x8 a8[4][2], b8[4][2];
+    auto rd_a = [&](const char* sA) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          const int r = wm * WTM + i * 16 + frow, kc = kk * 4 + fk;
+          a8[i][kk] = *(const f16x8*)(sA + r * 128 + ((kc ^ (r & 7)) << 4));
+        }
+    };
+    auto rd_b = [&](const char* sB, int half) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          const int r = wn * WTN + (half * 4 + j) * 16 + frow, kc = kk * 4 + fk;
+          b8[j][kk] = *(const f16x8*)(sB + r * 128 + ((kc ^ (r & 7)) << 4));
+        }
+    };
+    auto mma_q = [&](auto ah, auto bh) {
+      constexpr int AH = decltype(ah)::value, BH = decltype(bh)::value;
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[AH * 2 + i][BH * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a8[AH * 2 + i][kk], b8[j][kk], acc[AH * 2 + i][BH * 4 + j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+    };
+    auto bar = [&]() {
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    auto lgkm0 = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
+    constexpr std::integral_constant<int, 0> Q0{};
+    constexpr std::integral_constant<int, 1> Q1{};
+    const bool g1 = wave >= 4;
+
+    stage(0, 0, ALO); stage(0, 0, AHI); stage(0, 0, BLO); stage(0, 0, BHI);
+    stage(1, 1, ALO); stage(1, 1, AHI); stage(1, 1, BLO);
+    wait_vmcnt<6>();                 // this wave's share of K-tile 0
+    bar();                           // ... everyone's
+    if (g1) bar();                   // group 1 runs one barrier behind group 0
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = kt & 1;
+      const char* sA = smem + cur * STAGE;
+      const char* sB = sA + A_TILE;
+      // phase 1
+      rd_a(sA); rd_b(sB, 0); stage(kt + 1, cur ^ 1, BHI);
+      bar(); lgkm0(); mma_q(Q0, Q0); bar();
+      // phase 2
+      stage(kt + 2, cur, ALO);
+      bar(); mma_q(Q1, Q0); bar();
+      // phase 3
+      rd_b(sB, 1); stage(kt + 2, cur, AHI); lgkm0();
+      bar(); mma_q(Q1, Q1); bar();
+      // phase 4
+      stage(kt + 2, cur, BLO); wait_vmcnt<6>();
+      bar(); mma_q(Q0, Q1); bar();
+    }
+    if (!g1) bar();
+    wait_vmcnt<0>();                 // the over-staged tiles must not land in the epilogue's staging area
+  } else if (STAGES == 2) {
     issue(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
       // tile kt has landed (all outstanding DMA of this wave) and every wave is done reading buf[(kt+1)&1]
@@ -510,7 +612,7 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_dit_kernel(const GemmParams p)
 template <int MODE, int BM, int BN, int STAGES, bool GEGLU, bool DIT = false>
 static hipError_t launch_t(const GemmParams& p, hipStream_t s) {
   const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
-  const int smem = STAGES * (BM * 128 + BN * 128);
+  const int smem = (STAGES == 8 ? 2 : STAGES) * (BM * 128 + BN * 128);
   static bool attr_done = false;
   if (!attr_done) {
     const void* fn;
@@ -545,8 +647,8 @@ static hipError_t launch_t(const GemmParams& p, hipStream_t s) {
 static int pick_variant(const GemmParams& p) {
   if (p.dit) {   // MMDiT widths are multiples of 256 (3072 = 24 x 128): 256x256 tiles (128 KiB ring, 1 workgroup / CU)
     const long t256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
-    if (p.variant == 128 || p.variant == 1256 || p.variant == 2128) return p.variant;
-    if (p.N % 256 == 0 && t256 >= 128) return 1256;
+    if (p.variant == 128 || p.variant == 1256 || p.variant == 2128 || p.variant == 8256) return p.variant;
+    if (p.N % 256 == 0 && t256 >= 128) return 8256;      // 8-phase schedule: 1177-1362 vs 1002-1188 TFLOP/s (2-stage ring) at the Flux shapes
     return (p.N % 128 == 0 && (long)((p.M + 255) / 256) * (p.N / 128) >= 256) ? 2128 : 128;   // PixArt: C = 1152 = 9 x 128
   }
   if (p.bn == 16) return 16;
@@ -581,7 +683,7 @@ const char* gemm_kernel_name(const GemmParams& p) {
   if (v == 16) bn = 16; else if (v == 160) bn = 160; else if (v == 256) { bm = 256; st = 3; } else if (v == 320) { bm = 256; bn = 320; }
   if (p.mode == A_CONV_SMALLC && v != 160) { bm = 128; bn = 128; st = 2; }
   char tmp[64];
-  if (p.dit) snprintf(tmp, sizeof tmp, "gemm_dit_kernel<%d, %d, %d>", v == 128 ? 128 : 256, v == 1256 ? 256 : 128, v == 2128 ? 3 : 2);
+  if (p.dit) snprintf(tmp, sizeof tmp, "gemm_dit_kernel<%d, %d, %d>", v == 128 ? 128 : 256, (v == 1256 || v == 8256) ? 256 : 128, v == 8256 ? 8 : v == 2128 ? 3 : 2);
   else snprintf(tmp, sizeof tmp, "gemm_kernel<%d, %d, %d, %d, %s>", p.mode, bm, bn, st, p.geglu ? "true" : "false");
   for (int i = 0; i < nb; ++i) if (!strcmp(buf[i], tmp)) return buf[i];
   if (nb < 16) { strcpy(buf[nb], tmp); return buf[nb++]; }
@@ -596,6 +698,7 @@ hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {
   if (v != 16 && ((p.geglu ? p.N / 2 : p.N) % 8) != 0) return hipErrorInvalidValue;   // ragged N only in the BN = 16 variant
   if (p.dit) {
     if (p.mode != A_DENSE || p.geglu || p.batch > 1) return hipErrorInvalidValue;
+    if (v == 8256) return launch_t<A_DENSE, 256, 256, 8, false, true>(p, s);
     if (v == 1256) return launch_t<A_DENSE, 256, 256, 2, false, true>(p, s);
     if (v == 2128) return launch_t<A_DENSE, 256, 128, 3, false, true>(p, s);
     return launch_t<A_DENSE, 128, 128, 2, false, true>(p, s);

@@ -28,7 +28,9 @@ def _region_major(x_txt, x_img):
     return torch.cat([x_txt.reshape(-1, x_txt.shape[-1]), x_img.reshape(-1, x_img.shape[-1])], 0).contiguous()
 
 
-@pytest.mark.parametrize("M,N,K,variant", [(300, 256, 192, 128), (1024, 512, 256, 1256), (700, 768, 1280, 1256), (520, 64, 256, 128)])
+@pytest.mark.parametrize("M,N,K,variant", [(300, 256, 192, 128), (1024, 512, 256, 1256), (700, 768, 1280, 1256), (520, 64, 256, 128),
+                                            # 8-phase main loop: 1, 3 and 20 K-tiles, ragged M / N tiles
+                                            (512, 512, 64, 8256), (700, 768, 192, 8256), (1030, 520, 1280, 8256), (4096, 1024, 3072, 8256)])
 @pytest.mark.parametrize("mode", ["plain", "gelu", "gate_res", "gate_res_seg"])
 def test_gemm_dit(M, N, K, variant, mode):
     L, P, ok, stream = _ops()
