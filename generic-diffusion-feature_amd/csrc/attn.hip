@@ -160,6 +160,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
 
     // ---- S^T = K Q^T : two 32-key blocks; every K fragment feeds QW query blocks ----
     f32x16 s[QW][2];
+    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int st = 0; st < NS; ++st) {
 #pragma unroll
@@ -176,6 +177,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
         }
       }
     }
+    __builtin_amdgcn_s_setprio(0);
     // ---- mask the tail tile, online softmax (per-lane query column) ----
     if ((t + 1) * KT > Sk) {
 #pragma unroll
@@ -227,6 +229,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
     }
 
     // ---- O^T += V^T P^T : 4 steps of 16 (relabelled) keys; every V^T fragment feeds QW query blocks ----
+    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4) {
 #pragma unroll
@@ -245,6 +248,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
       }
     }
 
+    __builtin_amdgcn_s_setprio(0);
     // ---- stage tile t+1 into the other buffer (last read during tile t-1, fenced by the previous barrier) ----
     if (t + 1 < ntiles) lstore((t + 1) & 1);
     __syncthreads();

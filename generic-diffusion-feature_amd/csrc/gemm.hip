@@ -80,7 +80,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
   constexpr int NW = BM / 32;                    // waves per workgroup (4 or 8)
   // waves along N (the GEGLU form of the 256x320 tile uses 4x2 waves of 64x160: an EVEN number of 16-column fragments,
   // so that every h fragment has its gate fragment in the same lane and register index)
-  constexpr int WGN = (BN == 320 && !GEGLU) ? 4 : (BN >= 128) ? 2 : 1;
+  constexpr int WGN = (BN == 320 && !GEGLU && STAGES != 8) ? 4 : (BN >= 128) ? 2 : 1;
   constexpr int WGM = NW / WGN;                  // waves along M
   constexpr int WTM = BM / WGM;                  // 64 or 32
   constexpr int WTN = BN / WGN;                  // 80, 64 or 16
@@ -252,27 +252,54 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
     // only), B slots in phase 3 with the reads retired (lgkmcnt) BEFORE the reader's next barrier; a slot is restaged by
     // a wave that has passed a barrier the last reader arrived at after retiring its reads.  Tiles >= nk are staged too
     // (garbage or zeros, never read) so that the wait count is the same in every iteration.
-    static_assert(MODE == A_DENSE && BM == 256 && BN == 256 && FM == 4 && FN == 8, "8-phase schedule: 256x256 dense tile");
-    uint32_t ha[2][2], hb[2][2];
+    static_assert(MODE == A_DENSE && BM == 256 && (BN == 256 || BN == 320) && FM == 4 && FN == BN / 32, "8-phase schedule: 4x2 waves of 64 x BN/2");
+    // A half-tile = 128 rows = 16 DMA instructions, 2 per wave.  B half-tile = BN/2 rows: 16 instructions (2 per wave) at
+    // BN = 256; 20 at BN = 320: the group whose turn it is (group 0 for B-lo, group 1 for B-hi) issues 3 per wave, the other 2,
+    // so every wave issues 5 per B tile and the counted wait is 6 or 7 depending on the group.
+    constexpr int FNH = FN / 2;                         // 16-column fragments per B half
+    constexpr int BHALF = BN / 2;                       // rows per B half-tile
+    constexpr bool B3 = (BN == 320);
+    const bool g1 = wave >= 4;
+    uint32_t ha[2][2], hb[2][3];
+    int hbq[2];                                         // first instruction index of this wave in B half-tile h
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
+    for (int h = 0; h < 2; ++h) {
+      const bool big = B3 && (g1 == (h == 1));
+      hbq[h] = !B3 ? wave * 2 : (big ? (wave & 3) * 3 : 12 + (wave & 3) * 2);
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int r = h * 128 + (wave * 2 + j) * 8 + lrow;
         ha[h][j] = (m0 + r < p.M) ? (uint32_t)(m0 + r) * (uint32_t)p.lda * 2u + (uint32_t)chunk * 16u : OOB;
+      }
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int r = h * BHALF + (hbq[h] + j) * 8 + lrow;
         hb[h][j] = (n0 + r < p.N) ? (uint32_t)(n0 + r) * (uint32_t)p.K * 2u + (uint32_t)chunk * 16u : OOB;
       }
+    }
     auto stage = [&](int kt, int buf, auto which) {            // which: 0 A-lo, 1 A-hi, 2 B-lo, 3 B-hi
       constexpr int W = decltype(which)::value;
-      char* base = smem + buf * STAGE + (W >= 2 ? A_TILE : 0) + (W & 1) * 16384 + wave * 2048;
+      if constexpr (W < 2) {
+        char* base = smem + buf * STAGE + W * 16384 + wave * 2048;
 #pragma unroll
-      for (int j = 0; j < 2; ++j) glds16(W < 2 ? rsA : rsB, base + j * 1024, (W < 2 ? ha[W & 1][j] : hb[W & 1][j]) + (uint32_t)kt * 128u);
+        for (int j = 0; j < 2; ++j) glds16(rsA, base + j * 1024, ha[W][j] + (uint32_t)kt * 128u);
+      } else {
+        constexpr int H = W - 2;
+        char* base = smem + buf * STAGE + A_TILE + H * (BHALF * 128) + hbq[H] * 1024;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) glds16(rsB, base + j * 1024, hb[H][j] + (uint32_t)kt * 128u);
+        if (B3 && (g1 == (H == 1))) glds16(rsB, base + 2 * 1024, hb[H][2] + (uint32_t)kt * 128u);
+      }
+    };
+    // DMA instructions of this wave in the three youngest stagings at the phase-4 wait (A-lo, A-hi, B-lo of tile T+2)
+    auto wait_tile = [&]() {
+      if (B3 && !g1) wait_vmcnt<7>(); else wait_vmcnt<6>();
     };
     constexpr std::integral_constant<int, 0> ALO{};
     constexpr std::integral_constant<int, 1> AHI{};
     constexpr std::integral_constant<int, 2> BLO{};
     constexpr std::integral_constant<int, 3> BHI{};
-    f16x8 a8[4][2], b8[4][2];
+    f16x8 a8[4][2], b8[FNH][2];
     auto rd_a = [&](const char* sA) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -284,10 +311,10 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
     };
     auto rd_b = [&](const char* sB, int half) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < FNH; ++j)
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-          const int r = wn * WTN + (half * 4 + j) * 16 + frow, kc = kk * 4 + fk;
+          const int r = wn * WTN + (half * FNH + j) * 16 + frow, kc = kk * 4 + fk;
           b8[j][kk] = *(const f16x8*)(sB + r * 128 + ((kc ^ (r & 7)) << 4));
         }
     };
@@ -299,8 +326,8 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
-            acc[AH * 2 + i][BH * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a8[AH * 2 + i][kk], b8[j][kk], acc[AH * 2 + i][BH * 4 + j], 0, 0, 0);
+          for (int j = 0; j < FNH; ++j)
+            acc[AH * 2 + i][BH * FNH + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a8[AH * 2 + i][kk], b8[j][kk], acc[AH * 2 + i][BH * FNH + j], 0, 0, 0);
       __builtin_amdgcn_s_setprio(0);
     };
     auto bar = [&]() {
@@ -311,11 +338,10 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
     auto lgkm0 = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
     constexpr std::integral_constant<int, 0> Q0{};
     constexpr std::integral_constant<int, 1> Q1{};
-    const bool g1 = wave >= 4;
 
     stage(0, 0, ALO); stage(0, 0, AHI); stage(0, 0, BLO); stage(0, 0, BHI);
     stage(1, 1, ALO); stage(1, 1, AHI); stage(1, 1, BLO);
-    wait_vmcnt<6>();                 // this wave's share of K-tile 0
+    wait_tile();                     // this wave's share of K-tile 0
     bar();                           // ... everyone's
     if (g1) bar();                   // group 1 runs one barrier behind group 0
     for (int kt = 0; kt < nk; ++kt) {
@@ -332,7 +358,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
       rd_b(sB, 1); stage(kt + 2, cur, AHI); lgkm0();
       bar(); mma_q(Q1, Q1); bar();
       // phase 4
-      stage(kt + 2, cur, BLO); wait_vmcnt<6>();
+      stage(kt + 2, cur, BLO); wait_tile();
       bar(); mma_q(Q0, Q1); bar();
     }
     if (!g1) bar();
@@ -656,6 +682,8 @@ static int pick_variant(const GemmParams& p) {
   const long tiles256 = (long)((p.M + 255) / 256) * ((p.N + 127) / 128);
   const long tiles320 = (long)((p.M + 255) / 256) * ((p.N + 319) / 320);
   if (p.geglu) {
+    // 8-phase 256x256: 1130 vs 1073 TFLOP/s (256x320 ring) at 16384 x 10240 x 1280, 899 vs 869 at 65536 x 5120 x 640
+    if (p.N % 256 == 0 && (long)((p.M + 255) / 256) * (p.N / 256) >= 256) return 825;
     if (p.N % 320 == 0 && tiles320 >= 128) return 320;
     return tiles256 >= 512 ? 256 : 128;
   }
@@ -681,6 +709,7 @@ const char* gemm_kernel_name(const GemmParams& p) {
   static int nb = 0;
   int bm = 128, bn = 128, st = 2;
   if (v == 16) bn = 16; else if (v == 160) bn = 160; else if (v == 256) { bm = 256; st = 3; } else if (v == 320) { bm = 256; bn = 320; }
+  else if (v == 832) { bm = 256; bn = 320; st = 8; } else if (v == 825) { bm = 256; bn = 256; st = 8; }
   if (p.mode == A_CONV_SMALLC && v != 160) { bm = 128; bn = 128; st = 2; }
   char tmp[64];
   if (p.dit) snprintf(tmp, sizeof tmp, "gemm_dit_kernel<%d, %d, %d>", v == 128 ? 128 : 256, (v == 1256 || v == 8256) ? 256 : 128, v == 8256 ? 8 : v == 2128 ? 3 : 2);
@@ -706,6 +735,8 @@ hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {
   if (p.geglu) {
     // weight rows / bias interleaved [16 h | 16 gate] (launch_relayout_rows geglu = 16)
     if (p.mode != A_DENSE || (p.N % 32) != 0) return hipErrorInvalidValue;
+    if (v == 832) return launch_t<A_DENSE, 256, 320, 8, true>(p, s);
+    if (v == 825) return launch_t<A_DENSE, 256, 256, 8, true>(p, s);
     if (v == 320) return launch_t<A_DENSE, 256, 320, 2, true>(p, s);
     return v == 256 ? launch_t<A_DENSE, 256, 128, 3, true>(p, s) : launch_t<A_DENSE, 128, 128, 2, true>(p, s);
   }
@@ -717,6 +748,7 @@ hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {
   switch (p.mode) {
     case A_DENSE:
       if (v == 160) return launch_t<A_DENSE, 128, 160, 2, false>(p, s);
+      if (v == 832) return launch_t<A_DENSE, 256, 320, 8, false>(p, s);
       if (v == 320) return launch_t<A_DENSE, 256, 320, 2, false>(p, s);
       if (v == 256) return launch_t<A_DENSE, 256, 128, 3, false>(p, s);
       return launch_t<A_DENSE, 128, 128, 2, false>(p, s);
