@@ -106,10 +106,20 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
     // 2-D super-block order: the workgroups one XCD runs concurrently cover sb_gm x sb_gn tiles, so its private L2
     // fetches sb_gm A panels + sb_gn B panels per round instead of one A panel + a whole row of B panels
     // (N = 10240 GEGLU: 27 MB -> 8.5 MB of L2 fills per XCD and round; the "fixed cost" of that GEMM was this traffic).
-    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    // The super-blocks are dealt to the XCDs in groups of 8; when their number is not a multiple of 8 the last few
+    // are walked in plain order (one super-block after the other, round-robin over the XCDs: only that tail loses locality).
     const int conc = p.sb_gm * p.sb_gn;
-    const int sb = (j / conc) * 8 + xcd, li = j - (j / conc) * conc;
     const int sbn = tiles_n / p.sb_gn;
+    const int nsb = (nblk / conc);
+    const int grouped = (nsb >> 3) * 8 * conc;            // workgroups covered by whole groups of 8 super-blocks
+    int sb, li;
+    if ((int)blockIdx.x < grouped) {
+      const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+      sb = (j / conc) * 8 + xcd; li = j - (j / conc) * conc;
+    } else {
+      const int t = blockIdx.x - grouped;
+      sb = (nsb >> 3) * 8 + t / conc; li = t - (t / conc) * conc;
+    }
     const int sbr = sb / sbn, sbc = sb - sbr * sbn;
     tile_m = sbr * p.sb_gm + li / p.sb_gn;
     tile_n = sbc * p.sb_gn + li % p.sb_gn;
@@ -654,7 +664,7 @@ static hipError_t launch_t(const GemmParams& p, hipStream_t s) {
     const int conc = 32 * ((BM == 256) ? 1 : 2);         // workgroups one XCD keeps resident (32 CUs x 1 or 2)
     for (int gn = 4; gn >= 2; gn >>= 1) {
       const int gm = conc / gn;
-      if (tiles_n % gn == 0 && tiles_m % gm == 0 && ((tiles_m / gm) * (tiles_n / gn)) % 8 == 0 && tiles_n > gn) {
+      if (tiles_n % gn == 0 && tiles_m % gm == 0 && (tiles_m / gm) * (tiles_n / gn) >= 8 && tiles_n > gn) {
         q.sb_gm = gm; q.sb_gn = gn;
         break;
       }
