@@ -45,8 +45,10 @@ __device__ __forceinline__ size_t seg_row(int b, int j, int per_b, int seg_T, in
   return j < seg_T ? (size_t)b * seg_T + j : (size_t)B * seg_T + (size_t)b * (S_tot - seg_T) + (j - seg_T);
 }
 
-template <int D, int QW>
-__global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
+// NW = waves per workgroup (4, or 8: twice the query rows share every staged K / V tile)
+template <int D, int QW, int NW = 4>
+__global__ __launch_bounds__(NW * 64, 2) void attn_kernel(const AttnParams p) {
+  constexpr int NT = NW * 64;                    // threads per workgroup
   constexpr int DQK = (D + 15) / 16 * 16;        // contraction length of QK^T, padded
   constexpr int DV = (D + 31) / 32 * 32;         // output rows of O^T, padded
   constexpr int DP = DV;                         // data halves per LDS row (DV >= DQK)
@@ -55,11 +57,11 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
   // stride must be an odd multiple of 64 B (PMC: with the K stride half of all LDS cycles were bank conflicts)
   constexpr int LDV = (DP % 64 == 32) ? DP : DP + 32;
   constexpr int CPR = DP / 8;                    // 16-B chunks per row
-  constexpr int NCH = (KT * CPR + 255) / 256;    // chunks per thread per tile
+  constexpr int NCH = (KT * CPR + NT - 1) / NT;  // chunks per thread per tile
   constexpr int NS = DQK / 16;                   // k-steps of QK^T
   constexpr int NDB = DV / 32;                   // 32-row blocks of O^T
   constexpr int QBW = 32 * QW;                   // query rows per wave
-  constexpr int QBLK = 4 * QBW;                  // query rows per workgroup
+  constexpr int QBLK = NW * QBW;                 // query rows per workgroup
   constexpr bool PADDED = (DP != D);             // head dims 40 / 80: zero-filled pad chunks
 
   // double-buffered K / V tiles: one barrier per tile
@@ -123,13 +125,13 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
   auto gload = [&](int t) {
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-      const int idx = tid + c * 256;
+      const int idx = tid + c * NT;
       const int row = idx / CPR, ch = idx - row * CPR;
       int kv = t * KT + row;
       kv = min(kv, Sk - 1);                    // tail rows re-read the last key: their scores are masked to -inf below
       const uint32_t r = (uint32_t)kv + (kv < segT ? c0 : c1);
       f16x8 kk = {0, 0, 0, 0, 0, 0, 0, 0}, vv = kk;
-      if ((KT * CPR) % 256 == 0 || idx < KT * CPR) {
+      if ((KT * CPR) % NT == 0 || idx < KT * CPR) {
         if (!PADDED || ch * 8 < D) {
           kk = *(const f16x8*)(kbase + (r * ldk + (uint32_t)(ch * 8)));
           vv = *(const f16x8*)(vbase + (r * ldv + (uint32_t)(ch * 8)));
@@ -141,9 +143,9 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
   auto lstore = [&](int buf) {
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-      const int idx = tid + c * 256;
+      const int idx = tid + c * NT;
       const int row = idx / CPR, ch = idx - row * CPR;
-      if ((KT * CPR) % 256 == 0 || idx < KT * CPR) {
+      if ((KT * CPR) % NT == 0 || idx < KT * CPR) {
         *(f16x8*)(&sK[buf][row * LDR + ch * 8]) = kreg[c];
         *(f16x8*)(&sV[buf][row * LDV + ch * 8]) = vreg[c];
       }
@@ -691,6 +693,11 @@ static hipError_t launch_d(const AttnParams& p, hipStream_t s) {
     if (can2 && p.Sq >= 512) {
       const int nqb = (p.Sq + 255) / 256;
       hipLaunchKernelGGL((attn_kernel<D, can2 ? 2 : 1>), dim3(p.B * p.heads * nqb), dim3(256), 0, s, p);
+    } else if (D == 128 && p.Sq >= 1024) {
+      // 8 waves share every staged K / V tile (half the L2 -> LDS traffic per query row): 877 -> 917 TFLOP/s on the Flux joint
+      // shape; at D = 72 the 768-chunk tile does not split evenly over 512 threads (690 -> 591), so only D = 128 takes it
+      const int nqb = (p.Sq + 255) / 256;
+      hipLaunchKernelGGL((attn_kernel<D, 1, D == 128 ? 8 : 4>), dim3(p.B * p.heads * nqb), dim3(D == 128 ? 512 : 256), 0, s, p);
     } else {
       const int nqb = (p.Sq + 127) / 128;
       hipLaunchKernelGGL((attn_kernel<D, 1>), dim3(p.B * p.heads * nqb), dim3(256), 0, s, p);
