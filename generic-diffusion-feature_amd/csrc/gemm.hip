@@ -92,7 +92,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
   constexpr int B_INSTR = BN / 8;                // 1-KiB wave-instructions per B tile
   constexpr int B_PER_WAVE = (B_INSTR + NW - 1) / NW;
   constexpr int LPT = A_PER_WAVE + B_PER_WAVE;   // DMA instructions per wave per K-tile (uniform when BN == 128)
-  static_assert(STAGES == 2 || STAGES == 8 || (STAGES == 3 && B_INSTR % NW == 0), "3-stage ring needs a uniform per-wave load count");
+  static_assert(STAGES == 2 || STAGES == 8 || STAGES == 9 || (STAGES == 3 && B_INSTR % NW == 0), "3-stage ring needs a uniform per-wave load count");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -373,6 +373,135 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
     }
     if (!g1) bar();
     wait_vmcnt<0>();                 // the over-staged tiles must not land in the epilogue's staging area
+  } else if constexpr (STAGES == 9) {
+    // ---- 8-phase schedule on the 256x320 tile (2x4 waves of 128x80, dense or 3x3-conv A operand) ----
+    // Same two-group ping-pong as STAGES == 8, with the roles of A and B swapped so that the 160 accumulators leave room:
+    // a wave keeps ALL of its B fragments (80 columns x 64 K = 10 registers of 8 halves) after phase 1 and reads one quarter
+    // of its A rows (32 rows) per phase: 20 MFMAs per phase, 26 ds_read_b128 per K-tile.  DMA units: A_q = the q-th 32-row
+    // quarter of BOTH 128-row halves (64 rows, one instruction per wave), B_1 = B rows 0-191 (3 per wave), B_2 = rows
+    // 192-319 (2 per wave).  Unit lifetimes in K-tile T: B is read in phase 1 only, A_q in phase q+1 only; every read is
+    // retired (lgkmcnt) before the reader's next barrier, so a unit may be restaged from the phase after its read:
+    //   phase 1: read B, A_0   stage A_3 of T+1             phase 3: read A_2   stage B_2, A_0 of T+2
+    //   phase 2: read A_1      stage B_1 of T+2             phase 4: read A_3   stage A_1, A_2 of T+2,  wait vmcnt(8)
+    // (8 = the DMA instructions of phases 2-4: everything staged up to phase 1, i.e. all of tile T+1, has landed).
+    static_assert((MODE == A_DENSE || MODE == A_CONV3) && BM == 256 && BN == 320 && FM == 8 && FN == 5 && WGN == 4,
+                  "8-phase schedule, 2x4 waves of 128x80");
+    // A unit q: this wave's instruction covers rows (wave>>2)*128 + q*32 + (wave&3)*8 + lrow
+    uint32_t ua[4];                                     // DENSE: byte offset of (row, chunk); CONV: pixel base of the sample
+    int uy[4], ux[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int m = m0 + (wave >> 2) * 128 + q * 32 + (wave & 3) * 8 + lrow;
+      if (MODE == A_DENSE) {
+        ua[q] = (m < p.M) ? (uint32_t)m * (uint32_t)p.lda * 2u + (uint32_t)chunk * 16u : OOB;
+        uy[q] = ux[q] = 0;
+      } else {
+        const int hw = p.OH * p.OW;
+        const int n = m / hw;
+        const int rem = m - n * hw;
+        const int oy = rem / p.OW, ox = rem - oy * p.OW;
+        ua[q] = (uint32_t)(n * p.H * p.W);
+        uy[q] = (m < p.M) ? oy * p.stride - 1 + p.pad0 : -(1 << 20);
+        ux[q] = ox * p.stride - 1 + p.pad0;
+      }
+    }
+    uint32_t ub[5];                                     // B_1: instructions wave*3 + {0,1,2}; B_2: 24 + wave*2 + {0,1}
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const int qi = j < 3 ? wave * 3 + j : 24 + wave * 2 + (j - 3);
+      const int n = n0 + qi * 8 + lrow;
+      ub[j] = (n < p.N) ? (uint32_t)n * (uint32_t)p.K * 2u + (uint32_t)chunk * 16u : OOB;
+    }
+    // filter tap / channel block of K-tile kt (conv): K-tiles are tap-major, cpb tiles per tap
+    auto stage_a = [&](int kt, int buf, int q) {
+      char* dst = smem + buf * STAGE + ((wave >> 2) * 128 + q * 32 + (wave & 3) * 8) * 128;
+      uint32_t off;
+      if (MODE == A_DENSE) {
+        off = ua[q] + (uint32_t)kt * 128u;
+      } else {
+        const int tp = kt / cpb, cbk = kt - tp * cpb;
+        const int ky = tp / 3, kx = tp - ky * 3;
+        const int iy = uy[q] + ky, ix = ux[q] + kx;
+        const bool okk = (tp < 9) & (iy >= 0) & (iy < IH) & (ix >= 0) & (ix < IW);
+        const int sy = p.ups ? (iy >> 1) : iy, sx = p.ups ? (ix >> 1) : ix;
+        off = okk ? (ua[q] + (uint32_t)(sy * p.W + sx)) * (uint32_t)p.lda * 2u + (uint32_t)(cbk * BK + chunk * 8) * 2u : OOB;
+      }
+      glds16(rsA, dst, off);
+    };
+    auto stage_b = [&](int kt, int buf, auto part) {
+      constexpr int PT = decltype(part)::value;           // 0: B_1 (3 instructions), 1: B_2 (2)
+      char* base = smem + buf * STAGE + A_TILE;
+#pragma unroll
+      for (int j = (PT ? 3 : 0); j < (PT ? 5 : 3); ++j) {
+        const int qi = j < 3 ? wave * 3 + j : 24 + wave * 2 + (j - 3);
+        glds16(rsB, base + qi * 1024, ub[j] + (uint32_t)kt * 128u);
+      }
+    };
+    constexpr std::integral_constant<int, 0> B1{};
+    constexpr std::integral_constant<int, 1> B2{};
+    f16x8 a4[2][2], b10[5][2];
+    auto rd_aq = [&](const char* sA, int q) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          const int r = wm * WTM + (q * 2 + i) * 16 + frow, kc = kk * 4 + fk;
+          a4[i][kk] = *(const f16x8*)(sA + r * 128 + ((kc ^ (r & 7)) << 4));
+        }
+    };
+    auto rd_ball = [&](const char* sB) {
+#pragma unroll
+      for (int j = 0; j < 5; ++j)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          const int r = wn * WTN + j * 16 + frow, kc = kk * 4 + fk;
+          b10[j][kk] = *(const f16x8*)(sB + r * 128 + ((kc ^ (r & 7)) << 4));
+        }
+    };
+    auto mma_q = [&](auto qq) {
+      constexpr int Q = decltype(qq)::value;
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 5; ++j)
+            acc[Q * 2 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a4[i][kk], b10[j][kk], acc[Q * 2 + i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+    };
+    auto bar = [&]() {
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    auto lgkm0 = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
+    constexpr std::integral_constant<int, 0> P0{};
+    constexpr std::integral_constant<int, 1> P1{};
+    constexpr std::integral_constant<int, 2> P2{};
+    constexpr std::integral_constant<int, 3> P3{};
+    const bool g1 = wave >= 4;
+
+    stage_b(0, 0, B1); stage_b(0, 0, B2); stage_a(0, 0, 0); stage_a(0, 0, 1); stage_a(0, 0, 2); stage_a(0, 0, 3);
+    stage_b(1, 1, B1); stage_b(1, 1, B2); stage_a(1, 1, 0); stage_a(1, 1, 1); stage_a(1, 1, 2);
+    wait_vmcnt<8>();                 // this wave's share of K-tile 0
+    bar();                           // ... everyone's
+    if (g1) bar();                   // group 1 runs one barrier behind group 0
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = kt & 1;
+      const char* sA = smem + cur * STAGE;
+      const char* sB = sA + A_TILE;
+      rd_ball(sB); rd_aq(sA, 0); stage_a(kt + 1, cur ^ 1, 3); lgkm0();
+      bar(); mma_q(P0); bar();
+      rd_aq(sA, 1); stage_b(kt + 2, cur, B1); lgkm0();
+      bar(); mma_q(P1); bar();
+      rd_aq(sA, 2); stage_b(kt + 2, cur, B2); stage_a(kt + 2, cur, 0); lgkm0();
+      bar(); mma_q(P2); bar();
+      rd_aq(sA, 3); stage_a(kt + 2, cur, 1); stage_a(kt + 2, cur, 2); wait_vmcnt<8>(); lgkm0();
+      bar(); mma_q(P3); bar();
+    }
+    if (!g1) bar();
+    wait_vmcnt<0>();                 // the over-staged tiles must not land in the epilogue's staging area
   } else if (STAGES == 2) {
     issue(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
@@ -648,7 +777,7 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_dit_kernel(const GemmParams p)
 template <int MODE, int BM, int BN, int STAGES, bool GEGLU, bool DIT = false>
 static hipError_t launch_t(const GemmParams& p, hipStream_t s) {
   const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
-  const int smem = (STAGES == 8 ? 2 : STAGES) * (BM * 128 + BN * 128);
+  const int smem = (STAGES >= 8 ? 2 : STAGES) * (BM * 128 + BN * 128);
   static bool attr_done = false;
   if (!attr_done) {
     const void* fn;
@@ -698,15 +827,15 @@ static int pick_variant(const GemmParams& p) {
     return tiles256 >= 512 ? 256 : 128;
   }
   if (p.mode != A_DENSE) {                                                 // convs (K = 9 Cin is long)
-    if (p.N % 320 == 0 && p.K >= 5760 && tiles320 >= 128) return 320;     // 1070-1236 TFLOP/s
-    if (p.N % 160 == 0) return 160;                                        // 1000-1107
+    if (p.N % 320 == 0 && tiles320 >= 128) return 932;                     // 8-phase 256x320: 1150-1350 TFLOP/s (ring 1090-1310, 128x160 950-1140)
+    if (p.N % 160 == 0) return 160;
     return (p.N <= 128 && p.M >= (1 << 20)) ? 256 : 128;                   // VAE level-0 convs (N = 128, 4 M pixels): 797 vs 697
   }
   // short-K GEMMs with the fp32 residual epilogue (attention out-projections: 10 B/element of epilogue traffic against
   // 20 K-tiles of MFMA work) fill the chip in ONE round of 256x320 tiles, so main loop and epilogue traffic never overlap;
   // 128x160 tiles run 2 workgroups per CU and 2+ rounds (80 vs 89 us at 16384 x 1280 x 1280)
   if (p.res32 && p.K <= 1536 && p.N % 160 == 0 && tiles320 <= 512) return 160;
-  if (p.N % 320 == 0 && tiles320 >= 128) return 320;                       // qkv 1049, ff_out 1009, attn2_q 1046, shortcut 1044
+  if (p.N % 320 == 0 && tiles320 >= 128) return 932;                       // 8-phase: qkv 1113, ff_out 1088, attn2_q 1045, shortcut 1086 (ring: 1051 / 983 / 980 / 1002)
   if (p.N % 160 == 0 && p.K >= 1024) return 160;
   if ((long)p.M * p.N >= (1L << 26) && tiles256 >= 512) return 256;        // short-K, large MxN (qkv @ C=640): 712 vs 642
   return 128;
@@ -719,7 +848,7 @@ const char* gemm_kernel_name(const GemmParams& p) {
   static int nb = 0;
   int bm = 128, bn = 128, st = 2;
   if (v == 16) bn = 16; else if (v == 160) bn = 160; else if (v == 256) { bm = 256; st = 3; } else if (v == 320) { bm = 256; bn = 320; }
-  else if (v == 832) { bm = 256; bn = 320; st = 8; } else if (v == 825) { bm = 256; bn = 256; st = 8; }
+  else if (v == 832) { bm = 256; bn = 320; st = 8; } else if (v == 825) { bm = 256; bn = 256; st = 8; } else if (v == 932) { bm = 256; bn = 320; st = 9; }
   if (p.mode == A_CONV_SMALLC && v != 160) { bm = 128; bn = 128; st = 2; }
   char tmp[64];
   if (p.dit) snprintf(tmp, sizeof tmp, "gemm_dit_kernel<%d, %d, %d>", v == 128 ? 128 : 256, (v == 1256 || v == 8256) ? 256 : 128, v == 8256 ? 8 : v == 2128 ? 3 : 2);
@@ -759,11 +888,13 @@ hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {
     case A_DENSE:
       if (v == 160) return launch_t<A_DENSE, 128, 160, 2, false>(p, s);
       if (v == 832) return launch_t<A_DENSE, 256, 320, 8, false>(p, s);
+      if (v == 932) return launch_t<A_DENSE, 256, 320, 9, false>(p, s);
       if (v == 320) return launch_t<A_DENSE, 256, 320, 2, false>(p, s);
       if (v == 256) return launch_t<A_DENSE, 256, 128, 3, false>(p, s);
       return launch_t<A_DENSE, 128, 128, 2, false>(p, s);
     case A_CONV3:
       if (v == 160) return launch_t<A_CONV3, 128, 160, 2, false>(p, s);
+      if (v == 932) return launch_t<A_CONV3, 256, 320, 9, false>(p, s);
       if (v == 320) return launch_t<A_CONV3, 256, 320, 2, false>(p, s);
       if (v == 256) return launch_t<A_CONV3, 256, 128, 3, false>(p, s);
       return launch_t<A_CONV3, 128, 128, 2, false>(p, s);

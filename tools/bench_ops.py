@@ -43,10 +43,10 @@ def bench_gemm():
         o32 = torch.empty(M, No, device=dev) if mode in ("res", "o32") else None
         res = torch.randn(M, No, device=dev) if mode == "res" else None
         out = []
-        for var in (128, 160, 256, 320, 832, 825):
+        for var in (128, 160, 256, 320, 832, 825, 932):
             early = var >> 12; var &= 4095
             flags = (early << 20) | (var << 8) | ((1 | (8 if var in (160, 320) else 0)) if mode == "geglu" else 0)
-            if (var in (160, 320) and N % var) or (var == 160 and mode == "geglu") or (var == 832 and N % 320) or (var == 825 and (mode != "geglu" or N % 256)):
+            if (var in (160, 320) and N % var) or (var == 160 and mode == "geglu") or (var == 832 and N % 320) or (var == 825 and (mode != "geglu" or N % 256)) or (var == 932 and (mode == "geglu" or N % 320)):
                 out.append(" " * 17); continue
             fn = lambda: ok(L.gdf_op_gemm(P(A), K, P(W), P(bias), P(res), None, No, P(o16), No, P(o32), No, M, N, K,
                                           flags, stream()), L)
@@ -56,7 +56,7 @@ def bench_gemm():
         Wt = W.t().contiguous(); lib16 = torch.empty(M, N, device=dev, dtype=torch.half)
         ms_nt = timeit(lambda: torch.matmul(A, W.t(), out=lib16)); ms_nn = timeit(lambda: torch.matmul(A, Wt, out=lib16))
         ms_l = min(ms_nt, ms_nn)
-        print(f"{name:14s} {M:6d} {N:6d} {K:5d} 128x128 {out[0]}  128x160 {out[1]}  256x128 {out[2]}  256x320 {out[3]}  8ph320 {out[4]}  8ph256 {out[5]}"
+        print(f"{name:14s} {M:6d} {N:6d} {K:5d} 128x128 {out[0]}  128x160 {out[1]}  256x128 {out[2]}  256x320 {out[3]}  8ph320 {out[4]}  8ph256 {out[5]}  8ph320b {out[6]}"
               f"  hipBLASLt {ms_l:8.4f} {2.0 * M * N * K / ms_l / 1e9:8.1f}")
 
 
@@ -73,12 +73,14 @@ def bench_conv():
         OH = (2 * H if ups else H) // st; OW = (2 * W if ups else W) // st
         o16 = torch.empty(B, OH, OW, Co, device=dev, dtype=torch.half)
         out = []
-        for var in (128, 160, 256, 320):
+        for var in (128, 160, 256, 320, 932):
+            if var == 932 and Co % 320:
+                out.append(" " * 17); continue
             fn = lambda: ok(L.gdf_op_conv3x3(P(x), Ci, B, H, W, Ci, P(w), Co, P(bias), None, st, ups, None, None, P(o16), None,
                                              ((var >> 12) << 20) | ((var & 4095) << 8), stream()), L)
             ms = timeit(fn, iters=10)
             out.append(f"{ms:8.4f} {2.0 * B * OH * OW * Co * 9 * Ci / ms / 1e9:8.1f}")
-        print(f"{name:16s} 128x128 {out[0]}  128x160 {out[1]}  256x128 {out[2]}  256x320 {out[3]}")
+        print(f"{name:16s} 128x128 {out[0]}  128x160 {out[1]}  256x128 {out[2]}  256x320 {out[3]}  8ph320b {out[4]}")
 
 
 def bench_attn():
