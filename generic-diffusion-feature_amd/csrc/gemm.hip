@@ -262,7 +262,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
     // only), B slots in phase 3 with the reads retired (lgkmcnt) BEFORE the reader's next barrier; a slot is restaged by
     // a wave that has passed a barrier the last reader arrived at after retiring its reads.  Tiles >= nk are staged too
     // (garbage or zeros, never read) so that the wait count is the same in every iteration.
-    static_assert(MODE == A_DENSE && BM == 256 && (BN == 256 || BN == 320) && FM == 4 && FN == BN / 32, "8-phase schedule: 4x2 waves of 64 x BN/2");
+    static_assert((MODE == A_DENSE || MODE == A_CONV3) && BM == 256 && (BN == 256 || BN == 320) && FM == 4 && FN == BN / 32, "8-phase schedule: 4x2 waves of 64 x BN/2");
     // A half-tile = 128 rows = 16 DMA instructions, 2 per wave.  B half-tile = BN/2 rows: 16 instructions (2 per wave) at
     // BN = 256; 20 at BN = 320: the group whose turn it is (group 0 for B-lo, group 1 for B-hi) issues 3 per wave, the other 2,
     // so every wave issues 5 per B tile and the counted wait is 6 or 7 depending on the group.
@@ -270,7 +270,8 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
     constexpr int BHALF = BN / 2;                       // rows per B half-tile
     constexpr bool B3 = (BN == 320);
     const bool g1 = wave >= 4;
-    uint32_t ha[2][2], hb[2][3];
+    uint32_t ha[2][2], hb[2][3];                        // ha: DENSE byte offset of (row, chunk); CONV pixel base of the sample
+    int hy[2][2], hx[2][2];                             // CONV: top-left input pixel of the 3x3 window
     int hbq[2];                                         // first instruction index of this wave in B half-tile h
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -278,8 +279,19 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
       hbq[h] = !B3 ? wave * 2 : (big ? (wave & 3) * 3 : 12 + (wave & 3) * 2);
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        const int r = h * 128 + (wave * 2 + j) * 8 + lrow;
-        ha[h][j] = (m0 + r < p.M) ? (uint32_t)(m0 + r) * (uint32_t)p.lda * 2u + (uint32_t)chunk * 16u : OOB;
+        const int m = m0 + h * 128 + (wave * 2 + j) * 8 + lrow;
+        if (MODE == A_DENSE) {
+          ha[h][j] = (m < p.M) ? (uint32_t)m * (uint32_t)p.lda * 2u + (uint32_t)chunk * 16u : OOB;
+          hy[h][j] = hx[h][j] = 0;
+        } else {
+          const int hw = p.OH * p.OW;
+          const int n = m / hw;
+          const int rem = m - n * hw;
+          const int oy = rem / p.OW, ox = rem - oy * p.OW;
+          ha[h][j] = (uint32_t)(n * p.H * p.W);
+          hy[h][j] = (m < p.M) ? oy * p.stride - 1 + p.pad0 : -(1 << 20);
+          hx[h][j] = ox * p.stride - 1 + p.pad0;
+        }
       }
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
@@ -292,7 +304,20 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
       if constexpr (W < 2) {
         char* base = smem + buf * STAGE + W * 16384 + wave * 2048;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) glds16(rsA, base + j * 1024, ha[W][j] + (uint32_t)kt * 128u);
+        for (int j = 0; j < 2; ++j) {
+          uint32_t off;
+          if (MODE == A_DENSE) {
+            off = ha[W][j] + (uint32_t)kt * 128u;
+          } else {                                             // K-tiles are tap-major, cpb tiles per filter tap
+            const int tp = kt / cpb, cbk = kt - tp * cpb;
+            const int ky = tp / 3, kx = tp - ky * 3;
+            const int iy = hy[W][j] + ky, ix = hx[W][j] + kx;
+            const bool okk = (tp < 9) & (iy >= 0) & (iy < IH) & (ix >= 0) & (ix < IW);
+            const int sy = p.ups ? (iy >> 1) : iy, sx = p.ups ? (ix >> 1) : ix;
+            off = okk ? (ha[W][j] + (uint32_t)(sy * p.W + sx)) * (uint32_t)p.lda * 2u + (uint32_t)(cbk * BK + chunk * 8) * 2u : OOB;
+          }
+          glds16(rsA, base + j * 1024, off);
+        }
       } else {
         constexpr int H = W - 2;
         char* base = smem + buf * STAGE + A_TILE + H * (BHALF * 128) + hbq[H] * 1024;
@@ -829,6 +854,7 @@ static int pick_variant(const GemmParams& p) {
   if (p.mode != A_DENSE) {                                                 // convs (K = 9 Cin is long)
     if (p.N % 320 == 0 && tiles320 >= 128) return 932;                     // 8-phase 256x320: 1150-1350 TFLOP/s (ring 1090-1310, 128x160 950-1140)
     if (p.N % 160 == 0) return 160;
+    if (p.N % 256 == 0 && (long)((p.M + 255) / 256) * (p.N / 256) >= 256) return 826;   // VAE widths 256 / 512: 989-1146 vs 830-965 (256x128 ring)
     return (p.N <= 128 && p.M >= (1 << 20)) ? 256 : 128;                   // VAE level-0 convs (N = 128, 4 M pixels): 797 vs 697
   }
   // short-K GEMMs with the fp32 residual epilogue (attention out-projections: 10 B/element of epilogue traffic against
@@ -848,7 +874,7 @@ const char* gemm_kernel_name(const GemmParams& p) {
   static int nb = 0;
   int bm = 128, bn = 128, st = 2;
   if (v == 16) bn = 16; else if (v == 160) bn = 160; else if (v == 256) { bm = 256; st = 3; } else if (v == 320) { bm = 256; bn = 320; }
-  else if (v == 832) { bm = 256; bn = 320; st = 8; } else if (v == 825) { bm = 256; bn = 256; st = 8; } else if (v == 932) { bm = 256; bn = 320; st = 9; }
+  else if (v == 832) { bm = 256; bn = 320; st = 8; } else if (v == 825) { bm = 256; bn = 256; st = 8; } else if (v == 932) { bm = 256; bn = 320; st = 9; } else if (v == 826) { bm = 256; bn = 256; st = 8; }
   if (p.mode == A_CONV_SMALLC && v != 160) { bm = 128; bn = 128; st = 2; }
   char tmp[64];
   if (p.dit) snprintf(tmp, sizeof tmp, "gemm_dit_kernel<%d, %d, %d>", v == 128 ? 128 : 256, (v == 1256 || v == 8256) ? 256 : 128, v == 8256 ? 8 : v == 2128 ? 3 : 2);
@@ -895,6 +921,7 @@ hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {
     case A_CONV3:
       if (v == 160) return launch_t<A_CONV3, 128, 160, 2, false>(p, s);
       if (v == 932) return launch_t<A_CONV3, 256, 320, 9, false>(p, s);
+      if (v == 826) return launch_t<A_CONV3, 256, 256, 8, false>(p, s);
       if (v == 320) return launch_t<A_CONV3, 256, 320, 2, false>(p, s);
       if (v == 256) return launch_t<A_CONV3, 256, 128, 3, false>(p, s);
       return launch_t<A_CONV3, 128, 128, 2, false>(p, s);

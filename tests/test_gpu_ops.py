@@ -79,10 +79,11 @@ def test_gemm_geglu(M, C, variant):
     assert rel(out, ref) < TOL16
 
 
-@pytest.mark.parametrize("variant", [0, 128, 160, 256, 320, 932])     # 932: 8-phase main loop, conv A operand
+@pytest.mark.parametrize("variant", [0, 128, 160, 256, 320, 932, 826])     # 932 / 826: 8-phase main loops, conv A operand
 @pytest.mark.parametrize("B,H,W,Cin,Cout,stride,ups", [
     (2, 8, 8, 64, 64, 1, 0), (1, 12, 10, 128, 192, 1, 0), (2, 8, 8, 64, 128, 2, 0), (2, 6, 6, 64, 64, 1, 1),
-    (1, 16, 16, 320, 320, 1, 0), (2, 20, 12, 128, 320, 1, 0), (1, 10, 10, 192, 640, 1, 1), (2, 16, 16, 64, 320, 2, 0)])
+    (1, 16, 16, 320, 320, 1, 0), (2, 20, 12, 128, 320, 1, 0), (1, 10, 10, 192, 640, 1, 1), (2, 16, 16, 64, 320, 2, 0),
+    (2, 20, 12, 128, 256, 1, 0), (1, 24, 24, 64, 512, 1, 0)])
 def test_conv3x3(B, H, W, Cin, Cout, stride, ups, variant):
     L = lib()
     x = rnd(B, Cin, H, W); w = rnd(Cout, Cin, 3, 3, scale=(9 * Cin) ** -0.5)
