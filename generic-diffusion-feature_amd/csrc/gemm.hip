@@ -249,7 +249,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
   if constexpr (STAGES == 8) {
     // ---- 8-phase schedule (256x256 dense tile, 2 K-tile buffers of 64 KiB) ----
     // The two waves of a SIMD (w, w + 4) belong to two groups that run ONE BARRIER apart: while one group multiplies a
-    // quadrant of its 64x128 wave tile (16 MFMAs under s_setprio 1) the other reads its next fragments from LDS and issues
+    // quadrant of its 64x128 wave tile (16 MFMAs) the other reads its next fragments from LDS and issues
     // its share of the next half-tile DMA, then they swap (2 barriers per phase, 4 phases per K-tile).  The MFMA pipe of
     // every SIMD therefore always has a wave that is multiplying.  DMA runs 1.5 K-tiles ahead in 16-KiB half-tiles
     // (A rows 0-127 / 128-255, B rows likewise; every wave issues 2 of a half-tile's 16 instructions), the one counted wait
@@ -355,7 +355,6 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
     };
     auto mma_q = [&](auto ah, auto bh) {
       constexpr int AH = decltype(ah)::value, BH = decltype(bh)::value;
-      __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -363,7 +362,6 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
 #pragma unroll
           for (int j = 0; j < FNH; ++j)
             acc[AH * 2 + i][BH * FNH + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a8[AH * 2 + i][kk], b8[j][kk], acc[AH * 2 + i][BH * FNH + j], 0, 0, 0);
-      __builtin_amdgcn_s_setprio(0);
     };
     auto bar = [&]() {
       __builtin_amdgcn_sched_barrier(0);
@@ -485,7 +483,6 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
     };
     auto mma_q = [&](auto qq) {
       constexpr int Q = decltype(qq)::value;
-      __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -493,7 +490,6 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
 #pragma unroll
           for (int j = 0; j < 5; ++j)
             acc[Q * 2 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a4[i][kk], b10[j][kk], acc[Q * 2 + i][j], 0, 0, 0);
-      __builtin_amdgcn_s_setprio(0);
     };
     auto bar = [&]() {
       __builtin_amdgcn_sched_barrier(0);
