@@ -4,6 +4,13 @@
 
 using namespace gdf;
 
+// the GEMM / conv kernels address both operands with 32-bit buffer offsets whose top bit marks "out of range"
+static bool span_ok(size_t a_bytes, size_t w_bytes, const char* what) {
+  if (a_bytes < (1ull << 31) && w_bytes < (1ull << 31)) return true;
+  set_error(std::string(what) + ": operand larger than 2 GiB (32-bit buffer offsets); split the rows");
+  return false;
+}
+
 static int fin(hipError_t e, const char* what) {
   if (e == hipSuccess) return GDF_OK;
   set_error(std::string(what) + ": " + hipGetErrorString(e));
@@ -16,6 +23,7 @@ int gdf_op_gemm(const void* A, int lda, const void* W, const float* bias, const 
                 int ldres, void* out16, int ldo16, float* out32, int ldo32, int M, int N, int K, int flags,
                 void* stream) {
   GemmParams g{};
+  if (!span_ok(((size_t)M - 1) * lda * 2 + (size_t)K * 2, (size_t)N * K * 2, "gemm")) return GDF_ERR_UNSUPPORTED;
   g.A = (const half_t*)A; g.lda = lda; g.a_bytes = (uint32_t)(((size_t)M - 1) * lda * 2 + (size_t)K * 2);
   g.M = M; g.N = N; g.K = K; g.mode = A_DENSE;
   g.Wt = (const half_t*)W; g.w_bytes = (uint32_t)((size_t)N * K * 2);
@@ -31,6 +39,7 @@ int gdf_op_conv3x3(const void* x, int ld, int B, int H, int W, int Cin, const vo
   const int IH = ups ? 2 * H : H, IW = ups ? 2 * W : W;
   const int OH = (IH - 1) / stride + 1, OW = (IW - 1) / stride + 1;
   GemmParams g{};
+  if (!span_ok(((size_t)B * H * W - 1) * ld * 2 + (size_t)Cin * 2, (size_t)Cout * 9 * Cin * 2, "conv3x3")) return GDF_ERR_UNSUPPORTED;
   g.A = (const half_t*)x; g.lda = ld; g.a_bytes = (uint32_t)(((size_t)B * H * W - 1) * ld * 2 + (size_t)Cin * 2);
   g.M = B * OH * OW; g.N = Cout; g.K = 9 * Cin; g.mode = A_CONV3; g.H = H; g.W = W; g.OH = OH; g.OW = OW;
   g.stride = stride; g.ups = ups; g.Cin = Cin;
@@ -118,6 +127,7 @@ int gdf_op_gemm_dit(const void* A, int lda, const void* W, const float* bias, in
                     int rps, int seg_rows, int rps2, const float* res32, int ldres, void* aux16, int ldaux, void* out16,
                     int ldo16, float* out32, int ldo32, int M, int N, int K, int variant, void* stream) {
   GemmParams g{};
+  if (!span_ok(((size_t)M - 1) * lda * 2 + (size_t)K * 2, (size_t)N * K * 2, "gemm_dit")) return GDF_ERR_UNSUPPORTED;
   g.A = (const half_t*)A; g.lda = lda; g.a_bytes = (uint32_t)(((size_t)M - 1) * lda * 2 + (size_t)K * 2);
   g.M = M; g.N = N; g.K = K; g.mode = A_DENSE;
   g.Wt = (const half_t*)W; g.w_bytes = (uint32_t)((size_t)N * K * 2);

@@ -12,7 +12,9 @@ extern "C" {
 /* out[M,N] = A[M,K](lda) * W[N,K]^T + bias (+ residual).  fp16 operands, fp32 accumulate.
  * flags: bit0 GEGLU (W rows / bias already interleaved [16 h | 16 gate] by gdf_op_relayout_geglu(group 16); out is
  *        [M,N/2]); bit1 narrow-N tile (BN=16);
- *        bits 8.. force a tile variant (128 / 160 / 256, 0 = auto).  Replaces nn.Linear / 1x1 conv
+ *        bits 8..19 force a tile variant (0 = auto; 128 / 160 / 256 / 320 = LDS-ring kernels of that tile, 932 / 832 / 825 / 826 =
+ *        8-phase main loops: 256x320 B-resident, 256x320 A-resident, 256x256 GEGLU, 256x256 conv).  Operands larger than 2 GiB
+ *        are rejected (GDF_ERR_UNSUPPORTED: 32-bit buffer offsets).  Replaces nn.Linear / 1x1 conv
  *        (/root/reference/feature/diffusers/models/attention_processor.py:241-267, attention.py:1238-1258). */
 int gdf_op_gemm(const void* A, int lda, const void* W, const float* bias, const float* res32, const void* res16,
                 int ldres, void* out16, int ldo16, float* out32, int ldo32, int M, int N, int K, int flags,
