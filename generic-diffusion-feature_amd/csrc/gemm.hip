@@ -834,7 +834,9 @@ static int pick_variant(const GemmParams& p) {
   if (p.dit) {   // MMDiT widths are multiples of 256 (3072 = 24 x 128): 256x256 tiles (128 KiB ring, 1 workgroup / CU)
     const long t256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
     if (p.variant == 128 || p.variant == 1256 || p.variant == 2128 || p.variant == 8256) return p.variant;
-    if (p.N % 256 == 0 && t256 >= 128) return 8256;      // 8-phase schedule: 1177-1362 vs 1002-1188 TFLOP/s (2-stage ring) at the Flux shapes
+    // 8-phase schedule: 1177-1362 vs 1002-1188 TFLOP/s (2-stage ring) at the Flux shapes.  A ragged last column tile is fine up to
+    // 1/8 of padding (PixArt C = 1152 = 4.5 x 256: 1017-1187 vs 873-1020 on the 256x128 ring)
+    if (t256 >= 128 && (long)((p.N + 255) / 256) * 256 <= (long)p.N + p.N / 8) return 8256;
     return (p.N % 128 == 0 && (long)((p.M + 255) / 256) * (p.N / 128) >= 256) ? 2128 : 128;   // PixArt: C = 1152 = 9 x 128
   }
   if (p.bn == 16) return 16;

@@ -14,7 +14,8 @@ def t(fn, it=10):
     e1.record(); torch.cuda.synchronize(); return e0.elapsed_time(e1) / it
 shapes = [("flux_qkv", 36864, 9216, 3072), ("flux_proj_mlp", 36864, 12288, 3072), ("flux_proj_out", 36864, 3072, 15360),
           ("flux_ff_out", 32768, 3072, 12288), ("sdxl_ff1", 16384, 10240, 1280), ("sdxl_qkv", 16384, 3840, 1280),
-          ("sdxl_ff_out", 16384, 1280, 5120), ("square4k", 4096, 4096, 4096), ("square8k", 8192, 8192, 8192)]
+          ("sdxl_ff_out", 16384, 1280, 5120), ("pixart_qkv", 65536, 3456, 1152), ("pixart_out", 65536, 1152, 1152),
+          ("pixart_ff_out", 65536, 1152, 4608), ("pixart_ff_in", 65536, 4608, 1152), ("square4k", 4096, 4096, 4096), ("square8k", 8192, 8192, 8192)]
 for name, M, N, K in shapes:
     A = torch.randn(M, K, device="cuda").half(); W = (torch.randn(N, K, device="cuda") * K ** -0.5).half()
     bias = torch.randn(N, device="cuda"); o16 = torch.empty(M, N, device="cuda", dtype=torch.half)
