@@ -430,16 +430,22 @@ __global__ __launch_bounds__(256) void small_linear_wide_kernel(const float* x, 
 hipError_t launch_small_linear(const float* x, int ldx, int M, int K, const half_t* Wt, const float* bias, int N,
                                int silu_in, int accumulate, float* out, int ldo, hipStream_t s) {
   if (K % 8) return hipErrorInvalidValue;
-  if (N >= 65536 && M <= 8 && (size_t)K * 32 <= 128 * 1024) {
+  // The LDS-staged kernel (activation applied once per workgroup, 4 weight streams per lane) also serves the mid-size stacked
+  // linears (all time_emb_proj of a UNet in one matrix, N ~ 18 k: the column-per-wave kernel re-evaluated SiLU per column,
+  // 0.54 ms) and more than 8 rows (one launch per 8 rows).
+  if (N >= 1024 && (size_t)K * 32 <= 128 * 1024) {
     static bool attr_done = false;
     if (!attr_done) {
       hipError_t e = hipFuncSetAttribute((const void*)small_linear_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
       if (e != hipSuccess) return e;
       attr_done = true;
     }
-    const int cpb = 512;                               // 32 steps of 16 columns per workgroup: x staging amortised
-    hipLaunchKernelGGL(small_linear_wide_kernel, dim3((N + cpb - 1) / cpb), dim3(256), (size_t)K * 32, s, x, ldx, M, K, Wt, bias,
-                       N, silu_in, accumulate, out, ldo, cpb);
+    // 512 columns per workgroup when N is huge (x staging amortised); fewer for mid-size N so that >= ~512 workgroups exist
+    int cpb = 512;
+    while (cpb > 16 && (N + cpb - 1) / cpb < 512) cpb >>= 1;
+    for (int m0 = 0; m0 < M; m0 += 8)
+      hipLaunchKernelGGL(small_linear_wide_kernel, dim3((N + cpb - 1) / cpb), dim3(256), (size_t)K * 32, s, x + (size_t)m0 * ldx, ldx,
+                         (M - m0 < 8 ? M - m0 : 8), K, Wt, bias, N, silu_in, accumulate, out + (size_t)m0 * ldo, ldo, cpb);
     return hipGetLastError();
   }
   hipLaunchKernelGGL(small_linear_kernel, dim3((N + 3) / 4), dim3(256), 0, s, x, ldx, M, K, Wt, bias, N, silu_in,

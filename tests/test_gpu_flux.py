@@ -66,9 +66,10 @@ def test_gemm_dit(M, N, K, variant, mode):
     assert rel_l2(got, ref) < 1e-3, (mode, rel_l2(got, ref))
 
 
-@pytest.mark.parametrize("M,K,N,silu,acc", [(8, 3072, 70000, 0, 0), (3, 512, 65536 + 37, 1, 1), (8, 256, 1000, 1, 0), (2, 3072, 4096, 0, 1)])
+@pytest.mark.parametrize("M,K,N,silu,acc", [(8, 3072, 70000, 0, 0), (3, 512, 65536 + 37, 1, 1), (8, 256, 1000, 1, 0), (2, 3072, 4096, 0, 1),
+                                            (16, 1280, 18000, 1, 0), (12, 320, 5000 + 3, 1, 1), (16, 2816, 1280, 0, 0), (4, 64, 1023, 1, 0)])     # more than 8 rows: one launch per 8
 def test_small_linear_both_kernels(M, K, N, silu, acc):
-    """N >= 65536 takes the LDS-staged wide kernel (stacked adaLN modulation), smaller N the column-per-wave kernel."""
+    """N >= 1024 takes the LDS-staged wide kernel (stacked adaLN modulation / time_emb_proj), smaller N the column-per-wave kernel."""
     L, P, ok, stream = _ops()
     g = torch.Generator(device="cuda").manual_seed(N)
     x = torch.randn(M, K + 8, device="cuda", generator=g)
