@@ -288,35 +288,41 @@ struct B : PlanBuilder {   // UNet op program
       if (stop) break;
       // --- cross attention ---
       ln = layernorm(tok, bw.ln2);
-      const size_t q2 = tmp(nb);
-      { Epi e; e.out16 = ws(q2); e.has_o16 = true; e.ldo16 = C; gemm("attn2_q", ws(ln), C, n, bw.q2, C, C, 0, e); }
+      // a hooked `cross-q` / `ffn-inner` is a whole contiguous tensor with one producer: the GEMM writes it straight into
+      // the caller's hook buffer and the consumer reads it from there (no workspace copy, no hook_store pass)
+      const int hq = want(bid + "-cross-q", C, x.H, x.W);
+      const size_t q2 = hq >= 0 ? 0 : tmp(nb);
+      const Ref q2r = hq >= 0 ? Ref{BUF_HOOK0 + hq, 0} : ws(q2);
+      { Epi e; e.out16 = q2r; e.has_o16 = true; e.ldo16 = C; gemm("attn2_q", ws(ln), C, n, bw.q2, C, C, 0, e); }
       untmp(ln, nb);
-      hook_copy(want(bid + "-cross-q", C, x.H, x.W), ws(q2), C, n, C);
+      if (hq >= 0) hook_done();
       // text K/V: precomputed for all blocks by the grouped GEMM at the head of the plan; with one prompt repeated over
       // the batch (reference diffusion_feature.py:272, opts.reserved[0]) there is a single K/V set per block
       const bool shared = opt.reserved[0] != 0;
       const size_t kv = dry ? 0 : kv_bufs[bw.kv_group].first + (size_t)bw.kv_index * kv_bufs[bw.kv_group].second;
       ao = tmp(nb);
       const int mc = maps ? want_map(bid + "-cross-map", heads, S, n_ctx) : (dry_map(bid + "-cross-map"), -1);
-      attention("attn2", ws(q2), C, ws(kv), 2 * C, ws(kv + (size_t)C * 2), 2 * C, ws(ao), C, heads, S, n_ctx, D, mc,
+      attention("attn2", q2r, C, ws(kv), 2 * C, ws(kv + (size_t)C * 2), 2 * C, ws(ao), C, heads, S, n_ctx, D, mc,
                 shared ? 0 : n_ctx);
-      untmp(q2, nb);
+      if (hq < 0) untmp(q2, nb);
       { Epi e; e.bias = wt(bw.o2.b); e.has_bias = true; residual_from(e, tok); out_to(e, tok, false);
         gemm("attn2_out", ws(ao), C, n, bw.o2, C, C, 0, e); }
       untmp(ao, nb);
       if (stop) break;
       // --- feed forward (GEGLU) ---
       ln = layernorm(tok, bw.ln3);
-      const size_t inner = tmp(n * 4 * C * 2);
-      { Epi e; e.bias = wt(bw.ff1.b); e.has_bias = true; e.geglu = geglu_group(8 * C); e.out16 = ws(inner); e.has_o16 = true; e.ldo16 = 4 * C;
+      const int hi = want(bid + "-ffn-inner", 4 * C, x.H, x.W);                             // attention.py:1255-1257
+      const size_t inner = hi >= 0 ? 0 : tmp(n * 4 * C * 2);
+      const Ref innr = hi >= 0 ? Ref{BUF_HOOK0 + hi, 0} : ws(inner);
+      { Epi e; e.bias = wt(bw.ff1.b); e.has_bias = true; e.geglu = geglu_group(8 * C); e.out16 = innr; e.has_o16 = true; e.ldo16 = 4 * C;
         gemm("ff_geglu", ws(ln), C, n, bw.ff1, 8 * C, C, 0, e); }
       untmp(ln, nb);
-      hook_copy(want(bid + "-ffn-inner", 4 * C, x.H, x.W), ws(inner), 4 * C, n, 4 * C);   // attention.py:1255-1257
+      if (hi >= 0) hook_done();
       { // the fp16 image of the block output is only needed by the `blockN-out` hook and by proj_out (last block)
         const bool shadow = (bi + 1 == w.blocks.size()) || (!dry && P.requested.count(bid + "-out"));
         Epi e; e.bias = wt(bw.ff2.b); e.has_bias = true; residual_from(e, tok); out_to(e, tok, shadow);
-        gemm("ff_out", ws(inner), 4 * C, n, bw.ff2, C, 4 * C, 0, e); }
-      untmp(inner, n * 4 * C * 2);
+        gemm("ff_out", innr, 4 * C, n, bw.ff2, C, 4 * C, 0, e); }
+      if (hi < 0) untmp(inner, n * 4 * C * 2);
       gather(bid + "-out", tok);                                                           // attention.py:589-590
     }
     if (!stop) {

@@ -109,12 +109,13 @@ struct Model {
 // Flux reuses the slots: LAT = hidden_states, T = timestep, CTX = encoder_hidden_states, TXT = pooled_projections,
 // TID = guidance, NOISE = output; IDS_IMG / IDS_TXT = img_ids / txt_ids
 enum { BUF_WS = 0, BUF_WT, BUF_LAT, BUF_T, BUF_CTX, BUF_TXT, BUF_TID, BUF_NOISE, BUF_IDS_IMG, BUF_IDS_TXT, BUF_COUNT };
+enum { BUF_HOOK0 = 1 << 16 };                   // Ref.buf = BUF_HOOK0 + slot: the caller's hook buffer `slot` (an op's output IS the hook)
 struct Ref { int buf = BUF_WS; size_t off = 0; };
 struct Bind {
   char* base[BUF_COUNT] = {nullptr};
   void* const* hooks = nullptr;
   float f[8] = {0, 0, 0, 0, 0, 0, 0, 0};     // run-time scalars (VAE: scaling_factor, noise_a, noise_b, input_scale)
-  void* p(const Ref& r) const { return base[r.buf] + r.off; }
+  void* p(const Ref& r) const { return (r.buf >= BUF_HOOK0 ? (char*)hooks[r.buf - BUF_HOOK0] : base[r.buf]) + r.off; }
   void* ws(size_t off) const { return base[BUF_WS] + off; }
   void* hook(int slot) const { return hooks[slot]; }
 };
