@@ -46,6 +46,10 @@ __device__ __forceinline__ size_t seg_row(int b, int j, int per_b, int seg_T, in
 }
 
 // NW = waves per workgroup (4, or 8: twice the query rows share every staged K / V tile)
+// (Measured and rejected: an explicit ping-pong — 8 waves, the two waves of a SIMD one workgroup barrier apart, iteration =
+// softmax phase | barrier | PV(t) + QK^T(t+1) phase | barrier — which is what lifts the GEMM main loops.  Here the two phases
+// are data dependent and unequal, and the lock step costs more than the free-running overlap of two independent workgroups
+// per CU gives: D = 128 928 -> 821 TFLOP/s, D = 64 726 -> 573 (32 rows per wave) / 366 (64 rows per wave: 76 VGPRs spilled).)
 template <int D, int QW, int NW = 4>
 __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(const AttnParams p) {
   constexpr int NT = NW * 64;                    // threads per workgroup
