@@ -257,6 +257,15 @@ struct PlanBuilder {
   size_t groupnorm(const Act& x, const NormW& w, float eps, bool silu) {
     const size_t n = rows(x);
     const size_t y = tmp(n * x.C * 2);
+    if (gn_fused_slab(Bn, x.H * x.W, x.C, 32)) {            // small feature map: statistics + apply in one launch
+      const Ref xh = x.h; const int ld = x.ld, C = x.C, HW = x.H * x.W, Bq = Bn;
+      const Ref g = wt(w.g), bt = wt(w.b);
+      op(silu ? "gn_fused_silu" : "gn_fused", 0, [=](const Bind& b, hipStream_t s) {
+        return launch_gn_fused((const half_t*)b.p(xh), nullptr, ld, Bq, HW, C, 32, eps, (const float*)b.p(g), (const float*)b.p(bt),
+                               silu ? 1 : 0, (half_t*)b.ws(y), s);
+      });
+      return y;
+    }
     const size_t part_b = gn_partial_floats(Bn, x.H * x.W, x.C) * 4, ab_b = (size_t)Bn * x.C * 8;
     const size_t part = tmp(part_b), ab = tmp(ab_b);
     const Ref xh = x.h; const int ld = x.ld, C = x.C, HW = x.H * x.W, Bq = Bn;

@@ -100,6 +100,10 @@ hipError_t launch_gn_stats(const half_t* x16, const float* x32, int ld, int B, i
                            const float* gamma, const float* beta, float* partial, float* ab, hipStream_t s);
 hipError_t launch_gn_apply(const half_t* x16, const float* x32, int ld, int B, int HW, int C,
                            const float* ab, int silu, half_t* y, hipStream_t s);
+// single-launch GroupNorm (+SiLU) for small feature maps; gn_fused_slab(...) != 0 says whether it applies
+int gn_fused_slab(int B, int HW, int C, int G);
+hipError_t launch_gn_fused(const half_t* x16, const float* x32, int ld, int B, int HW, int C, int G, float eps, const float* gamma,
+                           const float* beta, int silu, half_t* y, hipStream_t s);
 // LayerNorm over the last dim (C), rows x [R][ld]; y contiguous fp16 [R][C]
 hipError_t launch_layernorm(const half_t* x16, const float* x32, int ld, int R, int C, float eps,
                             const float* gamma, const float* beta, half_t* y, hipStream_t s);

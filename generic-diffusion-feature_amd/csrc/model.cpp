@@ -621,6 +621,7 @@ const char* kernel_label(const char* n) {
   if (is("layernorm")) return "layernorm_kernel";
   if (is("gn_stats")) return "gn_partial_kernel+gn_finalize_kernel";
   if (is("gn_apply") || is("gn_apply_silu")) return "gn_apply_kernel";
+  if (is("gn_fused") || is("gn_fused_silu")) return "gn_fused_kernel";
   if (is("hook_store")) return "copy2d_kernel";
   return n;
 }

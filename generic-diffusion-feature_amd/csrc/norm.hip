@@ -156,6 +156,99 @@ hipError_t launch_gn_apply(const half_t* x16, const float* x32, int ld, int B, i
   return hipGetLastError();
 }
 
+// Small feature maps (<= 32 x 32 pixels): the three launches above are latency bound (1280 channels at 32^2, batch 16: 75 us for
+// 126 MB of traffic).  One workgroup per (sample, slab of whole groups) instead: pass 1 accumulates per-channel sums over the
+// slab's HW x SC block, the slab's group statistics are combined in double in LDS, pass 2 re-reads the block (L2 / MALL
+// resident: it was just read), applies the affine (+SiLU) and writes fp16.  One launch, same 6 B/element.
+__global__ __launch_bounds__(256) void gn_fused_kernel(const half_t* x16, const float* x32, int ld, int HW, int C, int G, float eps,
+                                                       const float* gamma, const float* beta, int silu, half_t* y, int SC) {
+  extern __shared__ float red[];                  // [RPP][SC][2] floats, then reused: double chan[SC][2], float ab[SC][2]
+  const int b = blockIdx.y, c0 = blockIdx.x * SC;
+  const int LPR = SC / 8, RPP = 256 / LPR;
+  const int lc = threadIdx.x % LPR, tr = threadIdx.x / LPR;
+  const bool act = tr < RPP;
+  const size_t rowbase = (size_t)b * HW;
+  float s[8], q[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.f;
+  if (act) {
+    for (int r = tr; r < HW; r += RPP) {
+      float v[8];
+      load8(x16, x32, (rowbase + r) * ld + c0 + lc * 8, v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { s[e] += v[e]; q[e] += v[e] * v[e]; }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      red[(tr * SC + lc * 8 + e) * 2 + 0] = s[e];
+      red[(tr * SC + lc * 8 + e) * 2 + 1] = q[e];
+    }
+  }
+  __syncthreads();
+  double* chan = (double*)(red + (size_t)RPP * SC * 2);        // [SC][2]
+  float* ab = (float*)(chan + SC * 2);                         // [SC][2]
+  for (int i = threadIdx.x; i < SC * 2; i += 256) {
+    double a = 0.0;
+    for (int g = 0; g < RPP; ++g) a += (double)red[g * SC * 2 + i];
+    chan[i] = a;
+  }
+  __syncthreads();
+  const int cpg = C / G, ngs = SC / cpg;                       // groups in this slab
+  if (threadIdx.x < ngs) {
+    double sum = 0.0, sq = 0.0;
+    for (int c = threadIdx.x * cpg; c < (threadIdx.x + 1) * cpg; ++c) { sum += chan[c * 2]; sq += chan[c * 2 + 1]; }
+    const double n = (double)HW * cpg;
+    const double mean = sum / n;
+    double var = sq / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    for (int c = threadIdx.x * cpg; c < (threadIdx.x + 1) * cpg; ++c) {
+      const float a = rstd * gamma[c0 + c];
+      ab[c * 2] = a;
+      ab[c * 2 + 1] = beta[c0 + c] - (float)mean * a;
+    }
+  }
+  __syncthreads();
+  if (!act) return;
+  float a[8], bb[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { a[e] = ab[(lc * 8 + e) * 2]; bb[e] = ab[(lc * 8 + e) * 2 + 1]; }
+  for (int r = tr; r < HW; r += RPP) {
+    float v[8];
+    load8(x16, x32, (rowbase + r) * ld + c0 + lc * 8, v);
+    f16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float t = v[e] * a[e] + bb[e];
+      if (silu) t = t / (1.0f + __expf(-t));
+      o[e] = (_Float16)t;
+    }
+    *(f16x8*)(y + (rowbase + r) * C + c0 + lc * 8) = o;
+  }
+}
+
+// channels per workgroup of the fused kernel: whole groups, whole 16-byte chunks, >= 64 channels; 0 = use the 3-launch path
+int gn_fused_slab(int B, int HW, int C, int G) {
+  if (C % 8 || C % G || HW > 1024) return 0;
+  const int cpg = C / G;
+  int L = cpg;
+  while (L % 8) L += cpg;                                      // lcm(cpg, 8)
+  int SC = L;
+  while (SC < 64 && C % (SC * 2) == 0) SC *= 2;
+  if (C % SC || SC > 256 || (long)B * (C / SC) < 64) return 0;
+  return SC;
+}
+
+hipError_t launch_gn_fused(const half_t* x16, const float* x32, int ld, int B, int HW, int C, int G, float eps, const float* gamma,
+                           const float* beta, int silu, half_t* y, hipStream_t s) {
+  const int SC = gn_fused_slab(B, HW, C, G);
+  if (!SC) return hipErrorInvalidValue;
+  const int LPR = SC / 8, RPP = 256 / LPR;
+  const size_t smem = (size_t)RPP * SC * 2 * 4 + (size_t)SC * 2 * 8 + (size_t)SC * 2 * 4;
+  hipLaunchKernelGGL(gn_fused_kernel, dim3(C / SC, B), dim3(256), smem, s, x16, x32, ld, HW, C, G, eps, gamma, beta, silu, y, SC);
+  return hipGetLastError();
+}
+
 // LayerNorm: one wave per row, row kept in registers (C <= 64*8*MAXC), exact two-pass statistics.
 template <int MAXC>
 __global__ __launch_bounds__(256) void layernorm_kernel(const half_t* x16, const float* x32, int ld, int R, int C,

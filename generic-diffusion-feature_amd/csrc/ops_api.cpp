@@ -84,6 +84,8 @@ size_t gdf_op_groupnorm_scratch_bytes(int B, int HW, int C) { return gn_partial_
 int gdf_op_groupnorm(const void* x16, const float* x32, int ld, int B, int HW, int C, int G, float eps,
                      const float* gamma, const float* beta, int silu, void* y, void* scratch, void* stream) {
   hipStream_t s = (hipStream_t)stream;
+  if (gn_fused_slab(B, HW, C, G))
+    return fin(launch_gn_fused((const half_t*)x16, x32, ld, B, HW, C, G, eps, gamma, beta, silu, (half_t*)y, s), "gn_fused");
   float* partial = (float*)scratch;
   float* ab = partial + (gn_partial_floats(B, HW, C) + 63) / 64 * 64;
   hipError_t e = launch_gn_stats((const half_t*)x16, x32, ld, B, HW, C, G, eps, gamma, beta, partial, ab, s);

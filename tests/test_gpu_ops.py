@@ -181,7 +181,12 @@ def test_attention_forced_rescale():
 
 
 @pytest.mark.parametrize("B,HW,C,ld,silu,eps,f32", [(2, 64, 64, 64, 1, 1e-5, 0), (2, 300, 320, 384, 1, 1e-5, 0),
-                                                    (1, 1024, 2560, 2560, 0, 1e-6, 0), (2, 64, 128, 128, 1, 1e-5, 1)])
+                                                    (1, 1024, 2560, 2560, 0, 1e-6, 0), (2, 64, 128, 128, 1, 1e-5, 1),
+                                                    # single-launch kernel (<= 32x32 pixels, >= 64 slabs): 10 / 30 / 40 / 80
+                                                    # channels per group, strided input, fp32 input, ragged row count
+                                                    (16, 1024, 1280, 1280, 1, 1e-5, 0), (8, 256, 960, 1280, 1, 1e-5, 0),
+                                                    (32, 64, 320, 320, 0, 1e-6, 0), (4, 1000, 2560, 2560, 1, 1e-5, 1),
+                                                    (16, 100, 1920, 1920, 1, 1e-5, 0)])
 def test_groupnorm(B, HW, C, ld, silu, eps, f32):
     L = lib()
     x = rnd(B, HW, ld, scale=2.0) + 0.5
