@@ -211,6 +211,9 @@ struct PlanBuilder {
     int dit = 0, act = 0, rv_mul = 0, rv_seg_rows = 0, rv_rps2 = 0;     // MMDiT epilogue (kernels.h)
     int pad0 = 0;                                                         // conv3: 1 = pad right / bottom only
     int rv_tok = 0;                                                       // row vector indexed by token (row % rps)
+    // fused RMSNorm(q), RMSNorm(k) + RoPE (GemmParams::qkn_*)
+    int qkn_nq = 0; Ref qkn_wq{}, qkn_wk{}, rope_cos{}, rope_sin{}; float qkn_eps = 1e-6f;
+    int qkn_pos0 = 0, qkn_rps = 1, qkn_seg_rows = 0, qkn_pos1 = 0, qkn_rps2 = 1;
   };
   void residual_from(Epi& e, const Act& x) {
     if (x.has_f) { e.res32 = x.f; e.has_r32 = true; e.ldres = x.C; }
@@ -232,6 +235,12 @@ struct PlanBuilder {
     g.aux16 = e.aux_slot >= 0 ? (half_t*)b.hook(e.aux_slot) : nullptr; g.ldaux = e.ldaux;
     g.geglu = e.geglu; g.bn = e.bn;
     g.dit = e.dit; g.act = e.act; g.rv_mul = e.rv_mul; g.rv_seg_rows = e.rv_seg_rows; g.rv_rps2 = e.rv_rps2; g.rv_tok = e.rv_tok;
+    g.qkn_nq = e.qkn_nq;
+    if (e.qkn_nq) {
+      g.qkn_wq = (const float*)b.p(e.qkn_wq); g.qkn_wk = (const float*)b.p(e.qkn_wk); g.qkn_eps = e.qkn_eps;
+      g.rope_cos = (const float*)b.p(e.rope_cos); g.rope_sin = (const float*)b.p(e.rope_sin);
+      g.qkn_pos0 = e.qkn_pos0; g.qkn_rps = e.qkn_rps; g.qkn_seg_rows = e.qkn_seg_rows; g.qkn_pos1 = e.qkn_pos1; g.qkn_rps2 = e.qkn_rps2;
+    }
   }
 
   // dense GEMM: A (fp16 [M][K], lda) x W[N][K]

@@ -114,6 +114,16 @@ struct FB : PlanBuilder {   // Flux op program
     });
     hook_done();
   }
+  // the fused form (GemmParams::qkn_*): possible when none of the block's pre-norm q / k / v hooks is requested
+  bool qkn_fusable(const std::string& bid) const {
+    if (f.D != 128) return false;
+    if (dry) return false;
+    return !P.requested.count(bid + "-q") && !P.requested.count(bid + "-k") && !P.requested.count(bid + "-v");
+  }
+  void qkn(Epi& e, size_t wq, size_t wk, int pos0, int rps, int seg_rows, int pos1, int rps2) {
+    e.qkn_nq = f.C; e.qkn_wq = wt(wq); e.qkn_wk = wt(wk); e.rope_cos = ws(cosb); e.rope_sin = ws(sinb); e.qkn_eps = 1e-6f;
+    e.qkn_pos0 = pos0; e.qkn_rps = rps; e.qkn_seg_rows = seg_rows; e.qkn_pos1 = pos1; e.qkn_rps2 = rps2;
+  }
   // RMSNorm(q), RMSNorm(k) + RoPE in place on rows [r0, r0+n) of the qkv buffer (ld 3C)
   void qk_norm_rope(size_t qkv, size_t r0, size_t n, size_t wq, size_t wk, int pos0, int rps) {
     const int C = f.C, heads = C / f.D, D = f.D;
@@ -245,9 +255,14 @@ struct FB : PlanBuilder {   // Flux op program
       adaln("adaln_txt", 0, nt, w.cmod + 0, w.cmod + C, T, 0, 0, ws(ln));
       adaln("adaln", nt, ns, w.mod + 0, w.mod + C, S, 0, 0, ws(ln + nt * C * 2));
       const size_t qkv = tmp(qkv_b);
+      // un-hooked blocks: RMSNorm(q), RMSNorm(k) + RoPE ride in the QKV GEMM epilogue (on the fp32 accumulators); the `q/k/v`
+      // hooks are the PRE-norm projections, so a block that has one of them requested keeps the separate pass
+      const bool fuse = qkn_fusable(bid) && gemm_qkn_ok((int)nt, 3 * C, C) && gemm_qkn_ok((int)ns, 3 * C, C);
       { Epi e = plain(w.cqkv); e.out16 = ws(qkv); e.has_o16 = true; e.ldo16 = 3 * C;
+        if (fuse) qkn(e, w.cnq, w.cnk, 0, T, 0, 0, 1);
         gemm("add_qkv_proj", ws(ln), C, nt, w.cqkv, 3 * C, C, 0, e); }
       { Epi e = plain(w.qkv); e.out16 = ws(qkv + nt * 3 * C * 2); e.has_o16 = true; e.ldo16 = 3 * C;
+        if (fuse) qkn(e, w.nq, w.nk, T, S, 0, 0, 1);
         gemm("attn_qkv", ws(ln + nt * C * 2), C, ns, w.qkv, 3 * C, C, 0, e); }
       untmp(ln, ln_b);
       const size_t qi = qkv + nt * 3 * C * 2;                                        // image rows of the qkv buffer
@@ -255,8 +270,10 @@ struct FB : PlanBuilder {   // Flux op program
       hook_rows16(bid + "-k", ws(qi + (size_t)C * 2), 3 * C, C);
       hook_rows16(bid + "-v", ws(qi + (size_t)2 * C * 2), 3 * C, C);
       if (stop) { untmp(qkv, qkv_b); break; }
-      qk_norm_rope(qkv, 0, nt, w.cnq, w.cnk, 0, T);                                  // norm_added_q/k, text positions
-      qk_norm_rope(qkv, nt, ns, w.nq, w.nk, T, S);                                   // norm_q/k, image positions
+      if (!fuse) {
+        qk_norm_rope(qkv, 0, nt, w.cnq, w.cnk, 0, T);                                // norm_added_q/k, text positions
+        qk_norm_rope(qkv, nt, ns, w.nq, w.nk, T, S);                                 // norm_q/k, image positions
+      }
       const size_t ao = tmp(ln_b);
       int mc = -1, ms = -1;
       map_slots(bid, mc, ms);
@@ -301,7 +318,9 @@ struct FB : PlanBuilder {   // Flux op program
       const size_t ln = tmp(ln_b);
       adaln("adaln", 0, nr, w.mod + 0, w.mod + C, T, nt, S, ws(ln));                 // AdaLayerNormZeroSingle: shift, scale, gate
       const size_t qkv = tmp(qkv_b), cat = tmp(nr * CK * 2);
+      const bool fuse = qkn_fusable(bid) && gemm_qkn_ok((int)nr, 3 * C, C);
       { Epi e = plain(w.qkv); e.out16 = ws(qkv); e.has_o16 = true; e.ldo16 = 3 * C;
+        if (fuse) qkn(e, w.nq, w.nk, 0, T, (int)nt, T, S);
         gemm("attn_qkv", ws(ln), C, nr, w.qkv, 3 * C, C, 0, e); }
       { Epi e = plain(w.mlp); e.act = 1; e.out16 = ws(cat + (size_t)C * 2); e.has_o16 = true; e.ldo16 = CK;   // :95
         gemm("proj_mlp", ws(ln), C, nr, w.mlp, hid, C, 0, e); }
@@ -311,8 +330,10 @@ struct FB : PlanBuilder {   // Flux op program
       hook_rows16(bid + "-k", ws(qi + (size_t)C * 2), 3 * C, C);
       hook_rows16(bid + "-v", ws(qi + (size_t)2 * C * 2), 3 * C, C);
       if (stop) { untmp(qkv, qkv_b); untmp(cat, nr * CK * 2); break; }
-      qk_norm_rope(qkv, 0, nt, w.nq, w.nk, 0, T);
-      qk_norm_rope(qkv, nt, ns, w.nq, w.nk, T, S);
+      if (!fuse) {
+        qk_norm_rope(qkv, 0, nt, w.nq, w.nk, 0, T);
+        qk_norm_rope(qkv, nt, ns, w.nq, w.nk, T, S);
+      }
       int mc = -1, ms = -1;
       map_slots(bid, mc, ms);
       joint_attention(qkv, ws(cat), CK, mc, ms);                                     // cat([attn_output, mlp], 2) in place (:103)

@@ -683,6 +683,40 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[it][e] = gelu_tanh(v[it][e]);
     }
+    if constexpr (DIT && WTN == 128) {
+      // RMSNorm per head + rotary embedding on the q / k columns: a wave tile is exactly one 128-column head, whose row lives in
+      // the 16 lanes of one staged row (8 consecutive columns = 4 rotary pairs per lane)
+      if (p.qkn_nq > 0 && ocol0 < 2 * p.qkn_nq) {
+        const float* nw = (ocol0 < p.qkn_nq ? p.qkn_wq : p.qkn_wk) + lc;
+        const f32x4 w0 = *(const f32x4*)nw, w1 = *(const f32x4*)(nw + 4);
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+          float ss = 0.f;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) ss += v[it][e] * v[it][e];
+#pragma unroll
+          for (int off = 8; off > 0; off >>= 1) ss += __shfl_xor(ss, off);       // the 16 lanes of this row
+          const float r = rsqrtf(ss * (1.0f / 128.0f) + p.qkn_eps);
+          const int row = rowi[it];
+          const int pos = (p.qkn_seg_rows > 0 && row >= p.qkn_seg_rows) ? p.qkn_pos1 + (row - p.qkn_seg_rows) % p.qkn_rps2
+                                                                        : p.qkn_pos0 + row % p.qkn_rps;
+          f32x4 c0 = {1.f, 1.f, 1.f, 1.f}, c1 = c0, s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+          if (okr[it]) {
+            const float* cp = p.rope_cos + (size_t)pos * 128 + lc;
+            const float* sp = p.rope_sin + (size_t)pos * 128 + lc;
+            c0 = *(const f32x4*)cp; c1 = *(const f32x4*)(cp + 4); s0 = *(const f32x4*)sp; s1 = *(const f32x4*)(sp + 4);
+          }
+          float t[8];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { t[e] = v[it][e] * r * w0[e]; t[4 + e] = v[it][4 + e] * r * w1[e]; }
+          // x * cos + stack([-x_imag, x_real]) * sin
+          v[it][0] = t[0] * c0[0] - t[1] * s0[0]; v[it][1] = t[1] * c0[1] + t[0] * s0[1];
+          v[it][2] = t[2] * c0[2] - t[3] * s0[2]; v[it][3] = t[3] * c0[3] + t[2] * s0[3];
+          v[it][4] = t[4] * c1[0] - t[5] * s1[0]; v[it][5] = t[5] * c1[1] + t[4] * s1[1];
+          v[it][6] = t[6] * c1[2] - t[7] * s1[2]; v[it][7] = t[7] * c1[3] + t[6] * s1[3];
+        }
+      }
+    }
     const bool aux_early = DIT && p.rv_mul && p.aux16;     // MMDiT `attn-out` hook: the projection BEFORE the gate
     if (!RAGGED && aux_early) {
 #pragma unroll
@@ -865,6 +899,13 @@ static int pick_variant(const GemmParams& p) {
   return 128;
 }
 
+// true when an MMDiT GEMM of this shape runs on the 256x256 tile, i.e. may carry the fused RMSNorm + RoPE epilogue (qkn_*)
+bool gemm_qkn_ok(int M, int N, int K) {
+  GemmParams g{}; g.M = M; g.N = N; g.K = K; g.dit = 1; g.mode = A_DENSE;
+  const int v = pick_variant(g);
+  return v == 8256 || v == 1256;
+}
+
 // kernel symbol (as rocprofv3 prints it) that launch_gemm would pick for these parameters
 const char* gemm_kernel_name(const GemmParams& p) {
   const int v = pick_variant(p);
@@ -890,6 +931,7 @@ hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {
   if (v != 16 && ((p.geglu ? p.N / 2 : p.N) % 8) != 0) return hipErrorInvalidValue;   // ragged N only in the BN = 16 variant
   if (p.dit) {
     if (p.mode != A_DENSE || p.geglu || p.batch > 1) return hipErrorInvalidValue;
+    if (p.qkn_nq && ((v != 8256 && v != 1256) || (p.qkn_nq % 128) != 0)) return hipErrorInvalidValue;   // one head per 128-column wave tile
     if (v == 8256) return launch_t<A_DENSE, 256, 256, 8, false, true>(p, s);
     if (v == 1256) return launch_t<A_DENSE, 256, 256, 2, false, true>(p, s);
     if (v == 2128) return launch_t<A_DENSE, 256, 128, 3, false, true>(p, s);

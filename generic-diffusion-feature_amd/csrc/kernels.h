@@ -65,9 +65,18 @@ struct GemmParams {
   int rv_mul;
   int rv_seg_rows, rv_rps2;
   int rv_tok;            // 1: the row vector is per TOKEN (row % rows_per_sample), e.g. the PatchEmbed positional table
+  // MMDiT QKV projection (dit only, 256x256 tile: one 128-wide head per wave tile): RMSNorm over each 128-column head of the
+  // q columns [0, qkn_nq) and the k columns [qkn_nq, 2 qkn_nq), then the rotary embedding of the row's position
+  // (Attention.norm_q / norm_k + apply_rotary_emb, attention_processor.py:2300-2335), applied to the fp32 accumulators
+  int qkn_nq;            // 0 = off
+  const float* qkn_wq; const float* qkn_wk; float qkn_eps;
+  const float* rope_cos; const float* rope_sin;      // [position][128]
+  int qkn_pos0, qkn_rps;                             // position of row r: qkn_pos0 + r % qkn_rps           (r <  qkn_seg_rows or no segment)
+  int qkn_seg_rows, qkn_pos1, qkn_rps2;              //                    qkn_pos1 + (r - seg_rows) % rps2  (r >= qkn_seg_rows > 0)
 };
 hipError_t launch_gemm(const GemmParams& p, hipStream_t s);
-const char* gemm_kernel_name(const GemmParams& p);   // kernel symbol launch_gemm would pick (only M,N,K,mode,geglu,bn,variant are read)
+const char* gemm_kernel_name(const GemmParams& p);
+bool gemm_qkn_ok(int M, int N, int K);   // kernel symbol launch_gemm would pick (only M,N,K,mode,geglu,bn,variant are read)
 
 // ------------------------------------------------------------------------------------------------
 // flash attention (self / cross), fp16 in, fp32 softmax, fp16 out

@@ -38,3 +38,15 @@ print(json.dumps(dict(model="flux widths, %d double + %d single blocks, 4096+512
                       cpu_forward_s=round(t_cpu, 1), worst=max(errs.values()), median=sorted(errs.values())[len(errs) // 2])))
 for k, e in errs.items():
     print(f"# {k:28s} {e:.2e}")
+# second pass without the pre-norm q / k / v hooks: those blocks take the fused RMSNorm + RoPE epilogue of the QKV GEMM
+ids2 = [i for i in FR.hook_ids(arch) if not i.endswith(("-q", "-k", "-v"))]
+out2, hooks2 = net.forward_raw(I["hidden_states"].cuda(), I["encoder_hidden_states"].cuda(), I["pooled_projections"].cuda(),
+                               I["timestep"].cuda(), I["img_ids"].cuda(), I["txt_ids"].cuda(), guidance=I["guidance"].cuda(),
+                               hook_ids=ids2, grid=(64, 64))
+torch.cuda.synchronize()
+errs2 = {k: rel_l2(hooks2[k], st.feats[k]) for k in ids2}
+errs2["output"] = rel_l2(out2, y)
+print(json.dumps(dict(pass2="q/k/v un-hooked: RMSNorm + RoPE fused into the QKV GEMM epilogue", worst=max(errs2.values()),
+                      median=sorted(errs2.values())[len(errs2) // 2])))
+for k, e in errs2.items():
+    print(f"# fused {k:22s} {e:.2e}")
