@@ -176,6 +176,32 @@ def test_flux_tiny_all_hooks_vs_oracle():
     print("flux tiny: worst rel L2", worst)
 
 
+def test_flux_fused_qk_norm_rope_epilogue():
+    """Blocks without a requested pre-norm q / k / v hook take RMSNorm + RoPE inside the QKV GEMM epilogue; that needs the
+    256x256 tile, i.e. a mid-size model: 8 heads x 128, 3 x (1024 + 1024) tokens, 1 double + 1 single block."""
+    arch = FR.tiny_arch(heads=8, num_layers=1, num_single_layers=1, joint_dim=256, pooled_dim=64)
+    P = FR.synth_params(arch, seed=2)
+    I = FR.synth_inputs(arch, batch=3, grid=32, n_txt=1024, seed=3, same_prompt=False)
+    st = FR.Store(None)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    y = FR.flux_forward(P, arch, I["hidden_states"], I["encoder_hidden_states"], I["pooled_projections"], I["timestep"],
+                        I["img_ids"], I["txt_ids"], I["guidance"], store=st, want_map=False)
+    ids = [i for i in FR.hook_ids(arch) if not i.endswith(("-q", "-k", "-v"))]
+    net, out, hooks = _run_native(arch, P, I, ids, 32)
+    assert list(hooks.keys()) == ids
+    assert rel_l2(out, y) < TOL, rel_l2(out, y)
+    for k in ids:
+        assert rel_l2(hooks[k], st.feats[k]) < TOL, (k, rel_l2(hooks[k], st.feats[k]))
+    # the fused path really ran: no separate pass is left in the op program of this hook set
+    _, _, prof = net.forward_raw(I["hidden_states"].cuda(), I["encoder_hidden_states"].cuda(), I["pooled_projections"].cuda(),
+                                 I["timestep"].cuda(), I["img_ids"].cuda(), I["txt_ids"].cuda(), guidance=I["guidance"].cuda(),
+                                 hook_ids=ids, grid=(32, 32), profile=True)
+    assert "qk_norm_rope" not in [r[0] for r in prof] and "attn_qkv" in [r[0] for r in prof]
+    # same model, q/k/v hooked (separate in-place pass): identical within fp16 rounding of q / k
+    net2, out2, hooks2 = _run_native(arch, P, I, FR.hook_ids(arch), 32)
+    assert rel_l2(out2, out) < 1e-3
+
+
 def test_flux_matches_reference_golden():
     """tests/golden/flux_tiny.npz = outputs of the reference's own FluxTransformer2DModel (gen_golden_flux.py);
     flux_tiny_maps.npz = the same model on the reference's FluxAttnStoreProcessor (`cross-map` / `self-map` hooks)."""
