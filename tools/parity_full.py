@@ -14,6 +14,7 @@ from helpers import cfg_from_oracle_arch, rel_l2
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--version", default="xl"); ap.add_argument("--lat", type=int, default=0); ap.add_argument("--threads", type=int, default=32)
+ap.add_argument("--all", action="store_true", help="every non-map hook id of the full layer set (472 ids for SDXL) instead of a sample")
 a = ap.parse_args()
 torch.set_num_threads(min(a.threads, os.cpu_count() or 1))
 arch = R.ARCHS[a.version]
@@ -27,6 +28,8 @@ if a.version == "xl":
     pick += ["up-level0-repeat0-vit-block7-out", "up-level0-repeat0-vit-block5-out", "up-level1-repeat0-vit-block0-cross-q",
              "up-level1-repeat0-vit-block0-out"]
 pick = [i for i in allids if i in set(pick)]
+if a.all:
+    pick = [i for i in allids if not i.endswith("-map")]
 st = R.Store({k: True for k in pick})
 t0 = time.time()
 with torch.no_grad():
@@ -40,5 +43,18 @@ torch.cuda.synchronize()
 errs = {k: rel_l2(hooks[k], st.feats[k]) for k in st.feats}
 print(json.dumps(dict(version=a.version, latent=lat, weights_s=round(t_w, 1), cpu_forward_s=round(t_cpu, 1),
                       worst=max(errs.values()), median=sorted(errs.values())[len(errs) // 2])))
-for k, e in errs.items():
-    print(f"# {k:44s} {e:.2e}")
+if a.all:
+    ev = sorted(errs.values())
+    print(json.dumps(dict(hooks=len(ev), below_1e3=sum(e < 1e-3 for e in ev), below_1p2e3=sum(e < 1.2e-3 for e in ev),
+                          p50=ev[len(ev) // 2], p90=ev[int(len(ev) * 0.9)], p99=ev[int(len(ev) * 0.99)], worst=ev[-1])))
+    kinds = {}
+    for k, e in errs.items():
+        kind = k.split("-")[-1] if not k.endswith("-out") else "-".join(k.split("-")[-2:])
+        kinds.setdefault(kind, []).append(e)
+    for kind, v in sorted(kinds.items()):
+        print(f"# kind {kind:16s} n={len(v):3d}  median {sorted(v)[len(v) // 2]:.2e}  worst {max(v):.2e}")
+    for k, e in errs.items():
+        if e >= 1e-3: print(f"# >=1e-3 {k:44s} {e:.2e}")
+else:
+    for k, e in errs.items():
+        print(f"# {k:44s} {e:.2e}")
