@@ -233,3 +233,13 @@ def test_copy2d_hook_store():
     ok(L.gdf_op_copy2d(P(s4d), None, 4, P(d4), 4, 37, 4, stream()), L)
     torch.cuda.synchronize()
     assert torch.equal(dst.cpu(), src[:, 16:56]) and torch.equal(d4.cpu(), s4)      # bit-exact: pure byte movement
+
+
+def test_gemm_8phase_reproduces_ring_bitwise():
+    """Race screen (tools/stress_gemm8.py): the 8-phase main loops keep the K order of the LDS-ring kernels, so every launch must
+    match them bit for bit, also with a bandwidth hog on a second stream."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_gemm8.py"), "6"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "0 mismatches" in r.stdout
