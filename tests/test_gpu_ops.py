@@ -2,6 +2,7 @@
 against a plain PyTorch fp32 CPU computation of the same op on the same fp16-rounded inputs.
 Tolerances: fp16 storage of outputs => relative L2 error <= 1e-3 per tensor (fp32 outputs: 2e-4)."""
 import math
+import os
 
 import pytest
 import torch
