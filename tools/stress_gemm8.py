@@ -45,5 +45,22 @@ for B, H, Ci, Co in [(2, 64, 64, 320), (4, 64, 320, 640), (2, 32, 1280, 1280), (
     var_new, var_ref = (932, 320) if Co % 320 == 0 else (826, 256)
     g = lambda var: (lambda: ok(L.gdf_op_conv3x3(P(x), Ci, B, H, H, Ci, P(w), Co, P(bias), None, 1, 0, None, None, P(o16), None, var << 8, stream()), L))
     run(f"conv {var_new} vs {var_ref}   {B}x{H}x{H}x{Ci}->{Co}", g(var_ref), g(var_new), o16)
+# attention-map kernel with the loader wave: repeated launches must agree bit for bit (its asm loads use hand-counted waits)
+import ctypes
+for B, h, S, D in [(2, 8, 1024, 40), (1, 4, 2048, 32)]:
+    C = h * D
+    qkv = torch.randn(B * S, 3 * C, device="cuda").half(); o = torch.empty(B * S, C, device="cuda", dtype=torch.half)
+    m = torch.empty(B, h, S, S, device="cuda", dtype=torch.half)
+    pk = ctypes.c_void_p(qkv.data_ptr() + C * 2); pv = ctypes.c_void_p(qkv.data_ptr() + 2 * C * 2)
+    f = lambda: ok(L.gdf_op_attention(P(qkv), 3 * C, pk, 3 * C, pv, 3 * C, P(o), C, B, h, S, S, D, P(m), stream()), L)
+    f(); torch.cuda.synchronize(); m0, o0 = m.clone(), o.clone()
+    nb = 0
+    for i in range(iters):
+        if i % 3 == 1:
+            with torch.cuda.stream(side): hog_b.copy_(hog_a)
+        m.zero_(); o.zero_(); f(); torch.cuda.synchronize(); total += 1
+        if not (torch.equal(m, m0) and torch.equal(o, o0)): nb += 1
+    bad += nb
+    print(f"{'attn map (loader wave) ' + str((B, h, S, D)):48s} {'ok' if nb == 0 else 'FAILED'}")
 print(f"{total} launches, {bad} mismatches")
 sys.exit(1 if bad else 0)
