@@ -10,11 +10,14 @@
 //   Downsample2D.conv stride 2 (downsampling.py:115-118), Upsample2D nearest x2 + conv (upsampling.py:176-193),
 //   UNet conv_in / conv_out (unet/unet_2d_condition.py:260-262,480-482).
 //
-// Structure: BM x BN x 64 block tile, one 64x64 (or 32x16) sub-tile per 64-lane wave, mfma_f32_16x16x32_f16.
-//   * main variant 256x128, 8 waves, 3-stage LDS ring (144 KiB): tiles kt+1 and kt+2 are in flight while
-//     tile kt is multiplied; waits are COUNTED (`s_waitcnt vmcnt(N)`, never 0 in steady state) and the
-//     workgroup barrier is the raw `s_barrier`, one per K-tile.
-//   * small variant 128x128 / 128x16, 4 waves, 2-stage ring, 2 workgroups per CU (narrow N, few tiles).
+// Structure: BM x BN x 64 block tile, mfma_f32_16x16x32_f16, template <MODE, BM, BN, STAGES, GEGLU, DIT>:
+//   * STAGES = 9 / 8: the 8-phase main loops of the large tiles (256x320 with 2x4 waves of 128x80 and B resident in registers;
+//     256x256 with 4x2 waves of 64x128 and A resident): the two waves of a SIMD run one workgroup barrier apart, so one multiplies
+//     while the other reads fragments and issues DMA; half-tile / quarter-tile DMA runs 1.5 K-tiles ahead with ONE counted
+//     `s_waitcnt vmcnt(N)` per K-tile.  These carry 65 % of an SDXL step and 70 % of a Flux step (see the blocks below).
+//   * STAGES = 3: 256x128, 8 waves, 3-stage LDS ring (144 KiB), counted waits, raw `s_barrier`, one per K-tile.
+//   * STAGES = 2: 128x128 / 128x160 / 128x16 (4 waves, 2 workgroups per CU: narrow N, few tiles, epilogue-heavy GEMMs) and
+//     the 2-stage ring form of the 256-row tiles (kept as the bit-exact reference of the 8-phase loops, tools/stress_gemm8.py).
 //   * Both operands are streamed HBM -> LDS with `buffer_load_dwordx4 ... lds` (no VGPR round trip).
 //     The LDS image is lane-linear, so the bank-conflict XOR swizzle is applied on the SOURCE address
 //     (chunk ^= row&7) and mirrored on the ds_read_b128 side.
