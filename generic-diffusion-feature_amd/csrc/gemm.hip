@@ -867,6 +867,13 @@ static hipError_t launch_t(const GemmParams& p, hipStream_t s) {
 // (2 workgroups per CU, 72 KiB LDS each) covers N without a ragged last column tile and makes M/128 * N/160 a
 // multiple of the 512 workgroup slots for the SDXL batch-16 shapes (no tail round).  128x128 serves other N;
 // 256x128 (8 waves, 3-stage ring) wins for very large problems.
+// fraction of the workgroup slots that do useful work when `tiles` equal tiles run on `slots` concurrent slots (whole rounds)
+static double round_fill(long tiles, int slots) {
+  if (tiles <= 0) return 0.0;
+  const long rounds = (tiles + slots - 1) / slots;
+  return (double)tiles / (double)(rounds * slots);
+}
+
 static int pick_variant(const GemmParams& p) {
   if (p.dit) {   // MMDiT widths are multiples of 256 (3072 = 24 x 128): 256x256 tiles (128 KiB ring, 1 workgroup / CU)
     const long t256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
@@ -882,12 +889,23 @@ static int pick_variant(const GemmParams& p) {
   const long tiles320 = (long)((p.M + 255) / 256) * ((p.N + 319) / 320);
   if (p.geglu) {
     // 8-phase 256x256: 1130 vs 1073 TFLOP/s (256x320 ring) at 16384 x 10240 x 1280, 899 vs 869 at 65536 x 5120 x 640
-    if (p.N % 256 == 0 && (long)((p.M + 255) / 256) * (p.N / 256) >= 256) return 825;
-    if (p.N % 320 == 0 && tiles320 >= 128) return 320;
-    return tiles256 >= 512 ? 256 : 128;
+    // The batch-16 shapes fill whole rounds of every tile; other batch sizes may leave a mostly idle last round, so the
+    // candidates are ranked by (measured rate at full rounds) x (fill of the rounds they need)
+    const long tm256 = (p.M + 255) / 256, tm128 = (p.M + 127) / 128;
+    double best = 0.0; int bv = 128;
+    auto cand = [&](int v, double rate, long tiles, int slots) { const double sc = rate * round_fill(tiles, slots); if (sc > best) { best = sc; bv = v; } };
+    if (p.N % 256 == 0) cand(825, 1.00, tm256 * (p.N / 256), 256);
+    if (p.N % 320 == 0) cand(320, 0.95, tm256 * (p.N / 320), 256);
+    cand(256, 0.80, tm256 * ((p.N + 127) / 128), 256);
+    cand(128, 0.70, tm128 * ((p.N + 127) / 128), 512);
+    return bv;
   }
   if (p.mode != A_DENSE) {                                                 // convs (K = 9 Cin is long)
-    if (p.N % 320 == 0 && tiles320 >= 128) return 932;                     // 8-phase 256x320: 1150-1350 TFLOP/s (ring 1090-1310, 128x160 950-1140)
+    if (p.N % 320 == 0) {                                                  // 8-phase 256x320: 1150-1350 TFLOP/s (ring 1090-1310, 128x160 950-1140)
+      const double s932 = 1.00 * round_fill(tiles320, 256), s160 = 0.85 * round_fill((long)((p.M + 127) / 128) * (p.N / 160), 512);
+      const double s128 = 0.70 * round_fill((long)((p.M + 127) / 128) * ((p.N + 127) / 128), 512);
+      return (s932 >= s160 && s932 >= s128) ? 932 : (s160 >= s128 ? 160 : 128);
+    }
     if (p.N % 160 == 0) return 160;
     if (p.N % 256 == 0 && (long)((p.M + 255) / 256) * (p.N / 256) >= 256) return 826;   // VAE widths 256 / 512: 989-1146 vs 830-965 (256x128 ring)
     return (p.N <= 128 && p.M >= (1 << 20)) ? 256 : 128;                   // VAE level-0 convs (N = 128, 4 M pixels): 797 vs 697
@@ -896,7 +914,11 @@ static int pick_variant(const GemmParams& p) {
   // 20 K-tiles of MFMA work) fill the chip in ONE round of 256x320 tiles, so main loop and epilogue traffic never overlap;
   // 128x160 tiles run 2 workgroups per CU and 2+ rounds (80 vs 89 us at 16384 x 1280 x 1280)
   if (p.res32 && p.K <= 1536 && p.N % 160 == 0 && tiles320 <= 512) return 160;
-  if (p.N % 320 == 0 && tiles320 >= 128) return 932;                       // 8-phase: qkv 1113, ff_out 1088, attn2_q 1045, shortcut 1086 (ring: 1051 / 983 / 980 / 1002)
+  if (p.N % 320 == 0) {                                                    // 8-phase: qkv 1113, ff_out 1088, attn2_q 1045, shortcut 1086 (ring: 1051 / 983 / 980 / 1002)
+    const double s932 = 1.00 * round_fill(tiles320, 256), s160 = 0.87 * round_fill((long)((p.M + 127) / 128) * (p.N / 160), 512);
+    const double s128 = 0.72 * round_fill((long)((p.M + 127) / 128) * ((p.N + 127) / 128), 512);
+    return (s932 >= s160 && s932 >= s128) ? 932 : (s160 >= s128 ? 160 : 128);
+  }
   if (p.N % 160 == 0 && p.K >= 1024) return 160;
   if ((long)p.M * p.N >= (1L << 26) && tiles256 >= 512) return 256;        // short-K, large MxN (qkv @ C=640): 712 vs 642
   return 128;
