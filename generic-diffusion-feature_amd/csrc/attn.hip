@@ -739,7 +739,11 @@ static hipError_t launch_d(const AttnParams& p, hipStream_t s) {
     // accumulators fit (D <= 64); 32 rows per wave otherwise
     // (D = 128 with 64 rows per wave needs all 512 registers, one wave per SIMD: measured 822 vs 886 TFLOP/s on the Flux joint shape)
     constexpr bool can2 = D <= 64;
-    if (can2 && p.Sq >= 512) {
+    // 64 rows per wave wins even at 2.5 rounds of the slots (S = 1024, batch 16: 0.125 vs 0.130 ms) but halves the number of
+    // workgroups: pick by rate x fill of the 512 workgroup slots
+    const long nb2 = (long)p.B * p.heads * ((p.Sq + 255) / 256), nb1 = (long)p.B * p.heads * ((p.Sq + 127) / 128);
+    auto fill = [](long n, long slots) { const long r = (n + slots - 1) / slots; return (double)n / (double)(r * slots); };
+    if (can2 && p.Sq >= 512 && 1.00 * fill(nb2, 512) >= 0.80 * fill(nb1, 512)) {
       const int nqb = (p.Sq + 255) / 256;
       hipLaunchKernelGGL((attn_kernel<D, can2 ? 2 : 1>), dim3(p.B * p.heads * nqb), dim3(256), 0, s, p);
     } else if (D == 128 && p.Sq >= 1024) {
