@@ -87,22 +87,50 @@ def unet_flops_per_image(cfg, lat):
 
 def cpu_baseline(version, lat_full, budget_s=30.0):
     """Time the CPU oracle (oracle/unet_ref.py, fp32) on a BOUNDED sample of the same workload: thread count
-    calibrated on one conv, then the largest resolution whose predicted time fits `budget_s` (scaled by the
-    algorithmic FLOP ratio when that is not the full resolution)."""
-    import torch.nn.functional as F
+    calibrated on one ResnetBlock2D + one BasicTransformerBlock (best of 16/32/64/128), then the largest resolution whose
+    predicted time fits `budget_s` (scaled by the algorithmic FLOP ratio when that is not the full resolution)."""
     from oracle import unet_ref as R
     arch = R.ARCHS[version]
     cores = os.cpu_count() or 1
-    # 1. calibrate the thread count on a level-0 ResnetBlock conv (320->320 @ 64x64, 2.4 GFLOP)
-    xc, wc = torch.randn(1, 320, 64, 64), torch.randn(320, 320, 3, 3) * 0.02
+    # 1. calibrate the thread count on the two block types that carry the forward: one ResnetBlock2D at level 0
+    #    (320 -> 320 @ lat x lat) + one BasicTransformerBlock at the deepest attention level (C = 1280), both through the
+    #    oracle's own block functions; candidates 16 / 32 / 64 / 128 threads (capped by the host)
+    g = torch.Generator().manual_seed(0)
+    c0, cd = arch["block_out_channels"][0], arch["cross_dim"]
+    lv = max(i for i, a_ in enumerate(arch["down_attn"]) if a_)
+    c2, tok = arch["block_out_channels"][lv], (lat_full >> lv) ** 2
+    heads = arch["heads"][lv]
+    rp = {"r.norm1.weight": torch.ones(c0), "r.norm1.bias": torch.zeros(c0), "r.norm2.weight": torch.ones(c0), "r.norm2.bias": torch.zeros(c0),
+          "r.conv1.weight": torch.randn(c0, c0, 3, 3, generator=g) * 0.02, "r.conv1.bias": torch.zeros(c0),
+          "r.conv2.weight": torch.randn(c0, c0, 3, 3, generator=g) * 0.02, "r.conv2.bias": torch.zeros(c0),
+          "r.time_emb_proj.weight": torch.randn(c0, 1280, generator=g) * 0.02, "r.time_emb_proj.bias": torch.zeros(c0)}
+    bp = {}
+    for n_ in ("norm1", "norm2", "norm3"):
+        bp[f"b.{n_}.weight"] = torch.ones(c2); bp[f"b.{n_}.bias"] = torch.zeros(c2)
+    for n_, (o_, i_) in {"attn1.to_q": (c2, c2), "attn1.to_k": (c2, c2), "attn1.to_v": (c2, c2), "attn1.to_out.0": (c2, c2),
+                         "attn2.to_q": (c2, c2), "attn2.to_k": (c2, cd), "attn2.to_v": (c2, cd), "attn2.to_out.0": (c2, c2),
+                         "ff.net.0.proj": (8 * c2, c2), "ff.net.2": (c2, 4 * c2)}.items():
+        bp[f"b.{n_}.weight"] = torch.randn(o_, i_, generator=g) * i_ ** -0.5
+        if n_.endswith("to_out.0") or n_.startswith("ff"):
+            bp[f"b.{n_}.bias"] = torch.zeros(o_)
+    xr, emb = torch.randn(1, c0, lat_full, lat_full, generator=g), torch.randn(1, 1280, generator=g)
+    xb, ctxb = torch.randn(1, tok, c2, generator=g), torch.randn(1, 77, cd, generator=g)
+    cal_flops = 2.0 * lat_full * lat_full * c0 * c0 * 18 + 2.0 * tok * c2 * c2 * (6 + 12) + 4.0 * tok * tok * c2
+    nostore = R.Store({"none": True})
+
+    def cal_once():
+        with torch.no_grad():
+            R.resnet_block(rp, "r", xr, emb, nostore, "x")
+            R.basic_transformer_block(bp, "b", xb, ctxb, heads, nostore, "x", False)
+
     best = (0.0, 1)
-    for nt in sorted({min(cores, c) for c in (8, 16, 32, 64, 128)}):
+    for nt in sorted({min(cores, c) for c in (16, 32, 64, 128)}):
         torch.set_num_threads(nt)
-        F.conv2d(xc, wc, padding=1)
+        cal_once()
         t = time.time(); n = 0
-        while time.time() - t < 0.3:
-            F.conv2d(xc, wc, padding=1); n += 1
-        rate = n * 2.0 * 64 * 64 * 320 * 320 * 9 / (time.time() - t)
+        while time.time() - t < 1.0:
+            cal_once(); n += 1
+        rate = n * cal_flops / (time.time() - t)
         if rate > best[0]:
             best = (rate, nt)
     rate, threads = best
@@ -145,7 +173,7 @@ def cpu_baseline(version, lat_full, budget_s=30.0):
             R.unet_forward(P, arch, I["sample"], I["timestep"], I["ctx"], I.get("text_embeds"), I.get("time_ids"), store=st)
         return time.time() - t
 
-    eff = 0.5 * rate                                   # whole-UNet efficiency relative to the calibration conv
+    eff = 0.8 * rate                                   # whole-UNet efficiency relative to the two calibration blocks
     lat = lat_full
     for cand in (lat_full, lat_full // 2, lat_full // 4):
         lat = cand
@@ -158,12 +186,23 @@ def cpu_baseline(version, lat_full, budget_s=30.0):
            f"{lat_full * 8}x{lat_full * 8}")
     return dict(value=round(1.0 / per_img, 5), unit="images/s", cores=threads, kind="port",
                 sample=f"oracle/unet_ref.py fp32, {how}: {t_run:.1f} s of CPU work on {threads} threads "
-                       f"(of {cores} host CPUs; thread count calibrated on a 320->320 3x3 conv, {rate / 1e9:.0f} GFLOP/s)")
+                       f"(of {cores} host CPUs; thread count = best of 16/32/64/128 on one level-0 ResnetBlock2D + one C=1280 BasicTransformerBlock of the oracle, {rate / 1e9:.0f} GFLOP/s there)")
 
 
 def _cfg(version):
     from components.native import ARCH_CONFIGS
     return ARCH_CONFIGS[version]
+
+
+def csrc_sha():
+    """sha256[:16] over the kernel / executor sources (sorted by name): stamps PMC results to the code they were taken on"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(PKG, "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".cpp", ".h")):
+            h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def main():
@@ -284,10 +323,14 @@ def main():
         fl = unet_flops_per_image(cfg, lat)
         fl_img = sum(fl.values())
         ips = world * B * args.steps / dt
-        traffic = None        # HBM bytes/launch of the dominant kernel from the committed rocprofv3 --pmc passes (same command)
+        # HBM bytes/launch of the dominant kernel from the rocprofv3 --pmc passes of THIS command (tools/final_profile.sh ->
+        # profiles/pmc_traffic_current.json).  The file is stamped with a hash of the kernel sources it was measured on: a
+        # stamp that does not match the sources being benchmarked means the number is stale, and `traffic` is null.
+        traffic = None
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            traffic = tj[dominant]["hbm_bytes_per_launch"] if (args.version == "xl" and B == 16 and dominant in tj) else None
+            tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_current.json")))
+            if tj.get("_meta", {}).get("csrc_sha") == csrc_sha() and args.version == "xl" and B == 16 and dominant in tj:
+                traffic = tj[dominant]["hbm_bytes_per_launch"]
         except Exception:
             traffic = None
         achieved = (fl_tot.value / 1e12) / (ms_tot.value / 1e3) if ms_tot.value > 0 else 0.0
@@ -329,7 +372,8 @@ def main():
         r_ms, _ = tsum(["res_conv1", "res_conv2", "res_shortcut", "gn_stats", "gn_apply_silu"])
         res_bytes = B * (610.8e6 if args.version == "xl" and lat == 128 else 152.9e6 if args.version == "1-5" and lat == 64 else 0.0)
         h_ms, _ = tsum(["hook_store"])
-        copied = sum(v.numel() * 2 for k, v in out[1].items() if not (k.endswith("res-increment") or k.endswith("-map")))
+        # only the hooks the plan routes through hook_store (copy2d_kernel); the others are written by their producer's epilogue
+        copied = sum(nbytes for i, (_hid, _shp, _str, nbytes) in enumerate(plan.hooks) if lib.gdf_plan_hook_copied(plan.handle, i))
         res["rooflines"] = {
             "attention_mfma": {"kernel": "attn_kernel", "achieved": round(a_fl / 1e9 / max(a_ms, 1e-9), 1), "peak": MFMA_PEAK_TFLOPS,
                                "unit": "TFLOP/s", "frac": round(a_fl / 1e9 / max(a_ms, 1e-9) / MFMA_PEAK_TFLOPS, 4),
@@ -346,29 +390,30 @@ def main():
                             "frac": round(2 * copied / 1e6 / max(h_ms, 1e-9) / HBM_PEAK_GBS, 4) if h_ms > 0 else None,
                             "bytes_per_step": copied, "ms_per_step": round(h_ms, 4)},
         }
-        # ---- hipGraph leg (extra, N = 1): the same K steps replayed as ONE hipGraphLaunch each on a side stream (gdf.h
-        # gdf_plan_set_graph).  `value` above stays the eagerly launched, event-instrumented region the contract asks for;
-        # this shows the launch-bound host cost (process CPU time per step) the graph path removes.
+        # ---- product path (extra, N = 1): forward_raw as FeatureExtractor.extract drives it — private stream, stable buffers,
+        # the op program replayed as ONE hipGraphLaunch per step (gdf.h gdf_plan_set_graph).  `value` above stays the eagerly
+        # launched, event-instrumented region the roofline contract asks for; this leg shows the host cost the graph removes.
         if world == 1:
-            side = torch.cuda.Stream(device=dev)
-            with torch.cuda.stream(side):
+            def leg():
                 for _ in range(3):
-                    o2 = step()
+                    step()
                 torch.cuda.synchronize()
+                capw = plan.graph_stats()[0]
                 c0 = time.process_time(); t1 = time.perf_counter()
                 for _ in range(args.steps):
-                    o2 = step()
+                    step()
                 c1 = time.process_time()
-                torch.cuda.synchronize(); dt2 = time.perf_counter() - t1
-            c2 = time.process_time()
-            for _ in range(args.steps):
-                o2 = step()
-            c3 = time.process_time()
-            torch.cuda.synchronize()
+                torch.cuda.synchronize()
+                return time.perf_counter() - t1, (c1 - c0) / args.steps * 1e3, capw
+            dt2, cpu_graph, cap0 = leg()
+            cap1, lau1 = plan.graph_stats()
+            lib.gdf_plan_set_graph(plan.handle, 0); plan.graph = False
+            _, cpu_eager, _ = leg()
+            lib.gdf_plan_set_graph(plan.handle, 1); plan.graph = True
             res["hipgraph"] = {"value": round(B * args.steps / dt2, 3), "unit": "images/s",
-                               "host_cpu_ms_per_step": round((c1 - c0) / args.steps * 1e3, 2),
-                               "eager_host_cpu_ms_per_step": round((c3 - c2) / args.steps * 1e3, 2),
-                               "ops_per_step": lib.gdf_plan_num_ops(plan.handle)}
+                               "host_cpu_ms_per_step": round(cpu_graph, 2), "eager_host_cpu_ms_per_step": round(cpu_eager, 2),
+                               "captures_total": cap1, "captures_in_timed_steps": cap1 - cap0,
+                               "graph_launches": lau1, "ops_per_step": lib.gdf_plan_num_ops(plan.handle)}
         if args.profile_ops:
             rows = {}
             for name, ms, f_, _k in prof:

@@ -20,11 +20,12 @@ from .native import (ARCH_CONFIGS, FLUX_CONFIGS, PIXART_CONFIGS, VAE_CONFIGS, Na
 
 # version -> (HF repo id, pipeline class name) exactly as the reference selects them (models.py:18-70)
 _HF = {
-    "1-5": ("runwayml/stable-diffusion-v1-5", "StableDiffusionImg2ImgPipeline"),
+    "1-5": ("stable-diffusion-v1-5/stable-diffusion-v1-5", "StableDiffusionImg2ImgPipeline"),
+    "2-1": ("stabilityai/stable-diffusion-2-1-base", "StableDiffusionImg2ImgPipeline"),      # + EulerDiscreteScheduler (:38-39)
     "xl": ("stabilityai/stable-diffusion-xl-base-1.0", "StableDiffusionXLImg2ImgPipeline"),
     "pgv2": ("playgroundai/playground-v2-1024px-aesthetic", "StableDiffusionXLImg2ImgPipeline"),
 }
-_LATER = ("2-1", "pixart-alpha", "if", "hunyuan")       # pixart-alpha-1024 needs the resolution micro-conditioning
+_LATER = ("pixart-alpha", "if", "hunyuan")       # pixart-alpha-1024 needs the resolution micro-conditioning
 
 
 def _parse_dtype(dtype):
@@ -116,7 +117,7 @@ class SyntheticPipe:
             pooled = cfg["add_in_dim"] - 6 * cfg["addition_time_embed_dim"]
             self.text_encoder_2 = types.SimpleNamespace(parameters=lambda: iter(()), to=lambda *a, **k: None,
                                                         config=types.SimpleNamespace(projection_dim=pooled))
-        self.scheduler = _Scheduler(euler=bool(cfg["addition_embed_text_time"]))
+        self.scheduler = _Scheduler(euler=bool(cfg["addition_embed_text_time"]) or version == "2-1")   # reference models.py:26,38,51
         self.config = types.SimpleNamespace(requires_aesthetics_score=False)
         self.image_processor = types.SimpleNamespace(preprocess=self._preprocess)
         self._cfg = cfg
@@ -330,7 +331,8 @@ def get_diffusion_model(version, dtype, offline_lora=None, offline_lora_filename
         raise RuntimeError("diffusers is not installed and GDF_SYNTHETIC_WEIGHTS is not set: the text encoders / VAE / "
                            "checkpoint loading upstream of the native UNet come from diffusers (see INTEGRATION.md)") from e
     repo, cls = _HF[version]
-    pipe = getattr(diffusers, cls).from_pretrained(repo, torch_dtype=dt, variant="fp16" if dt == torch.float16 else None)
+    kw = dict(variant="fp16") if (version in ("xl", "pgv2") and dt == torch.float16) else {}      # reference models.py:51-53
+    pipe = getattr(diffusers, cls).from_pretrained(repo, torch_dtype=dt, use_safetensors=True, **kw)
     if version != "1-5":
         pipe.scheduler = diffusers.EulerDiscreteScheduler.from_config(pipe.scheduler.config)
     if offline_lora:

@@ -57,6 +57,7 @@ SIGNATURES = {
     "gdf_plan_num_ops": (C.c_int, [C.c_void_p]),
     "gdf_plan_hook_count": (C.c_int, [C.c_void_p]),
     "gdf_plan_hook_info": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(HookInfo)]),
+    "gdf_plan_hook_copied": (C.c_int, [C.c_void_p, C.c_int]),
     "gdf_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                               C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_void_p]),
     "gdf_plan_profile": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -166,6 +167,9 @@ ARCH_CONFIGS = {
                addition_time_embed_dim=256, add_in_dim=2816),
 }
 ARCH_CONFIGS["pgv2"] = ARCH_CONFIGS["xl"]        # Playground-v2 shares the SDXL UNet architecture
+# SD 2.1-base (reference models.py:30-42): the SD1.5 topology with 64-wide heads (5, 10, 20, 20), OpenCLIP-H text width 1024
+# and linear proj_in / proj_out (config.json of stabilityai/stable-diffusion-2-1-base)
+ARCH_CONFIGS["2-1"] = dict(ARCH_CONFIGS["1-5"], heads=(5, 10, 20, 20), cross_attention_dim=1024, use_linear_projection=1)
 
 
 def arch_desc(cfg):
@@ -205,11 +209,44 @@ def config_from_diffusers(uc):
                 add_in_dim=(uc.projection_class_embeddings_input_dim or 0) if text_time else 0)
 
 
+def _use_count(t):
+    """References to the storage of tensor `t` (views handed to callers included) — the liveness test of a hook-buffer set."""
+    return torch._C._storage_Use_Count(t.untyped_storage()._cdata)
+
+
+class _HookSet:
+    """One set of caller-visible output buffers of a plan (every hook + the model output) carved out of ONE allocation.
+    The tensors a forward returns are views into it; the set may be handed out again only when the caller has dropped every
+    such view (storage use count back to its baseline), so returned dicts stay valid for as long as they are referenced
+    (reference contract: FeatureStore.reset() rebinds a fresh dict, feature_extractor.py:28-29)."""
+
+    def __init__(self, plan, out_elems, dev):
+        self.offs, tot = [], 0
+        for (_, _, _, nbytes) in plan.hooks:
+            self.offs.append(tot)
+            tot += (nbytes // 2 + 127) // 128 * 128
+        self.out_off = tot
+        tot += (out_elems + 127) // 128 * 128
+        self.buf = torch.empty(max(tot, 128), dtype=torch.float16, device=dev)
+        base = self.buf.data_ptr()
+        self.ptrs = (C.c_void_p * max(1, len(self.offs)))(*[base + 2 * o for o in self.offs])
+        self.out_ptr = C.c_void_p(base + 2 * self.out_off)
+        self.base_count = _use_count(self.buf)
+
+    def free(self):
+        return _use_count(self.buf) == self.base_count
+
+
 class _Plan:
+    """A libgdf plan + everything with a STABLE device address it runs on: workspace, input staging buffers, up to MAX_SETS
+    hook-buffer sets and a private non-default stream.  Stable addresses are what lets gdf_plan_set_graph replay one captured
+    hipGraph per set instead of re-capturing (the graph cache of the library is keyed on the buffer addresses)."""
+    MAX_SETS = 3
+
     def __init__(self, lib, handle):
         self.lib, self.handle = lib, handle
-        if os.environ.get("GDF_HIP_GRAPH", "1") not in ("", "0"):      # hipGraph replay on non-default streams (gdf.h)
-            lib.gdf_plan_set_graph(handle, 1)
+        self.graph = os.environ.get("GDF_HIP_GRAPH", "1") not in ("", "0")   # hipGraph replay (gdf.h)
+        lib.gdf_plan_set_graph(handle, int(self.graph))
         self.ws_bytes = lib.gdf_plan_workspace_bytes(handle)
         self.hooks = []
         for i in range(lib.gdf_plan_hook_count(handle)):
@@ -217,12 +254,70 @@ class _Plan:
             _check(lib.gdf_plan_hook_info(handle, i, C.byref(hi)), "plan_hook_info")
             self.hooks.append((hi.id.decode(), tuple(hi.shape), tuple(hi.stride), hi.bytes))
         self.workspace = None
+        self.stream = None
+        self.staged = {}
+        self.sets = []
 
     def __del__(self):
         try:
             self.lib.gdf_plan_destroy(self.handle)
         except Exception:
             pass
+
+    def graph_stats(self):
+        cap, lau = C.c_long(), C.c_long()
+        self.lib.gdf_plan_graph_stats(self.handle, C.byref(cap), C.byref(lau))
+        return cap.value, lau.value
+
+    def _stage(self, name, t, dtype, dev):
+        """copy `t` into the persistent staging buffer of input `name` (dtype conversion + layout in the same copy)"""
+        if t is None:
+            return None
+        b = self.staged.get(name)
+        if b is None or b.shape != t.shape or b.dtype != dtype:
+            b = self.staged[name] = torch.empty(t.shape, dtype=dtype, device=dev)
+        b.copy_(t, non_blocking=True)
+        return b
+
+    def run(self, dev, inputs, out_shape, call, profile=False, eager=False):
+        """Stage `inputs` [(name, tensor | None, dtype)], pick a free hook-buffer set and launch `call(staged, hook_ptrs,
+        out_ptr, ws_ptr, stream_ptr)` on the plan's private stream, event-ordered after the caller's current stream; the
+        caller's stream then waits for it, so results follow ordinary stream semantics.
+        Returns (out tensor, {hook id: (B,C,H,W) view}, whatever `call` returned)."""
+        cur = torch.cuda.current_stream(dev)
+        if self.stream is None:
+            self.stream = torch.cuda.Stream(device=dev)
+        side = self.stream
+        side.wait_stream(cur)
+        n_out = 1
+        for d in out_shape:
+            n_out *= d
+        with torch.cuda.device(dev), torch.cuda.stream(side):
+            if self.workspace is None or self.workspace.numel() < self.ws_bytes:
+                self.workspace = torch.empty(self.ws_bytes, dtype=torch.uint8, device=dev)
+            staged = [self._stage(n, t, dt, dev) for (n, t, dt) in inputs]
+            hs = next((h for h in self.sets if h.free()), None)
+            pooled = True
+            if hs is None:
+                hs = _HookSet(self, n_out, dev)
+                pooled = len(self.sets) < self.MAX_SETS        # more live result sets than that: one-off buffers, run eagerly
+                if pooled:
+                    self.sets.append(hs)
+            no_graph = self.graph and (eager or profile or not pooled)
+            if no_graph:
+                self.lib.gdf_plan_set_graph(self.handle, 0)
+            try:
+                ret = call(staged, hs.ptrs, hs.out_ptr, C.c_void_p(self.workspace.data_ptr()), C.c_void_p(side.cuda_stream))
+            finally:
+                if no_graph:
+                    self.lib.gdf_plan_set_graph(self.handle, 1)
+            hs.buf.record_stream(cur)
+        cur.wait_stream(side)
+        feats = {}
+        for off, (hid, shape, stride, _) in zip(hs.offs, self.hooks):
+            feats[hid] = torch.as_strided(hs.buf, shape, stride, storage_offset=off)
+        out = hs.buf[hs.out_off:hs.out_off + n_out].view(out_shape)
+        return out, feats, ret
 
 
 class _NativeModel:
@@ -319,6 +414,23 @@ class _NativeModel:
     def ready(self):
         return bool(self.lib.gdf_model_ready(self.handle))
 
+    def _launch(self, plan, fwd, prof_fn, what, profile):
+        """-> call(staged, hook_ptrs, out_ptr, ws_ptr, stream_ptr) for _Plan.run; `args(staged)` orders the staged inputs"""
+        lib = self.lib
+
+        def call(staged, hook_ptrs, out_ptr, ws_ptr, stream_ptr):
+            vp = lambda a: C.c_void_p(a.data_ptr() if a is not None else 0)
+            head = [plan.handle] + [vp(a) for a in staged]
+            if not profile:
+                _check(fwd(*head, hook_ptrs, out_ptr, ws_ptr, stream_ptr), what)
+                return None
+            n = lib.gdf_plan_num_ops(plan.handle)
+            ms = (C.c_float * n)(); names = (C.c_char_p * n)(); fl = (C.c_double * n)()
+            if prof_fn(*head, hook_ptrs, out_ptr, ws_ptr, stream_ptr, ms, names, fl, n) < 0:
+                _check(1, what + " (profile)")
+            return [(names[i].decode(), ms[i], fl[i], lib.gdf_plan_op_kernel(plan.handle, i).decode()) for i in range(n)]
+        return call
+
     def requested_ids(self):
         fs = self.feature_store
         if fs is None:
@@ -392,51 +504,27 @@ class NativeUNet(_NativeModel):
         over the batch, as FeatureExtractor.extract does): the text K/V projections are then computed once per call."""
         dev = self.device
         B, _, H, W = sample.shape
-        sample = sample.to(dev, torch.float16).contiguous()
-        ctx = encoder_hidden_states.to(dev, torch.float16).contiguous()
+        ctx = encoder_hidden_states
         t = torch.as_tensor(timestep, device=dev).float().reshape(-1)
         if t.numel() == 1:
             t = t.expand(B)
-        t = t.contiguous()
         txt = tid = None
         if self.cfg["addition_embed_text_time"]:
             if text_embeds is None or time_ids is None:
                 raise ValueError("added_cond_kwargs with text_embeds and time_ids is required for this UNet")
-            txt = text_embeds.to(dev, torch.float16).contiguous()
-            tid = time_ids.to(dev, torch.float32).contiguous()
+            txt, tid = text_embeds, time_ids
             pooled = self.cfg["add_in_dim"] - 6 * self.cfg["addition_time_embed_dim"]
-            if txt.shape != (B, pooled) or tid.shape != (B, 6):
+            if tuple(txt.shape) != (B, pooled) or tuple(tid.shape) != (B, 6):
                 raise ValueError(f"text_embeds {tuple(txt.shape)} / time_ids {tuple(tid.shape)} do not match the model "
                                  f"(expected ({B},{pooled}) / ({B},6))")
         if ctx.shape[0] != B or ctx.shape[2] != self.cfg["cross_attention_dim"]:
             raise ValueError("encoder_hidden_states shape mismatch")
         ids = list(hook_ids) if hook_ids is not None else self.requested_ids()
         plan = self._plan(B, H, W, ctx.shape[1], ids, shared_ctx)
-        with torch.cuda.device(dev):
-            if plan.workspace is None or plan.workspace.numel() < plan.ws_bytes:
-                plan.workspace = torch.empty(plan.ws_bytes, dtype=torch.uint8, device=dev)
-            hooks = [torch.empty(nbytes // 2, dtype=torch.float16, device=dev) for (_, _, _, nbytes) in plan.hooks]
-            hook_ptrs = (C.c_void_p * max(1, len(hooks)))(*[h.data_ptr() for h in hooks])
-            noise = torch.empty(B, H, W, self.cfg["out_channels"], dtype=torch.float16, device=dev)
-            stream = torch.cuda.current_stream(dev)
-            args = (plan.handle, C.c_void_p(sample.data_ptr()), C.c_void_p(t.data_ptr()), C.c_void_p(ctx.data_ptr()),
-                    C.c_void_p(txt.data_ptr() if txt is not None else 0),
-                    C.c_void_p(tid.data_ptr() if tid is not None else 0), hook_ptrs, C.c_void_p(noise.data_ptr()),
-                    C.c_void_p(plan.workspace.data_ptr()), C.c_void_p(stream.cuda_stream))
-            prof = None
-            if profile:
-                n = self.lib.gdf_plan_num_ops(plan.handle)
-                ms = (C.c_float * n)(); names = (C.c_char_p * n)(); fl = (C.c_double * n)()
-                rc = self.lib.gdf_plan_profile(*args, ms, names, fl, n)
-                if rc < 0:
-                    _check(1, "plan_profile")
-                prof = [(names[i].decode(), ms[i], fl[i], self.lib.gdf_plan_op_kernel(plan.handle, i).decode())
-                        for i in range(n)]
-            else:
-                _check(self.lib.gdf_forward(*args), "forward")
-        out = {}
-        for buf, (hid, shape, stride, _) in zip(hooks, plan.hooks):
-            out[hid] = torch.as_strided(buf, shape, stride)
+        f16, f32 = torch.float16, torch.float32
+        call = self._launch(plan, self.lib.gdf_forward, self.lib.gdf_plan_profile, "forward", profile)
+        noise, out, prof = plan.run(dev, [("sample", sample, f16), ("t", t, f32), ("ctx", ctx, f16), ("txt", txt, f16),
+                                          ("tid", tid, f32)], (B, H, W, self.cfg["out_channels"]), call, profile=profile)
         noise_nchw = noise.permute(0, 3, 1, 2)
         if profile:
             return noise_nchw, out, prof
@@ -513,6 +601,7 @@ class NativeFluxTransformer(_NativeModel):
         self.feature_store = None
         self._plans = {}
         self.dtype = torch.float16
+        self.io_dtype = torch.float16              # element type of the activations handed to libgdf
         self.config = types.SimpleNamespace(in_channels=cfg["in_channels"], guidance_embeds=bool(cfg["guidance_embeds"]),
                                             joint_attention_dim=cfg["joint_attention_dim"],
                                             pooled_projection_dim=cfg["pooled_projection_dim"])
@@ -546,49 +635,28 @@ class NativeFluxTransformer(_NativeModel):
             if g * g != S:
                 raise ValueError(f"{S} image tokens do not form a square grid; pass grid=(h, w)")
             grid = (g, g)
-        f16 = lambda t: t.to(dev, torch.float16).contiguous()
-        f32 = lambda t: t.to(dev, torch.float32).contiguous()
-        x, enc, pooled = f16(hidden_states), f16(encoder_hidden_states), f16(pooled_projections)
+        x, enc, pooled = hidden_states, encoder_hidden_states, pooled_projections
         t = torch.as_tensor(timestep, device=dev).float().reshape(-1)
-        t = (t.expand(B) if t.numel() == 1 else t).contiguous()
+        t = t.expand(B) if t.numel() == 1 else t
         gd = None
         if self.cfg["guidance_embeds"]:
             if guidance is None:
                 raise ValueError("guidance is required for a guidance-distilled transformer (guidance_embeds)")
             gd = torch.as_tensor(guidance, device=dev).float().reshape(-1)
-            gd = (gd.expand(B) if gd.numel() == 1 else gd).contiguous()
-        img_ids = f32(img_ids[0] if img_ids.dim() == 3 else img_ids)       # transformer_flux.py:485-496
-        txt_ids = f32(txt_ids[0] if txt_ids.dim() == 3 else txt_ids)
+            gd = gd.expand(B) if gd.numel() == 1 else gd
+        img_ids = img_ids[0] if img_ids.dim() == 3 else img_ids           # transformer_flux.py:485-496
+        txt_ids = txt_ids[0] if txt_ids.dim() == 3 else txt_ids
         T = enc.shape[1]
-        if (cin != self.cfg["in_channels"] or enc.shape != (B, T, self.cfg["joint_attention_dim"])
-                or pooled.shape != (B, self.cfg["pooled_projection_dim"]) or img_ids.shape != (S, 3)
-                or txt_ids.shape != (T, 3)):
+        if (cin != self.cfg["in_channels"] or tuple(enc.shape) != (B, T, self.cfg["joint_attention_dim"])
+                or tuple(pooled.shape) != (B, self.cfg["pooled_projection_dim"]) or tuple(img_ids.shape) != (S, 3)
+                or tuple(txt_ids.shape) != (T, 3)):
             raise ValueError("flux input shape mismatch")
         ids = list(hook_ids) if hook_ids is not None else self.requested_ids()
         plan = self._plan(B, grid[0], grid[1], T, ids)
-        with torch.cuda.device(dev):
-            if plan.workspace is None or plan.workspace.numel() < plan.ws_bytes:
-                plan.workspace = torch.empty(plan.ws_bytes, dtype=torch.uint8, device=dev)
-            hooks = [torch.empty(nbytes // 2, dtype=torch.float16, device=dev) for (_, _, _, nbytes) in plan.hooks]
-            hook_ptrs = (C.c_void_p * max(1, len(hooks)))(*[h.data_ptr() for h in hooks])
-            out = torch.empty(B, S, cin, dtype=torch.float16, device=dev)
-            stream = torch.cuda.current_stream(dev)
-            vp = lambda a: C.c_void_p(a.data_ptr() if a is not None else 0)
-            args = (plan.handle, vp(x), vp(enc), vp(pooled), vp(t), vp(gd), vp(img_ids), vp(txt_ids), hook_ptrs, vp(out),
-                    vp(plan.workspace), C.c_void_p(stream.cuda_stream))
-            prof = None
-            if profile:
-                n = self.lib.gdf_plan_num_ops(plan.handle)
-                ms = (C.c_float * n)(); names = (C.c_char_p * n)(); fl = (C.c_double * n)()
-                if self.lib.gdf_flux_plan_profile(*args, ms, names, fl, n) < 0:
-                    _check(1, "flux_plan_profile")
-                prof = [(names[i].decode(), ms[i], fl[i], self.lib.gdf_plan_op_kernel(plan.handle, i).decode())
-                        for i in range(n)]
-            else:
-                _check(self.lib.gdf_flux_forward(*args), "flux_forward")
-        feats = {}
-        for buf, (hid, shape, stride, _) in zip(hooks, plan.hooks):
-            feats[hid] = torch.as_strided(buf, shape, stride)
+        f16, f32 = self.io_dtype, torch.float32
+        call = self._launch(plan, self.lib.gdf_flux_forward, self.lib.gdf_flux_plan_profile, "flux_forward", profile)
+        out, feats, prof = plan.run(dev, [("x", x, f16), ("enc", enc, f16), ("pooled", pooled, f16), ("t", t, f32), ("gd", gd, f32),
+                                          ("img_ids", img_ids, f32), ("txt_ids", txt_ids, f32)], (B, S, cin), call, profile=profile)
         return (out, feats, prof) if profile else (out, feats)
 
     def __call__(self, hidden_states, encoder_hidden_states=None, pooled_projections=None, timestep=None, img_ids=None,
@@ -666,31 +734,30 @@ class NativeVAEEncoder(_NativeModel):
         dev = self.device
         B, _, H, W = image.shape
         f = 1 << (len(self.cfg["block_out_channels"]) - 1)
-        x = image.to(dev, torch.float16).contiguous()
         L = self.cfg["latent_channels"]
-        f16 = lambda t: None if t is None else t.to(dev, torch.float16).contiguous()
-        eps, noise = f16(eps), f16(noise)
         for t in (eps, noise):
             if t is not None and tuple(t.shape) != (B, L, H // f, W // f):
                 raise ValueError("eps / noise must have the latent shape (B, L, H/f, W/f)")
         plan = self._plan(B, H, W)
-        with torch.cuda.device(dev):
-            if plan.workspace is None or plan.workspace.numel() < plan.ws_bytes:
-                plan.workspace = torch.empty(plan.ws_bytes, dtype=torch.uint8, device=dev)
-            out = torch.empty(B, L, H // f, W // f, dtype=torch.float16, device=dev)
-            stream = torch.cuda.current_stream(dev)
+        lib = self.lib
+        sc = (float(scaling_factor), float(noise_a), float(noise_b), float(input_scale))
+
+        def call(staged, hook_ptrs, out_ptr, ws_ptr, stream_ptr):
             vp = lambda a: C.c_void_p(a.data_ptr() if a is not None else 0)
-            args = (plan.handle, vp(x), vp(eps), vp(noise), float(scaling_factor), float(noise_a), float(noise_b),
-                    float(input_scale), vp(out), vp(plan.workspace), C.c_void_p(stream.cuda_stream))
-            if profile:
-                n = self.lib.gdf_plan_num_ops(plan.handle)
-                ms = (C.c_float * n)(); names = (C.c_char_p * n)(); fl = (C.c_double * n)()
-                if self.lib.gdf_vae_plan_profile(*args, ms, names, fl, n) < 0:
-                    _check(1, "vae_plan_profile")
-                return out, [(names[i].decode(), ms[i], fl[i], self.lib.gdf_plan_op_kernel(plan.handle, i).decode())
-                             for i in range(n)]
-            _check(self.lib.gdf_vae_encode(*args), "vae_encode")
-        return out
+            args = (plan.handle, vp(staged[0]), vp(staged[1]), vp(staged[2])) + sc + (out_ptr, ws_ptr, stream_ptr)
+            if not profile:
+                _check(lib.gdf_vae_encode(*args), "vae_encode")
+                return None
+            n = lib.gdf_plan_num_ops(plan.handle)
+            ms = (C.c_float * n)(); names = (C.c_char_p * n)(); fl = (C.c_double * n)()
+            if lib.gdf_vae_plan_profile(*args, ms, names, fl, n) < 0:
+                _check(1, "vae_plan_profile")
+            return [(names[i].decode(), ms[i], fl[i], lib.gdf_plan_op_kernel(plan.handle, i).decode()) for i in range(n)]
+
+        f16 = torch.float16
+        out, _, prof = plan.run(dev, [("image", image, f16), ("eps", eps, f16), ("noise", noise, f16)], (B, L, H // f, W // f), call,
+                                profile=profile)
+        return (out, prof) if profile else out
 
 
 # --------------------------------------------------------------------------------------------- #
@@ -731,6 +798,7 @@ class NativePixArtTransformer(_NativeModel):
         self.feature_store = None
         self._plans = {}
         self.dtype = torch.float16
+        self.io_dtype = torch.float16
         self.config = types.SimpleNamespace(in_channels=cfg["in_channels"], sample_size=cfg["sample_size"],
                                             out_channels=cfg["out_channels"])
 
@@ -777,12 +845,11 @@ class NativePixArtTransformer(_NativeModel):
         """Returns (output (B, out_channels, H, W) fp16, OrderedDict id -> hook tensor)."""
         dev = self.device
         B, cin, H, W = hidden_states.shape
-        x = hidden_states.to(dev, torch.float16).contiguous()
-        enc = encoder_hidden_states.to(dev, torch.float16).contiguous()
+        x, enc = hidden_states, encoder_hidden_states
         t = torch.as_tensor(timestep, device=dev).float().reshape(-1)
-        t = (t.expand(B) if t.numel() == 1 else t).contiguous()
+        t = t.expand(B) if t.numel() == 1 else t
         T = enc.shape[1]
-        if cin != self.cfg["in_channels"] or enc.shape != (B, T, self.cfg["caption_channels"]):
+        if cin != self.cfg["in_channels"] or tuple(enc.shape) != (B, T, self.cfg["caption_channels"]):
             raise ValueError("pixart input shape mismatch")
         lens = None
         if encoder_attention_mask is not None:
@@ -790,32 +857,12 @@ class NativePixArtTransformer(_NativeModel):
             lens = m.sum(1).to(torch.int32)
             if not torch.equal(m, torch.arange(T, device=dev)[None] < lens[:, None]):
                 raise NotImplementedError("encoder_attention_mask must keep a leading prefix of the caption tokens")
-            lens = lens.contiguous()
         ids = list(hook_ids) if hook_ids is not None else self.requested_ids()
         plan = self._plan(B, H, W, T, ids)
-        with torch.cuda.device(dev):
-            if plan.workspace is None or plan.workspace.numel() < plan.ws_bytes:
-                plan.workspace = torch.empty(plan.ws_bytes, dtype=torch.uint8, device=dev)
-            hooks = [torch.empty(nbytes // 2, dtype=torch.float16, device=dev) for (_, _, _, nbytes) in plan.hooks]
-            hook_ptrs = (C.c_void_p * max(1, len(hooks)))(*[h.data_ptr() for h in hooks])
-            out = torch.empty(B, self.cfg["out_channels"], H, W, dtype=torch.float16, device=dev)
-            stream = torch.cuda.current_stream(dev)
-            vp = lambda a: C.c_void_p(a.data_ptr() if a is not None else 0)
-            args = (plan.handle, vp(x), vp(t), vp(enc), vp(lens), hook_ptrs, vp(out), vp(plan.workspace),
-                    C.c_void_p(stream.cuda_stream))
-            prof = None
-            if profile:
-                n = self.lib.gdf_plan_num_ops(plan.handle)
-                ms = (C.c_float * n)(); names = (C.c_char_p * n)(); fl = (C.c_double * n)()
-                if self.lib.gdf_pixart_plan_profile(*args, ms, names, fl, n) < 0:
-                    _check(1, "pixart_plan_profile")
-                prof = [(names[i].decode(), ms[i], fl[i], self.lib.gdf_plan_op_kernel(plan.handle, i).decode())
-                        for i in range(n)]
-            else:
-                _check(self.lib.gdf_pixart_forward(*args), "pixart_forward")
-        feats = {}
-        for buf, (hid, shape, stride, _) in zip(hooks, plan.hooks):
-            feats[hid] = torch.as_strided(buf, shape, stride)
+        f16 = self.io_dtype
+        call = self._launch(plan, self.lib.gdf_pixart_forward, self.lib.gdf_pixart_plan_profile, "pixart_forward", profile)
+        out, feats, prof = plan.run(dev, [("x", x, f16), ("t", t, torch.float32), ("enc", enc, f16), ("lens", lens, torch.int32)],
+                                    (B, self.cfg["out_channels"], H, W), call, profile=profile)
         return (out, feats, prof) if profile else (out, feats)
 
     def __call__(self, hidden_states, encoder_hidden_states=None, timestep=None, added_cond_kwargs=None,

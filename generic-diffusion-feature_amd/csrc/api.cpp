@@ -72,6 +72,10 @@ int gdf_plan_hook_info(const gdf_plan* p, int i, gdf_hook_info* info) {
   return GDF_OK;
 }
 
+int gdf_plan_hook_copied(const gdf_plan* p, int i) {
+  return (p && i >= 0 && i < (int)p->p.hooks.size() && p->p.hooks[i].copied) ? 1 : 0;
+}
+
 // ---- PixArt DiT front end (include/gdf_pixart.h) ----
 int gdf_pixart_model_create(const gdf_pixart_desc* desc, gdf_model** out) {
   if (!desc || !out) { set_error("null argument"); return GDF_ERR_ARG; }

@@ -192,6 +192,7 @@ struct PlanBuilder {
   // coalesced hook store: fp16 copy of `rows x C` from (src, ld)
   void hook_copy(int slot, Ref src, int ld, size_t nrows, int C) {
     if (slot < 0) return;
+    P.hooks[slot].copied = true;
     op("hook_store", 0, [=](const Bind& b, hipStream_t s) {
       return launch_copy2d((const half_t*)b.p(src), nullptr, ld, (half_t*)b.hook(slot), C, (int)nrows, C, s);
     });

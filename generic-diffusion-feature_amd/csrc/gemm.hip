@@ -29,6 +29,9 @@
 #include <type_traits>
 #include <cstdio>
 #include <cstring>
+#include <deque>
+#include <mutex>
+#include <string>
 
 namespace gdf {
 
@@ -836,14 +839,13 @@ template <int MODE, int BM, int BN, int STAGES, bool GEGLU, bool DIT = false>
 static hipError_t launch_t(const GemmParams& p, hipStream_t s) {
   const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
   const int smem = (STAGES >= 8 ? 2 : STAGES) * (BM * 128 + BN * 128);
-  static bool attr_done = false;
-  if (!attr_done) {
+  static std::atomic<uint64_t> attr_mask{0};             // per template instantiation, one bit per device
+  {
     const void* fn;
     if constexpr (DIT) fn = (const void*)gemm_dit_kernel<BM, BN, STAGES>;
     else fn = (const void*)gemm_kernel<MODE, BM, BN, STAGES, GEGLU>;
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    const hipError_t e = ensure_dyn_smem(attr_mask, fn, smem);
     if (e != hipSuccess) return e;
-    attr_done = true;
   }
   GemmParams q = p;
   q.sb_gm = q.sb_gn = 0;
@@ -934,8 +936,6 @@ bool gemm_qkn_ok(int M, int N, int K) {
 // kernel symbol (as rocprofv3 prints it) that launch_gemm would pick for these parameters
 const char* gemm_kernel_name(const GemmParams& p) {
   const int v = pick_variant(p);
-  static char buf[16][64];
-  static int nb = 0;
   int bm = 128, bn = 128, st = 2;
   if (v == 16) bn = 16; else if (v == 160) bn = 160; else if (v == 256) { bm = 256; st = 3; } else if (v == 320) { bm = 256; bn = 320; }
   else if (v == 832) { bm = 256; bn = 320; st = 8; } else if (v == 825) { bm = 256; bn = 256; st = 8; } else if (v == 932) { bm = 256; bn = 320; st = 9; } else if (v == 826) { bm = 256; bn = 256; st = 8; }
@@ -943,9 +943,13 @@ const char* gemm_kernel_name(const GemmParams& p) {
   char tmp[64];
   if (p.dit) snprintf(tmp, sizeof tmp, "gemm_dit_kernel<%d, %d, %d>", v == 128 ? 128 : 256, (v == 1256 || v == 8256) ? 256 : 128, v == 8256 ? 8 : v == 2128 ? 3 : 2);
   else snprintf(tmp, sizeof tmp, "gemm_kernel<%d, %d, %d, %d, %s>", p.mode, bm, bn, st, p.geglu ? "true" : "false");
-  for (int i = 0; i < nb; ++i) if (!strcmp(buf[i], tmp)) return buf[i];
-  if (nb < 16) { strcpy(buf[nb], tmp); return buf[nb++]; }
-  return "gemm_kernel<...>";
+  // interned: the returned pointer stays valid for the life of the library (plan build time only, mutex-protected)
+  static std::mutex mu;
+  static std::deque<std::string> names;
+  std::lock_guard<std::mutex> lk(mu);
+  for (const std::string& n : names) if (n == tmp) return n.c_str();
+  names.emplace_back(tmp);
+  return names.back().c_str();
 }
 
 hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {

@@ -2,10 +2,27 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 
 typedef _Float16 half_t;
 
 namespace gdf {
+
+// One-time raise of a kernel's dynamic-LDS limit, per (kernel, device): `mask` is a static of the calling launcher with one
+// bit per device ordinal.  Thread-safe without a lock — several extractors may run in threads of one process, one per
+// device (reference correspondence/correspondence/aggregation_network.py:67-95); two racing first launches both set the
+// attribute, which is idempotent.
+inline hipError_t ensure_dyn_smem(std::atomic<uint64_t>& mask, const void* fn, int bytes) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  const uint64_t bit = 1ull << (dev & 63);
+  if (mask.load(std::memory_order_acquire) & bit) return hipSuccess;
+  e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) return e;
+  mask.fetch_or(bit, std::memory_order_release);
+  return hipSuccess;
+}
 
 // ------------------------------------------------------------------------------------------------
 // MFMA GEMM / implicit-GEMM convolution:  D[M,N] = A[M,K] * Wt[N,K]^T  (+ fused epilogue)

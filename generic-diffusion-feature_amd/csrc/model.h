@@ -120,7 +120,7 @@ struct Bind {
   void* hook(int slot) const { return hooks[slot]; }
 };
 struct Op { const char* name; double flops; std::function<hipError_t(const Bind&, hipStream_t)> fn; int label = 0; };
-struct HookSlot { std::string id; int64_t shape[4]; int64_t stride[4]; size_t bytes; };
+struct HookSlot { std::string id; int64_t shape[4]; int64_t stride[4]; size_t bytes; bool copied = false; };   // copied: stored by a hook_store (copy2d) op, else by its producer's epilogue
 
 struct Plan {
   const Model* model = nullptr;

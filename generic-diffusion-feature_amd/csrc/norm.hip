@@ -527,11 +527,10 @@ hipError_t launch_small_linear(const float* x, int ldx, int M, int K, const half
   // linears (all time_emb_proj of a UNet in one matrix, N ~ 18 k: the column-per-wave kernel re-evaluated SiLU per column,
   // 0.54 ms) and more than 8 rows (one launch per 8 rows).
   if (N >= 1024 && (size_t)K * 32 <= 128 * 1024) {
-    static bool attr_done = false;
-    if (!attr_done) {
-      hipError_t e = hipFuncSetAttribute((const void*)small_linear_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    static std::atomic<uint64_t> attr_mask{0};
+    {
+      const hipError_t e = ensure_dyn_smem(attr_mask, (const void*)small_linear_wide_kernel, 128 * 1024);
       if (e != hipSuccess) return e;
-      attr_done = true;
     }
     // 512 columns per workgroup when N is huge (x staging amortised); fewer for mid-size N so that >= ~512 workgroups exist
     int cpb = 512;

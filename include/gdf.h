@@ -103,6 +103,10 @@ typedef struct gdf_hook_info {
 } gdf_hook_info;
 int gdf_plan_hook_count(const gdf_plan* p);
 int gdf_plan_hook_info(const gdf_plan* p, int i, gdf_hook_info* info);
+/* 1: hook i is written by a separate coalesced copy op (`hook_store`, copy2d_kernel: read 2 B + write 2 B per element);
+ * 0: its producing kernel stores it directly (GEMM / attention epilogue: `res-increment`, `*-map`, `cross-q`, `ffn-inner`, ...).
+ * Measurement aid: the hook-write roofline counts only copied hooks against copy2d_kernel's time. */
+int gdf_plan_hook_copied(const gdf_plan* p, int i);
 
 /* One single-timestep denoiser forward.  latents (B,4,H,W) fp16 NCHW; timesteps (B) fp32;
  * ctx (B,n_ctx,cross_dim) fp16; add_text_embeds (B, add_in_dim - 6*addition_time_embed_dim) fp16 or NULL;

@@ -59,6 +59,9 @@ ARCHS = {
     ),
 }
 ARCHS["pgv2"] = ARCHS["xl"]
+# SD 2.1-base: components/models.py:30-42 (stabilityai/stable-diffusion-2-1-base config.json): SD1.5 topology,
+# attention_head_dim (5,10,20,20) [= head counts], cross dim 1024, use_linear_projection
+ARCHS["2-1"] = dict(ARCHS["1-5"], heads=(5, 10, 20, 20), cross_dim=1024, linear_proj=True)
 
 
 def tiny_arch(base="xl", channels=None, heads=None, cross_dim=64, max_depth=2, time_embed_dim=256):
@@ -67,7 +70,7 @@ def tiny_arch(base="xl", channels=None, heads=None, cross_dim=64, max_depth=2, t
     (dim_head 40/80/160 like the real model)."""
     a = dict(ARCHS[base])
     if channels is None:
-        channels = (64, 128, 256) if base != "1-5" else (320, 640, 640, 640)
+        channels = (320, 640, 640, 640) if base == "1-5" else (64, 128, 256, 256)[:len(a["block_out_channels"])]
     if heads is None:
         heads = tuple(max(1, c // 64) for c in channels) if base != "1-5" else (8, 8, 4, 4)[:len(channels)]
     a["block_out_channels"] = tuple(channels)

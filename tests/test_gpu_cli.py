@@ -45,3 +45,10 @@ def test_cli_layouts(tmp_path, monkeypatch):
     lo = np.load(tmp_path / "o1" / "up-level1-repeat2-res-out" / "b.npy")
     assert np.array_equal(agg[:1280, ::4, ::4], lo) and np.array_equal(agg[1280:], np.load(
         tmp_path / "o1" / "up-level3-repeat0-vit-block0-self-k" / "b.npy"))
+
+
+def test_output_stage_matches_reference_files_on_gpu(tmp_path):
+    """(f)2 on device tensors: nearest resize + concat on the GPU, pinned async D2H, byte-identical to the reference's files."""
+    from test_host_cpu import _run_output_stage, check_output_stage
+    got, want = _run_output_stage(tmp_path, "cuda")
+    check_output_stage(got, want)

@@ -1,0 +1,202 @@
+"""FULL-SIZE parity (-m gpu): the TRUE SDXL / SD1.5 / Flux.1-dev widths at the BASELINE.json batch sizes, through the C ABI,
+against the fp32 CPU oracle on identical seeded weights / latents / timestep / prompt-embeds.
+
+Reference contract: every `feature_gatherer.gather` site of unet_2d_condition.py:1040-1319 (+ resnet.py, attention.py,
+attention_processor.py, transformer_2d.py) and of transformer_flux.py:414-603.  Metric: relative L2 error per hooked tensor.
+
+Stated tolerances (north star: 1e-3):
+  * SDXL 1024^2, every hook kind                  <= 1.0e-3, except `ffn-inner` and `unet-out`      <= 1.3e-3
+  * SD1.5 512^2 (narrower layers average less)    <= 1.1e-3, except `ffn-inner` and `unet-out`      <= 1.35e-3; maps <= 1.0e-3
+  * Flux widths, fp16 operands                    <= 6e-4
+  * and for the UNets: every hook within 1.15x (+2e-5) of the fp16-OPERAND FLOOR (oracle/operand_floor.py) — the error of
+    the fp32 oracle with nothing but its matmul operands rounded to fp16, i.e. what any fp16-MFMA implementation commits at
+    best.  `ffn-inner` (h * gelu(g): the product of two GEMM outputs that each carry the stream error) and `unet-out` sit
+    above 1e-3 ON THAT FLOOR (profiles/r02_operand_floor_*.txt), which is why they have their own bound.
+The oracle runs at batch 1 (2 for SD1.5); the GPU runs at the BASELINE batch (SDXL 16, SD1.5 32, Flux 8) on the same
+sample repeated, so the tile selection of configs C2 / C3 / C5 is the one that is checked, and EVERY sample is compared.
+"""
+import os
+
+import pytest
+import torch
+
+from helpers import cfg_from_oracle_arch
+from oracle import unet_ref as R
+from oracle.operand_floor import fp16_operands, kind_of
+
+pytestmark = pytest.mark.gpu
+
+
+def _threads():
+    torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
+
+
+def _oracle(arch, P, I, ids, floor=False, want_map=None):
+    st = R.Store({k: True for k in ids})
+    with torch.no_grad():
+        if floor:
+            with fp16_operands():
+                R.unet_forward(P, arch, I["sample"], I["timestep"], I["ctx"], I.get("text_embeds"), I.get("time_ids"), store=st,
+                               want_map=want_map)
+        else:
+            R.unet_forward(P, arch, I["sample"], I["timestep"], I["ctx"], I.get("text_embeds"), I.get("time_ids"), store=st,
+                           want_map=want_map)
+    return st.feats
+
+
+def _rel_each(hook, ref):
+    """relative L2 error of every sample of `hook` (Bg, ...) against ref (Br, ...) (sample i vs ref[i % Br]), on the GPU"""
+    r = ref.cuda().float()
+    rn = r.flatten(1).norm(dim=1)
+    out = []
+    for i in range(hook.shape[0]):
+        j = i % r.shape[0]
+        out.append(float((hook[i].float() - r[j]).norm() / rn[j]))
+    return out
+
+
+def _native(arch, P):
+    from components.native import NativeUNet
+    u = NativeUNet(cfg_from_oracle_arch(arch), device="cuda:0")
+    u.load_state_dict({k: v.half() for k, v in P.items()})
+    return u
+
+
+def _rep(I, B):
+    out = {}
+    for k, v in I.items():
+        out[k] = v if k == "timestep" else v[:1].expand(B, *v.shape[1:]).contiguous()
+    return out
+
+
+def _check(errs, floor, bound, floor_mult=1.15, floor_abs=2e-5):
+    """errs / floor: {id: worst-over-samples error}; bound(kind) -> absolute tolerance"""
+    kinds = {}
+    bad = []
+    for k, e in errs.items():
+        kd = kind_of(k)
+        kinds.setdefault(kd, []).append(e)
+        if not e <= bound(kd):
+            bad.append((k, e, "bound", bound(kd)))
+        if floor is not None and not e <= floor_mult * floor[k] + floor_abs:
+            bad.append((k, e, "floor", floor[k]))
+    for kd, v in sorted(kinds.items()):
+        fl = [floor[k] for k in errs if kind_of(k) == kd] if floor is not None else [0.0]
+        print(f"  kind {kd:16s} n={len(v):3d}  gpu median {sorted(v)[len(v) // 2]:.2e} worst {max(v):.2e}   floor worst {max(fl):.2e}")
+    assert not bad, bad[:10]
+
+
+def test_sdxl_1024_batch16_all_non_map_hooks():
+    """BASELINE config C3 (SDXL 1024^2, B = 16): all 472 non-map ids of config_xl_full, every sample."""
+    _threads()
+    arch = R.ARCHS["xl"]
+    P = R.synth_params(arch, seed=0)
+    I = R.synth_inputs(arch, 1, 128, seed=1)
+    ids = [i for i in R.stored_hook_ids(arch) if not i.endswith("-map")]
+    assert len(ids) == 472
+    ref = _oracle(arch, P, I, ids)
+    floor_f = _oracle(arch, P, I, ids, floor=True)
+    floor = {k: float((floor_f[k].float() - ref[k].float()).norm() / ref[k].float().norm()) for k in ids}
+    del floor_f
+    u = _native(arch, P)
+    B = 16
+    Ib = _rep(I, B)
+    g = lambda k: Ib[k].cuda()
+    noise, hooks = u.forward_raw(g("sample"), g("timestep"), g("ctx"), g("text_embeds"), g("time_ids"), hook_ids=ids, shared_ctx=True)
+    torch.cuda.synchronize()
+    assert list(hooks.keys()) == ids
+    errs, n_differ, first_differ = {}, 0, None
+    for k in ids:
+        assert tuple(hooks[k].shape[1:]) == tuple(ref[k].shape[1:]) and hooks[k].shape[0] == B and hooks[k].dtype == torch.float16
+        e = _rel_each(hooks[k], ref[k])
+        errs[k] = max(e)
+        nd = sum(1 for i in range(1, B) if not torch.equal(hooks[k][i], hooks[k][0]))
+        if nd and first_differ is None:
+            first_differ = k
+        n_differ += nd
+    ev = sorted(errs.values())
+    print(f"\n[sdxl 1024^2 B=16] hooks={len(ev)} median {ev[len(ev) // 2]:.2e} worst {ev[-1]:.2e}; below 1e-3: {sum(e < 1e-3 for e in ev)}; "
+          f"(sample, hook) pairs not bit-identical to sample 0: {n_differ} (first: {first_differ})")
+    _check(errs, floor, lambda kd: 1.3e-3 if kd in ("ffn-inner", "unet-out") else 1.0e-3)
+    # the four practical hooks of the headline bench (config_xl_practical) meet the north star with margin
+    for k in ("up-level0-repeat0-vit-block7-out", "up-level0-repeat0-vit-block5-out", "up-level1-repeat0-vit-block0-cross-q",
+              "up-level1-repeat0-vit-block0-out"):
+        assert errs[k] < 9.5e-4, (k, errs[k])
+
+
+def test_sd15_512_full_layer_set_with_maps_batch2_and_batch32():
+    """BASELINE config C2 (SD1.5 512^2, full 197-id layer set incl. attention maps): B = 2 on two different samples and
+    prompts against the oracle, then the B = 32 plan on sample 0 repeated (every sample compared)."""
+    _threads()
+    arch = R.ARCHS["1-5"]
+    P = R.synth_params(arch, seed=0)
+    I = R.synth_inputs(arch, 2, 64, seed=1, same_prompt=False)
+    ids = R.stored_hook_ids(arch)
+    assert len(ids) == 197
+    ref = _oracle(arch, P, I, ids, want_map=True)
+    nm = [i for i in ids if not i.endswith("-map")]
+    floor_f = _oracle(arch, P, I, nm, floor=True, want_map=True)
+    floor = {k: float((floor_f[k].float() - ref[k].float()).norm() / ref[k].float().norm()) for k in nm}
+    del floor_f
+    u = _native(arch, P)
+    g = lambda k: I[k].cuda()
+    _, hooks = u.forward_raw(g("sample"), g("timestep"), g("ctx"), hook_ids=ids)
+    torch.cuda.synchronize()
+    assert list(hooks.keys()) == ids
+    bound = lambda kd: 1.35e-3 if kd in ("ffn-inner", "unet-out") else (1.0e-3 if kd == "map" else 1.1e-3)
+    errs = {k: max(_rel_each(hooks[k], ref[k])) for k in ids}
+    ev = sorted(errs.values())
+    print(f"\n[sd1.5 512^2 B=2, 197 ids] median {ev[len(ev) // 2]:.2e} worst {ev[-1]:.2e}; below 1e-3: {sum(e < 1e-3 for e in ev)}")
+    _check({k: errs[k] for k in nm}, floor, bound)
+    _check({k: errs[k] for k in ids if k.endswith("-map")}, None, bound)
+    del hooks
+    torch.cuda.empty_cache()
+    # ---- the batch-32 plan of config C2 (56 GB of hooks) on sample 0 repeated ----
+    B = 32
+    I0 = {k: (v if k == "timestep" else v[:1]) for k, v in I.items()}
+    Ib = _rep(I0, B)
+    gb = lambda k: Ib[k].cuda()
+    _, hooks = u.forward_raw(gb("sample"), gb("timestep"), gb("ctx"), hook_ids=ids, shared_ctx=True)
+    torch.cuda.synchronize()
+    errs32 = {}
+    for k in ids:
+        assert hooks[k].shape[0] == B
+        errs32[k] = max(_rel_each(hooks[k], ref[k][:1]))
+    ev = sorted(errs32.values())
+    print(f"[sd1.5 512^2 B=32, 197 ids] median {ev[len(ev) // 2]:.2e} worst {ev[-1]:.2e}")
+    floor0 = None      # (the floor above was taken over both samples; the absolute bounds are what is asserted at B = 32)
+    _check({k: errs32[k] for k in nm}, floor0, bound)
+    _check({k: errs32[k] for k in ids if k.endswith("-map")}, None, bound)
+
+
+def test_flux_full_width_batch8():
+    """BASELINE config C5 widths (24 heads x 128, 4096 + 512 tokens, T5 width 4096) with a reduced stack (2 double + 3 single
+    blocks so the CPU oracle finishes within a minute), batch 8 on one sample repeated: every non-map hook, both QKV paths
+    (pre-norm q / k / v hooked: separate RMSNorm + RoPE pass; un-hooked: fused into the QKV GEMM epilogue)."""
+    _threads()
+    from oracle import flux_ref as FR
+    from components.native import NativeFluxTransformer
+    arch = dict(FR.ARCH_FLUX_DEV); arch.update(num_layers=2, num_single_layers=3)
+    P = FR.synth_params(arch, seed=0)
+    I = FR.synth_inputs(arch, 1, 64, 512, seed=1)
+    st = FR.Store(None)
+    with torch.no_grad():
+        y = FR.flux_forward(P, arch, I["hidden_states"], I["encoder_hidden_states"], I["pooled_projections"], I["timestep"],
+                            I["img_ids"], I["txt_ids"], I["guidance"], store=st, want_map=False)
+    net = NativeFluxTransformer(arch, device="cuda:0")
+    net.load_state_dict({k: v.half() for k, v in P.items()})
+    B = 8
+    rep = lambda t: t[:1].expand(B, *t.shape[1:]).contiguous().cuda()
+    args = (rep(I["hidden_states"]), rep(I["encoder_hidden_states"]), rep(I["pooled_projections"]), I["timestep"].cuda(),
+            I["img_ids"].cuda(), I["txt_ids"].cuda())
+    all_ids = FR.hook_ids(arch)
+    for ids in (all_ids, [i for i in all_ids if not i.endswith(("-q", "-k", "-v"))]):
+        out, hooks = net.forward_raw(*args, guidance=I["guidance"].cuda(), hook_ids=ids, grid=(64, 64))
+        torch.cuda.synchronize()
+        assert list(hooks.keys()) == ids
+        errs = {k: max(_rel_each(hooks[k], st.feats[k])) for k in ids}
+        errs["output"] = max(_rel_each(out, y))
+        worst = max(errs, key=errs.get)
+        print(f"\n[flux widths B=8, {len(ids)} hooks] worst {worst} = {errs[worst]:.2e}")
+        assert errs[worst] <= 6e-4, (worst, errs[worst])
+        del hooks, out

@@ -1,8 +1,10 @@
 """Whole-path parity (-m gpu): libgdf.so (through the C ABI, via components.native.NativeUNet) against the CPU
 oracle on identical seeded weights / latents / timestep / prompt-embeds.
 
-Stated tolerance: per hooked tensor  ||gpu - oracle||_2 / ||oracle||_2  <= 3e-3  (fp16 storage, fp32 accumulate,
-fp32 residual stream; the north-star target is 1e-3 and the measured values are printed / asserted per case)."""
+Stated tolerance for these SHRUNKEN-width models: per hooked tensor  ||gpu - oracle||_2 / ||oracle||_2  <= 2e-3 and
+<= 1.3x the fp16-operand floor of the same model (oracle/operand_floor.py): with 64..640 channels a tensor averages the
+fp16 operand rounding over far fewer elements than the true widths, so the floor itself reaches 1.5e-3 here.  The north-star
+bound (1e-3) is asserted on the TRUE widths at the BASELINE batch sizes in tests/test_gpu_fullsize.py."""
 import os
 
 import pytest
@@ -10,9 +12,10 @@ import torch
 
 from helpers import cfg_from_oracle_arch, oracle_run, rel_l2
 from oracle import unet_ref as R
+from oracle.operand_floor import fp16_operands
 
 pytestmark = pytest.mark.gpu
-TOL = 3e-3
+TOL = 2e-3
 
 
 def native(arch, P, **kw):
@@ -29,7 +32,7 @@ def run_native(u, I, ids):
     return noise, hooks
 
 
-@pytest.mark.parametrize("base,lat,batch", [("xl", 16, 2), ("1-5", 16, 1), ("xl", 32, 1)])
+@pytest.mark.parametrize("base,lat,batch", [("xl", 16, 2), ("1-5", 16, 1), ("xl", 32, 1), ("2-1", 16, 2)])
 def test_all_hooks_match_oracle(base, lat, batch):
     arch = R.tiny_arch(base)
     P = R.synth_params(arch, seed=0)
@@ -49,6 +52,10 @@ def test_all_hooks_match_oracle(base, lat, batch):
     bad = {k: v for k, v in errs.items() if not v < TOL}
     assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:8]
     assert rel_l2(noise, ref["unet-out"]) < TOL
+    with fp16_operands():
+        flo = oracle_run(arch, P, I)
+    over = {k: (errs[k], rel_l2(flo[k], r)) for k, r in ref.items() if not errs[k] <= 1.3 * rel_l2(flo[k], r) + 5e-5}
+    assert not over, sorted(over.items(), key=lambda kv: -kv[1][0])[:8]
 
 
 def test_fp16_stream_option_and_selected_hooks():
@@ -152,8 +159,9 @@ def test_aggregated_attention_feature(monkeypatch):
 
 
 def test_hipgraph_replay_equals_eager():
-    """gdf_plan_set_graph: on a non-default stream the op program is captured once per buffer set and replayed."""
-    import ctypes as C
+    """Product default (gdf_plan_set_graph + components.native._Plan): every forward runs on the plan's private stream over
+    buffers with stable addresses; after one eager warm-up forward the op program is captured ONCE per hook-buffer set and
+    replayed.  A set is handed out again only when the caller dropped every tensor of it, so results stay valid."""
     from components.native import NativeUNet
     arch = R.tiny_arch("xl")
     P = R.synth_params(arch, seed=0)
@@ -162,31 +170,120 @@ def test_hipgraph_replay_equals_eager():
     unet.load_state_dict({k: v.half() for k, v in P.items()})
     ids = ["down-level1-repeat0-vit-block0-cross-q", "mid-vit-block1-out", "up-level2-repeat2-res-out", "unet-out"]
     args = [I[k].cuda() for k in ("sample", "timestep", "ctx", "text_embeds", "time_ids")]
-    _, eager = unet.forward_raw(*args, hook_ids=ids)                 # default stream: always eager
+    _, eager = unet.forward_raw(*args, hook_ids=ids)                 # first forward of a plan: eager (lazy kernel attribute setup)
     torch.cuda.synchronize()
-    side = torch.cuda.Stream()
-    outs = []
-    with torch.cuda.stream(side):
-        for _ in range(4):                                           # new hook buffers each time -> one capture each
-            outs.append(unet.forward_raw(*args, hook_ids=ids)[1])
-    side.synchronize()
     plan = unet._plan(2, 16, 16, 77, ids, False)
-    cap, lau = C.c_long(), C.c_long()
-    unet.lib.gdf_plan_graph_stats(plan.handle, C.byref(cap), C.byref(lau))
-    assert lau.value == 4 and 1 <= cap.value <= 4, (cap.value, lau.value)
+    assert plan.graph_stats() == (0, 0)
+    outs = [unet.forward_raw(*args, hook_ids=ids)[1] for _ in range(4)]   # all results kept alive: two more pooled sets get a
+    torch.cuda.synchronize()                                              # graph each, the rest run eagerly on one-off buffers
+    assert plan.graph_stats() == (2, 2), plan.graph_stats()
+    ptrs = {o[ids[0]].data_ptr() for o in outs} | {eager[ids[0]].data_ptr()}
+    assert len(ptrs) == 5                                                 # five live results, five different buffers
     for o in outs:
         for k in ids:
             assert torch.equal(o[k], eager[k]), k
-    # steady state: results dropped before the next call -> the allocator hands the same buffers back -> replays only
+    # steady state: results dropped before the next call -> the same set is reused -> replays only, no capture
     del outs, o
-    with torch.cuda.stream(side):
-        for _ in range(6):
-            last = unet.forward_raw(*args, hook_ids=ids)[1]
-            side.synchronize()
-            chk = {k: v.clone() for k, v in last.items()}
-            del last
-    cap2, lau2 = C.c_long(), C.c_long()
-    unet.lib.gdf_plan_graph_stats(plan.handle, C.byref(cap2), C.byref(lau2))
-    assert lau2.value == 10 and cap2.value < 10, (cap2.value, lau2.value)
+    for _ in range(6):
+        last = unet.forward_raw(*args, hook_ids=ids)[1]
+        torch.cuda.synchronize()
+        chk = {k: v.clone() for k, v in last.items()}
+        del last
+    assert plan.graph_stats() == (2, 8), plan.graph_stats()
     for k in ids:
         assert torch.equal(chk[k], eager[k]), k
+    # new input VALUES flow through the staging buffers of the captured graph
+    args2 = [a.clone() for a in args]
+    args2[0] = torch.randn_like(args2[0])
+    _, other = unet.forward_raw(*args2, hook_ids=ids)
+    ref2 = oracle_run(arch, P, dict(I, sample=args2[0].float().cpu()), ids)
+    assert plan.graph_stats()[0] == 2
+    for k in ids:
+        assert not torch.equal(other[k], eager[k]) and rel_l2(other[k], ref2[k]) < TOL, k
+
+
+def test_feature_extractor_steady_state_replays_one_graph(monkeypatch):
+    """FeatureExtractor.extract in a loop (results consumed, then dropped): no capture after the start-up phase, host side is a
+    single hipGraphLaunch per forward, features identical call to call."""
+    monkeypatch.setenv("GDF_SYNTHETIC_WEIGHTS", "1")
+    import diffusion_feature
+    layer = {"up-level1-repeat1-vit-block0-cross-q": True, "up-level1-repeat2-res-out": True}
+    df = diffusion_feature.FeatureExtractor(layer=layer, version='1-5', img_size=256, device='cuda')
+    prompt = df.encode_prompt('a photo of a cat')
+    lat = torch.randn(2, 4, 32, 32, generator=torch.Generator().manual_seed(0)).half()
+    first = {k: v.clone() for k, v in df.extract(prompt, batch_size=2, image=lat, image_type='latents', t=100).items()}
+    feats = None
+    for _ in range(8):
+        feats = df.extract(prompt, batch_size=2, image=lat, image_type='latents', t=100)   # previous dict alive during the call
+    plan = next(iter(df.pipe.unet._plans.values()))
+    cap, lau = plan.graph_stats()
+    assert cap <= 2 and lau == 8, (cap, lau)
+    for k in first:
+        assert torch.equal(first[k], feats[k])
+
+
+@pytest.mark.parametrize("tag", ["xl", "15", "21"])
+def test_matches_reference_whole_unet_golden(tag):
+    """HIP path vs tests/golden/unet_tiny_*.npz = the reference's own UNet2DConditionModel.forward (gen_golden_unet.py):
+    relative L2 error over the 2048 sampled positions of every hook (the full tensors are covered by the oracle tests)."""
+    from test_oracle_golden import unet_golden
+    meta, I, gold, out = unet_golden(tag)
+    arch = meta["arch"]
+    P = R.synth_params(arch, seed=meta["wseed"])
+    u = native(arch, P)
+    noise, hooks = run_native(u, I, meta["order"])
+    assert list(hooks.keys()) == meta["order"]
+    worst = ("", 0.0)
+    for k, (idx, vals, norm, shape) in gold.items():
+        got = hooks[k].float().cpu().contiguous()
+        assert tuple(got.shape) == shape, k
+        e = float((got.flatten()[idx] - vals).norm() / (vals.norm() + 1e-30))
+        worst = max(worst, (k, e), key=lambda t: t[1])
+        assert e < 2.5e-3, (k, e)
+    assert rel_l2(noise, out) < TOL
+    print(f"[golden {tag}] worst sampled rel L2 {worst[1]:.2e} at {worst[0]}")
+
+
+def test_aggregated_attention_feature_matches_oracle():
+    """(f)3 end to end: FeatureExtractor(attention=[...]).extract -> feats['attn'] on the HIP path (maps written by
+    attn_map_kernel) against the oracle's aggregation (oracle/attn_agg_ref.py, pinned to the reference AttentionStore) of the
+    ORACLE's own attention maps for the same weights / latents / timestep / prompt embeds."""
+    import diffusion_feature
+    from components.models import SyntheticPipe
+    from components.native import NativeUNet
+    from oracle import attn_agg_ref as AR
+    arch = R.ARCHS["1-5"]
+    P = R.synth_params(arch, seed=0)
+    pipe = SyntheticPipe("1-5", "cuda:0", seed=0)
+    pipe.unet.load_state_dict({k: v.half() for k, v in P.items()})
+    sel = ["up_cross", "down_self"]
+    layer = {"up-level1-repeat0-vit-block0-cross-map": True, "up-level2-repeat2-vit-block0-out": True}
+    df = diffusion_feature.FeatureExtractor(layer=layer, version='1-5', img_size=256, device='cuda:0', attention=sel,
+                                            external_model=pipe)
+    seen = {}
+    raw = NativeUNet.forward_raw
+
+    def spy(self, sample, timestep, encoder_hidden_states, *a, **kw):
+        seen.update(sample=sample.float().cpu(), timestep=torch.as_tensor(timestep).float().cpu().reshape(-1)[:1],
+                    ctx=encoder_hidden_states.float().cpu())
+        return raw(self, sample, timestep, encoder_hidden_states, *a, **kw)
+    NativeUNet.forward_raw = spy
+    try:
+        prompt = df.encode_prompt('a photo of a cat')
+        lat = torch.randn(2, 4, 32, 32, generator=torch.Generator().manual_seed(0)).half()
+        feats = df.extract(prompt, batch_size=2, image=lat, image_type='latents', t=100)
+    finally:
+        NativeUNet.forward_raw = raw
+    assert list(feats.keys()) == list(layer.keys()) + ['attn']
+    st = R.Store(None)                                                # accept-all: every map, like the reference's AttentionStore sees
+    with torch.no_grad():
+        R.unet_forward(P, arch, seen["sample"], seen["timestep"], seen["ctx"], store=st, want_map=True)
+    maps = [(k, v) for k, v in st.feats.items() if k.endswith("-map")]
+    want = AR.aggregate(maps, sel, 256 // 32, 256 // 16, 256 // 8)
+    got = feats['attn']
+    assert got.shape == want.shape == (2, 77 + 77 + 256 + 64, 32, 32)        # up_cross @ 8x8, 16x16; down_self @ 16x16 (K = 256), 8x8 (K = 64)
+    e = rel_l2(got, want)
+    print(f"[attn aggregate] shape {tuple(got.shape)} rel L2 {e:.2e}")
+    assert e < 1e-3, e
+    for k in layer:
+        assert rel_l2(feats[k], st.feats[k]) < TOL, k

@@ -4,6 +4,7 @@ import ctypes
 import json
 import os
 import re
+import sys
 
 import pytest
 import torch
@@ -167,3 +168,81 @@ def test_flux_layer_ids_match_oracle_and_reference_golden():
     assert flux_layer_ids(meta["arch"]) == ast.literal_eval(str(zm["meta"]))["order"] == FR.hook_ids(meta["arch"], maps=True)
     ids = flux_layer_ids(FLUX_CONFIGS["flux"])
     assert len(ids) == 19 * 9 + 38 * 7 and ids[0] == "vit-block0-q" and ids[-1] == "vit-block56-out"
+
+
+def _run_output_stage(tmp_path, device):
+    """extract_feature.HostWriter on the fixture's feature tensors (as channels-last strided views, the layout the native
+    path hands out) -> {mode: {relative path: array}}"""
+    import ast
+    import types
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    import extract_feature as cli
+    z = np.load(os.path.join(GOLD, "cli_output_stage.npz"))
+    meta = ast.literal_eval(str(z["meta"]))
+    feats = {}
+    for k in meta["order"]:
+        t = torch.from_numpy(z["feat:" + k]).to(device)
+        feats[k] = t.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)          # (B,C,H,W) view of NHWC storage
+    got = {}
+    for mode, kw in meta["modes"].items():
+        d = tmp_path / mode
+        args = types.SimpleNamespace(output_dir=str(d), aggregate_output=kw["aggregate_output"], sample_name_first=kw["sample_name_first"])
+        names = meta["names"][kw["nested_input_dir"]] if kw["use_original_filename"] else [f"{kw['split']}{j}" for j in range(3)]
+        w = cli.HostWriter(args)
+        w.submit(feats, names)
+        w.flush()
+        got[mode] = {}
+        for root, _, files in os.walk(d):
+            for f in files:
+                got[mode][os.path.relpath(os.path.join(root, f), d)] = np.load(os.path.join(root, f))
+    want = {}
+    for k in z.files:
+        if k.startswith("file:"):
+            _, mode, rel = k.split(":", 2)
+            want.setdefault(mode, {})[rel] = z[k]
+    return got, want
+
+
+def check_output_stage(got, want):
+    import numpy as np
+    assert got.keys() == want.keys()
+    for mode in want:
+        assert sorted(got[mode]) == sorted(want[mode]), mode                   # same directory tree, same file names
+        for rel, arr in want[mode].items():
+            g = got[mode][rel]
+            assert g.dtype == arr.dtype and g.shape == arr.shape, (mode, rel)
+            assert np.array_equal(g.view(np.uint16), arr.view(np.uint16)), (mode, rel)   # byte-exact
+
+
+def test_output_stage_matches_reference_files(tmp_path):
+    """(f)2: `--aggregate_output` / per-layer / --sample_name_first files are byte-identical to what the reference's own
+    output stage (/root/reference/extract_feature.py:112-148, executed by tests/golden/gen_golden_cli.py) wrote for the same
+    feature tensors — incl. a non-integer nearest-resize ratio (6 -> 8)."""
+    got, want = _run_output_stage(tmp_path, "cpu")
+    check_output_stage(got, want)
+
+
+def _attn_golden():
+    import ast
+    import numpy as np
+    z = np.load(os.path.join(GOLD, "attn_aggregate.npz"))
+    meta = ast.literal_eval(str(z["meta"]))
+    maps = [(h, torch.from_numpy(z["map:" + h])) for h in meta["order"]]
+    cases = [(ast.literal_eval(str(z["sel:" + n])), torch.from_numpy(z["out:" + n])) for n in ("a", "b")]
+    return meta, maps, cases
+
+
+def test_aggregated_attention_matches_reference_golden():
+    """(f)3: oracle/attn_agg_ref.py AND the product's aggregate_attention / attention_map_ids-style selection against
+    tests/golden/attn_aggregate.npz = the reference's own AttentionStore (gen_golden_attn.py)."""
+    from components.feature_extractor import aggregate_attention
+    from oracle import attn_agg_ref as AR
+    meta, maps, cases = _attn_golden()
+    for sel, want in cases:
+        got = AR.aggregate(maps, sel, meta["min_size"], meta["max_size"], meta["out_size"])
+        assert got.shape == want.shape and torch.allclose(got, want, atol=1e-6), float((got - want).abs().max())
+        by_cat = {c: [m for h, m in maps if AR.category_of(h) == c and meta["min_size"] ** 2 <= m.shape[2] <= meta["max_size"] ** 2]
+                  for c in sel}
+        prod = aggregate_attention(by_cat, meta["out_size"])
+        assert prod.dtype == torch.float16 and torch.allclose(prod.float(), want, atol=1e-3)

@@ -227,3 +227,39 @@ def test_pixart_param_count():
     assert abs(n - 610.9e6) < 1.0e6, n          # PixArt-Sigma-XL-2: ~0.6 B parameters
     tf = PR.flops_per_image(PR.ARCH_PIXART_SIGMA, 4096, 300) / 1e12
     assert abs(tf - 6.63) < 0.4, tf
+
+
+def unet_golden(tag):
+    """tests/golden/unet_tiny_<tag>.npz (gen_golden_unet.py): the reference's own UNet2DConditionModel.forward +
+    prepare_feature_extractor on a shrunken architecture -> (meta, inputs, {id: (sample idx, values, norm, shape)}, out)"""
+    z = np.load(os.path.join(GOLD, f"unet_tiny_{tag}.npz"))
+    meta = ast.literal_eval(str(z["meta"]))
+    I = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("in:")}
+    hooks = {}
+    for n, k in enumerate(meta["order"]):
+        shape = tuple(int(s) for s in z["shape:" + k])
+        numel = int(np.prod(shape))
+        idx = torch.randint(0, numel, (min(meta["ns"], numel),), generator=torch.Generator().manual_seed(n))
+        hooks[k] = (idx, torch.from_numpy(z["hook:" + k]), float(z["norm:" + k]), shape)
+    return meta, I, hooks, torch.from_numpy(z["out"])
+
+
+@pytest.mark.parametrize("tag", ["xl", "15", "21"])
+def test_whole_unet_orchestration_matches_reference_forward(tag):
+    """Numerical pin of the orchestration: time / text_time embedding path, skip-stack pops, mid block,
+    conv_norm_out and the hook-id scheme of oracle/unet_ref.py against the reference's own unet_2d_condition.py:1040-1319
+    driving its own blocks (hybrid oracle, oracle/ref_unet.py)."""
+    meta, I, hooks, out = unet_golden(tag)
+    arch = meta["arch"]
+    P = R.synth_params(arch, seed=meta["wseed"])
+    st = R.Store(None, out_dtype=None)
+    with torch.no_grad():
+        y = R.unet_forward(P, arch, I["sample"], I["timestep"], I["ctx"], I.get("text_embeds"), I.get("time_ids"), store=st,
+                           want_map=False)
+    assert list(st.feats.keys()) == meta["order"]                  # ids and execution order as the reference stored them
+    assert torch.allclose(y, out, atol=2e-5, rtol=1e-5)
+    for k, (idx, vals, norm, shape) in hooks.items():
+        got = st.feats[k].float().contiguous()
+        assert tuple(got.shape) == shape, k
+        assert torch.allclose(got.flatten()[idx], vals, atol=3e-5, rtol=1e-5), (k, float((got.flatten()[idx] - vals).abs().max()))
+        assert abs(float(got.double().norm()) - norm) <= 1e-5 * norm + 1e-6, k
