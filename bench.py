@@ -215,13 +215,14 @@ def main():
                     help="xl = BASELINE headline (configs[2]); 1-5 = configs[1]; flux = configs[4] (single GPU, tools/bench_flux.py)")
     ap.add_argument("--img", type=int, default=0, help="image size (default 1024 for xl, 512 for 1-5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--flux-dtype", default="bfloat16", choices=("bfloat16", "float16"), help="--version flux only")
     ap.add_argument("--fp16-stream", action="store_true", help="disable the fp32 master of the residual stream")
     ap.add_argument("--early-exit", action="store_true", help="opt-in: stop after the last requested hook")
     ap.add_argument("--profile-ops", action="store_true", help="print a per-op time table (extra synchronising pass)")
     args = ap.parse_args()
 
     if args.version == "flux":                    # BASELINE configs[4]: same JSON schema, single GPU (tools/bench_flux.py)
-        sys.argv = [sys.argv[0], "--steps", str(args.steps), "--warmup", str(args.warmup)] + \
+        sys.argv = [sys.argv[0], "--steps", str(args.steps), "--warmup", str(args.warmup)] + (["--dtype", args.flux_dtype]) + \
                    (["--batch", str(args.batch)] if args.batch != 16 else []) + (["--no-cpu-baseline"] if args.no_cpu_baseline else [])
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import bench_flux
@@ -254,17 +255,14 @@ def main():
     lat = img // 8
     B = args.batch
 
-    # ---- weights: generated on rank 0 in HBM, broadcast once over RCCL in <=512 MiB fp16 buckets ----
+    # ---- weights: generated on rank 0 in HBM (already in the kernels' layout), the arena broadcast once over RCCL ----
     unet = NativeUNet(cfg, device=dev, stream_fp32=not args.fp16_stream, early_exit=args.early_exit)
     t0 = time.time()
-    if world == 1:
+    from components import dist as D
+    if rank == 0:
         unet.init_synthetic(seed=0)
-    else:
-        from components import dist as D
-        gen = torch.Generator(device=dev).manual_seed(0)
-        D.broadcast_state_dict(unet.param_shapes(), lambda n, shp: D.synthetic_param(n, shp, gen, dev),
-                               lambda sd: unet.load_state_dict(sd, strict=False), dev)
-        assert unet.ready()
+    D.broadcast_model_weights(unet)        # flat device arena, 512 MiB pieces, rank 0 -> all (no-op for one process)
+    assert unet.ready()
     torch.cuda.synchronize()
     t_weights = time.time() - t0
 
@@ -309,7 +307,7 @@ def main():
     torch.cuda.synchronize(); barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tt = torch.tensor([dt], device="cpu" if share_gpu else dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     ms_tot = C.c_double(); launches = C.c_long(); fl_tot = C.c_double()

@@ -10,6 +10,12 @@ extract_feature.py (/root/reference/extract_feature.py:18-43 flags, :113-148 out
 
 The reference's own script also runs unchanged against this package (it only needs `import diffusion_feature`);
 this version overlaps the device->host copies of batch i with the extraction of batch i+1 through pinned buffers.
+
+Data-parallel (one process per GPU, no collective in the loop):
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 extract_feature.py ...
+rank r extracts the contiguous slice shard_range(len(images), r, W) of the sorted image list and writes its own files
+(<split><GLOBAL index> names, so the output directory is identical to a single-process run); rank 0 alone reads / generates
+the denoiser weights and broadcasts the flat device arena once over RCCL (components/dist.py).
 """
 import argparse
 import glob
@@ -123,29 +129,53 @@ class _null:
         return False
 
 
+def init_data_parallel():
+    """torchrun environment -> (rank, world, device string).  Must run before anything touches the GPU."""
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1:
+        return 0, 1, 'cuda'
+    import torch.distributed as dist
+    share = os.environ.get("GDF_SHARE_GPU", "0") == "1"              # test hook: every rank on cuda:0, gloo instead of RCCL
+    local = 0 if share else int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if share:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    else:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"))
+    return rank, world, f"cuda:{local}"
+
+
 def main(argv=None):
     from PIL import Image
     args = parse_args(argv)
+    rank, world, device = init_data_parallel()
     os.makedirs(args.output_dir, exist_ok=True)
-    print(f'Run folder: {args.output_dir}')
+    if rank == 0:
+        print(f'Run folder: {args.output_dir}')
     if args.show_all_layers:
         args.layer = None
     df = diffusion_feature.FeatureExtractor(
-        args.layer, args.version, device='cuda', dtype=args.dtype, offline_lora=args.offline_lora,
+        args.layer, args.version, device=device, dtype=args.dtype, offline_lora=args.offline_lora,
         offline_lora_filename=args.offline_lora_filename, feature_resize=args.feature_resize, control=args.control,
         attention=args.attention, img_size=args.img_size)
 
     paths = sorted(glob.glob(args.input_dir, recursive=True))
+    lo, hi = 0, len(paths)
+    if world > 1:
+        from components.dist import shard_range
+        lo, hi = shard_range(len(paths), rank, world)
     with open(args.prompt_file, 'r') as f:
         prompt_text = f.read()
-    print('prompt:', prompt_text)
+    if rank == 0:
+        print('prompt:', prompt_text)
     # reference extract_feature.py:81-82: flux / hunyuan pipelines take the raw prompt text
     prompts = prompt_text if args.version in ('flux', 'hunyuan') else df.encode_prompt(prompt_text)
 
     writer = HostWriter(args)
     with torch.no_grad():
-        for i in range(0, len(paths), args.batch_size):
-            chunk = paths[i:i + args.batch_size]
+        for i in range(lo, hi, args.batch_size):
+            chunk = paths[i:min(i + args.batch_size, hi)]
             images = [Image.open(p) for p in chunk]
             feats = df.extract(prompts, len(images), images, t=args.t, denoising_from=args.denoising_from,
                                use_control=args.control is not None, use_ddim_inversion=args.use_ddim_inversion)
@@ -158,9 +188,15 @@ def main(argv=None):
             names = [sample_name(p, args.nested_input_dir) if args.use_original_filename else f'{args.split}{i + j}'
                      for j, p in enumerate(chunk)]
             writer.submit(feats, names)
-            print(f'{min(i + len(chunk), len(paths))}/{len(paths)}', end='\r')
+            if rank == 0:
+                print(f'{min(i + len(chunk), hi) - lo}/{hi - lo}', end='\r')
     writer.flush()
-    print()
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print()
 
 
 if __name__ == '__main__':

@@ -49,6 +49,36 @@ def broadcast_state_dict(shapes, make_tensor, consume, device, src=0, bucket_ele
         i = j
 
 
+def rank_world():
+    """(rank, world) of the initialised process group, (0, 1) without one."""
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def broadcast_model_weights(model, src=0, chunk_bytes=1 << 29):
+    """Broadcast the flat device weight arena of a native model (components.native `weight_blob`) from rank `src` in
+    512 MiB pieces (few, large collectives: ring broadcast over xGMI is per-link bound); receivers mark the model ready.
+    The arena is already in the kernels' layout, so no rank but `src` reads or re-lays-out a checkpoint."""
+    rank, world = rank_world()
+    if world == 1:
+        return model
+    blob = model.weight_blob()
+    via_host = dist.get_backend() == "gloo"            # CPU-side test backend (two ranks on one GPU): stage through host memory
+    for off in range(0, blob.numel(), chunk_bytes):
+        piece = blob[off:off + chunk_bytes]
+        if via_host:
+            h = piece.cpu() if rank == src else torch.empty(piece.shape, dtype=piece.dtype)
+            dist.broadcast(h, src=src)
+            if rank != src:
+                piece.copy_(h)
+        else:
+            dist.broadcast(piece, src=src)
+    if rank != src:
+        model.set_ready()
+    return model
+
+
 def synthetic_param(name, shape, gen, device):
     """Seeded synthetic weight (no checkpoints offline): W ~ N(0,1/fan_in), bias 0.05 N, gamma 1+0.1 N, beta 0.1 N."""
     is_norm = ".norm" in name or name.startswith("conv_norm_out")

@@ -28,6 +28,17 @@ _HF = {
 _LATER = ("pixart-alpha", "if", "hunyuan")       # pixart-alpha-1024 needs the resolution micro-conditioning
 
 
+def _fill(model, loader):
+    """Weights of a native model in a data-parallel launch (one process per GPU, extract_feature.py under torchrun):
+    rank 0 runs `loader(model)` (checkpoint re-layout or synthetic init), every other rank receives the flat device arena
+    over RCCL (components/dist.py broadcast_model_weights).  Single process: just the loader."""
+    from . import dist as D
+    rank, _world = D.rank_world()
+    if rank == 0:
+        loader(model)
+    return D.broadcast_model_weights(model)
+
+
 def _parse_dtype(dtype):
     if dtype == 'float32':
         return torch.float32
@@ -106,12 +117,12 @@ class SyntheticPipe:
         cfg = ARCH_CONFIGS[version]
         self.version = version
         self.device = device
-        self.unet = NativeUNet(cfg, device=device, stream_fp32=stream_fp32).init_synthetic(seed)
+        self.unet = _fill(NativeUNet(cfg, device=device, stream_fp32=stream_fp32), lambda m: m.init_synthetic(seed))
         empty = types.SimpleNamespace(parameters=lambda: iter(()), to=lambda *a, **k: None)
         self.vae = types.SimpleNamespace(parameters=lambda: iter(()), config=types.SimpleNamespace(
             scaling_factor=0.13025 if cfg["addition_embed_text_time"] else 0.18215))
         # true-architecture AutoencoderKL encoder (seeded random weights) in libgdf.so: the step before the hot path
-        self.native_vae = NativeVAEEncoder(VAE_CONFIGS["sd"], device=device).init_synthetic(seed + 1)
+        self.native_vae = _fill(NativeVAEEncoder(VAE_CONFIGS["sd"], device=device), lambda m: m.init_synthetic(seed + 1))
         self.text_encoder = empty
         if cfg["addition_embed_text_time"]:
             pooled = cfg["add_in_dim"] - 6 * cfg["addition_time_embed_dim"]
@@ -171,11 +182,11 @@ class SyntheticPixartPipe(SyntheticPipe):
         self.device = device
         self._pcfg = cfg
         self.n_txt = n_txt
-        self.transformer = NativePixArtTransformer(cfg, device=device).init_synthetic(seed)
+        self.transformer = _fill(NativePixArtTransformer(cfg, device=device), lambda m: m.init_synthetic(seed))
         self.unet = self.transformer               # reference models.py:91 `pipe.unet = pipe.transformer`
         empty = types.SimpleNamespace(parameters=lambda: iter(()), to=lambda *a, **k: None)
         self.vae = types.SimpleNamespace(parameters=lambda: iter(()), config=types.SimpleNamespace(scaling_factor=0.13025))
-        self.native_vae = NativeVAEEncoder(VAE_CONFIGS["sd"], device=device).init_synthetic(seed + 1)
+        self.native_vae = _fill(NativeVAEEncoder(VAE_CONFIGS["sd"], device=device), lambda m: m.init_synthetic(seed + 1))
         self.text_encoder = empty
         self.scheduler = _Scheduler(euler=False)
         self.config = types.SimpleNamespace(requires_aesthetics_score=False)
@@ -202,7 +213,7 @@ class SyntheticFluxPipe:
         self.device = device
         self._cfg = dict(cfg or FLUX_CONFIGS["flux"])
         self.n_txt = n_txt
-        self.transformer = NativeFluxTransformer(self._cfg, device=device).init_synthetic(seed)
+        self.transformer = _fill(NativeFluxTransformer(self._cfg, device=device), lambda m: m.init_synthetic(seed))
         self.unet = self.transformer               # reference models.py:169 `pipe.unet = pipe.transformer`
         empty = types.SimpleNamespace(parameters=lambda: iter(()), to=lambda *a, **k: None)
         self.vae = types.SimpleNamespace(parameters=lambda: iter(()), config=types.SimpleNamespace(scaling_factor=0.3611, shift_factor=0.1159))
@@ -266,7 +277,7 @@ def _native_flux_from_diffusers(pipe, device):
                joint_attention_dim=c.joint_attention_dim, pooled_projection_dim=c.pooled_projection_dim,
                guidance_embeds=int(bool(c.guidance_embeds)), axes_dims_rope=tuple(c.axes_dims_rope), mlp_ratio=4)
     net = NativeFluxTransformer(cfg, device=device)
-    net.load_state_dict(pipe.transformer.state_dict())
+    _fill(net, lambda m: m.load_state_dict(pipe.transformer.state_dict()))
     pipe.transformer = net
     pipe.unet = net
     return pipe
@@ -274,8 +285,9 @@ def _native_flux_from_diffusers(pipe, device):
 
 def _native_from_diffusers(pipe, device):
     """Swap pipe.unet (diffusers UNet2DConditionModel) for the native implementation with the same weights."""
-    unet = NativeUNet(config_from_diffusers(pipe.unet.config), device=device)
-    unet.load_state_dict(pipe.unet.state_dict())
+    ucfg = pipe.unet.config if pipe.unet is not None else pipe._gdf_unet_config      # ranks > 0 skip the UNet checkpoint
+    unet = NativeUNet(config_from_diffusers(ucfg), device=device)
+    _fill(unet, lambda m: m.load_state_dict(pipe.unet.state_dict()))
     pipe.unet = unet
     # the step before the hot path (SURVEY.md §8f rank 1): VAE encode + sample + noise-add in libgdf.so as well.
     # GDF_NATIVE_VAE=0 keeps diffusers' prepare_latents (e.g. the original SDXL VAE, whose activations need fp32).
@@ -284,7 +296,7 @@ def _native_from_diffusers(pipe, device):
         enc = NativeVAEEncoder(dict(in_channels=vc.in_channels, latent_channels=vc.latent_channels,
                                     block_out_channels=tuple(vc.block_out_channels), layers_per_block=vc.layers_per_block,
                                     use_quant_conv=int(getattr(vc, "use_quant_conv", True))), device=device)
-        enc.load_vae_state_dict(pipe.vae.state_dict())
+        _fill(enc, lambda m: m.load_vae_state_dict(pipe.vae.state_dict()))
         pipe.native_vae = enc
         pipe.prepare_latents = types.MethodType(native_prepare_latents, pipe)
     return pipe
@@ -318,7 +330,7 @@ def get_diffusion_model(version, dtype, offline_lora=None, offline_lora_filename
         repo = "PixArt-alpha/PixArt-Sigma-XL-2-1024-MS" if version == "pixart-sigma" else "PixArt-alpha/PixArt-Sigma-XL-2-512-MS"
         pipe = diffusers.PixArtSigmaPipeline.from_pretrained(repo, torch_dtype=dt, use_safetensors=True).to(device)
         net = NativePixArtTransformer(PIXART_CONFIGS[version], device=device)
-        net.load_state_dict({k: v for k, v in pipe.transformer.state_dict().items() if k != "pos_embed.pos_embed"})
+        _fill(net, lambda m: m.load_state_dict({k: v for k, v in pipe.transformer.state_dict().items() if k != "pos_embed.pos_embed"}))
         pipe.transformer = pipe.unet = net
         return pipe
     if version not in _HF:
@@ -332,7 +344,14 @@ def get_diffusion_model(version, dtype, offline_lora=None, offline_lora_filename
                            "checkpoint loading upstream of the native UNet come from diffusers (see INTEGRATION.md)") from e
     repo, cls = _HF[version]
     kw = dict(variant="fp16") if (version in ("xl", "pgv2") and dt == torch.float16) else {}      # reference models.py:51-53
+    from . import dist as D
+    rank, world = D.rank_world()
+    ucfg = None
+    if world > 1 and rank != 0:          # data-parallel launch: only rank 0 reads the 5 GB UNet checkpoint, the rest receive it (_fill)
+        ucfg = types.SimpleNamespace(**diffusers.UNet2DConditionModel.load_config(repo, subfolder="unet"))
+        kw["unet"] = None
     pipe = getattr(diffusers, cls).from_pretrained(repo, torch_dtype=dt, use_safetensors=True, **kw)
+    pipe._gdf_unet_config = ucfg
     if version != "1-5":
         pipe.scheduler = diffusers.EulerDiscreteScheduler.from_config(pipe.scheduler.config)
     if offline_lora:

@@ -13,7 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(os.path.dirname(_HERE), "libgdf.so")
 
-GDF_F16, GDF_F32 = 0, 1
+GDF_F16, GDF_F32, GDF_BF16 = 0, 1, 2
 MAX_LEVELS = 4
 
 
@@ -48,6 +48,8 @@ SIGNATURES = {
     "gdf_model_set_param": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int, C.c_void_p]),
     "gdf_model_ready": (C.c_int, [C.c_void_p]),
     "gdf_model_weight_bytes": (C.c_size_t, [C.c_void_p]),
+    "gdf_model_weights": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+    "gdf_model_set_ready": (C.c_int, [C.c_void_p]),
     "gdf_model_hook_count": (C.c_int, [C.c_void_p]),
     "gdf_model_hook_name": (C.c_char_p, [C.c_void_p, C.c_int]),
     "gdf_plan_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_char_p), C.c_int,
@@ -78,7 +80,7 @@ class FluxDesc(C.Structure):
     _fields_ = [("in_channels", C.c_int), ("num_layers", C.c_int), ("num_single_layers", C.c_int),
                 ("attention_head_dim", C.c_int), ("num_attention_heads", C.c_int), ("joint_attention_dim", C.c_int),
                 ("pooled_projection_dim", C.c_int), ("guidance_embeds", C.c_int), ("axes_dims_rope", C.c_int * 3),
-                ("mlp_ratio", C.c_int)]
+                ("mlp_ratio", C.c_int), ("compute_dtype", C.c_int)]
 
 
 class VaeDesc(C.Structure):
@@ -279,7 +281,7 @@ class _Plan:
         b.copy_(t, non_blocking=True)
         return b
 
-    def run(self, dev, inputs, out_shape, call, profile=False, eager=False):
+    def run(self, dev, inputs, out_shape, call, profile=False, eager=False, out_dtype=torch.float16):
         """Stage `inputs` [(name, tensor | None, dtype)], pick a free hook-buffer set and launch `call(staged, hook_ptrs,
         out_ptr, ws_ptr, stream_ptr)` on the plan's private stream, event-ordered after the caller's current stream; the
         caller's stream then waits for it, so results follow ordinary stream semantics.
@@ -316,7 +318,7 @@ class _Plan:
         feats = {}
         for off, (hid, shape, stride, _) in zip(hs.offs, self.hooks):
             feats[hid] = torch.as_strided(hs.buf, shape, stride, storage_offset=off)
-        out = hs.buf[hs.out_off:hs.out_off + n_out].view(out_shape)
+        out = hs.buf[hs.out_off:hs.out_off + n_out].view(out_dtype).view(out_shape)      # fp16 or bf16: same 16-bit container
         return out, feats, ret
 
 
@@ -375,11 +377,11 @@ class _NativeModel:
                 t = sd[name]
                 if tuple(t.shape) != shp:
                     raise ValueError(f"{name}: expected shape {shp}, got {tuple(t.shape)}")
-                if t.dtype not in (torch.float16, torch.float32):
+                if t.dtype not in (torch.float16, torch.float32, torch.bfloat16):
                     t = t.float()
                 t = t.to(self.device, non_blocking=True).contiguous()
-                _check(self.lib.gdf_model_set_param(self.handle, name.encode(), C.c_void_p(t.data_ptr()),
-                                                    GDF_F16 if t.dtype == torch.float16 else GDF_F32,
+                code = {torch.float16: GDF_F16, torch.float32: GDF_F32, torch.bfloat16: GDF_BF16}[t.dtype]
+                _check(self.lib.gdf_model_set_param(self.handle, name.encode(), C.c_void_p(t.data_ptr()), code,
                                                     C.c_void_p(stream.cuda_stream)), f"set_param({name})")
                 del t
             stream.synchronize()
@@ -413,6 +415,19 @@ class _NativeModel:
 
     def ready(self):
         return bool(self.lib.gdf_model_ready(self.handle))
+
+    def weight_blob(self):
+        """The device weight arena as a flat uint8 tensor (zero-copy view; include/gdf.h gdf_model_weights)."""
+        ptr, n = C.c_void_p(), C.c_size_t()
+        _check(self.lib.gdf_model_weights(self.handle, C.byref(ptr), C.byref(n)), "model_weights")
+        holder = types.SimpleNamespace(__cuda_array_interface__=dict(shape=(n.value,), typestr="|u1", data=(ptr.value, False),
+                                                                     version=2), _owner=self)
+        with torch.cuda.device(self.device):
+            return torch.as_tensor(holder, device=self.device)
+
+    def set_ready(self):
+        _check(self.lib.gdf_model_set_ready(self.handle), "model_set_ready")
+        return self
 
     def _launch(self, plan, fwd, prof_fn, what, profile):
         """-> call(staged, hook_ptrs, out_ptr, ws_ptr, stream_ptr) for _Plan.run; `args(staged)` orders the staged inputs"""
@@ -569,6 +584,7 @@ def flux_desc(cfg):
         setattr(d, k, int(cfg[k]))
     d.guidance_embeds = int(bool(cfg["guidance_embeds"]))
     d.mlp_ratio = int(cfg.get("mlp_ratio", 4))
+    d.compute_dtype = {"bfloat16": GDF_BF16, "float16": GDF_F16}[cfg.get("compute_dtype", "bfloat16")]
     for i in range(3):
         d.axes_dims_rope[i] = int(cfg["axes_dims_rope"][i])
     return d
@@ -586,13 +602,18 @@ class NativeFluxTransformer(_NativeModel):
     ids `vit-block{i}-{q,k,v,attn-out,norm-out,ffn-inner,out}` (components/feature_extractor.py:98-123).
     """
 
-    def __init__(self, cfg, device="cuda", early_exit=False):
+    def __init__(self, cfg, device="cuda", early_exit=False, compute_dtype=None):
+        """compute_dtype: "bfloat16" (default — what the reference loads Flux in, components/models.py:158-169) or "float16"
+        (3 more mantissa bits, fp16 range: activations beyond +-65504 saturate)."""
         if not torch.cuda.is_available():
             raise RuntimeError("NativeFluxTransformer needs an MI355X (HIP device); there is no CPU fallback")
         self.lib = load_library()
         self.cfg = dict(cfg)
+        if compute_dtype is not None:
+            self.cfg["compute_dtype"] = compute_dtype
+        self.cfg.setdefault("compute_dtype", "bfloat16")
         self.device = torch.device(device if str(device) != "cuda" else f"cuda:{torch.cuda.current_device()}")
-        self._desc = flux_desc(cfg)
+        self._desc = flux_desc(self.cfg)
         h = C.c_void_p()
         with torch.cuda.device(self.device):
             _check(self.lib.gdf_flux_model_create(C.byref(self._desc), C.byref(h)), "flux_model_create")
@@ -600,8 +621,8 @@ class NativeFluxTransformer(_NativeModel):
         self.early_exit = bool(early_exit)
         self.feature_store = None
         self._plans = {}
-        self.dtype = torch.float16
-        self.io_dtype = torch.float16              # element type of the activations handed to libgdf
+        self.io_dtype = torch.bfloat16 if self.cfg["compute_dtype"] == "bfloat16" else torch.float16   # inputs / `out` of libgdf
+        self.dtype = self.io_dtype
         self.config = types.SimpleNamespace(in_channels=cfg["in_channels"], guidance_embeds=bool(cfg["guidance_embeds"]),
                                             joint_attention_dim=cfg["joint_attention_dim"],
                                             pooled_projection_dim=cfg["pooled_projection_dim"])
@@ -656,7 +677,8 @@ class NativeFluxTransformer(_NativeModel):
         f16, f32 = self.io_dtype, torch.float32
         call = self._launch(plan, self.lib.gdf_flux_forward, self.lib.gdf_flux_plan_profile, "flux_forward", profile)
         out, feats, prof = plan.run(dev, [("x", x, f16), ("enc", enc, f16), ("pooled", pooled, f16), ("t", t, f32), ("gd", gd, f32),
-                                          ("img_ids", img_ids, f32), ("txt_ids", txt_ids, f32)], (B, S, cin), call, profile=profile)
+                                          ("img_ids", img_ids, f32), ("txt_ids", txt_ids, f32)], (B, S, cin), call, profile=profile,
+                                    out_dtype=f16)
         return (out, feats, prof) if profile else (out, feats)
 
     def __call__(self, hidden_states, encoder_hidden_states=None, pooled_projections=None, timestep=None, img_ids=None,

@@ -38,6 +38,17 @@ int gdf_model_set_param(gdf_model* m, const char* name, const void* dev_ptr, int
   return model_set_param(m->m, name, dev_ptr, dtype, (hipStream_t)stream);
 }
 int gdf_model_ready(const gdf_model* m) { return m && m->m->n_set == (int)m->m->params.size(); }
+int gdf_model_weights(const gdf_model* m, void** dev_ptr, size_t* bytes) {
+  if (!m || !dev_ptr || !bytes) { set_error("null argument"); return GDF_ERR_ARG; }
+  *dev_ptr = m->m->weights; *bytes = m->m->weight_bytes;
+  return GDF_OK;
+}
+int gdf_model_set_ready(gdf_model* m) {
+  if (!m) { set_error("null model"); return GDF_ERR_ARG; }
+  for (auto& p : m->m->params) p.set = true;
+  m->m->n_set = (int)m->m->params.size();
+  return GDF_OK;
+}
 size_t gdf_model_weight_bytes(const gdf_model* m) { return m ? m->m->weight_bytes : 0; }
 int gdf_model_hook_count(const gdf_model* m) { return m ? (int)m->m->hook_names.size() : 0; }
 const char* gdf_model_hook_name(const gdf_model* m, int i) {

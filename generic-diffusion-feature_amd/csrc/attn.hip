@@ -25,6 +25,30 @@ typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
 
 static constexpr int KT = 64;     // keys per tile
 
+// ---- element type of q / k / v / o: fp16, or bf16 for a bf16 MMDiT model (BF; the 16-byte fragments are only containers) ----
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+template <bool BF>
+__device__ __forceinline__ f32x16 mfma32(const f16x8 a, const f16x8 b, const f32x16 c) {
+  if constexpr (BF) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+template <bool BF>
+__device__ __forceinline__ f16x2_t cvt_pair(float e0, float e1) {       // v_cvt_pk_f16_f32 / v_cvt_pk_bf16_f32
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  if constexpr (BF) {
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(f16x2_t, __builtin_convertvector(f32x2{e0, e1}, bf16x2));
+  } else {
+    return __builtin_convertvector(f32x2{e0, e1}, f16x2_t);
+  }
+}
+template <bool BF>
+__device__ __forceinline__ _Float16 out16(float v) {
+  if constexpr (BF) return __builtin_bit_cast(_Float16, (__bf16)v);
+  else return (_Float16)v;
+}
+
 // combine a value with the one held by lane ^ 32 (the other half-wave owns the other keys of the same query):
 // v_permlane32_swap instead of an LDS round trip (ds_bpermute)
 __device__ __forceinline__ float half_max(float v) {
@@ -50,7 +74,7 @@ __device__ __forceinline__ size_t seg_row(int b, int j, int per_b, int seg_T, in
 // softmax phase | barrier | PV(t) + QK^T(t+1) phase | barrier — which is what lifts the GEMM main loops.  Here the two phases
 // are data dependent and unequal, and the lock step costs more than the free-running overlap of two independent workgroups
 // per CU gives: D = 128 928 -> 821 TFLOP/s, D = 64 726 -> 573 (32 rows per wave) / 366 (64 rows per wave: 76 VGPRs spilled).)
-template <int D, int QW, int NW = 4>
+template <int D, int QW, int NW = 4, bool BF = false>
 __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(const AttnParams p) {
   constexpr int NT = NW * 64;                    // threads per workgroup
   constexpr int DQK = (D + 15) / 16 * 16;        // contraction length of QK^T, padded
@@ -191,9 +215,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(const AttnParams p) {
         for (int w = 0; w < QW; ++w) {
           if (st == 0) {
             const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            s[w][kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[w][st], z, 0, 0, 0);
+            s[w][kb] = mfma32<BF>(kf, qf[w][st], z);
           } else {
-            s[w][kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[w][st], s[w][kb], 0, 0, 0);
+            s[w][kb] = mfma32<BF>(kf, qf[w][st], s[w][kb]);
           }
         }
       }
@@ -231,9 +255,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(const AttnParams p) {
           const float e0 = __builtin_amdgcn_exp2f(s[w][kb][r] * sl2 - m_new);
           const float e1 = __builtin_amdgcn_exp2f(s[w][kb][r + 1] * sl2 - m_new);
           psum += e0 + e1;
-          typedef float f32x2 __attribute__((ext_vector_type(2)));
-          typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-          const f16x2 h2 = __builtin_convertvector(f32x2{e0, e1}, f16x2);     // v_cvt_pk_f16_f32
+          const f16x2_t h2 = cvt_pair<BF>(e0, e1);
           pf[w][kb * 2 + (r >> 3)][r & 7] = h2[0];
           pf[w][kb * 2 + (r >> 3)][(r & 7) + 1] = h2[1];
         }
@@ -265,7 +287,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(const AttnParams p) {
         vf.q[0] = lo; vf.q[1] = hi;
 #pragma unroll
         for (int w = 0; w < QW; ++w)
-          o[w][db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf.h, pf[w][s4], o[w][db], 0, 0, 0);
+          o[w][db] = mfma32<BF>(vf.h, pf[w][s4], o[w][db]);
       }
     }
 
@@ -292,7 +314,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(const AttnParams p) {
           if (d0 < D) {
             f16x4 hv;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) hv[e] = (_Float16)(o[w][db][rq * 4 + e] * inv);
+            for (int e = 0; e < 4; ++e) hv[e] = out16<BF>(o[w][db][rq * 4 + e] * inv);
             *(f16x4*)(stg + (w * 32 + lq) * RSH + d0) = hv;
           }
         }
@@ -321,7 +343,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(const AttnParams p) {
           if (d0 < D) {
             f16x4 hv;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) hv[e] = (_Float16)(o[w][db][rq * 4 + e] * inv);
+            for (int e = 0; e < 4; ++e) hv[e] = out16<BF>(o[w][db][rq * 4 + e] * inv);
             *(f16x4*)(op + d0) = hv;
           }
         }
@@ -363,7 +385,7 @@ __device__ __forceinline__ void lds_barrier() {
 // compiled out the kernel takes 0.63 ms, a pure 128-byte-strip store of the same tensor 0.39 ms
 // (tools/micro/strip_store.hip, 5.1-5.5 TB/s): the remaining gap is issue latency of the two-pass softmax (PMC: VALU busy
 // 33 %, MFMA 16 % of SIMD time), not HBM.
-template <int D, bool FULL, int OCC, bool LW>
+template <int D, bool FULL, int OCC, bool LW, bool BF = false>
 __global__ __launch_bounds__(LW ? 320 : 256, OCC) void attn_map_kernel(const AttnParams p) {
   static_assert(!LW || FULL, "the loader-wave variant has no bounds predicates");
   constexpr int DQK = (D + 15) / 16 * 16;
@@ -468,9 +490,9 @@ __global__ __launch_bounds__(LW ? 320 : 256, OCC) void attn_map_kernel(const Att
         const f16x8 kf = *(const f16x8*)(cK + (kb * 32 + lq) * LDK + 16 * st + 8 * lh);
         if (st == 0) {
           const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-          s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[st], z, 0, 0, 0);
+          s[kb] = mfma32<BF>(kf, qf[st], z);
         } else {
-          s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[st], s[kb], 0, 0, 0);
+          s[kb] = mfma32<BF>(kf, qf[st], s[kb]);
         }
       }
     if (!FULL && (t + 1) * KT > Skv) {
@@ -633,18 +655,22 @@ __global__ __launch_bounds__(LW ? 320 : 256, OCC) void attn_map_kernel(const Att
     const _Float16* cV = sV[cb];
     f32x16 s[2];
     scores(sK[cb], tt, s);
-    f16x8 pf[4];
+    f16x8 pf[4];                                     // fp16 probabilities: what the map stores (and the P V operand unless BF)
+    f16x8 pb[BF ? 4 : 1];                            // BF: the same probabilities rounded to bf16 for the P V MFMA
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {
         const float e0 = __builtin_amdgcn_exp2f(s[kb][r] * sl2 - m_fin);      // 1 / l folded into the exponent
         const float e1 = __builtin_amdgcn_exp2f(s[kb][r + 1] * sl2 - m_fin);
-        typedef float f32x2 __attribute__((ext_vector_type(2)));
-        typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-        const f16x2 h2 = __builtin_convertvector(f32x2{e0, e1}, f16x2);
+        const f16x2_t h2 = cvt_pair<false>(e0, e1);
         pf[kb * 2 + (r >> 3)][r & 7] = h2[0];
         pf[kb * 2 + (r >> 3)][(r & 7) + 1] = h2[1];
+        if constexpr (BF) {
+          const f16x2_t b2 = cvt_pair<true>(e0, e1);
+          pb[kb * 2 + (r >> 3)][r & 7] = b2[0];
+          pb[kb * 2 + (r >> 3)][(r & 7) + 1] = b2[1];
+        }
       }
     // stage K/V of tile t+1 BEFORE this tile's probability stores are issued: the wait for the loads then sits behind the
     // stores of tile t-1 only (a whole iteration old), not behind the ones about to be issued
@@ -700,7 +726,8 @@ __global__ __launch_bounds__(LW ? 320 : 256, OCC) void attn_map_kernel(const Att
         const fp16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((LDS_AS fp16x4_t*)(cV + (r0 + 8) * LDR + c0));
         union { fp16x4_t q[2]; f16x8 h; } vf;
         vf.q[0] = lo; vf.q[1] = hi;
-        o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf.h, pf[s4], o[db], 0, 0, 0);
+        if constexpr (BF) o[db] = mfma32<true>(vf.h, pb[s4], o[db]);
+        else o[db] = mfma32<false>(vf.h, pf[s4], o[db]);
       }
     lds_barrier();
   }
@@ -714,14 +741,14 @@ __global__ __launch_bounds__(LW ? 320 : 256, OCC) void attn_map_kernel(const Att
         if (d0 < D) {
           f16x4 hv;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) hv[e] = (_Float16)o[db][rq * 4 + e];
+          for (int e = 0; e < 4; ++e) hv[e] = out16<BF>(o[db][rq * 4 + e]);
           *(f16x4*)(op + d0) = hv;
         }
       }
   }
 }
 
-template <int D>
+template <int D, bool BF = false>
 static hipError_t launch_d(const AttnParams& p, hipStream_t s) {
   const bool maps = p.map || p.map2;
   if (maps && p.seg_T && (p.seg_T & 7)) return hipErrorInvalidValue;    // an 8-key chunk must not straddle the text / image boundary
@@ -730,10 +757,10 @@ static hipError_t launch_d(const AttnParams& p, hipStream_t s) {
     constexpr bool can3 = D <= 48;   // K trimmed to DQK columns: 3 workgroups per CU fit the 160 KiB of LDS
     constexpr bool canlw = D <= 48;  // loader-wave variant (two K+V tiles of staging registers must fit 128 VGPRs)
     const dim3 grid(p.B * p.heads * nqb);
-    if (p.Sq % 128 == 0 && p.Sk % KT == 0 && !p.seg_T && !p.kv_len) {
+    if (!BF && p.Sq % 128 == 0 && p.Sk % KT == 0 && !p.seg_T && !p.kv_len) {
       if (canlw && p.Sk % (2 * KT) == 0) hipLaunchKernelGGL((attn_map_kernel<D, true, can3 ? 3 : 2, canlw>), grid, dim3(320), 0, s, p);
       else hipLaunchKernelGGL((attn_map_kernel<D, true, can3 ? 3 : 2, false>), grid, dim3(256), 0, s, p);
-    } else hipLaunchKernelGGL((attn_map_kernel<D, false, 2, false>), grid, dim3(256), 0, s, p);
+    } else hipLaunchKernelGGL((attn_map_kernel<D, false, 2, false, BF>), grid, dim3(256), 0, s, p);
   } else {
     // 64 query rows per wave (every K / V fragment feeds two MFMAs) when the sequence is long and the
     // accumulators fit (D <= 64); 32 rows per wave otherwise
@@ -743,17 +770,17 @@ static hipError_t launch_d(const AttnParams& p, hipStream_t s) {
     // workgroups: pick by rate x fill of the 512 workgroup slots
     const long nb2 = (long)p.B * p.heads * ((p.Sq + 255) / 256), nb1 = (long)p.B * p.heads * ((p.Sq + 127) / 128);
     auto fill = [](long n, long slots) { const long r = (n + slots - 1) / slots; return (double)n / (double)(r * slots); };
-    if (can2 && p.Sq >= 512 && 1.00 * fill(nb2, 512) >= 0.80 * fill(nb1, 512)) {
+    if (!BF && can2 && p.Sq >= 512 && 1.00 * fill(nb2, 512) >= 0.80 * fill(nb1, 512)) {
       const int nqb = (p.Sq + 255) / 256;
       hipLaunchKernelGGL((attn_kernel<D, can2 ? 2 : 1>), dim3(p.B * p.heads * nqb), dim3(256), 0, s, p);
     } else if (D == 128 && p.Sq >= 1024) {
       // 8 waves share every staged K / V tile (half the L2 -> LDS traffic per query row): 877 -> 917 TFLOP/s on the Flux joint
       // shape; at D = 72 the 768-chunk tile does not split evenly over 512 threads (690 -> 591), so only D = 128 takes it
       const int nqb = (p.Sq + 255) / 256;
-      hipLaunchKernelGGL((attn_kernel<D, 1, D == 128 ? 8 : 4>), dim3(p.B * p.heads * nqb), dim3(D == 128 ? 512 : 256), 0, s, p);
+      hipLaunchKernelGGL((attn_kernel<D, 1, D == 128 ? 8 : 4, BF>), dim3(p.B * p.heads * nqb), dim3(D == 128 ? 512 : 256), 0, s, p);
     } else {
       const int nqb = (p.Sq + 127) / 128;
-      hipLaunchKernelGGL((attn_kernel<D, 1>), dim3(p.B * p.heads * nqb), dim3(256), 0, s, p);
+      hipLaunchKernelGGL((attn_kernel<D, 1, 4, BF>), dim3(p.B * p.heads * nqb), dim3(256), 0, s, p);
     }
   }
   return hipGetLastError();
@@ -762,6 +789,7 @@ static hipError_t launch_d(const AttnParams& p, hipStream_t s) {
 hipError_t launch_attention(const AttnParams& p, hipStream_t s) {
   if ((p.ldq | p.ldk | p.ldv) & 7) return hipErrorInvalidValue;     // 16-byte aligned rows
   if (p.ldo & 3) return hipErrorInvalidValue;
+  if (p.bf16) return p.D == 128 ? launch_d<128, true>(p, s) : hipErrorInvalidValue;      // bf16: the MMDiT head dim only
   switch (p.D) {
     case 32: return launch_d<32>(p, s);
     case 40: return launch_d<40>(p, s);

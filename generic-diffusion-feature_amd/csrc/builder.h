@@ -95,6 +95,7 @@ struct Arena {   // plan-time first-fit allocator with coalescing free list
 
 // fp16 activation view (+ optional fp32 master of the same logical tensor, contiguous ld = C)
 struct Act {
+  float hscale = 1.0f;        // the fp16 image holds value * hscale (a power of two; 1 everywhere but in the VAE encoder)
   Ref h{}; int ld = 0;        // fp16 [rows][C] with leading dimension ld
   Ref f{}; bool has_f = false;
   int C = 0, H = 0, W = 0;
@@ -111,6 +112,10 @@ struct PlanBuilder {
   bool stop = false;
   int remaining = 0;
   const PlanOpts& opt;
+  // fp16 images of new activations are stored scaled by this power of two (range control, GemmParams::out16_scale): consumers
+  // undo it exactly (GEMM: acc_scale; GroupNorm is scale invariant once eps is scaled by hscale^2).  Residual adds use the
+  // fp32 master, which always holds the true values.
+  float act_scale = 1.0f;
 
   PlanBuilder(const Model& mm, Plan& pp, bool d, const PlanOpts& o) : m(mm), P(pp), dry(d), opt(o) {}
 
@@ -132,7 +137,7 @@ struct PlanBuilder {
   size_t rows(const Act& a) const { return (size_t)Bn * a.H * a.W; }
 
   Act new_act(int C, int H, int W, bool master) {
-    Act a; a.C = C; a.H = H; a.W = W; a.ld = C;
+    Act a; a.C = C; a.H = H; a.W = W; a.ld = C; a.hscale = act_scale;
     a.h_bytes = (size_t)Bn * H * W * C * 2;
     a.h_alloc = dry ? 0 : ar.alloc(a.h_bytes);
     a.h = ws(a.h_alloc);
@@ -193,8 +198,9 @@ struct PlanBuilder {
   void hook_copy(int slot, Ref src, int ld, size_t nrows, int C) {
     if (slot < 0) return;
     P.hooks[slot].copied = true;
+    const int bf = m.bf16, sat = (m.kind == 1);          // MMDiT hooks: bf16 or range-critical fp16 source -> saturating fp16
     op("hook_store", 0, [=](const Bind& b, hipStream_t s) {
-      return launch_copy2d((const half_t*)b.p(src), nullptr, ld, (half_t*)b.hook(slot), C, (int)nrows, C, s);
+      return launch_copy2d((const half_t*)b.p(src), nullptr, ld, (half_t*)b.hook(slot), C, (int)nrows, C, s, bf, sat);
     });
     hook_done();
   }
@@ -210,6 +216,8 @@ struct PlanBuilder {
     int aux_slot = -1; int ldaux = 0;
     int geglu = 0; int bn = 128;
     int dit = 0, act = 0, rv_mul = 0, rv_seg_rows = 0, rv_rps2 = 0;     // MMDiT epilogue (kernels.h)
+    int bf16 = 0;                                                         // bf16 operands / activations (set by gemm() from the model)
+    float acc_scale = 0.f, out16_scale = 0.f;                             // fp16 range control (kernels.h), 0 = 1
     int pad0 = 0;                                                         // conv3: 1 = pad right / bottom only
     int rv_tok = 0;                                                       // row vector indexed by token (row % rps)
     // fused RMSNorm(q), RMSNorm(k) + RoPE (GemmParams::qkn_*)
@@ -218,12 +226,14 @@ struct PlanBuilder {
   };
   void residual_from(Epi& e, const Act& x) {
     if (x.has_f) { e.res32 = x.f; e.has_r32 = true; e.ldres = x.C; }
-    else { e.res16 = x.h; e.has_r16 = true; e.ldres = x.ld; }
+    else { e.res16 = x.h; e.has_r16 = true; e.ldres = x.ld; }      // (a scaled fp16 image always comes with an fp32 master)
   }
+  // A operand = the fp16 image of activation x: undo its storage scale on the accumulators
+  static void reads_image(Epi& e, const Act& x) { if (x.hscale != 1.0f) e.acc_scale = 1.0f / x.hscale; }
   // need_shadow = false: the fp16 image of a stream tensor is not stored when its only consumers read the fp32
   // master (LayerNorm + the next residual add): saves one 2-byte/element write per residual GEMM
   void out_to(Epi& e, const Act& y, bool need_shadow = true) {
-    if (need_shadow || !y.has_f) { e.out16 = y.h; e.has_o16 = true; e.ldo16 = y.ld; }
+    if (need_shadow || !y.has_f) { e.out16 = y.h; e.has_o16 = true; e.ldo16 = y.ld; if (y.hscale != 1.0f) e.out16_scale = y.hscale; }
     if (y.has_f) { e.out32 = y.f; e.has_o32 = true; e.ldo32 = y.C; }
   }
   static void fill_epi(GemmParams& g, const Epi& e, const Bind& b) {
@@ -234,7 +244,7 @@ struct PlanBuilder {
     g.out16 = e.has_o16 ? (half_t*)b.p(e.out16) : nullptr; g.ldo16 = e.ldo16;
     g.out32 = e.has_o32 ? (float*)b.p(e.out32) : nullptr; g.ldo32 = e.ldo32;
     g.aux16 = e.aux_slot >= 0 ? (half_t*)b.hook(e.aux_slot) : nullptr; g.ldaux = e.ldaux;
-    g.geglu = e.geglu; g.bn = e.bn;
+    g.geglu = e.geglu; g.bn = e.bn; g.bf16 = e.bf16; g.acc_scale = e.acc_scale; g.out16_scale = e.out16_scale;
     g.dit = e.dit; g.act = e.act; g.rv_mul = e.rv_mul; g.rv_seg_rows = e.rv_seg_rows; g.rv_rps2 = e.rv_rps2; g.rv_tok = e.rv_tok;
     g.qkn_nq = e.qkn_nq;
     if (e.qkn_nq) {
@@ -247,8 +257,9 @@ struct PlanBuilder {
   // dense GEMM: A (fp16 [M][K], lda) x W[N][K]
   void gemm(const char* name, Ref A, int lda, size_t M, const LinW& w, int N, int K, size_t w_off_bytes, const Epi& e0) {
     Epi e = e0;
+    e.bf16 = (e.dit && m.bf16) ? 1 : 0;
     const Ref W = wt(w.w + w_off_bytes);
-    GemmParams gk{}; gk.M = (int)M; gk.N = N; gk.K = K; gk.mode = A_DENSE; gk.geglu = e.geglu; gk.bn = e.bn; gk.dit = e.dit;
+    GemmParams gk{}; gk.M = (int)M; gk.N = N; gk.K = K; gk.mode = A_DENSE; gk.geglu = e.geglu; gk.bn = e.bn; gk.dit = e.dit; gk.bf16 = e.bf16;
     gk.res32 = e.has_r32 ? (const float*)1 : nullptr;      // tile selection looks at the epilogue form (never dereferenced)
     op(name, 2.0 * (double)M * N * K, [=](const Bind& b, hipStream_t s) {
       GemmParams g{};
@@ -264,7 +275,8 @@ struct PlanBuilder {
 
   // ---- primitive emitters -----------------------------------------------------------------------
   // GroupNorm (+SiLU) of x -> contiguous fp16 tensor (workspace offset returned)
-  size_t groupnorm(const Act& x, const NormW& w, float eps, bool silu) {
+  size_t groupnorm(const Act& x, const NormW& w, float eps_true, bool silu) {
+    const float eps = eps_true * x.hscale * x.hscale;      // GN(s x, s^2 eps) == GN(x, eps): the scaled fp16 image normalises identically
     const size_t n = rows(x);
     const size_t y = tmp(n * x.C * 2);
     if (gn_fused_slab(Bn, x.H * x.W, x.C, 32)) {            // small feature map: statistics + apply in one launch
@@ -339,6 +351,7 @@ struct PlanBuilder {
     if (w.has_sc) {
       sc = tmp(sc_b);
       Epi e; e.bias = wt(w.sc.b); e.has_bias = true; e.out32 = ws(sc); e.has_o32 = true; e.ldo32 = w.cout;
+      reads_image(e, x);
       gemm("res_shortcut", x.h, x.ld, n, w.sc, w.cout, x.C, 0, e);
     }
     {

@@ -19,7 +19,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 template <int MAXC>
 __global__ __launch_bounds__(256) void layernorm_mod_kernel(const half_t* x16, const float* x32, int ld, int R, int C,
                                                             float eps, const float* scale, const float* shift, int ldm,
-                                                            int rps, int seg_rows, int rps2, half_t* y) {
+                                                            int rps, int seg_rows, int rps2, half_t* y, int bf) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= R) return;
@@ -70,8 +70,8 @@ __global__ __launch_bounds__(256) void layernorm_mod_kernel(const half_t* x16, c
       f16x8 o;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        o[e] = (_Float16)((v[i][e] - mean) * rstd * (1.0f + g0[e]) + b0[e]);
-        o[4 + e] = (_Float16)((v[i][4 + e] - mean) * rstd * (1.0f + g1[e]) + b1[e]);
+        o[e] = f32_to_e16((v[i][e] - mean) * rstd * (1.0f + g0[e]) + b0[e], bf);
+        o[4 + e] = f32_to_e16((v[i][4 + e] - mean) * rstd * (1.0f + g1[e]) + b1[e], bf);
       }
       *(f16x8*)(y + (size_t)row * C + c * 8) = o;
     }
@@ -79,12 +79,13 @@ __global__ __launch_bounds__(256) void layernorm_mod_kernel(const half_t* x16, c
 }
 
 hipError_t launch_layernorm_mod(const half_t* x16, const float* x32, int ld, int R, int C, float eps, const float* scale,
-                                const float* shift, int ldm, int rps, int seg_rows, int rps2, half_t* y, hipStream_t s) {
+                                const float* shift, int ldm, int rps, int seg_rows, int rps2, half_t* y, hipStream_t s,
+                                int bf16) {
   if (C % 8 || C > 64 * 8 * 8 || (ldm & 3) || rps <= 0) return hipErrorInvalidValue;
   if (R <= 0) return hipSuccess;
   const int CH = C / 8;
   dim3 grid((R + 3) / 4), blk(256);
-#define GDF_LNM(N) hipLaunchKernelGGL(layernorm_mod_kernel<N>, grid, blk, 0, s, x16, x32, ld, R, C, eps, scale, shift, ldm, rps, seg_rows, rps2, y)
+#define GDF_LNM(N) hipLaunchKernelGGL(layernorm_mod_kernel<N>, grid, blk, 0, s, x16, x32, ld, R, C, eps, scale, shift, ldm, rps, seg_rows, rps2, y, bf16)
   if (CH <= 64) GDF_LNM(1);
   else if (CH <= 128) GDF_LNM(2);
   else if (CH <= 256) GDF_LNM(4);
@@ -97,7 +98,7 @@ hipError_t launch_layernorm_mod(const half_t* x16, const float* x32, int ld, int
 // 16 lanes per (row, head): 8 halves (= 4 rotary pairs) per lane, D = 128.  q then k of the same (row, head).
 __global__ __launch_bounds__(256) void qk_norm_rope_kernel(half_t* x, int ld, long R, int heads, int q_col, int k_col,
                                                            const float* wq, const float* wk, float eps,
-                                                           const float* cos_t, const float* sin_t, int pos0, int rps) {
+                                                           const float* cos_t, const float* sin_t, int pos0, int rps, int bf) {
   constexpr int D = 128;
   const long g = (long)blockIdx.x * 16 + (threadIdx.x >> 4);     // (row, head) pair
   if (g >= R * heads) return;
@@ -118,7 +119,7 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(half_t* x, int ld, lo
     float v[8];
     float ss = 0.f;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { v[e] = (float)hv[e]; ss += v[e] * v[e]; }
+    for (int e = 0; e < 8; ++e) { v[e] = e16_to_f32(hv[e], bf); ss += v[e] * v[e]; }
 #pragma unroll
     for (int off = 8; off > 0; off >>= 1) ss += __shfl_xor(ss, off);   // the 16 lanes of this (row, head)
     const float r = rsqrtf(ss / (float)D + eps);
@@ -128,8 +129,8 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(half_t* x, int ld, lo
     f16x8 o;
 #pragma unroll
     for (int e = 0; e < 8; e += 2) {       // x * cos + stack([-x_imag, x_real]) * sin
-      o[e] = (_Float16)(v[e] * cs[e] - v[e + 1] * sn[e]);
-      o[e + 1] = (_Float16)(v[e + 1] * cs[e + 1] + v[e] * sn[e + 1]);
+      o[e] = f32_to_e16(v[e] * cs[e] - v[e + 1] * sn[e], bf);
+      o[e + 1] = f32_to_e16(v[e + 1] * cs[e + 1] + v[e] * sn[e + 1], bf);
     }
     *(f16x8*)px = o;
   }
@@ -137,12 +138,12 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(half_t* x, int ld, lo
 
 hipError_t launch_qk_norm_rope(half_t* x, int ld, int R, int heads, int D, int q_col, int k_col, const float* wq,
                                const float* wk, float eps, const float* cos_t, const float* sin_t, int pos0, int rps,
-                               hipStream_t s) {
+                               hipStream_t s, int bf16) {
   if (D != 128 || (ld & 7) || (q_col & 7) || (k_col & 7) || rps <= 0) return hipErrorInvalidValue;
   if (R <= 0) return hipSuccess;
   const long groups = (long)R * heads;
   hipLaunchKernelGGL(qk_norm_rope_kernel, dim3((unsigned)((groups + 15) / 16)), dim3(256), 0, s, x, ld, (long)R, heads, q_col,
-                     k_col, wq, wk, eps, cos_t, sin_t, pos0, rps);
+                     k_col, wq, wk, eps, cos_t, sin_t, pos0, rps, bf16);
   return hipGetLastError();
 }
 

@@ -96,10 +96,10 @@ struct FB : PlanBuilder {   // Flux op program
   // y[rows r0..r0+n) = LN(stream rows) * (1 + scale) + shift  -> fp16 [n][C] at `dst`
   void adaln(const char* name, size_t r0, size_t n, int shift_col, int scale_col, int rps, size_t seg_rows, int rps2, Ref dst) {
     const Ref x = stream_rows(r0), sc = modv(scale_col), sh = modv(shift_col);
-    const int C = f.C, ldm = f.mod_total;
+    const int C = f.C, ldm = f.mod_total, bf = m.bf16;
     op(name, 0, [=](const Bind& b, hipStream_t s) {
       return launch_layernorm_mod(nullptr, (const float*)b.p(x), C, (int)n, C, 1e-6f, (const float*)b.p(sc), (const float*)b.p(sh),
-                                  ldm, rps, (int)seg_rows, rps2, (half_t*)b.p(dst), s);
+                                  ldm, rps, (int)seg_rows, rps2, (half_t*)b.p(dst), s, bf);
     });
   }
   void hook_rows16(const std::string& id, Ref src, int ld, int C) {      // image-token hook from an fp16 matrix
@@ -109,8 +109,9 @@ struct FB : PlanBuilder {   // Flux op program
     const int slot = want(id, C, gh, gw);
     if (slot < 0) return;
     const size_t n = NS;
+    P.hooks[slot].copied = true;
     op("hook_store", 0, [=](const Bind& b, hipStream_t s) {
-      return launch_copy2d(nullptr, (const float*)b.p(src), ld, (half_t*)b.hook(slot), C, (int)n, C, s);
+      return launch_copy2d(nullptr, (const float*)b.p(src), ld, (half_t*)b.hook(slot), C, (int)n, C, s, 0, /*sat=*/1);
     });
     hook_done();
   }
@@ -126,24 +127,24 @@ struct FB : PlanBuilder {   // Flux op program
   }
   // RMSNorm(q), RMSNorm(k) + RoPE in place on rows [r0, r0+n) of the qkv buffer (ld 3C)
   void qk_norm_rope(size_t qkv, size_t r0, size_t n, size_t wq, size_t wk, int pos0, int rps) {
-    const int C = f.C, heads = C / f.D, D = f.D;
+    const int C = f.C, heads = C / f.D, D = f.D, bf = m.bf16;
     const Ref x = ws(qkv + r0 * (size_t)(3 * C) * 2), q = wt(wq), k = wt(wk), cs = ws(cosb), sn = ws(sinb);
     op("qk_norm_rope", 0, [=](const Bind& b, hipStream_t s) {
       return launch_qk_norm_rope((half_t*)b.p(x), 3 * C, (int)n, heads, D, 0, C, (const float*)b.p(q), (const float*)b.p(k), 1e-6f,
-                                 (const float*)b.p(cs), (const float*)b.p(sn), pos0, rps, s);
+                                 (const float*)b.p(cs), (const float*)b.p(sn), pos0, rps, s, bf);
     });
   }
   // cross_slot / self_slot: hook slots of `cross-map` (B, heads, S, T) / `self-map` (B, heads, S, S) or -1
   // (FluxAttnStoreProcessor, components/attention.py:493-502: image queries only, split by key)
   void joint_attention(size_t qkv, Ref o, int ldo, int cross_slot = -1, int self_slot = -1) {
-    const int C = f.C, D = f.D, heads = C / D, Bq = Bn, Sj = T + S, Tq = T;
+    const int C = f.C, D = f.D, heads = C / D, Bq = Bn, Sj = T + S, Tq = T, bf = m.bf16;
     const Ref q = ws(qkv), k = ws(qkv + (size_t)C * 2), v = ws(qkv + (size_t)2 * C * 2);
     op("joint_attn", 4.0 * (double)Bn * heads * Sj * (double)Sj * D, [=](const Bind& b, hipStream_t s) {
       AttnParams a{};
       a.q = (const half_t*)b.p(q); a.ldq = 3 * C; a.k = (const half_t*)b.p(k); a.ldk = 3 * C;
       a.v = (const half_t*)b.p(v); a.ldv = 3 * C; a.o = (half_t*)b.p(o); a.ldo = ldo;
       a.B = Bq; a.heads = heads; a.Sq = Sj; a.Sk = Sj; a.D = D; a.scale = 1.0f / sqrtf((float)D);
-      a.kv_bstride = Sj; a.seg_T = Tq;
+      a.kv_bstride = Sj; a.seg_T = Tq; a.bf16 = bf;
       a.map = self_slot >= 0 ? (half_t*)b.hook(self_slot) : nullptr;
       a.map2 = cross_slot >= 0 ? (half_t*)b.hook(cross_slot) : nullptr;
       return launch_attention(a, s);
@@ -197,28 +198,28 @@ struct FB : PlanBuilder {   // Flux op program
       const Ref gw1 = wt(f.g1.w), gb1 = wt(f.g1.b), gw2 = wt(f.g2.w), gb2 = wt(f.g2.b);
       const Ref pw1 = wt(f.p1.w), pb1 = wt(f.p1.b), pw2 = wt(f.p2.w), pb2 = wt(f.p2.b);
       const bool guid = d.guidance_embeds != 0;
-      const int pd = d.pooled_projection_dim;
+      const int pd = d.pooled_projection_dim, bf = m.bf16;
       op("time_text_embed", 0, [=](const Bind& b, hipStream_t s) {
         hipError_t e = launch_sinusoid((const float*)b.base[BUF_T], Bq, 1, 256, (float*)b.ws(tsin), 256, 0, 0, s, 1000.0f);
         if (e != hipSuccess) return e;
-        e = launch_small_linear((const float*)b.ws(tsin), 256, Bq, 256, (const half_t*)b.p(w1), (const float*)b.p(b1), C, 0, 0, (float*)b.ws(t1), C, s);
+        e = launch_small_linear((const float*)b.ws(tsin), 256, Bq, 256, (const half_t*)b.p(w1), (const float*)b.p(b1), C, 0, 0, (float*)b.ws(t1), C, s, bf);
         if (e != hipSuccess) return e;
-        e = launch_small_linear((const float*)b.ws(t1), C, Bq, C, (const half_t*)b.p(w2), (const float*)b.p(b2), C, 1, 0, (float*)b.ws(temb), C, s);
+        e = launch_small_linear((const float*)b.ws(t1), C, Bq, C, (const half_t*)b.p(w2), (const float*)b.p(b2), C, 1, 0, (float*)b.ws(temb), C, s, bf);
         if (e != hipSuccess) return e;
         if (guid) {
           if (!b.base[BUF_TID]) return hipErrorInvalidValue;
           e = launch_sinusoid((const float*)b.base[BUF_TID], Bq, 1, 256, (float*)b.ws(tsin), 256, 0, 0, s, 1000.0f);
           if (e != hipSuccess) return e;
-          e = launch_small_linear((const float*)b.ws(tsin), 256, Bq, 256, (const half_t*)b.p(gw1), (const float*)b.p(gb1), C, 0, 0, (float*)b.ws(t1), C, s);
+          e = launch_small_linear((const float*)b.ws(tsin), 256, Bq, 256, (const half_t*)b.p(gw1), (const float*)b.p(gb1), C, 0, 0, (float*)b.ws(t1), C, s, bf);
           if (e != hipSuccess) return e;
-          e = launch_small_linear((const float*)b.ws(t1), C, Bq, C, (const half_t*)b.p(gw2), (const float*)b.p(gb2), C, 1, 1, (float*)b.ws(temb), C, s);
+          e = launch_small_linear((const float*)b.ws(t1), C, Bq, C, (const half_t*)b.p(gw2), (const float*)b.p(gb2), C, 1, 1, (float*)b.ws(temb), C, s, bf);
           if (e != hipSuccess) return e;
         }
-        e = launch_widen((const half_t*)b.base[BUF_TXT], Bq, pd, (float*)b.ws(pv), pd, 0, s);
+        e = launch_widen((const half_t*)b.base[BUF_TXT], Bq, pd, (float*)b.ws(pv), pd, 0, s, bf);
         if (e != hipSuccess) return e;
-        e = launch_small_linear((const float*)b.ws(pv), pd, Bq, pd, (const half_t*)b.p(pw1), (const float*)b.p(pb1), C, 0, 0, (float*)b.ws(t1), C, s);
+        e = launch_small_linear((const float*)b.ws(pv), pd, Bq, pd, (const half_t*)b.p(pw1), (const float*)b.p(pb1), C, 0, 0, (float*)b.ws(t1), C, s, bf);
         if (e != hipSuccess) return e;
-        e = launch_small_linear((const float*)b.ws(t1), C, Bq, C, (const half_t*)b.p(pw2), (const float*)b.p(pb2), C, 1, 1, (float*)b.ws(temb), C, s);
+        e = launch_small_linear((const float*)b.ws(t1), C, Bq, C, (const half_t*)b.p(pw2), (const float*)b.p(pb2), C, 1, 1, (float*)b.ws(temb), C, s, bf);
         if (e != hipSuccess) return e;
         return launch_silu_vec((const float*)b.ws(temb), (float*)b.ws(stemb), (long)Bq * C, s);
       });
@@ -228,11 +229,11 @@ struct FB : PlanBuilder {   // Flux op program
     mod = tmp(mod_b);
     {
       const Ref mw = wt(f.mod_all.w), mb = wt(f.mod_all.b);
-      const int mt = f.mod_total;
+      const int mt = f.mod_total, bf = m.bf16;
       const size_t mo = mod;
       op("adaln_mod_all", 2.0 * (double)Bn * mt * C, [=](const Bind& b, hipStream_t s) {
         return launch_small_linear((const float*)b.ws(stemb), C, Bq, C, (const half_t*)b.p(mw), (const float*)b.p(mb), mt, 0, 0,
-                                   (float*)b.ws(mo), mt, s);
+                                   (float*)b.ws(mo), mt, s, bf);
       });
     }
     untmp(tsin, (size_t)Bn * 256 * 4); untmp(t1, vb); untmp(temb, vb); untmp(pv, pv_b);
@@ -366,8 +367,10 @@ Model* flux_model_create(const gdf_flux_desc& d) {
   if (d.in_channels % 64 || d.joint_attention_dim % 64 || d.pooled_projection_dim % 8) {
     set_error("in_channels / joint_attention_dim must be multiples of 64, pooled_projection_dim of 8"); return nullptr;
   }
+  if (d.compute_dtype != GDF_F16 && d.compute_dtype != GDF_BF16) { set_error("compute_dtype must be GDF_F16 or GDF_BF16"); return nullptr; }
   Model* m = new Model();
   m->kind = 1;
+  m->bf16 = d.compute_dtype == GDF_BF16;
   m->flux.d = d;
   m->flux.D = d.attention_head_dim;
   m->flux.C = d.num_attention_heads * d.attention_head_dim;

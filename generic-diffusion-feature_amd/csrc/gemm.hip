@@ -47,6 +47,28 @@ __device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rsrc, char* lds_wa
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (LDS_AS void*)lds_wave_base, 16, voff, 0, 0, 0);
 }
 
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+// BF: the 16-byte fragments hold bf16 (MMDiT path of a bf16 model); same MFMA rate, same register layout
+template <bool BF>
+__device__ __forceinline__ f32x4 mfma16(const f16x8 a, const f16x8 b, const f32x4 c) {
+  if constexpr (BF) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+// 16-bit store conversions of the epilogue.  UNet kernels (DIT = false): plain fp16 casts, unchanged code.  MMDiT kernels:
+// activations (out16) are bf16 or SATURATING fp16, hook copies (aux16) always saturating fp16 (the reference's hooks are fp16,
+// feature_extractor.py:59-60, and real FLUX.1-dev activations leave the fp16 range).
+template <bool DIT, bool BF>
+__device__ __forceinline__ _Float16 act16(float v) {
+  if constexpr (BF) return __builtin_bit_cast(_Float16, (__bf16)v);
+  else if constexpr (DIT) return f32_to_f16_sat(v);
+  else return (_Float16)v;
+}
+template <bool DIT>
+__device__ __forceinline__ _Float16 hook16(float v) {
+  if constexpr (DIT) return f32_to_f16_sat(v);
+  else return (_Float16)v;
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -81,8 +103,12 @@ __device__ __forceinline__ float gelu_tanh(float x) {
 // DIT = true adds the MMDiT epilogue forms (Flux): optional tanh-GELU on (acc + bias), the per-sample
 // row vector applied as a GATE (multiply) instead of an addend, and a two-region row -> sample map (text rows first,
 // image rows second).  It is a compile-time switch so that the UNet kernels keep their code and register budget.
-template <int MODE, int BM, int BN, int STAGES, bool GEGLU, bool DIT>
+// QKN: compile the fused RMSNorm(q) / RMSNorm(k) + RoPE epilogue (GemmParams::qkn_*; 256x256 MMDiT QKV projections only).  It is
+// its own instantiation because its live state (cos / sin rows, norm gains) on top of the gated-residual operands pushed the
+// one-size-fits-all MMDiT epilogue over 256 VGPRs (9 spilled, 40 B of scratch per lane in EVERY 256x256 MMDiT GEMM).
+template <int MODE, int BM, int BN, int STAGES, bool GEGLU, bool DIT, bool BF = false, bool QKN = false>
 __device__ __forceinline__ void gemm_body(const GemmParams& p) {
+  static_assert(!BF || DIT, "bf16 operands exist on the MMDiT path only");
   constexpr int NW = BM / 32;                    // waves per workgroup (4 or 8)
   // waves along N (the GEGLU form of the 256x320 tile uses 4x2 waves of 64x160: an EVEN number of 16-column fragments,
   // so that every h fragment has its gate fragment in the same lane and register index)
@@ -246,7 +272,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
 #pragma unroll
     for (int i = 0; i < FM; ++i)
 #pragma unroll
-      for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+      for (int j = 0; j < FN; ++j) acc[i][j] = mfma16<BF>(af[i], bf[j], acc[i][j]);
   };
   // compile-time off for the 256x320 variant: its 160 accumulator VGPRs leave no room for the second code path
   constexpr bool EARLY_OK = (NW == 8) && (FM * FN <= 16);
@@ -367,7 +393,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
         for (int i = 0; i < 2; ++i)
 #pragma unroll
           for (int j = 0; j < FNH; ++j)
-            acc[AH * 2 + i][BH * FNH + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a8[AH * 2 + i][kk], b8[j][kk], acc[AH * 2 + i][BH * FNH + j], 0, 0, 0);
+            acc[AH * 2 + i][BH * FNH + j] = mfma16<BF>(a8[AH * 2 + i][kk], b8[j][kk], acc[AH * 2 + i][BH * FNH + j]);
     };
     auto bar = [&]() {
       __builtin_amdgcn_sched_barrier(0);
@@ -567,6 +593,13 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
   __syncthreads();   // all waves finished reading the last tile: LDS is free for epilogue staging
 
   // ---- epilogue: per-wave staging of 32-row slabs through LDS ----
+  // epilogue operands; the QKN instantiation (QKV projection: bias -> RMSNorm + RoPE -> 16-bit store) has none of the
+  // residual / row-vector / aux forms, and compiling them out is what keeps it inside the register budget
+  const float* const e_res32 = QKN ? nullptr : p.res32;
+  const float* const e_rowvec = QKN ? nullptr : p.rowvec;
+  const _Float16* const e_res16 = QKN ? nullptr : p.res16;
+  _Float16* const e_aux16 = QKN ? nullptr : p.aux16;
+  float* const e_out32 = QKN ? nullptr : p.out32;
   // Every epilogue operand (bias, temb row vector, residual) is fetched BEFORE the staging pass that needs
   // it, so the pass itself is LDS + stores only (a dependent global load per iteration made the first
   // version of this epilogue latency bound: ~17k cycles per tile).
@@ -594,6 +627,8 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
   const int nv = (col < Nout) ? ((Nout - col >= 8) ? 8 : (Nout - col)) : 0;
   const bool full = nv == 8;
 
+  const float a_sc = p.acc_scale != 0.f ? p.acc_scale : 1.0f;     // range control of the fp16 images (kernels.h)
+  const float o_sc = p.out16_scale != 0.f ? p.out16_scale : 1.0f;
   float bv[8];                                         // bias of this lane's 8 output columns (plain epilogue)
   float bh[FNV], bgt[FNV];                             // GEGLU: bias of this lane's h / gate accumulator column per fragment pair
 #pragma unroll
@@ -619,7 +654,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
   // Uniform epilogue flags are tested OUTSIDE the per-iteration loops (one scalar branch per flag and pass; the
   // first version branched inside every unrolled iteration: ~800 basic blocks, no overlap between iterations).
   constexpr bool RAGGED = (BN == 16);                    // only the narrow-N variant handles N % 8 != 0 (host-checked)
-  const bool rv_in_opnd = p.rowvec && !p.res32;
+  const bool rv_in_opnd = e_rowvec && !e_res32;
   auto sample_of = [&](int row) -> int {                 // row of the per-sample vector table that applies to `row`
     if (DIT && p.rv_seg_rows > 0 && row >= p.rv_seg_rows) return (row - p.rv_seg_rows) / p.rv_rps2;
     if (DIT && p.rv_tok) return row % p.rows_per_sample;
@@ -641,24 +676,24 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
       opnd[it][0] = opnd[it][1] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     if (!RAGGED) {
-      if (p.res32) {
+      if (e_res32) {
 #pragma unroll
         for (int it = 0; it < NIT; ++it)
           if (okr[it]) {
-            const f32x4* rp = (const f32x4*)(p.res32 + (size_t)rowi[it] * p.ldres + col);
+            const f32x4* rp = (const f32x4*)(e_res32 + (size_t)rowi[it] * p.ldres + col);
             opnd[it][0] = rp[0]; opnd[it][1] = rp[1];
           }
-      } else if (p.rowvec) {
+      } else if (e_rowvec) {
 #pragma unroll
         for (int it = 0; it < NIT; ++it)
           if (okr[it]) {
-            const f32x4* rv = (const f32x4*)(p.rowvec + (size_t)sample_of(rowi[it]) * p.ldrv + col);
+            const f32x4* rv = (const f32x4*)(e_rowvec + (size_t)sample_of(rowi[it]) * p.ldrv + col);
             opnd[it][0] = rv[0]; opnd[it][1] = rv[1];
           }
-      } else if (p.res16) {
+      } else if (e_res16) {
 #pragma unroll
         for (int it = 0; it < NIT; ++it)
-          if (okr[it]) opnd[it][0] = *(const f32x4*)(p.res16 + (size_t)rowi[it] * p.ldres + col);
+          if (okr[it]) opnd[it][0] = *(const f32x4*)(e_res16 + (size_t)rowi[it] * p.ldres + col);
       }
     }
 #pragma unroll
@@ -669,7 +704,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
         for (int r = 0; r < 4; ++r) {
           float x;
           if (GEGLU) x = (acc[ps * FPP + i2][2 * j][r] + bh[j]) * gelu_erf(acc[ps * FPP + i2][2 * j + 1][r] + bgt[j]);
-          else x = acc[ps * FPP + i2][j][r];
+          else x = acc[ps * FPP + i2][j][r] * a_sc;
           st[(i2 * 16 + fk * 4 + r) * SLD + j * 16 + frow] = x;
         }
     // same-wave LDS RAW across lanes: DS ops of one wave execute in order
@@ -689,7 +724,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[it][e] = gelu_tanh(v[it][e]);
     }
-    if constexpr (DIT && WTN == 128) {
+    if constexpr (DIT && WTN == 128 && QKN) {
       // RMSNorm per head + rotary embedding on the q / k columns: a wave tile is exactly one 128-column head, whose row lives in
       // the 16 lanes of one staged row (8 consecutive columns = 4 rotary pairs per lane)
       if (p.qkn_nq > 0 && ocol0 < 2 * p.qkn_nq) {
@@ -723,15 +758,15 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
         }
       }
     }
-    const bool aux_early = DIT && p.rv_mul && p.aux16;     // MMDiT `attn-out` hook: the projection BEFORE the gate
+    const bool aux_early = DIT && p.rv_mul && e_aux16;     // MMDiT `attn-out` hook: the projection BEFORE the gate
     if (!RAGGED && aux_early) {
 #pragma unroll
       for (int it = 0; it < NIT; ++it)
         if (okr[it]) {
           f16x8 hv;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) hv[e] = (_Float16)v[it][e];
-          *(f16x8*)(p.aux16 + (size_t)rowi[it] * p.ldaux + col) = hv;
+          for (int e = 0; e < 8; ++e) hv[e] = hook16<DIT>(v[it][e]);
+          *(f16x8*)(e_aux16 + (size_t)rowi[it] * p.ldaux + col) = hv;
         }
     }
     if (!RAGGED) {
@@ -747,11 +782,11 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v[it][e] += opnd[it][0][e]; v[it][4 + e] += opnd[it][1][e]; }
         }
-      } else if (p.rowvec) {                             // row vector AND fp32 residual (MMDiT gate + residual): late load
+      } else if (e_rowvec) {                             // row vector AND fp32 residual (MMDiT gate + residual): late load
 #pragma unroll
         for (int it = 0; it < NIT; ++it)
           if (okr[it]) {
-            const f32x4* rv = (const f32x4*)(p.rowvec + (size_t)sample_of(rowi[it]) * p.ldrv + col);
+            const f32x4* rv = (const f32x4*)(e_rowvec + (size_t)sample_of(rowi[it]) * p.ldrv + col);
             if (DIT && p.rv_mul) {
 #pragma unroll
               for (int e = 0; e < 4; ++e) { v[it][e] *= rv[0][e]; v[it][4 + e] *= rv[1][e]; }
@@ -761,26 +796,26 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
             }
           }
       }
-      if (p.aux16 && !aux_early) {
+      if (e_aux16 && !aux_early) {
 #pragma unroll
         for (int it = 0; it < NIT; ++it)
           if (okr[it]) {
             f16x8 hv;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) hv[e] = (_Float16)v[it][e];
-            *(f16x8*)(p.aux16 + (size_t)rowi[it] * p.ldaux + col) = hv;
+            for (int e = 0; e < 8; ++e) hv[e] = hook16<DIT>(v[it][e]);
+            *(f16x8*)(e_aux16 + (size_t)rowi[it] * p.ldaux + col) = hv;
           }
       }
-      if (p.res32) {
+      if (e_res32) {
 #pragma unroll
         for (int it = 0; it < NIT; ++it)
 #pragma unroll
           for (int e = 0; e < 4; ++e) { v[it][e] += opnd[it][0][e]; v[it][4 + e] += opnd[it][1][e]; }
-      } else if (p.res16) {
+      } else if (e_res16) {
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
           f16x8 rh = __builtin_bit_cast(f16x8, opnd[it][0]);
-          if (p.rowvec && okr[it]) rh = *(const f16x8*)(p.res16 + (size_t)rowi[it] * p.ldres + col);   // (not produced by the plan)
+          if (e_rowvec && okr[it]) rh = *(const f16x8*)(e_res16 + (size_t)rowi[it] * p.ldres + col);   // (not produced by the plan)
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[it][e] += (float)rh[e];
         }
@@ -791,15 +826,15 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
           if (okr[it]) {
             f16x8 hv;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) hv[e] = (_Float16)v[it][e];
+            for (int e = 0; e < 8; ++e) hv[e] = act16<DIT, BF>(v[it][e] * o_sc);
             *(f16x8*)(out16 + (size_t)rowi[it] * p.ldo16 + col) = hv;
           }
       }
-      if (p.out32) {
+      if (e_out32) {
 #pragma unroll
         for (int it = 0; it < NIT; ++it)
           if (okr[it]) {
-            f32x4* op = (f32x4*)(p.out32 + (size_t)rowi[it] * p.ldo32 + col);
+            f32x4* op = (f32x4*)(e_out32 + (size_t)rowi[it] * p.ldo32 + col);
             op[0] = f32x4{v[it][0], v[it][1], v[it][2], v[it][3]};
             op[1] = f32x4{v[it][4], v[it][5], v[it][6], v[it][7]};
           }
@@ -811,12 +846,12 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
           const int row = rowi[it];
           for (int e = 0; e < nv; ++e) {
             float x = v[it][e];
-            if (p.rowvec) x += p.rowvec[(size_t)(row / p.rows_per_sample) * p.ldrv + col + e];
-            if (p.aux16) p.aux16[(size_t)row * p.ldaux + col + e] = (_Float16)x;
-            if (p.res32) x += p.res32[(size_t)row * p.ldres + col + e];
-            else if (p.res16) x += (float)p.res16[(size_t)row * p.ldres + col + e];
+            if (e_rowvec) x += e_rowvec[(size_t)(row / p.rows_per_sample) * p.ldrv + col + e];
+            if (e_aux16) e_aux16[(size_t)row * p.ldaux + col + e] = (_Float16)x;
+            if (e_res32) x += e_res32[(size_t)row * p.ldres + col + e];
+            else if (e_res16) x += (float)e_res16[(size_t)row * p.ldres + col + e];
             if (out16) out16[(size_t)row * p.ldo16 + col + e] = (_Float16)x;
-            if (p.out32) p.out32[(size_t)row * p.ldo32 + col + e] = x;
+            if (e_out32) e_out32[(size_t)row * p.ldo32 + col + e] = x;
           }
         }
     }
@@ -829,20 +864,20 @@ template <int MODE, int BM, int BN, int STAGES, bool GEGLU>
 __global__ __launch_bounds__(BM * 2, 2) void gemm_kernel(const GemmParams p) {
   gemm_body<MODE, BM, BN, STAGES, GEGLU, false>(p);
 }
-// dense GEMM with the MMDiT epilogue (tanh-GELU / per-sample gate / two-region sample map)
-template <int BM, int BN, int STAGES>
+// dense GEMM with the MMDiT epilogue (tanh-GELU / per-sample gate / two-region sample map); BF: bf16 operands and activations
+template <int BM, int BN, int STAGES, bool BF, bool QKN>
 __global__ __launch_bounds__(BM * 2, 2) void gemm_dit_kernel(const GemmParams p) {
-  gemm_body<A_DENSE, BM, BN, STAGES, false, true>(p);
+  gemm_body<A_DENSE, BM, BN, STAGES, false, true, BF, QKN>(p);
 }
 
-template <int MODE, int BM, int BN, int STAGES, bool GEGLU, bool DIT = false>
+template <int MODE, int BM, int BN, int STAGES, bool GEGLU, bool DIT = false, bool BF = false, bool QKN = false>
 static hipError_t launch_t(const GemmParams& p, hipStream_t s) {
   const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
   const int smem = (STAGES >= 8 ? 2 : STAGES) * (BM * 128 + BN * 128);
   static std::atomic<uint64_t> attr_mask{0};             // per template instantiation, one bit per device
   {
     const void* fn;
-    if constexpr (DIT) fn = (const void*)gemm_dit_kernel<BM, BN, STAGES>;
+    if constexpr (DIT) fn = (const void*)gemm_dit_kernel<BM, BN, STAGES, BF, QKN>;
     else fn = (const void*)gemm_kernel<MODE, BM, BN, STAGES, GEGLU>;
     const hipError_t e = ensure_dyn_smem(attr_mask, fn, smem);
     if (e != hipSuccess) return e;
@@ -860,7 +895,7 @@ static hipError_t launch_t(const GemmParams& p, hipStream_t s) {
     }
   }
   const dim3 grid(tiles_m * tiles_n, p.batch > 1 ? p.batch : 1);
-  if constexpr (DIT) hipLaunchKernelGGL((gemm_dit_kernel<BM, BN, STAGES>), grid, dim3(BM * 2), smem, s, q);
+  if constexpr (DIT) hipLaunchKernelGGL((gemm_dit_kernel<BM, BN, STAGES, BF, QKN>), grid, dim3(BM * 2), smem, s, q);
   else hipLaunchKernelGGL((gemm_kernel<MODE, BM, BN, STAGES, GEGLU>), grid, dim3(BM * 2), smem, s, q);
   return hipGetLastError();
 }
@@ -938,10 +973,10 @@ const char* gemm_kernel_name(const GemmParams& p) {
   const int v = pick_variant(p);
   int bm = 128, bn = 128, st = 2;
   if (v == 16) bn = 16; else if (v == 160) bn = 160; else if (v == 256) { bm = 256; st = 3; } else if (v == 320) { bm = 256; bn = 320; }
-  else if (v == 832) { bm = 256; bn = 320; st = 8; } else if (v == 825) { bm = 256; bn = 256; st = 8; } else if (v == 932) { bm = 256; bn = 320; st = 9; } else if (v == 826) { bm = 256; bn = 256; st = 8; }
+  else if (v == 825) { bm = 256; bn = 256; st = 8; } else if (v == 932) { bm = 256; bn = 320; st = 9; } else if (v == 826) { bm = 256; bn = 256; st = 8; }
   if (p.mode == A_CONV_SMALLC && v != 160) { bm = 128; bn = 128; st = 2; }
   char tmp[64];
-  if (p.dit) snprintf(tmp, sizeof tmp, "gemm_dit_kernel<%d, %d, %d>", v == 128 ? 128 : 256, (v == 1256 || v == 8256) ? 256 : 128, v == 8256 ? 8 : v == 2128 ? 3 : 2);
+  if (p.dit) snprintf(tmp, sizeof tmp, "gemm_dit_kernel<%d, %d, %d, %s, %s>", v == 128 ? 128 : 256, (v == 1256 || v == 8256) ? 256 : 128, v == 8256 ? 8 : v == 2128 ? 3 : 2, p.bf16 ? "true" : "false", p.qkn_nq ? "true" : "false");
   else snprintf(tmp, sizeof tmp, "gemm_kernel<%d, %d, %d, %d, %s>", p.mode, bm, bn, st, p.geglu ? "true" : "false");
   // interned: the returned pointer stays valid for the life of the library (plan build time only, mutex-protected)
   static std::mutex mu;
@@ -958,18 +993,25 @@ hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {
   if (p.mode == A_CONV3 && (p.Cin % BK) != 0) return hipErrorInvalidValue;
   const int v = pick_variant(p);
   if (v != 16 && ((p.geglu ? p.N / 2 : p.N) % 8) != 0) return hipErrorInvalidValue;   // ragged N only in the BN = 16 variant
+  if (p.bf16 && !p.dit) return hipErrorInvalidValue;                                      // bf16 exists on the MMDiT path only
   if (p.dit) {
     if (p.mode != A_DENSE || p.geglu || p.batch > 1) return hipErrorInvalidValue;
     if (p.qkn_nq && ((v != 8256 && v != 1256) || (p.qkn_nq % 128) != 0)) return hipErrorInvalidValue;   // one head per 128-column wave tile
-    if (v == 8256) return launch_t<A_DENSE, 256, 256, 8, false, true>(p, s);
-    if (v == 1256) return launch_t<A_DENSE, 256, 256, 2, false, true>(p, s);
+    if (p.qkn_nq && (p.res32 || p.res16 || p.rowvec || p.aux16 || p.out32)) return hipErrorInvalidValue;  // the QKN instantiation: bias -> norm + RoPE -> out16 only
+    if (p.bf16) {
+      if (v == 8256) return p.qkn_nq ? launch_t<A_DENSE, 256, 256, 8, false, true, true, true>(p, s) : launch_t<A_DENSE, 256, 256, 8, false, true, true>(p, s);
+      if (v == 1256) return p.qkn_nq ? launch_t<A_DENSE, 256, 256, 2, false, true, true, true>(p, s) : launch_t<A_DENSE, 256, 256, 2, false, true, true>(p, s);
+      if (v == 2128) return launch_t<A_DENSE, 256, 128, 3, false, true, true>(p, s);
+      return launch_t<A_DENSE, 128, 128, 2, false, true, true>(p, s);
+    }
+    if (v == 8256) return p.qkn_nq ? launch_t<A_DENSE, 256, 256, 8, false, true, false, true>(p, s) : launch_t<A_DENSE, 256, 256, 8, false, true>(p, s);
+    if (v == 1256) return p.qkn_nq ? launch_t<A_DENSE, 256, 256, 2, false, true, false, true>(p, s) : launch_t<A_DENSE, 256, 256, 2, false, true>(p, s);
     if (v == 2128) return launch_t<A_DENSE, 256, 128, 3, false, true>(p, s);
     return launch_t<A_DENSE, 128, 128, 2, false, true>(p, s);
   }
   if (p.geglu) {
     // weight rows / bias interleaved [16 h | 16 gate] (launch_relayout_rows geglu = 16)
     if (p.mode != A_DENSE || (p.N % 32) != 0) return hipErrorInvalidValue;
-    if (v == 832) return launch_t<A_DENSE, 256, 320, 8, true>(p, s);
     if (v == 825) return launch_t<A_DENSE, 256, 256, 8, true>(p, s);
     if (v == 320) return launch_t<A_DENSE, 256, 320, 2, true>(p, s);
     return v == 256 ? launch_t<A_DENSE, 256, 128, 3, true>(p, s) : launch_t<A_DENSE, 128, 128, 2, true>(p, s);
@@ -982,7 +1024,6 @@ hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {
   switch (p.mode) {
     case A_DENSE:
       if (v == 160) return launch_t<A_DENSE, 128, 160, 2, false>(p, s);
-      if (v == 832) return launch_t<A_DENSE, 256, 320, 8, false>(p, s);
       if (v == 932) return launch_t<A_DENSE, 256, 320, 9, false>(p, s);
       if (v == 320) return launch_t<A_DENSE, 256, 320, 2, false>(p, s);
       if (v == 256) return launch_t<A_DENSE, 256, 128, 3, false>(p, s);

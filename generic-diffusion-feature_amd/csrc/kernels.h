@@ -24,6 +24,22 @@ inline hipError_t ensure_dyn_smem(std::atomic<uint64_t>& mask, const void* fn, i
   return hipSuccess;
 }
 
+// ---- 16-bit element type of the MMDiT (Flux) path --------------------------------------------------------------------
+// The reference runs Flux in torch.bfloat16 (components/models.py:158-169): real FLUX.1-dev activations leave the fp16 range.
+// A model created with compute_dtype = GDF_BF16 keeps weights, activations and MFMA operands in bf16 (`half_t` is then only
+// the 16-bit container); hooks stay fp16 like the reference's (feature_extractor.py:59-60), written with SATURATING casts.
+#if defined(__HIPCC__)
+__device__ __forceinline__ float e16_to_f32(half_t h, int bf) {
+  return bf ? __uint_as_float((uint32_t)__builtin_bit_cast(unsigned short, h) << 16) : (float)h;
+}
+__device__ __forceinline__ half_t f32_to_e16(float v, int bf) {          // round to nearest even in both formats
+  return bf ? __builtin_bit_cast(half_t, (__bf16)v) : (half_t)v;
+}
+__device__ __forceinline__ half_t f32_to_f16_sat(float v) {              // fp16 with saturation instead of +-inf (NaN stays NaN)
+  return (half_t)__builtin_amdgcn_fmed3f(v, -65504.0f, 65504.0f);
+}
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // MFMA GEMM / implicit-GEMM convolution:  D[M,N] = A[M,K] * Wt[N,K]^T  (+ fused epilogue)
 // ------------------------------------------------------------------------------------------------
@@ -90,6 +106,11 @@ struct GemmParams {
   const float* rope_cos; const float* rope_sin;      // [position][128]
   int qkn_pos0, qkn_rps;                             // position of row r: qkn_pos0 + r % qkn_rps           (r <  qkn_seg_rows or no segment)
   int qkn_seg_rows, qkn_pos1, qkn_rps2;              //                    qkn_pos1 + (r - seg_rows) % rps2  (r >= qkn_seg_rows > 0)
+  int bf16;              // dit only: A, Wt and out16 are bf16 (mfma_f32_16x16x32_bf16); aux16 (a hook) stays fp16, saturating
+  // fp16 RANGE control (VAE encoder: the stock SDXL VAE's residual stream leaves the fp16 range, the reference upcasts it to
+  // fp32).  v = acc * acc_scale + bias ...; out16 = fp16(v * out16_scale).  A tensor whose fp16 image is stored with
+  // out16_scale = 2^-k is read back by its consumer GEMM with acc_scale = 2^k (exact: powers of two).  0 means 1.
+  float acc_scale, out16_scale;
 };
 hipError_t launch_gemm(const GemmParams& p, hipStream_t s);
 const char* gemm_kernel_name(const GemmParams& p);
@@ -111,6 +132,7 @@ struct AttnParams {
   half_t* map2;          // seg_T > 0 only: `cross-map` (B, heads, Sq - seg_T, seg_T) (image queries x text keys)
   const int* kv_len;     // optional [B]: keys [kv_len[b], Sk) of sample b are masked out (prefix text mask)
   int seg_T;             // > 0: MMDiT joint sequence, region-major rows [B x seg_T text][B x (Sq - seg_T) image] (Sq == Sk)
+  int bf16;              // D = 128 only: q, k, v, o are bf16 (mfma_f32_32x32x16_bf16, P rounded to bf16); maps stay fp16
 };
 hipError_t launch_attention(const AttnParams& p, hipStream_t s);
 
@@ -137,12 +159,13 @@ hipError_t launch_layernorm(const half_t* x16, const float* x32, int ld, int R, 
 // the MMDiT blocks): y = LN(x, eps) * (1 + scale[s][c]) + shift[s][c]; s = row / rps for row < seg_rows (or
 // seg_rows == 0), else (row - seg_rows) / rps2.  x fp32 (or fp16) [R][ld], y fp16 [R][C], scale/shift fp32 rows of ldm.
 hipError_t launch_layernorm_mod(const half_t* x16, const float* x32, int ld, int R, int C, float eps, const float* scale,
-                                const float* shift, int ldm, int rps, int seg_rows, int rps2, half_t* y, hipStream_t s);
+                                const float* shift, int ldm, int rps, int seg_rows, int rps2, half_t* y, hipStream_t s,
+                                int bf16 = 0);
 // RMSNorm(q), RMSNorm(k) per head + rotary embedding, in place on rows [R][ld] fp16: q heads at columns
 // q_col + h*D, k heads at k_col + h*D (D = 128); position of row r = pos0 + r % rps; cos/sin fp32 [pos][D].
 hipError_t launch_qk_norm_rope(half_t* x, int ld, int R, int heads, int D, int q_col, int k_col, const float* wq,
                                const float* wk, float eps, const float* cos_t, const float* sin_t, int pos0, int rps,
-                               hipStream_t s);
+                               hipStream_t s, int bf16 = 0);
 // FluxPosEmbed: ids fp32 [S][n_axes] -> cos/sin fp32 [S][sum(axes_dim)] (float64 angles, repeat-interleaved pairs)
 hipError_t launch_rope_table(const float* ids, int S, int n_axes, const int* axes_dim, double theta, float* cos_t,
                              float* sin_t, int row0, hipStream_t s);
@@ -168,8 +191,9 @@ hipError_t launch_relayout_rows_padk(const void* src, int src_f32, half_t* dst, 
 // out[i] = silu(x[i])
 hipError_t launch_silu_vec(const float* x, float* out, long n, hipStream_t s);
 // strided 2-D copy with cast to fp16: dst[r][c] = src[r][c]   (hook stores)
+// src_bf16: s16 holds bf16; sat: clamp to the fp16 range instead of producing +-inf (hook stores of the bf16 / MMDiT path)
 hipError_t launch_copy2d(const half_t* s16, const float* s32, int lds_, half_t* dst, int ldd, int R, int C,
-                         hipStream_t s);
+                         hipStream_t s, int src_bf16 = 0, int sat = 0);
 // latents NCHW fp16 (B,Cin,H,W) -> NHWC padded to 8 channels (conv_in operand) and optional NHWC hook copy
 hipError_t launch_pack_latents(const half_t* x, int B, int Cin, int H, int W, half_t* nhwc8, half_t* hook_nhwc,
                                hipStream_t s);
@@ -178,20 +202,21 @@ hipError_t launch_pack_latents(const half_t* x, int B, int Cin, int H, int W, ha
 hipError_t launch_sinusoid(const float* t, int B, int n_per_row, int dim, float* out, int ldo, int col_off,
                            int round_f16, hipStream_t s, float tscale = 1.0f);
 // widen fp16 vector rows into fp32: out[b][col_off + j] = x[b][j]
-hipError_t launch_widen(const half_t* x, int B, int n, float* out, int ldo, int col_off, hipStream_t s);
+hipError_t launch_widen(const half_t* x, int B, int n, float* out, int ldo, int col_off, hipStream_t s, int src_bf16 = 0);
 // small-M linear in fp32 vectors: out[m][n] = (accum? out : 0) + bias[n] + sum_k act(x[m][k]) * W[n][k]
 hipError_t launch_small_linear(const float* x, int ldx, int M, int K, const half_t* Wt, const float* bias, int N,
-                               int silu_in, int accumulate, float* out, int ldo, hipStream_t s);
+                               int silu_in, int accumulate, float* out, int ldo, hipStream_t s, int w_bf16 = 0);
 
 // ------------------------------------------------------------------------------------------------
 // weight re-layout (model load time)
 // ------------------------------------------------------------------------------------------------
-// generic: dst[o][t][i] = src[o][i][t]  (OIHW -> OHWI with T = kh*kw); src f16 or f32; i padded to ipad, t to tpad
+// `src_f32` is the source dtype code of gdf_model_set_param: 0 fp16, 1 fp32, 2 bf16
+// generic: dst[o][t][i] = src[o][i][t]  (OIHW -> OHWI with T = kh*kw); i padded to ipad, t to tpad
 hipError_t launch_relayout_conv(const void* src, int src_f32, half_t* dst, int O, int I, int T, int ipad, int tpad,
                                 hipStream_t s);
 // rows: dst[rowmap(r)][k] = src[r][k] for r in [0,R); rowmap: 0 identity+row_off, 1 GEGLU interleave (half = R/2)
 hipError_t launch_relayout_rows(const void* src, int src_f32, half_t* dst, int R, int K, int row_off, int geglu /*0 or interleave group (16)*/,
-                                hipStream_t s);
+                                hipStream_t s, int dst_bf16 = 0);
 // vectors to fp32 with the same row mapping
 hipError_t launch_relayout_vec(const void* src, int src_f32, float* dst, int R, int row_off, int geglu, hipStream_t s);
 

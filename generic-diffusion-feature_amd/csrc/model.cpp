@@ -204,7 +204,8 @@ int model_set_param(Model* m, const char* name, const void* src, int dtype, hipS
   auto it = m->index.find(name);
   if (it == m->index.end()) { set_error(std::string("unknown parameter: ") + name); return GDF_ERR_ARG; }
   ParamRec& p = m->params[it->second];
-  const int f32 = dtype == GDF_F32;
+  if (dtype != GDF_F16 && dtype != GDF_F32 && dtype != GDF_BF16) { set_error("dtype must be GDF_F16, GDF_F32 or GDF_BF16"); return GDF_ERR_ARG; }
+  const int f32 = dtype;                       // source dtype code of the relayout kernels: 0 fp16, 1 fp32, 2 bf16
   char* base = (char*)m->weights;
   hipError_t e = hipSuccess;
   switch (p.kind) {
@@ -213,7 +214,7 @@ int model_set_param(Model* m, const char* name, const void* src, int dtype, hipS
     case PK_VEC_GEGLU: e = launch_relayout_vec(src, f32, (float*)(base + p.dst), p.a0, 0, geglu_group(p.a0), s); break;
     case PK_CONV3: e = launch_relayout_conv(src, f32, (half_t*)(base + p.dst), p.a0, p.a1, 9, p.a1, 9, s); break;
     case PK_CONV_IN: e = launch_relayout_conv(src, f32, (half_t*)(base + p.dst), p.a0, p.a1, 9, 8, 16, s); break;
-    case PK_ROWS: e = launch_relayout_rows(src, f32, (half_t*)(base + p.dst), p.a0, p.a1, p.a2, 0, s); break;
+    case PK_ROWS: e = launch_relayout_rows(src, f32, (half_t*)(base + p.dst), p.a0, p.a1, p.a2, 0, s, m->bf16); break;
     case PK_ROWS_PADK: e = launch_relayout_rows_padk(src, f32, (half_t*)(base + p.dst), p.a0, p.a1, p.a2, s); break;
     case PK_ROWS_GEGLU: e = launch_relayout_rows(src, f32, (half_t*)(base + p.dst), p.a0, p.a1, 0, geglu_group(p.a0), s); break;
     default: set_error("bad param kind"); return GDF_ERR_STATE;

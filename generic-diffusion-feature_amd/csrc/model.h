@@ -83,6 +83,7 @@ struct VaeW {
 };
 
 struct Model {
+  int bf16 = 0;                                // 16-bit element type of weights / activations: 0 fp16, 1 bf16 (Flux only)
   int kind = 0;                                // 0: UNet2DConditionModel, 1: FluxTransformer2DModel, 2: AutoencoderKL encoder
   FluxW flux;
   VaeW vae;

@@ -312,8 +312,11 @@ hipError_t launch_layernorm(const half_t* x16, const float* x32, int ld, int R, 
 }
 
 // strided copy + cast (coalesced 16-B stores): the hook write when the producer cannot store directly
+// CVT = false: fp16 / fp32 source, plain casts (every UNet hook).  CVT = true (MMDiT path): the 16-bit source may be bf16
+// (`bf`) and the fp16 result saturates at +-65504 instead of overflowing to inf (`sat`).
+template <bool CVT>
 __global__ __launch_bounds__(256) void copy2d_kernel(const half_t* s16, const float* s32, int lds_, half_t* dst, int ldd,
-                                                     long R, int C) {
+                                                     long R, int C, int bf, int sat) {
   if ((C & 7) == 0 && (lds_ & 7) == 0 && (ldd & 7) == 0) {
     const int CH = C / 8;
     const long total = R * CH;
@@ -321,10 +324,16 @@ __global__ __launch_bounds__(256) void copy2d_kernel(const half_t* s16, const fl
       const long r = i / CH;
       const int c = (int)(i - r * CH) * 8;
       float v[8];
-      load8(s16, s32, (size_t)r * lds_ + c, v);
+      if (CVT && bf && !s32) {
+        const f16x8 raw = *(const f16x8*)(s16 + (size_t)r * lds_ + c);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = e16_to_f32(raw[e], 1);
+      } else {
+        load8(s16, s32, (size_t)r * lds_ + c, v);
+      }
       f16x8 o;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = (_Float16)v[e];
+      for (int e = 0; e < 8; ++e) o[e] = (CVT && sat) ? f32_to_f16_sat(v[e]) : (_Float16)v[e];
       *(f16x8*)(dst + (size_t)r * ldd + c) = o;
     }
   } else {
@@ -332,19 +341,22 @@ __global__ __launch_bounds__(256) void copy2d_kernel(const half_t* s16, const fl
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
       const long r = i / C;
       const int c = (int)(i - r * C);
-      const float v = s32 ? s32[(size_t)r * lds_ + c] : (float)s16[(size_t)r * lds_ + c];
-      dst[(size_t)r * ldd + c] = (_Float16)v;
+      const float v = s32 ? s32[(size_t)r * lds_ + c] : e16_to_f32(s16[(size_t)r * lds_ + c], CVT && bf);
+      dst[(size_t)r * ldd + c] = (CVT && sat) ? f32_to_f16_sat(v) : (_Float16)v;
     }
   }
 }
 
 hipError_t launch_copy2d(const half_t* s16, const float* s32, int lds_, half_t* dst, int ldd, int R, int C,
-                         hipStream_t s) {
+                         hipStream_t s, int src_bf16, int sat) {
   const long work = (long)R * ((C + 7) / 8);
   long blocks = (work + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(copy2d_kernel, dim3((unsigned)blocks), dim3(256), 0, s, s16, s32, lds_, dst, ldd, (long)R, C);
+  if (src_bf16 || sat)
+    hipLaunchKernelGGL(copy2d_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, s16, s32, lds_, dst, ldd, (long)R, C, src_bf16, sat);
+  else
+    hipLaunchKernelGGL(copy2d_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, s16, s32, lds_, dst, ldd, (long)R, C, 0, 0);
   return hipGetLastError();
 }
 
@@ -397,23 +409,23 @@ hipError_t launch_sinusoid(const float* t, int B, int n_per_row, int dim, float*
   return hipGetLastError();
 }
 
-__global__ void widen_kernel(const half_t* x, int n, float* out, int ldo, int col_off, int total) {
+__global__ void widen_kernel(const half_t* x, int n, float* out, int ldo, int col_off, int total, int bf) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   const int b = i / n, j = i - b * n;
-  out[(size_t)b * ldo + col_off + j] = (float)x[i];
+  out[(size_t)b * ldo + col_off + j] = e16_to_f32(x[i], bf);
 }
 
-hipError_t launch_widen(const half_t* x, int B, int n, float* out, int ldo, int col_off, hipStream_t s) {
+hipError_t launch_widen(const half_t* x, int B, int n, float* out, int ldo, int col_off, hipStream_t s, int src_bf16) {
   const int total = B * n;
-  hipLaunchKernelGGL(widen_kernel, dim3((total + 255) / 256), dim3(256), 0, s, x, n, out, ldo, col_off, total);
+  hipLaunchKernelGGL(widen_kernel, dim3((total + 255) / 256), dim3(256), 0, s, x, n, out, ldo, col_off, total, src_bf16);
   return hipGetLastError();
 }
 
 // small-M linear on fp32 vectors with fp16 weights: one wave per output column, 8 rows at a time
 __global__ __launch_bounds__(256) void small_linear_kernel(const float* x, int ldx, int M, int K, const half_t* Wt,
                                                            const float* bias, int N, int silu_in, int accumulate,
-                                                           float* out, int ldo) {
+                                                           float* out, int ldo, int wbf) {
   const int lane = threadIdx.x & 63;
   const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (n >= N) return;
@@ -432,7 +444,7 @@ __global__ __launch_bounds__(256) void small_linear_kernel(const float* x, int l
           for (int e = 0; e < 8; ++e) {
             float xv = xp[e];
             if (silu_in) xv = xv / (1.0f + expf(-xv));
-            acc[i] += xv * (float)wv[e];
+            acc[i] += xv * e16_to_f32(wv[e], wbf);
           }
         }
       }
@@ -461,7 +473,7 @@ __global__ __launch_bounds__(256) void small_linear_kernel(const float* x, int l
 // every wave owns 4 output columns per step (4 independent 16-byte weight streams in flight per lane).
 __global__ __launch_bounds__(256) void small_linear_wide_kernel(const float* x, int ldx, int M, int K, const half_t* Wt,
                                                                 const float* bias, int N, int silu_in, int accumulate,
-                                                                float* out, int ldo, int cols_per_block) {
+                                                                float* out, int ldo, int cols_per_block, int wbf) {
   extern __shared__ float xs[];                       // [8][K]
   for (int i = threadIdx.x; i < 8 * K; i += 256) {
     const int m = i / K, k = i - m * K;
@@ -485,13 +497,18 @@ __global__ __launch_bounds__(256) void small_linear_wide_kernel(const float* x, 
         const int n = min(n0 + c, N - 1);
         wv[c] = *(const f16x8*)(Wt + (size_t)n * K + k);
       }
+      float wf[4][8];                                   // weights widened once per step (fp16 or bf16 storage)
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) wf[c][e] = e16_to_f32(wv[c][e], wbf);
 #pragma unroll
       for (int m = 0; m < 8; ++m) {
         const f32x4 a = *(const f32x4*)(xs + m * K + k), b = *(const f32x4*)(xs + m * K + k + 4);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) acc[c][m] += a[e] * (float)wv[c][e] + b[e] * (float)wv[c][4 + e];
+          for (int e = 0; e < 4; ++e) acc[c][m] += a[e] * wf[c][e] + b[e] * wf[c][4 + e];
         }
       }
     }
@@ -521,7 +538,7 @@ __global__ __launch_bounds__(256) void small_linear_wide_kernel(const float* x, 
 }
 
 hipError_t launch_small_linear(const float* x, int ldx, int M, int K, const half_t* Wt, const float* bias, int N,
-                               int silu_in, int accumulate, float* out, int ldo, hipStream_t s) {
+                               int silu_in, int accumulate, float* out, int ldo, hipStream_t s, int w_bf16) {
   if (K % 8) return hipErrorInvalidValue;
   // The LDS-staged kernel (activation applied once per workgroup, 4 weight streams per lane) also serves the mid-size stacked
   // linears (all time_emb_proj of a UNet in one matrix, N ~ 18 k: the column-per-wave kernel re-evaluated SiLU per column,
@@ -537,19 +554,19 @@ hipError_t launch_small_linear(const float* x, int ldx, int M, int K, const half
     while (cpb > 16 && (N + cpb - 1) / cpb < 512) cpb >>= 1;
     for (int m0 = 0; m0 < M; m0 += 8)
       hipLaunchKernelGGL(small_linear_wide_kernel, dim3((N + cpb - 1) / cpb), dim3(256), (size_t)K * 32, s, x + (size_t)m0 * ldx, ldx,
-                         (M - m0 < 8 ? M - m0 : 8), K, Wt, bias, N, silu_in, accumulate, out + (size_t)m0 * ldo, ldo, cpb);
+                         (M - m0 < 8 ? M - m0 : 8), K, Wt, bias, N, silu_in, accumulate, out + (size_t)m0 * ldo, ldo, cpb, w_bf16);
     return hipGetLastError();
   }
   hipLaunchKernelGGL(small_linear_kernel, dim3((N + 3) / 4), dim3(256), 0, s, x, ldx, M, K, Wt, bias, N, silu_in,
-                     accumulate, out, ldo);
+                     accumulate, out, ldo, w_bf16);
   return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------------
 // weight re-layout
 // ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float ldsrc(const void* src, int f32, size_t i) {
-  return f32 ? ((const float*)src)[i] : (float)((const half_t*)src)[i];
+__device__ __forceinline__ float ldsrc(const void* src, int dt, size_t i) {      // dt: 0 fp16, 1 fp32, 2 bf16
+  return dt == 1 ? ((const float*)src)[i] : e16_to_f32(((const half_t*)src)[i], dt == 2);
 }
 __device__ __forceinline__ int geglu_row(int r, int half, int g) {
   // source row r of the [2*half][K] GEGLU projection -> GEMM row so that every 2g-column group is [g h | g gate]
@@ -580,21 +597,21 @@ hipError_t launch_relayout_conv(const void* src, int src_f32, half_t* dst, int O
 }
 
 __global__ void relayout_rows_kernel(const void* src, int f32, half_t* dst, int R, int K, int row_off, int geglu,
-                                     long total) {
+                                     long total, int dbf) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int r = (int)(i / K);
     const int k = (int)(i - (long)r * K);
     const int dr = geglu ? geglu_row(r, R / 2, geglu) : r + row_off;
-    dst[(size_t)dr * K + k] = (_Float16)ldsrc(src, f32, i);
+    dst[(size_t)dr * K + k] = f32_to_e16(ldsrc(src, f32, i), dbf);
   }
 }
 hipError_t launch_relayout_rows(const void* src, int src_f32, half_t* dst, int R, int K, int row_off, int geglu,
-                                hipStream_t s) {
+                                hipStream_t s, int dst_bf16) {
   const long total = (long)R * K;
   long blocks = (total + 255) / 256;
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(relayout_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src, src_f32, dst, R, K, row_off,
-                     geglu, total);
+                     geglu, total, dst_bf16);
   return hipGetLastError();
 }
 

@@ -125,6 +125,14 @@ int gdf_op_sincos_pos_embed(float* out, int C, int gh, int gw, int base_size, fl
   return fin(launch_sincos_pos_embed(out, C, gh, gw, base_size, interpolation_scale, (hipStream_t)stream), "sincos_pos_embed");
 }
 
+// element type of the 16-bit operands of the MMDiT entry points below, per calling thread (GDF_F16 default)
+static thread_local int g_e16_bf = 0;
+int gdf_op_set_e16(int dtype) {
+  if (dtype != GDF_F16 && dtype != GDF_BF16) { set_error("gdf_op_set_e16: GDF_F16 or GDF_BF16"); return GDF_ERR_ARG; }
+  g_e16_bf = dtype == GDF_BF16;
+  return GDF_OK;
+}
+
 int gdf_op_gemm_dit(const void* A, int lda, const void* W, const float* bias, int act, const float* vec, int ldvec, int vec_mul,
                     int rps, int seg_rows, int rps2, const float* res32, int ldres, void* aux16, int ldaux, void* out16,
                     int ldo16, float* out32, int ldo32, int M, int N, int K, int variant, void* stream) {
@@ -136,20 +144,20 @@ int gdf_op_gemm_dit(const void* A, int lda, const void* W, const float* bias, in
   g.bias = bias; g.dit = 1; g.act = act; g.rowvec = vec; g.ldrv = ldvec; g.rv_mul = vec_mul; g.rows_per_sample = rps > 0 ? rps : 1;
   g.rv_seg_rows = seg_rows; g.rv_rps2 = rps2 > 0 ? rps2 : 1;
   g.res32 = res32; g.ldres = ldres; g.aux16 = (half_t*)aux16; g.ldaux = ldaux;
-  g.out16 = (half_t*)out16; g.ldo16 = ldo16; g.out32 = out32; g.ldo32 = ldo32; g.bn = 128; g.variant = variant;
+  g.out16 = (half_t*)out16; g.ldo16 = ldo16; g.out32 = out32; g.ldo32 = ldo32; g.bn = 128; g.variant = variant; g.bf16 = g_e16_bf;
   return fin(launch_gemm(g, (hipStream_t)stream), "gemm_dit");
 }
 
 int gdf_op_layernorm_mod(const float* x32, int ld, int R, int C, float eps, const float* scale, const float* shift, int ldm,
                          int rps, int seg_rows, int rps2, void* y, void* stream) {
-  return fin(launch_layernorm_mod(nullptr, x32, ld, R, C, eps, scale, shift, ldm, rps, seg_rows, rps2, (half_t*)y, (hipStream_t)stream),
-             "layernorm_mod");
+  return fin(launch_layernorm_mod(nullptr, x32, ld, R, C, eps, scale, shift, ldm, rps, seg_rows, rps2, (half_t*)y, (hipStream_t)stream,
+                                  g_e16_bf), "layernorm_mod");
 }
 
 int gdf_op_qk_norm_rope(void* x, int ld, int R, int heads, int q_col, int k_col, const float* wq, const float* wk, float eps,
                         const float* cos_t, const float* sin_t, int pos0, int rps, void* stream) {
-  return fin(launch_qk_norm_rope((half_t*)x, ld, R, heads, 128, q_col, k_col, wq, wk, eps, cos_t, sin_t, pos0, rps, (hipStream_t)stream),
-             "qk_norm_rope");
+  return fin(launch_qk_norm_rope((half_t*)x, ld, R, heads, 128, q_col, k_col, wq, wk, eps, cos_t, sin_t, pos0, rps, (hipStream_t)stream,
+                                 g_e16_bf), "qk_norm_rope");
 }
 
 int gdf_op_rope_table(const float* ids, int S, int a0, int a1, int a2, float* cos_t, float* sin_t, int row0, void* stream) {
@@ -162,7 +170,7 @@ int gdf_op_attention_joint(const void* q, int ldq, const void* k, int ldk, const
   AttnParams a{};
   a.q = (const half_t*)q; a.ldq = ldq; a.k = (const half_t*)k; a.ldk = ldk; a.v = (const half_t*)v; a.ldv = ldv;
   a.o = (half_t*)o; a.ldo = ldo; a.B = B; a.heads = heads; a.Sq = T + S; a.Sk = T + S; a.D = D; a.kv_bstride = T + S;
-  a.scale = 1.0f / sqrtf((float)D); a.map = nullptr; a.seg_T = T;
+  a.scale = 1.0f / sqrtf((float)D); a.map = nullptr; a.seg_T = T; a.bf16 = g_e16_bf;
   return fin(launch_attention(a, (hipStream_t)stream), "attention_joint");
 }
 

@@ -94,10 +94,11 @@ struct VB : PlanBuilder {
     const float scale = 1.0f / sqrtf((float)C);
     for (int b = 0; b < Bn; ++b) {
       const size_t ro = (size_t)b * S * C * 2;                    // byte offset of image b's rows
-      { Epi e; e.out16 = ws(pm); e.has_o16 = true; e.ldo16 = S;     // scores = Q_b K_b^T
+      { Epi e; e.out16 = ws(pm); e.has_o16 = true; e.ldo16 = S;     // scores = scale * Q_b K_b^T (scaled BEFORE the fp16 store: range)
+        e.acc_scale = scale;
         gemm_raw("vae_attn_qk", ws(q + ro), C, S, ws(k + ro), S, C, e); }
       op("vae_attn_softmax", 0, [=](const Bind& bd, hipStream_t s) {
-        return launch_softmax_rows((half_t*)bd.ws(pm), S, S, S, scale, s);
+        return launch_softmax_rows((half_t*)bd.ws(pm), S, S, S, 1.0f, s);
       });
       { Epi e; e.out16 = ws(vt); e.has_o16 = true; e.ldo16 = S;     // V_b^T = W_v X_b^T  (A operand = the weight matrix)
         gemm_raw("vae_attn_vt", wt(v.v.w), C, C, ws(gn + ro), S, C, e); }
@@ -148,6 +149,7 @@ struct VB : PlanBuilder {
       if (lv != L - 1) {
         Act nxt = new_act(boc[lv], hh / 2, ww / 2, true);
         Epi e; e.bias = wt(v.downsamplers[lv].b); e.has_bias = true; e.pad0 = 1; out_to(e, nxt);
+        reads_image(e, cur);
         conv3("vae_downsample", cur.h, cur.ld, cur.C, hh, ww, 2, false, v.downsamplers[lv], e);     // downsampling.py:141-152
         free_act(cur);
         cur = nxt; hh /= 2; ww /= 2;
@@ -218,6 +220,10 @@ int vae_plan_build(const Model& m, Plan& P, int batch, int img_h, int img_w, boo
   P.opts = o;
   VB b(m, P, dry, P.opts);
   b.Bn = chunk;
+  // Range: the reference upcasts the SDXL VAE to fp32 because its residual stream exceeds 65504.  Here the stream lives in
+  // fp32 masters; its fp16 images (GroupNorm input, shortcut / downsample conv operand) and the resnet-internal conv1 output
+  // are stored scaled by 2^-6 (max magnitude 4.2e6), exactly undone by their consumers (builder.h act_scale).
+  b.act_scale = 1.0f / 64.0f;
   b.build(img_h, img_w);
   P.ws_bytes = b.ar.peak + 256;
   return GDF_OK;

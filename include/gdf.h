@@ -26,7 +26,7 @@ typedef struct gdf_model gdf_model;
 typedef struct gdf_plan gdf_plan;
 
 enum { GDF_OK = 0, GDF_ERR_ARG = 1, GDF_ERR_HIP = 2, GDF_ERR_STATE = 3, GDF_ERR_UNSUPPORTED = 4 };
-enum { GDF_F16 = 0, GDF_F32 = 1 };
+enum { GDF_F16 = 0, GDF_F32 = 1, GDF_BF16 = 2 };
 
 #define GDF_MAX_LEVELS 4
 
@@ -66,11 +66,17 @@ const char* gdf_model_param_name(const gdf_model* m, int i);
 int gdf_model_param_shape(const gdf_model* m, int i, int64_t shape[4]);
 
 /* Copy one parameter from a DEVICE buffer in diffusers layout into the model's own MFMA-friendly
- * layout (OHWI convs, fused QKV / KV, interleaved GEGLU, stacked time projections). dtype GDF_F16|GDF_F32. */
+ * layout (OHWI convs, fused QKV / KV, interleaved GEGLU, stacked time projections). dtype GDF_F16|GDF_F32|GDF_BF16. */
 int gdf_model_set_param(gdf_model* m, const char* name, const void* dev_ptr, int dtype, void* stream);
 /* 1 when every parameter has been set. */
 int gdf_model_ready(const gdf_model* m);
 size_t gdf_model_weight_bytes(const gdf_model* m);
+/* The model's device weight arena as ONE flat blob (already in the MFMA-friendly layout): what a data-parallel launch
+ * broadcasts from rank 0 at init (RCCL, few large buckets) instead of re-reading and re-laying-out the checkpoint on every
+ * rank; a receiving rank calls gdf_model_set_ready() after the blob has arrived.  Same architecture descriptor on both sides
+ * => same layout. */
+int gdf_model_weights(const gdf_model* m, void** dev_ptr, size_t* bytes);
+int gdf_model_set_ready(gdf_model* m);
 
 /* Every hook id this architecture can emit, in execution order (== the key order of the
  * reference's config_*_full.json dumps, extract_feature.py:103-110). */

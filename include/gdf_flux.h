@@ -15,9 +15,11 @@
  *
  * Handles (gdf_model / gdf_plan) and every model / plan query, hook-info, workspace and timing function are the ones
  * of gdf.h; only creation and the forward call differ.  Same conventions: plain C, int status (0 = ok), caller owns
- * all device buffers, asynchronous on the stream passed in.  Arithmetic: fp16 MFMA operands, fp32 accumulate, fp32
- * residual stream (the reference runs bfloat16: same operand width, 3 fewer mantissa bits; hooks are fp16 in both,
- * components/feature_extractor.py:59-60).
+ * all device buffers, asynchronous on the stream passed in.  Arithmetic (gdf_flux_desc.compute_dtype): GDF_BF16 — what the
+ * reference runs (torch.bfloat16, components/models.py:158-169): bf16 weights / activations / MFMA operands
+ * (mfma_f32_*_bf16), fp32 accumulate, fp32 residual stream; or GDF_F16 — same rate, 3 more mantissa bits, but fp16 RANGE:
+ * activations beyond +-65504 saturate (real FLUX.1-dev checkpoints reach that; synthetic weights do not).  Hooks are fp16
+ * in both, like the reference's (components/feature_extractor.py:59-60), written with saturating casts.
  */
 #ifndef GDF_FLUX_H
 #define GDF_FLUX_H
@@ -43,6 +45,7 @@ typedef struct gdf_flux_desc {
   int guidance_embeds;          /* 1 (FLUX.1-dev), 0 (schnell) */
   int axes_dims_rope[3];        /* 16, 56, 56 */
   int mlp_ratio;                /* 4 */
+  int compute_dtype;            /* GDF_F16 (0) or GDF_BF16 (2): element type of weights, activations, inputs and `out` */
 } gdf_flux_desc;
 
 int gdf_flux_model_create(const gdf_flux_desc* desc, gdf_model** out);
@@ -52,11 +55,11 @@ int gdf_flux_model_create(const gdf_flux_desc* desc, gdf_model** out);
 int gdf_flux_plan_create(gdf_model* m, int batch, int img_h, int img_w, int n_txt, const char* const* hook_ids,
                          int n_hooks, const gdf_plan_opts* opts, gdf_plan** out);
 
-/* One transformer forward.  hidden_states (B, img_h*img_w, in_channels) fp16; encoder_hidden_states
- * (B, n_txt, joint_attention_dim) fp16; pooled_projections (B, pooled_projection_dim) fp16; timestep (B) fp32 in
+/* One transformer forward.  "e16" = the model's compute_dtype (fp16 or bf16).  hidden_states (B, img_h*img_w, in_channels)
+ * e16; encoder_hidden_states (B, n_txt, joint_attention_dim) e16; pooled_projections (B, pooled_projection_dim) e16; timestep (B) fp32 in
  * [0,1] (the model multiplies by 1000, transformer_flux.py:472); guidance (B) fp32 or NULL when !guidance_embeds;
- * img_ids (img_h*img_w, 3) fp32, txt_ids (n_txt, 3) fp32; out (B, img_h*img_w, in_channels) fp16 or NULL with
- * early_exit. */
+ * img_ids (img_h*img_w, 3) fp32, txt_ids (n_txt, 3) fp32; out (B, img_h*img_w, in_channels) e16 or NULL with
+ * early_exit; hook_out buffers are fp16 in either mode. */
 int gdf_flux_forward(gdf_plan* p, const void* hidden_states, const void* encoder_hidden_states,
                      const void* pooled_projections, const float* timestep, const float* guidance,
                      const float* img_ids, const float* txt_ids, void* const* hook_out, void* out, void* workspace,

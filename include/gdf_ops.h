@@ -71,6 +71,10 @@ int gdf_op_sincos_pos_embed(float* out, int C, int gh, int gw, int base_size, fl
 
 /* ---- MMDiT (Flux) kernels (reference files cited in csrc/dit.hip, gdf_flux.h) ---- */
 
+/* Element type of the 16-bit operands ("e16": A, W, out16, q/k/v/o, y) of the MMDiT entry points below, per calling thread:
+ * GDF_F16 (default) or GDF_BF16 (what a gdf_flux_desc.compute_dtype = GDF_BF16 model runs).  aux16 (a hook) is always fp16. */
+int gdf_op_set_e16(int dtype);
+
 /* Dense GEMM with the MMDiT epilogue: v = A W^T + bias; act=1: tanh-GELU; vec != NULL: v = vec_mul ? v * vec[s] : v + vec[s]
  * (s = row / rps for row < seg_rows or seg_rows == 0, else (row - seg_rows) / rps2; vec fp32 rows of ldvec);
  * aux16 (optional) receives fp16(v) BEFORE the gate; then + res32, stores out16 / out32.

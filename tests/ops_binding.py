@@ -24,6 +24,7 @@ OPS = {
     "gdf_op_sincos_pos_embed": (ci, [vp, ci, ci, ci, ci, fp, vp]),
     "gdf_op_softmax_rows": (ci, [vp, ci, ci, ci, fp, vp]),
     "gdf_op_small_linear": (ci, [vp, ci, ci, ci, vp, vp, ci, ci, ci, vp, ci, vp]),
+    "gdf_op_set_e16": (ci, [ci]),
     "gdf_op_gemm_dit": (ci, [vp, ci, vp, vp, ci, vp, ci, ci, ci, ci, ci, vp, ci, vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, vp]),
     "gdf_op_layernorm_mod": (ci, [vp, ci, ci, ci, fp, vp, vp, ci, ci, ci, ci, vp, vp]),
     "gdf_op_qk_norm_rope": (ci, [vp, ci, ci, ci, ci, ci, vp, vp, fp, vp, vp, ci, ci, vp]),

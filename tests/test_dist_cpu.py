@@ -22,7 +22,20 @@ def _worker(rank, world, port, out):
     D.broadcast_state_dict(shapes, lambda n, s: D.synthetic_param(n, s, gen, "cpu"),
                            lambda sd: got.update({k: v.clone() for k, v in sd.items()}), "cpu", bucket_elems=400)
     lo, hi = D.shard_range(11, rank, world)
-    torch.save({"sd": got, "range": (lo, hi)}, os.path.join(out, f"r{rank}.pt"))
+
+    class Arena:                                             # stand-in for a native model's flat device weight arena
+        def __init__(self):
+            self.blob = torch.randint(0, 255, (1000,), dtype=torch.uint8, generator=torch.Generator().manual_seed(7 + rank))
+            self.ready = rank == 0
+
+        def weight_blob(self):
+            return self.blob
+
+        def set_ready(self):
+            self.ready = True
+    ar = Arena()
+    D.broadcast_model_weights(ar, chunk_bytes=300)           # 4 pieces
+    torch.save({"sd": got, "range": (lo, hi), "blob": ar.blob, "ready": ar.ready, "rw": D.rank_world()}, os.path.join(out, f"r{rank}.pt"))
     dist.destroy_process_group()
 
 
@@ -36,6 +49,10 @@ def test_broadcast_and_shard_gloo(tmp_path):
         ref = D.synthetic_param(n, s, gen, "cpu")
         assert torch.equal(r0["sd"][n], ref) and torch.equal(r1["sd"][n], ref), n     # bit-exact on both ranks
     assert r0["range"] == (0, 6) and r1["range"] == (6, 11)
+    # flat-arena broadcast (what extract_feature.py / bench.py use): rank 1 ends up with rank 0's bytes and is marked ready
+    want = torch.randint(0, 255, (1000,), dtype=torch.uint8, generator=torch.Generator().manual_seed(7))
+    assert torch.equal(r0["blob"], want) and torch.equal(r1["blob"], want) and r0["ready"] and r1["ready"]
+    assert r0["rw"] == (0, 2) and r1["rw"] == (1, 2)
 
 
 def test_shard_range_partitions():

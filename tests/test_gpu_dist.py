@@ -1,0 +1,114 @@
+"""Multi-process / multi-thread use of the native path on ONE GPU box (-m gpu).
+
+The driver owns the 8-GPU runs; what can be checked here is that the data-parallel code path is correct by construction:
+two ranks (fresh child processes, both on cuda:0 through the GDF_SHARE_GPU / GDF_BENCH_SHARE_GPU test hooks, gloo instead
+of RCCL) must reproduce the single-process result bit for bit, with rank 1 receiving its weights ONLY through the broadcast
+of rank 0's device arena; and two extractors in two Python threads of one process — the reference's own multi-device mode
+(correspondence/correspondence/aggregation_network.py:67-95) — must not disturb each other."""
+import json
+import os
+import socket
+import subprocess
+import sys
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _tree(d):
+    out = {}
+    for root, _, files in os.walk(d):
+        for f in files:
+            out[os.path.relpath(os.path.join(root, f), d)] = np.load(os.path.join(root, f))
+    return out
+
+
+def test_two_rank_cli_equals_single_process(tmp_path):
+    from PIL import Image
+    rs = np.random.RandomState(0)
+    (tmp_path / "imgs").mkdir()
+    for n in "abcd":
+        Image.fromarray((rs.rand(96, 120, 3) * 255).astype(np.uint8)).save(tmp_path / "imgs" / f"{n}.png")
+    (tmp_path / "prompt.txt").write_text("a photo of a cat")
+    (tmp_path / "layers.json").write_text(json.dumps({"up-level1-repeat2-res-out": True, "up-level3-repeat0-vit-block0-self-k": True}))
+    base = [os.path.join(ROOT, "extract_feature.py"), "--layer", str(tmp_path / "layers.json"), "--version", "1-5", "--img_size", "256",
+            "--t", "100", "-b", "2", "--input_dir", str(tmp_path / "imgs" / "*.png"), "--prompt_file", str(tmp_path / "prompt.txt")]
+    env = dict(os.environ, GDF_SYNTHETIC_WEIGHTS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable] + base + ["--output_dir", str(tmp_path / "one")], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    env2 = dict(env, GDF_SHARE_GPU="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port())] + base + ["--output_dir", str(tmp_path / "two")],
+                       env=env2, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    one, two = _tree(tmp_path / "one"), _tree(tmp_path / "two")
+    assert sorted(one) == sorted(two) and len(one) == 8                      # 2 layers x 4 images, <split><GLOBAL index> names
+    for k in one:
+        assert one[k].dtype == two[k].dtype and np.array_equal(one[k].view(np.uint16), two[k].view(np.uint16)), k
+        assert np.abs(one[k].astype(np.float32)).max() > 0                   # rank 1 really received weights (zeros otherwise)
+
+
+def test_two_rank_bench_line():
+    env = dict(os.environ, GDF_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--version", "1-5", "--batch", "4", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["global_batch"] == 8 and line["value"] > 0
+    assert line["roofline"]["launches"] > 0 and line["roofline"]["achieved"] > 0
+
+
+def test_two_threads_two_extractors(monkeypatch):
+    """One extractor per Python thread (reference aggregation_network.py:67-95), here both on cuda:0: concurrent plan
+    creation, first-launch attribute setup, graph capture and replay must give each thread exactly its sequential result."""
+    monkeypatch.setenv("GDF_SYNTHETIC_WEIGHTS", "1")
+    import diffusion_feature
+    layer = {"up-level1-repeat1-vit-block0-cross-q": True, "up-level2-repeat2-res-out": True}
+    lats = [torch.randn(2, 4, 32, 32, generator=torch.Generator().manual_seed(s)).half() for s in (0, 1)]
+
+    def make(seed):
+        monkeypatch.setenv("GDF_SYNTHETIC_SEED", str(seed))
+        return diffusion_feature.FeatureExtractor(layer=layer, version='1-5', img_size=256, device='cuda:0')
+    want = []
+    for s in (0, 1):                                                         # sequential reference, fresh extractors
+        df = make(s)
+        f = df.extract(df.encode_prompt('a photo of a cat'), batch_size=2, image=lats[s], image_type='latents', t=100)
+        want.append({k: v.clone() for k, v in f.items()})
+        del df, f
+    dfs = [make(0), make(1)]
+    got, errs = [None, None], []
+    gate = threading.Barrier(2)
+
+    def work(i):
+        try:
+            df = dfs[i]
+            prompt = df.encode_prompt('a photo of a cat')
+            gate.wait()
+            for _ in range(4):                                               # eager warm-up, capture, replays — all overlapping
+                f = df.extract(prompt, batch_size=2, image=lats[i], image_type='latents', t=100)
+            torch.cuda.synchronize()
+            got[i] = {k: v.clone() for k, v in f.items()}
+        except Exception as e:                                               # surfaced in the main thread
+            errs.append(e)
+    th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
+    for i in range(2):
+        for k in want[i]:
+            assert torch.equal(got[i][k], want[i][k]), (i, k)
+    assert not torch.equal(want[0]["up-level2-repeat2-res-out"], want[1]["up-level2-repeat2-res-out"])

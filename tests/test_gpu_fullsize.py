@@ -6,8 +6,9 @@ attention_processor.py, transformer_2d.py) and of transformer_flux.py:414-603.  
 
 Stated tolerances (north star: 1e-3):
   * SDXL 1024^2, every hook kind                  <= 1.0e-3, except `ffn-inner` and `unet-out`      <= 1.3e-3
-  * SD1.5 512^2 (narrower layers average less)    <= 1.1e-3, except `ffn-inner` and `unet-out`      <= 1.35e-3; maps <= 1.0e-3
-  * Flux widths, fp16 operands                    <= 6e-4
+  * SD1.5 512^2 (narrower layers average less)    <= 1.1e-3, except `ffn-inner` and `unet-out`      <= 1.35e-3;
+    `*-map` (softmax of q k^T: exponentiates the q / k errors)                                        <= 1.5e-3
+  * Flux widths: compute_dtype float16            <= 6e-4;   bfloat16 (the reference's dtype, 8 mantissa bits) <= 4e-3
   * and for the UNets: every hook within 1.15x (+2e-5) of the fp16-OPERAND FLOOR (oracle/operand_floor.py) — the error of
     the fp32 oracle with nothing but its matmul operands rounded to fp16, i.e. what any fp16-MFMA implementation commits at
     best.  `ffn-inner` (h * gelu(g): the product of two GEMM outputs that each carry the stream error) and `unet-out` sit
@@ -135,20 +136,19 @@ def test_sd15_512_full_layer_set_with_maps_batch2_and_batch32():
     assert len(ids) == 197
     ref = _oracle(arch, P, I, ids, want_map=True)
     nm = [i for i in ids if not i.endswith("-map")]
-    floor_f = _oracle(arch, P, I, nm, floor=True, want_map=True)
-    floor = {k: float((floor_f[k].float() - ref[k].float()).norm() / ref[k].float().norm()) for k in nm}
+    floor_f = _oracle(arch, P, I, ids, floor=True, want_map=True)
+    floor = {k: float((floor_f[k].float() - ref[k].float()).norm() / ref[k].float().norm()) for k in ids}
     del floor_f
     u = _native(arch, P)
     g = lambda k: I[k].cuda()
     _, hooks = u.forward_raw(g("sample"), g("timestep"), g("ctx"), hook_ids=ids)
     torch.cuda.synchronize()
     assert list(hooks.keys()) == ids
-    bound = lambda kd: 1.35e-3 if kd in ("ffn-inner", "unet-out") else (1.0e-3 if kd == "map" else 1.1e-3)
+    bound = lambda kd: 1.35e-3 if kd in ("ffn-inner", "unet-out") else (1.5e-3 if kd == "map" else 1.1e-3)
     errs = {k: max(_rel_each(hooks[k], ref[k])) for k in ids}
     ev = sorted(errs.values())
     print(f"\n[sd1.5 512^2 B=2, 197 ids] median {ev[len(ev) // 2]:.2e} worst {ev[-1]:.2e}; below 1e-3: {sum(e < 1e-3 for e in ev)}")
-    _check({k: errs[k] for k in nm}, floor, bound)
-    _check({k: errs[k] for k in ids if k.endswith("-map")}, None, bound)
+    _check(errs, floor, bound)
     del hooks
     torch.cuda.empty_cache()
     # ---- the batch-32 plan of config C2 (56 GB of hooks) on sample 0 repeated ----
@@ -169,7 +169,8 @@ def test_sd15_512_full_layer_set_with_maps_batch2_and_batch32():
     _check({k: errs32[k] for k in ids if k.endswith("-map")}, None, bound)
 
 
-def test_flux_full_width_batch8():
+@pytest.mark.parametrize("dt", ["bfloat16", "float16"])
+def test_flux_full_width_batch8(dt):
     """BASELINE config C5 widths (24 heads x 128, 4096 + 512 tokens, T5 width 4096) with a reduced stack (2 double + 3 single
     blocks so the CPU oracle finishes within a minute), batch 8 on one sample repeated: every non-map hook, both QKV paths
     (pre-norm q / k / v hooked: separate RMSNorm + RoPE pass; un-hooked: fused into the QKV GEMM epilogue)."""
@@ -179,12 +180,16 @@ def test_flux_full_width_batch8():
     arch = dict(FR.ARCH_FLUX_DEV); arch.update(num_layers=2, num_single_layers=3)
     P = FR.synth_params(arch, seed=0)
     I = FR.synth_inputs(arch, 1, 64, 512, seed=1)
+    tdt = torch.bfloat16 if dt == "bfloat16" else torch.float16
+    P = {k: v.to(tdt).float() for k, v in P.items()}            # the oracle runs on the values the model's element type holds
+    I = {k: (v.to(tdt).float() if k in ("hidden_states", "encoder_hidden_states", "pooled_projections") else v) for k, v in I.items()}
+    tol = 4e-3 if dt == "bfloat16" else 6e-4
     st = FR.Store(None)
     with torch.no_grad():
         y = FR.flux_forward(P, arch, I["hidden_states"], I["encoder_hidden_states"], I["pooled_projections"], I["timestep"],
                             I["img_ids"], I["txt_ids"], I["guidance"], store=st, want_map=False)
-    net = NativeFluxTransformer(arch, device="cuda:0")
-    net.load_state_dict({k: v.half() for k, v in P.items()})
+    net = NativeFluxTransformer(arch, device="cuda:0", compute_dtype=dt)
+    net.load_state_dict({k: v.to(tdt) for k, v in P.items()})
     B = 8
     rep = lambda t: t[:1].expand(B, *t.shape[1:]).contiguous().cuda()
     args = (rep(I["hidden_states"]), rep(I["encoder_hidden_states"]), rep(I["pooled_projections"]), I["timestep"].cuda(),
@@ -197,6 +202,6 @@ def test_flux_full_width_batch8():
         errs = {k: max(_rel_each(hooks[k], st.feats[k])) for k in ids}
         errs["output"] = max(_rel_each(out, y))
         worst = max(errs, key=errs.get)
-        print(f"\n[flux widths B=8, {len(ids)} hooks] worst {worst} = {errs[worst]:.2e}")
-        assert errs[worst] <= 6e-4, (worst, errs[worst])
+        print(f"\n[flux widths B=8 {dt}, {len(ids)} hooks] worst {worst} = {errs[worst]:.2e}")
+        assert errs[worst] <= tol, (worst, errs[worst])
         del hooks, out

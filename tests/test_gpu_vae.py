@@ -50,3 +50,34 @@ def test_vae_encode_matches_oracle(channels, img, batch):
         torch.cuda.synchronize()
         assert got.shape == ref.shape and got.dtype == torch.float16
         assert rel_l2(got, ref) < 3e-3, (kw, rel_l2(got, ref))
+
+
+def test_vae_encode_range_beyond_fp16():
+    """Range safety: the reference upcasts the SDXL VAE to fp32 because its activations exceed the fp16 range.  Here the
+    residual stream is pushed to ~1e5 (> 65504) by the first resnet (conv2 weights x 1e5: fp16-representable weights, K = 576
+    products per output) and stays there through every later resnet, the downsamplers and the mid attention: the fp32 masters + 2^-6-scaled fp16 images (csrc/vae.cpp) must reproduce the fp32
+    oracle at the normal tolerance — no inf / NaN, no saturation."""
+    from components.native import NativeVAEEncoder
+    channels = (64, 128, 128)
+    arch = VR.tiny_arch(channels)
+    P = VR.synth_params(arch, seed=0)
+    k = "encoder.down_blocks.0.resnets.0.conv2."
+    P[k + "weight"] = (P[k + "weight"] * 1.0e5).half().float()
+    assert torch.isfinite(P[k + "weight"]).all()
+    P[k + "bias"] = P[k + "bias"] * 1.0e5
+    g = torch.Generator().manual_seed(1)
+    image = (torch.rand(2, 3, 64, 64, generator=g) * 2 - 1).half().float()
+    cfg = dict(in_channels=3, latent_channels=4, block_out_channels=channels, layers_per_block=2, use_quant_conv=1)
+    enc = NativeVAEEncoder(cfg, device="cuda:0")
+    enc.load_vae_state_dict({k: v.float() for k, v in P.items()})           # fp32 source: 2e5 x weights do not fit fp16 themselves
+    import torch.nn.functional as F
+    x0 = F.conv2d(image, P["encoder.conv_in.weight"], P["encoder.conv_in.bias"], padding=1)
+    r = "encoder.down_blocks.0.resnets.0."
+    h = F.conv2d(F.silu(F.group_norm(x0, 32, P[r + "norm1.weight"], P[r + "norm1.bias"], 1e-6)), P[r + "conv1.weight"], P[r + "conv1.bias"], padding=1)
+    h = F.conv2d(F.silu(F.group_norm(h, 32, P[r + "norm2.weight"], P[r + "norm2.bias"], 1e-6)), P[r + "conv2.weight"], P[r + "conv2.bias"], padding=1)
+    assert float((x0 + h).abs().max()) > 65504 * 2                           # the stream really leaves the fp16 range
+    ref = VR.prepare_latents(P, arch, image, None, None, 1.0, 1.0, 0.0, 1.0)
+    got = enc.encode(image, eps=None, noise=None, scaling_factor=1.0)
+    torch.cuda.synchronize()
+    assert torch.isfinite(got.float()).all()
+    assert rel_l2(got, ref) < 3e-3, rel_l2(got, ref)

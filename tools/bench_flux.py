@@ -63,6 +63,8 @@ def main():
     ap.add_argument("--hooks", default="practical", choices=("practical", "all", "none"))
     ap.add_argument("--profile-ops", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dtype", default="bfloat16", choices=("bfloat16", "float16"),
+                    help="element type of weights / activations / MFMA operands (the reference loads Flux in bfloat16)")
     args = ap.parse_args()
     if not torch.cuda.is_available():
         sys.exit("needs an MI355X (no CPU fallback for the measured path)")
@@ -70,7 +72,7 @@ def main():
     from oracle.flux_ref import flops_per_image, latent_image_ids        # FLOP model + id helper only (not measured)
     dev = torch.device("cuda:0")
     cfg = dict(FLUX_CONFIGS["flux"]); cfg.update(num_layers=args.layers, num_single_layers=args.single_layers)
-    net = NativeFluxTransformer(cfg, device=dev)
+    net = NativeFluxTransformer(cfg, device=dev, compute_dtype=args.dtype)
     t0 = time.time()
     net.init_synthetic(seed=0)
     torch.cuda.synchronize()
@@ -124,7 +126,7 @@ def main():
     res = {"metric": "images/sec feature-extract, Flux.1-dev MMDiT 1024^2 single forward", "value": round(ips, 3),
            "unit": "images/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(1e3 * dt / args.steps, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-           "dtype": "f16", "data": "synthetic",
+           "dtype": "bf16" if args.dtype == "bfloat16" else "f16", "data": "synthetic",
            "config": {"workload": f"Flux MMDiT ({args.layers} double + {args.single_layers} single blocks, 24 heads x 128), "
                                   f"{S}+{T} tokens, batch {B}, hooks={args.hooks} ({len(out[1])} ids, "
                                   f"{hook_bytes / B / 1e6:.1f} MB/img)",

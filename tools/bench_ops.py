@@ -43,10 +43,10 @@ def bench_gemm():
         o32 = torch.empty(M, No, device=dev) if mode in ("res", "o32") else None
         res = torch.randn(M, No, device=dev) if mode == "res" else None
         out = []
-        for var in (128, 160, 256, 320, 832, 825, 932):
+        for var in (128, 160, 256, 320, 825, 932):
             early = var >> 12; var &= 4095
             flags = (early << 20) | (var << 8) | ((1 | (8 if var in (160, 320) else 0)) if mode == "geglu" else 0)
-            if (var in (160, 320) and N % var) or (var == 160 and mode == "geglu") or (var == 832 and N % 320) or (var == 825 and (mode != "geglu" or N % 256)) or (var == 932 and (mode == "geglu" or N % 320)):
+            if (var in (160, 320) and N % var) or (var == 160 and mode == "geglu") or (var == 825 and (mode != "geglu" or N % 256)) or (var == 932 and (mode == "geglu" or N % 320)):
                 out.append(" " * 17); continue
             fn = lambda: ok(L.gdf_op_gemm(P(A), K, P(W), P(bias), P(res), None, No, P(o16), No, P(o32), No, M, N, K,
                                           flags, stream()), L)
