@@ -82,10 +82,9 @@ class HostWriter:
             self.stream.wait_stream(torch.cuda.current_stream())
         ctx = torch.cuda.stream(self.stream) if self.stream is not None else _null()
         with ctx:
-            if self.args.aggregate_output:
-                size = max(v.shape[-1] for v in feats.values())
-                agg = torch.cat([torch.nn.functional.interpolate(v, size) for v in feats.values()], dim=1)
-                feats = {None: agg}
+            if self.args.aggregate_output:                      # reference :113-125; device tensors: resize_concat_kernel
+                from components.postproc import resize_concat
+                feats = {None: resize_concat(list(feats.values()))}
             for k, v in feats.items():
                 v = v.detach()
                 if v.is_cuda:

@@ -49,9 +49,9 @@ class FeatureStore:
             b, n, c = feat.shape
             s = int(math.sqrt(n))
             feat = feat.reshape(b, s, n // s, c).permute(0, 3, 1, 2)
-        if self.resize_ratio > 1:                             # feature_resize pooling (:51-53)
-            tgt = (feat.shape[2] // self.resize_ratio, feat.shape[3] // self.resize_ratio)
-            feat = F.adaptive_avg_pool2d(feat.float(), tgt).to(torch.float16)
+        if self.resize_ratio > 1:                             # feature_resize pooling (:51-53): avg_pool_kernel on device tensors
+            from .postproc import avg_pool
+            feat = avg_pool(feat, self.resize_ratio)
         # the reference's TF.normalize(mean=0,std=1) clone (:56) and fp16 cast (:59-60) are already
         # materialised by the kernels: `feat` is a freshly written fp16 buffer owned by this call.
         feat = feat.detach()
@@ -208,18 +208,7 @@ def attention_map_ids(cfg, all_ids, categories, lat, min_size, max_size):
 def aggregate_attention(maps_by_category, out_size):
     """Reference AttentionStore.aggregate_attention (components/attention.py:141-161) + diffusion_feature.py:492-500:
     head-mean maps (B,Q,K) -> (B,K,h,w), averaged over the layers of the same category and size, nearest-resized to
-    out_size and concatenated over the channel dim, in category order then first-seen size order."""
-    import torch
-    import torch.nn.functional as F
-    all_attns = []
-    for cat, maps in maps_by_category.items():
-        by_size = {}
-        for m in maps:                                     # m: (B, heads, Q, K) probabilities
-            a = m.float().mean(1)                          # to_store.mean(1), components/attention.py:241
-            b, q, k = a.shape
-            size = int(math.sqrt(q))
-            by_size.setdefault(size, []).append(a.reshape(b, size, q // size, k).permute(0, 3, 1, 2))
-        for size, lst in by_size.items():
-            avg = torch.stack(lst).mean(0)
-            all_attns.append(F.interpolate(avg, size=(out_size, out_size)).to(torch.float16))
-    return torch.cat(all_attns, dim=-3)
+    out_size and concatenated over the channel dim, in category order then first-seen size order.  Device tensors run on
+    maps_mean_kernel + resize_concat_kernel (components/postproc.py)."""
+    from .postproc import aggregate_maps
+    return aggregate_maps(maps_by_category, out_size)

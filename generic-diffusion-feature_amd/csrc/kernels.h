@@ -208,6 +208,18 @@ hipError_t launch_small_linear(const float* x, int ldx, int M, int K, const half
                                int silu_in, int accumulate, float* out, int ldo, hipStream_t s, int w_bf16 = 0);
 
 // ------------------------------------------------------------------------------------------------
+// output-stage post-processing (csrc/post.hip): `--aggregate_output`, `feature_resize`, aggregated attention feature
+// ------------------------------------------------------------------------------------------------
+// nearest-resize one layer (logical (B,C,H,W), element strides sb/sc/sy/sx, fp16 or fp32) to S x S and store it as channels
+// [coff, coff + C) of out (B, Ctot, S, S) fp16 contiguous
+hipError_t launch_resize_concat(const half_t* s16, const float* s32, long sb, long sc, long sy, long sx, int B, int C, int H, int W,
+                                half_t* out, int Ctot, int coff, int S, hipStream_t s);
+// r x r mean of a channels-last hook (B,C,H,W; strides sb, 1, sy, sx) -> (B, H/r, W/r, C) fp16
+hipError_t launch_avg_pool(const half_t* src, long sb, long sy, long sx, int B, int C, int H, int W, int r, half_t* out, hipStream_t s);
+// mean over heads and over n <= 16 maps (B, heads, Q, K) fp16 -> (B, Q, K) fp32
+hipError_t launch_maps_mean(const half_t* const* maps, int n, int B, int heads, int Q, int K, float* out, hipStream_t s);
+
+// ------------------------------------------------------------------------------------------------
 // weight re-layout (model load time)
 // ------------------------------------------------------------------------------------------------
 // `src_f32` is the source dtype code of gdf_model_set_param: 0 fp16, 1 fp32, 2 bf16

@@ -707,19 +707,28 @@ static int run_ops_graph(Plan& P, const Bind& b, hipStream_t s) {
   Plan::GraphEntry g;
   g.key = b; g.key.hooks = nullptr;
   for (size_t i = 0; i < nh; ++i) g.hook_ptrs.push_back(b.hooks[i]);
-  if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+  // Relaxed mode: the op program only launches kernels (no allocation, no synchronisation), and in this mode HIP neither lists
+  // the stream for its "unsafe call during capture" checks nor lets an unrelated call invalidate the capture — other host
+  // threads (one extractor per thread: aggregation_network.py:67-95) keep allocating, synchronising and capturing freely.
+  if (hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) != hipSuccess) {
     (void)hipGetLastError();
     return run_ops_eager(P, b, s);                       // e.g. the legacy default stream cannot be captured
   }
   const int rc = run_ops_eager(P, b, s);
   hipError_t e = hipStreamEndCapture(s, &g.graph);
   if (rc != GDF_OK || e != hipSuccess || !g.graph) {
+    // a capture that failed or was invalidated has executed nothing: drop it and run this forward eagerly (the ops are pure
+    // functions of their inputs); the next call tries to capture again
     if (g.graph) hipGraphDestroy(g.graph);
-    if (rc == GDF_OK) set_error("hipStreamEndCapture failed");
-    return rc != GDF_OK ? rc : GDF_ERR_HIP;
+    (void)hipGetLastError();
+    ++P.graph_capture_failures;
+    return run_ops_eager(P, b, s);
   }
   if (hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0) != hipSuccess) {
-    hipGraphDestroy(g.graph); set_error("hipGraphInstantiate failed"); return GDF_ERR_HIP;
+    hipGraphDestroy(g.graph);
+    (void)hipGetLastError();
+    ++P.graph_capture_failures;
+    return run_ops_eager(P, b, s);
   }
   ++P.graph_captures;
   if (P.graphs.size() >= 4) {                            // evict the least recently used entry

@@ -148,7 +148,7 @@ struct Plan {
   struct GraphEntry { Bind key; std::vector<void*> hook_ptrs; hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; long stamp = 0; };
   int graph_mode = 0;
   bool warmed = false;                        // first forward runs eagerly (lazy one-time kernel attribute setup)
-  long graph_clock = 0, graph_launches = 0, graph_captures = 0;
+  long graph_clock = 0, graph_launches = 0, graph_captures = 0, graph_capture_failures = 0;
   std::vector<GraphEntry> graphs;
   ~Plan();
 };

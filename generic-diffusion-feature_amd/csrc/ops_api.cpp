@@ -125,6 +125,18 @@ int gdf_op_sincos_pos_embed(float* out, int C, int gh, int gw, int base_size, fl
   return fin(launch_sincos_pos_embed(out, C, gh, gw, base_size, interpolation_scale, (hipStream_t)stream), "sincos_pos_embed");
 }
 
+int gdf_op_resize_concat(const void* src, int src_f32, long sb, long sc, long sy, long sx, int B, int C, int H, int W, void* out,
+                         int Ctot, int coff, int S, void* stream) {
+  return fin(launch_resize_concat(src_f32 ? nullptr : (const half_t*)src, src_f32 ? (const float*)src : nullptr, sb, sc, sy, sx, B, C, H, W,
+                                  (half_t*)out, Ctot, coff, S, (hipStream_t)stream), "resize_concat");
+}
+int gdf_op_avg_pool(const void* src, long sb, long sy, long sx, int B, int C, int H, int W, int r, void* out, void* stream) {
+  return fin(launch_avg_pool((const half_t*)src, sb, sy, sx, B, C, H, W, r, (half_t*)out, (hipStream_t)stream), "avg_pool");
+}
+int gdf_op_maps_mean(const void* const* maps, int n, int B, int heads, int Q, int K, float* out, void* stream) {
+  return fin(launch_maps_mean((const half_t* const*)maps, n, B, heads, Q, K, out, (hipStream_t)stream), "maps_mean");
+}
+
 // element type of the 16-bit operands of the MMDiT entry points below, per calling thread (GDF_F16 default)
 static thread_local int g_e16_bf = 0;
 int gdf_op_set_e16(int dtype) {

@@ -69,6 +69,21 @@ int gdf_op_softmax_rows(void* x, int ld, int R, int n, float scale, void* stream
 /* PatchEmbed positional table (PixArt): out fp32 [gh*gw][C] = get_2d_sincos_pos_embed(C, (gh, gw), base_size, interpolation_scale). */
 int gdf_op_sincos_pos_embed(float* out, int C, int gh, int gw, int base_size, float interpolation_scale, void* stream);
 
+/* ---- output-stage post-processing (csrc/post.hip) ---- */
+
+/* `--aggregate_output` (extract_feature.py:113-125): nearest-resize one layer — logical (B,C,H,W), element strides
+ * sb/sc/sy/sx, fp16 (src_f32 = 0) or fp32 — to S x S (PyTorch `nearest`: floor(dst * in / out)) and store it as channels
+ * [coff, coff + C) of out (B, Ctot, S, S) fp16 contiguous; one call per layer performs F.interpolate + torch.cat(dim=1). */
+int gdf_op_resize_concat(const void* src, int src_f32, long sb, long sc, long sy, long sx, int B, int C, int H, int W, void* out,
+                         int Ctot, int coff, int S, void* stream);
+/* `feature_resize` (components/feature_extractor.py:51-53): r x r mean (adaptive_avg_pool2d to (H/r, W/r)) of a channels-last
+ * hook (strides sb, 1, sy, sx; C % 8 == 0) -> (B, H/r, W/r, C) fp16, fp32 accumulation. */
+int gdf_op_avg_pool(const void* src, long sb, long sy, long sx, int B, int C, int H, int W, int r, void* out, void* stream);
+/* aggregated `attn` feature (components/attention.py:238-244, 141-161): mean over heads (rounded to fp16 like the
+ * reference's `attention_probs.mean(1)`), then mean over the n <= 16 maps (B, heads, Q, K) fp16 of one (category, size)
+ * group -> (B, Q, K) fp32; gdf_op_resize_concat then turns it into the (B, K, img/8, img/8) slice of the feature. */
+int gdf_op_maps_mean(const void* const* maps, int n, int B, int heads, int Q, int K, float* out, void* stream);
+
 /* ---- MMDiT (Flux) kernels (reference files cited in csrc/dit.hip, gdf_flux.h) ---- */
 
 /* Element type of the 16-bit operands ("e16": A, W, out16, q/k/v/o, y) of the MMDiT entry points below, per calling thread:

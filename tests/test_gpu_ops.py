@@ -244,3 +244,30 @@ def test_gemm_8phase_reproduces_ring_bitwise():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_gemm8.py"), "6"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "0 mismatches" in r.stdout
+
+
+def test_postproc_kernels_vs_torch():
+    """csrc/post.hip through components/postproc.py: resize_concat (nearest + concat, extract_feature.py:113-125), avg_pool
+    (`feature_resize`, feature_extractor.py:51-53), aggregate_maps (AttentionStore, attention.py:141-161) vs ATen / golden."""
+    import torch.nn.functional as F
+    from components.postproc import aggregate_maps, avg_pool, resize_concat
+    g = torch.Generator(device="cuda").manual_seed(0)
+    cl = lambda t: t.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)          # channels-last storage, like every hook
+    feats = [cl(torch.randn(3, 70, 12, 12, device="cuda", generator=g).half()), torch.randn(3, 64, 160, 160, device="cuda", generator=g).half(),
+             cl(torch.randn(3, 8, 40, 40, device="cuda", generator=g)), cl(torch.randn(3, 130, 53, 53, device="cuda", generator=g).half())]
+    got = resize_concat(feats)
+    ref = torch.cat([F.interpolate(v.float(), 160).half() for v in feats], dim=1)
+    assert got.shape == (3, 272, 160, 160) and torch.equal(got, ref)                # byte-exact (incl. non-integer ratios 53 -> 160)
+    x = cl(torch.randn(2, 320, 32, 48, device="cuda", generator=g).half())
+    for r in (2, 4):
+        p = avg_pool(x, r)
+        assert p.shape == (2, 320, 32 // r, 48 // r)
+        assert torch.allclose(p.float(), F.adaptive_avg_pool2d(x.float(), (32 // r, 48 // r)), atol=2e-3)
+    from test_host_cpu import _attn_golden
+    from oracle import attn_agg_ref as AR
+    meta, maps, cases = _attn_golden()
+    for sel, want in cases:
+        by_cat = {c: [m.cuda() for h, m in maps if AR.category_of(h) == c and meta["min_size"] ** 2 <= m.shape[2] <= meta["max_size"] ** 2]
+                  for c in sel}
+        out = aggregate_maps(by_cat, meta["out_size"])
+        assert out.is_cuda and out.dtype == torch.float16 and torch.allclose(out.float().cpu(), want, atol=1e-3)
