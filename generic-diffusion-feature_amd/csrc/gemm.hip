@@ -28,6 +28,7 @@
 #include "kernels.h"
 #include <type_traits>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <mutex>
@@ -886,7 +887,8 @@ static hipError_t launch_t(const GemmParams& p, hipStream_t s) {
   q.sb_gm = q.sb_gn = 0;
   if (!p.no_superblock) {
     const int conc = 32 * ((BM == 256) ? 1 : 2);         // workgroups one XCD keeps resident (32 CUs x 1 or 2)
-    for (int gn = 4; gn >= 2; gn >>= 1) {
+    static const int gn_max = [] { const char* e = getenv("GDF_SB_GN_MAX"); return e ? atoi(e) : 4; }();   // diagnostics: widest super-block
+    for (int gn = gn_max; gn >= 2; gn >>= 1) {
       const int gm = conc / gn;
       if (tiles_n % gn == 0 && tiles_m % gm == 0 && (tiles_m / gm) * (tiles_n / gn) >= 8 && tiles_n > gn) {
         q.sb_gm = gm; q.sb_gn = gn;
