@@ -205,6 +205,19 @@ def attention_map_ids(cfg, all_ids, categories, lat, min_size, max_size):
     return out
 
 
+def dit_attention_map_ids(all_ids, categories, grid, min_size, max_size):
+    """PixArt / DiT: the reference registers every attention layer with place_in_unet='up' and an AttentionStore(img/32, img/8)
+    (components/attention.py:567-590), so `up_cross` / `up_self` collect every block's map when the token grid is in range."""
+    out = {c: [] for c in categories}
+    if min_size <= grid <= max_size:
+        for i in all_ids:
+            if i.endswith('-cross-map') and 'up_cross' in out:
+                out['up_cross'].append(i)
+            elif i.endswith('-self-map') and 'up_self' in out:
+                out['up_self'].append(i)
+    return out
+
+
 def aggregate_attention(maps_by_category, out_size):
     """Reference AttentionStore.aggregate_attention (components/attention.py:141-161) + diffusion_feature.py:492-500:
     head-mean maps (B,Q,K) -> (B,K,h,w), averaged over the layers of the same category and size, nearest-resized to

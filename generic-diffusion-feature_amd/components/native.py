@@ -821,6 +821,8 @@ class NativePixArtTransformer(_NativeModel):
         self._plans = {}
         self.dtype = torch.float16
         self.io_dtype = torch.float16
+        self.extra_hook_ids = []         # '-map' hooks FeatureExtractor needs internally (aggregated `attention=` feature)
+        self.last_extra = {}
         self.config = types.SimpleNamespace(in_channels=cfg["in_channels"], sample_size=cfg["sample_size"],
                                             out_channels=cfg["out_channels"])
 
@@ -892,11 +894,15 @@ class NativePixArtTransformer(_NativeModel):
         akw = added_cond_kwargs or {}
         if akw.get("resolution") is not None or akw.get("aspect_ratio") is not None:
             raise NotImplementedError("PixArt-alpha micro-conditioning (use_additional_conditions) is not native")
-        out, hooks = self.forward_raw(hidden_states, encoder_hidden_states, timestep, encoder_attention_mask,
-                                      hook_ids=self.requested_ids())
+        ids = self.requested_ids()
+        have = set(ids)
+        ids = ids + [i for i in self.extra_hook_ids if i not in have]
+        out, hooks = self.forward_raw(hidden_states, encoder_hidden_states, timestep, encoder_attention_mask, hook_ids=ids)
+        self.last_extra = {k: v for k, v in hooks.items() if k in set(self.extra_hook_ids)}
         if self.feature_store is not None:
             for hid, tens in hooks.items():
-                self.feature_store.store(tens, hid)
+                if hid in have:
+                    self.feature_store.store(tens, hid)
         if return_dict:
             return types.SimpleNamespace(sample=out)
         return (out,)

@@ -108,7 +108,7 @@ def aggregate_maps(maps_by_category, out_size):
         out = torch.empty(B, ktot, out_size, out_size, dtype=torch.float16, device=dev)
         off = 0
         for size, lst in groups:
-            assert len(lst) <= 16, "more than 16 maps in one (category, size) group"     # SDXL up_cross @ 32x32: 3 x 10 blocks? no: <= 10
+            assert len(lst) <= 32, "more than 32 maps in one (category, size) group"     # SDXL up_* @ 32x32: 3 x 10 blocks = 30; PixArt: 28
             lst = [m.contiguous() for m in lst]
             _, heads, Q, K = lst[0].shape
             mean = torch.empty(B, Q, K, dtype=torch.float32, device=dev)

@@ -216,7 +216,7 @@ hipError_t launch_resize_concat(const half_t* s16, const float* s32, long sb, lo
                                 half_t* out, int Ctot, int coff, int S, hipStream_t s);
 // r x r mean of a channels-last hook (B,C,H,W; strides sb, 1, sy, sx) -> (B, H/r, W/r, C) fp16
 hipError_t launch_avg_pool(const half_t* src, long sb, long sy, long sx, int B, int C, int H, int W, int r, half_t* out, hipStream_t s);
-// mean over heads and over n <= 16 maps (B, heads, Q, K) fp16 -> (B, Q, K) fp32
+// mean over heads and over n <= 32 maps (B, heads, Q, K) fp16 -> (B, Q, K) fp32
 hipError_t launch_maps_mean(const half_t* const* maps, int n, int B, int heads, int Q, int K, float* out, hipStream_t s);
 
 // ------------------------------------------------------------------------------------------------

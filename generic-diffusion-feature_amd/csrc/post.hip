@@ -97,9 +97,9 @@ hipError_t launch_avg_pool(const half_t* src, long sb, long sy, long sx, int B, 
   return hipGetLastError();
 }
 
-// mean over heads and over `n` maps of one (category, size) group: maps[l] (B, heads, Q, K) fp16 contiguous ->
+// mean over heads and over `n` <= 32 maps of one (category, size) group: maps[l] (B, heads, Q, K) fp16 contiguous ->
 // out (B, Q, K) fp32 (= the channels-last image of the (B, K, sqrt Q, sqrt Q) tensor resize_concat_kernel then consumes)
-struct MapPtrs { const half_t* p[16]; };
+struct MapPtrs { const half_t* p[32]; };
 __global__ __launch_bounds__(256) void maps_mean_kernel(MapPtrs m, int n, int heads, long QK, float* out, long total) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;      // (b, q*K + k)
   if (i >= total) return;
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void maps_mean_kernel(MapPtrs m, int n, int he
 }
 
 hipError_t launch_maps_mean(const half_t* const* maps, int n, int B, int heads, int Q, int K, float* out, hipStream_t s) {
-  if (n < 1 || n > 16 || heads < 1) return hipErrorInvalidValue;
+  if (n < 1 || n > 32 || heads < 1) return hipErrorInvalidValue;
   MapPtrs m{};
   for (int l = 0; l < n; ++l) m.p[l] = maps[l];
   const long QK = (long)Q * K, total = (long)B * QK;

@@ -16,7 +16,7 @@ import torch.nn.functional as F
 
 from components.models import get_diffusion_model
 from components.feature_extractor import (ATTENTION_CATEGORIES, aggregate_attention, attention_map_ids,
-                                          prepare_feature_extractor)
+                                          dit_attention_map_ids, prepare_feature_extractor)
 
 
 class FeatureExtractor(nn.Module):
@@ -56,8 +56,9 @@ class FeatureExtractor(nn.Module):
         self.pipe = pipe
         self.control_pipe = None
         self.attention_store = None
-        if attention and version == 'flux':
-            raise NotImplementedError("aggregated attention maps of the MMDiT (FluxAttnStoreProcessor) are not native yet")
+        # (version == 'flux' with attention=[...]: the reference registers an AttentionStore but its flux branch of extract()
+        #  returns before the aggregation step (diffusion_feature.py:246-254 vs :492-500), so no 'attn' entry is ever produced —
+        #  accepted and ignored here as well)
         self.scheduler_backup = copy.deepcopy(self.pipe.scheduler)
         self.version = version
         self.img_size = img_size
@@ -172,9 +173,20 @@ class FeatureExtractor(nn.Module):
             self.pipe.unet.extra_hook_ids = [i for ids in attn_ids.values() for i in ids]
 
         if is_dit:                                                                       # reference :466-474
-            self.pipe.transformer(latent_model_input, encoder_hidden_states=prompt_embeds.to(device),
-                                  encoder_attention_mask=prompt_attention_mask.to(device), timestep=t, return_dict=False,
-                                  added_cond_kwargs={'resolution': None, 'aspect_ratio': None})
+            tr = self.pipe.transformer
+            dit_ids = None
+            if self.attention and hasattr(tr, 'extra_hook_ids'):                         # AttentionStore(img/32, img/8), all 'up'
+                grid = latents.shape[-1] // int(tr.cfg.get("patch_size", 2))
+                dit_ids = dit_attention_map_ids(tr.hook_names(), self.attention, grid, self.img_size // 32, self.img_size // 8)
+                tr.extra_hook_ids = [i for ids in dit_ids.values() for i in ids]
+            tr(latent_model_input, encoder_hidden_states=prompt_embeds.to(device),
+               encoder_attention_mask=prompt_attention_mask.to(device), timestep=t, return_dict=False,
+               added_cond_kwargs={'resolution': None, 'aspect_ratio': None})
+            if dit_ids is not None and any(dit_ids.values()):
+                extra = tr.last_extra
+                maps = {c: [extra[i] for i in ids if i in extra] for c, ids in dit_ids.items() if ids}
+                self.feature_store.stored_feats['attn'] = aggregate_attention(maps, self.img_size // 8)      # reference :492-500
+                tr.last_extra = {}
             return self.feature_store.stored_feats
         # ---- the hot path: native UNet forward, hooks written by the kernels (:445-465) ----
         if hasattr(self.pipe.unet, 'shared_ctx'):

@@ -80,7 +80,7 @@ int gdf_op_resize_concat(const void* src, int src_f32, long sb, long sc, long sy
  * hook (strides sb, 1, sy, sx; C % 8 == 0) -> (B, H/r, W/r, C) fp16, fp32 accumulation. */
 int gdf_op_avg_pool(const void* src, long sb, long sy, long sx, int B, int C, int H, int W, int r, void* out, void* stream);
 /* aggregated `attn` feature (components/attention.py:238-244, 141-161): mean over heads (rounded to fp16 like the
- * reference's `attention_probs.mean(1)`), then mean over the n <= 16 maps (B, heads, Q, K) fp16 of one (category, size)
+ * reference's `attention_probs.mean(1)`), then mean over the n <= 32 maps (B, heads, Q, K) fp16 of one (category, size)
  * group -> (B, Q, K) fp32; gdf_op_resize_concat then turns it into the (B, K, img/8, img/8) slice of the feature. */
 int gdf_op_maps_mean(const void* const* maps, int n, int B, int heads, int Q, int K, float* out, void* stream);
 

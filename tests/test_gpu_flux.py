@@ -354,3 +354,19 @@ def test_flux_range_beyond_fp16_bf16_matches_fp16_saturates():
     for k in ids:
         assert torch.isfinite(hooks16[k].float()).all(), k                           # saturated arithmetic, never inf / NaN
     assert torch.isfinite(out16.float()).all()
+
+
+def test_flux_attention_argument_is_accepted_and_ignored():
+    """Reference quirk: FeatureExtractor(version='flux', attention=[...]) registers an AttentionStore, but the flux branch of
+    extract() returns before the aggregation step (diffusion_feature.py:246-254 vs :492-500): no 'attn' entry.  Same here."""
+    import numpy as np
+    from PIL import Image
+    import diffusion_feature
+    from components.models import SyntheticFluxPipe
+    arch = FR.tiny_arch(num_layers=1, num_single_layers=1)
+    pipe = SyntheticFluxPipe("cuda:0", seed=0, cfg=arch, n_txt=16)
+    df = diffusion_feature.FeatureExtractor(layer={"vit-block0-out": True}, version='flux', img_size=128, device='cuda:0',
+                                            external_model=pipe, attention=['up_cross'])
+    img = Image.fromarray((np.random.RandomState(0).rand(90, 70, 3) * 255).astype(np.uint8))
+    feats = df.extract("a photo of a cat", batch_size=1, image=[img], t=10)
+    assert list(feats.keys()) == ["vit-block0-out"]

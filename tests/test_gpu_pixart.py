@@ -115,3 +115,28 @@ def test_pixart_early_exit_and_no_mask():
     assert list(outs[True].keys()) == list(st.feats.keys())
     for k, ref in st.feats.items():
         assert torch.equal(outs[True][k], outs[False][k]) and rel_l2(outs[True][k], ref) < TOL, k
+
+
+def test_pixart_aggregated_attention_feature():
+    """`attention=[...]` on the DiT branch (reference components/attention.py:567-590: every block registered as 'up',
+    AttentionStore(img/32, img/8); diffusion_feature.py:492-500): feats['attn'] = head mean -> mean over the 2 blocks ->
+    nearest resize to img/8, checked against the same aggregation of the explicitly hooked maps done with torch."""
+    import numpy as np
+    import torch.nn.functional as F
+    from PIL import Image
+    import diffusion_feature
+    from components.models import SyntheticPixartPipe
+    arch = PR.tiny_arch(heads=8, num_layers=2, sample_size=16)
+    pipe = SyntheticPixartPipe("pixart-sigma", "cuda:0", seed=0, cfg=arch, n_txt=24)
+    layer = {"vit-block0-cross-map": True, "vit-block1-cross-map": True, "vit-block1-out": True}
+    df = diffusion_feature.FeatureExtractor(layer=layer, version='pixart-sigma', img_size=128, device='cuda:0', external_model=pipe,
+                                            attention=['up_cross'])
+    prompt = df.encode_prompt('a photo of a cat on a mat')
+    img = Image.fromarray((np.random.RandomState(0).rand(90, 70, 3) * 255).astype(np.uint8))
+    feats = df.extract(prompt, batch_size=2, image=[img, img], t=100)
+    assert list(feats.keys()) == ["vit-block0-cross-map", "vit-block1-cross-map", "vit-block1-out", "attn"]
+    maps = [feats["vit-block0-cross-map"].float(), feats["vit-block1-cross-map"].float()]        # (B, heads, 64, 24)
+    avg = torch.stack([m.mean(1).half().float() for m in maps]).mean(0)                           # (B, 64, 24)
+    want = F.interpolate(avg.reshape(2, 8, 8, 24).permute(0, 3, 1, 2), size=(16, 16))
+    assert feats["attn"].shape == (2, 24, 16, 16) and feats["attn"].dtype == torch.float16
+    assert torch.allclose(feats["attn"].float(), want, atol=1e-3)
