@@ -9,6 +9,7 @@ Stated tolerances (north star: 1e-3):
   * SD1.5 512^2 (narrower layers average less)    <= 1.1e-3, except `ffn-inner` and `unet-out`      <= 1.35e-3;
     `*-map` (softmax of q k^T: exponentiates the q / k errors)                                        <= 1.5e-3
   * Flux widths: compute_dtype float16            <= 6e-4;   bfloat16 (the reference's dtype, 8 mantissa bits) <= 4e-3
+  * SDXL config_xl_full maps (140 `*-map` ids, B = 1) <= 1.5e-3;  PixArt-Sigma widths <= 6e-4;  VAE encoder 1024^2 latents <= 1e-3
   * and for the UNets: every hook within 1.15x (+2e-5) of the fp16-OPERAND FLOOR (oracle/operand_floor.py) — the error of
     the fp32 oracle with nothing but its matmul operands rounded to fp16, i.e. what any fp16-MFMA implementation commits at
     best.  `ffn-inner` (h * gelu(g): the product of two GEMM outputs that each carry the stream error) and `unet-out` sit
@@ -205,3 +206,83 @@ def test_flux_full_width_batch8(dt):
         print(f"\n[flux widths B=8 {dt}, {len(ids)} hooks] worst {worst} = {errs[worst]:.2e}")
         assert errs[worst] <= tol, (worst, errs[worst])
         del hooks, out
+
+
+def test_sdxl_1024_full_layer_set_with_maps_batch1():
+    """config_xl_full (every one of the 612 ids incl. the `*-map` hooks: 8.3 GB of hooks per image) on the TRUE SDXL UNet at
+    1024^2, batch 1: the eager-processor path (attn_map_kernel at 64-wide heads, 4096^2 and 1024^2 maps) vs the oracle."""
+    _threads()
+    arch = R.ARCHS["xl"]
+    P = R.synth_params(arch, seed=0)
+    I = R.synth_inputs(arch, 1, 128, seed=1)
+    ids = R.stored_hook_ids(arch)
+    assert len(ids) == 612
+    maps = [i for i in ids if i.endswith("-map")]
+    # the non-map hooks of this configuration are covered (at batch 16) by test_sdxl_1024_batch16_all_non_map_hooks; requesting
+    # any map switches every attention layer to the map-materialising kernel, so a sample of non-map hooks rides along
+    some = [i for i in ids if not i.endswith("-map")][::13]
+    want = [i for i in ids if i in set(maps) | set(some)]
+    ref = _oracle(arch, P, I, want, want_map=True)
+    u = _native(arch, P)
+    g = lambda k: I[k].cuda()
+    _, hooks = u.forward_raw(g("sample"), g("timestep"), g("ctx"), g("text_embeds"), g("time_ids"), hook_ids=want)
+    torch.cuda.synchronize()
+    assert list(hooks.keys()) == want
+    errs = {k: max(_rel_each(hooks[k], ref[k])) for k in want}
+    ev = sorted(errs.values())
+    print(f"\n[sdxl 1024^2 B=1, {len(maps)} maps + {len(some)} other hooks] median {ev[len(ev) // 2]:.2e} worst {ev[-1]:.2e}")
+    _check(errs, None, lambda kd: 1.5e-3 if kd == "map" else (1.3e-3 if kd in ("ffn-inner", "unet-out") else 1.0e-3))
+
+
+def test_pixart_sigma_full_width_batch4():
+    """PixArt-Sigma-XL-2 widths (16 heads x 72, caption width 4096, 4096 image + 300 caption tokens, ragged caption mask) with
+    a reduced stack (3 of 28 blocks), batch 4 on two samples: every non-map hook vs oracle/pixart_ref.py."""
+    _threads()
+    from oracle import pixart_ref as PR
+    from components.native import NativePixArtTransformer
+    arch = dict(PR.ARCH_PIXART_SIGMA); arch.update(num_layers=3)
+    P = PR.synth_params(arch, seed=0)
+    I = PR.synth_inputs(arch, 2, 128, 300, seed=1, valid=[300, 117])
+    st = PR.Store(None)
+    with torch.no_grad():
+        y = PR.pixart_forward(P, arch, I["hidden_states"], I["encoder_hidden_states"], I["timestep"], I["encoder_attention_mask"], st,
+                              want_map=False)
+    net = NativePixArtTransformer(arch, device="cuda:0")
+    net.load_state_dict({k: v.half() for k, v in P.items()})
+    rep = lambda t: torch.cat([t, t], 0).cuda()                       # batch 4 = the two samples twice
+    ids = PR.hook_ids(arch)
+    out, hooks = net.forward_raw(rep(I["hidden_states"]), rep(I["encoder_hidden_states"]), rep(I["timestep"]),
+                                 rep(I["encoder_attention_mask"]), hook_ids=ids)
+    torch.cuda.synchronize()
+    assert list(hooks.keys()) == ids
+    errs = {k: max(_rel_each(hooks[k], st.feats[k])) for k in ids}
+    errs["output"] = max(_rel_each(out, y))
+    worst = max(errs, key=errs.get)
+    print(f"\n[pixart-sigma widths B=4, {len(ids)} hooks] worst {worst} = {errs[worst]:.2e}")
+    assert errs[worst] <= 6.0e-4, (worst, errs[worst])
+
+
+def test_vae_encode_1024_batch2():
+    """The step before the hot path at its BASELINE size: SD / SDXL AutoencoderKL encoder (128-256-512-512) on two 1024^2 images,
+    posterior sample + Euler noise-add (SDXL scalars) vs oracle/vae_ref.py."""
+    _threads()
+    from oracle import vae_ref as VR
+    from components.native import NativeVAEEncoder
+    from helpers import rel_l2
+    arch = VR.ARCH_SD_VAE
+    P = VR.synth_params(arch, seed=0)
+    gen = torch.Generator().manual_seed(1)
+    image = (torch.rand(2, 3, 1024, 1024, generator=gen) * 2 - 1).half().float()
+    eps = torch.randn(2, 4, 128, 128, generator=gen).half().float()
+    noise = torch.randn(2, 4, 128, 128, generator=gen).half().float()
+    kw = dict(scaling_factor=0.13025, noise_a=1.0, noise_b=0.7, input_scale=0.82)
+    with torch.no_grad():
+        ref = VR.prepare_latents(P, arch, image, eps, noise, kw["scaling_factor"], kw["noise_a"], kw["noise_b"], kw["input_scale"])
+    enc = NativeVAEEncoder(dict(in_channels=3, latent_channels=4, block_out_channels=arch["block_out_channels"], layers_per_block=2,
+                                use_quant_conv=1), device="cuda:0")
+    enc.load_vae_state_dict({k: v.half() for k, v in P.items()})
+    got = enc.encode(image, eps=eps, noise=noise, **kw)
+    torch.cuda.synchronize()
+    e = rel_l2(got, ref)
+    print(f"\n[vae 1024^2 B=2] rel L2 {e:.2e}")
+    assert got.shape == ref.shape == (2, 4, 128, 128) and e <= 1e-3, e
