@@ -410,6 +410,31 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
     wait_tile();                     // this wave's share of K-tile 0
     bar();                           // ... everyone's
     if (g1) bar();                   // group 1 runs one barrier behind group 0
+#if !defined(GDF_PHASES4)
+    // TWO phases of 32 MFMAs per K-tile (round 2; the round-1 schedule below ran four phases of 16).  Per barrier interval one
+    // group multiplies while the other reads fragments / issues DMA; the hand-over itself costs ~115 cycles per interval
+    // (MFMA + barrier skeleton without reads and DMA: 70 % of the MFMA peak with 16-MFMA clusters, tools/ablate_gemm.py), so
+    // twice as long clusters halve that overhead with the SAME registers (A stays resident, the B halves take turns in b8), the
+    // same accumulation order (bit-identical results) and the same prefetch depth (the three youngest half-tiles stay in flight
+    // at the one counted wait).  Measured, 4 -> 2 phases: Flux QKV 1285 -> 1357, proj_out 1395 -> 1483, 8192^3 1412 -> 1501
+    // (hipBLASLt: 1491), SDXL GEGLU shape 1128 -> 1170..1186 TFLOP/s.  Splitting the DMA issue between the read slot and the
+    // middle of the MFMA cluster gives the gain back (1285 -> 1293): LDS-DMA issue belongs in the read role.
+    //   K-tile T (buffer T & 1)   phase 1: read A (all 64 rows), B cols 0-63      stage B-hi of T+1                  32 MFMAs (A, B-lo)
+    //                             phase 2: read B cols 64-127                     stage A-lo, A-hi, B-lo of T+2,     32 MFMAs (A, B-hi)
+    //                                                                            wait vmcnt(6) = tile T+1 has landed
+    // Slot lifetimes: A-lo is read by group 0 only and A-hi by group 1 only, both in phase 1 — group 1 one barrier after group 0 —
+    // and B-lo by both; every read is retired (lgkmcnt) before the reader's next barrier, so all three are free from phase 2's
+    // read slot of either group on; B-hi (read in phase 2) is free from the next tile's phase 1 on.
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = kt & 1;
+      const char* sA = smem + cur * STAGE;
+      const char* sB = sA + A_TILE;
+      rd_a(sA); rd_b(sB, 0); stage(kt + 1, cur ^ 1, BHI);
+      bar(); lgkm0(); mma_q(Q0, Q0); mma_q(Q1, Q0); bar();
+      rd_b(sB, 1); stage(kt + 2, cur, ALO); stage(kt + 2, cur, AHI); stage(kt + 2, cur, BLO); wait_tile(); lgkm0();
+      bar(); mma_q(Q1, Q1); mma_q(Q0, Q1); bar();
+    }
+#else
     for (int kt = 0; kt < nk; ++kt) {
       const int cur = kt & 1;
       const char* sA = smem + cur * STAGE;
@@ -427,6 +452,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
       stage(kt + 2, cur, BLO); wait_tile();
       bar(); mma_q(Q0, Q1); bar();
     }
+#endif
     if (!g1) bar();
     wait_vmcnt<0>();                 // the over-staged tiles must not land in the epilogue's staging area
   } else if constexpr (STAGES == 9) {
@@ -536,11 +562,60 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
     constexpr std::integral_constant<int, 3> P3{};
     const bool g1 = wave >= 4;
 
+    // Dense A operand: TWO phases of 40 MFMAs per K-tile, A read by 64-row halves (a8: 16 more VGPRs than the quarter form,
+    // 253 in all; the conv form would need 271 and keeps the four-phase schedule).  Same reasoning and same bit-identical
+    // results as the 256x256 tile above; measured 4 -> 2 phases: 8192x7680x8192 1390..1426 -> 1471..1478, SDXL qkv 1104..1122 ->
+    // 1158..1162, ff_out 1341..1362 -> 1404, attn2_q 1057..1072 -> 1096 TFLOP/s.
+    //   phase 1: read B, A rows 0-63 of the wave tile     stage B_2, A_2, A_3 of T+1                        40 MFMAs
+    //   phase 2: read A rows 64-127                       stage B_1, A_0, A_1 of T+2, wait vmcnt(5)         40 MFMAs
+    // (vmcnt(5): the five instructions just issued may be in flight, everything older — all of tile T+1 — has landed)
+#if defined(GDF_PHASES4) || defined(GDF_ABLATE)
+    constexpr bool TWO_PHASE = false;
+#else
+    constexpr bool TWO_PHASE = (MODE == A_DENSE);
+#endif
     stage_b(0, 0, B1); stage_b(0, 0, B2); stage_a(0, 0, 0); stage_a(0, 0, 1); stage_a(0, 0, 2); stage_a(0, 0, 3);
-    stage_b(1, 1, B1); stage_b(1, 1, B2); stage_a(1, 1, 0); stage_a(1, 1, 1); stage_a(1, 1, 2);
-    wait_vmcnt<8>();                 // this wave's share of K-tile 0
+    if constexpr (TWO_PHASE) {
+      stage_b(1, 1, B1); stage_a(1, 1, 0); stage_a(1, 1, 1);
+      wait_vmcnt<5>();
+    } else {
+      stage_b(1, 1, B1); stage_b(1, 1, B2); stage_a(1, 1, 0); stage_a(1, 1, 1); stage_a(1, 1, 2);
+      wait_vmcnt<8>();               // this wave's share of K-tile 0
+    }
     bar();                           // ... everyone's
     if (g1) bar();                   // group 1 runs one barrier behind group 0
+    if constexpr (TWO_PHASE) {
+      f16x8 a8[4][2];
+      auto rd_ah = [&](const char* sA_, int h) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int kk = 0; kk < 2; ++kk) {
+            const int r = wm * WTM + (h * 4 + i) * 16 + frow, kc = kk * 4 + fk;
+            a8[i][kk] = *(const f16x8*)(sA_ + r * 128 + ((kc ^ (r & 7)) << 4));
+          }
+      };
+      auto mma_h = [&](auto hh) {
+        constexpr int H = decltype(hh)::value;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 5; ++j)
+              acc[H * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a8[i][kk], b10[j][kk], acc[H * 4 + i][j], 0, 0, 0);
+      };
+      for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        const char* sA = smem + cur * STAGE;
+        const char* sB = sA + A_TILE;
+        rd_ball(sB); rd_ah(sA, 0); stage_b(kt + 1, cur ^ 1, B2); stage_a(kt + 1, cur ^ 1, 2); stage_a(kt + 1, cur ^ 1, 3); lgkm0();
+        bar(); mma_h(P0); bar();
+        rd_ah(sA, 1); stage_b(kt + 2, cur, B1); stage_a(kt + 2, cur, 0); stage_a(kt + 2, cur, 1); wait_vmcnt<5>(); lgkm0();
+        bar(); mma_h(P1); bar();
+      }
+    } else {
+#if !defined(GDF_ABLATE)
     for (int kt = 0; kt < nk; ++kt) {
       const int cur = kt & 1;
       const char* sA = smem + cur * STAGE;
@@ -553,6 +628,38 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
       bar(); mma_q(P2); bar();
       rd_aq(sA, 3); stage_a(kt + 2, cur, 1); stage_a(kt + 2, cur, 2); wait_vmcnt<8>(); lgkm0();
       bar(); mma_q(P3); bar();
+    }
+#else
+    // ---- diagnostics build (tools/ablate_gemm.sh): the same loop with parts compiled out; results are garbage, timing is the point ----
+    //   bit 0: no fragment reads   bit 1: no LDS-DMA   bit 2: no workgroup barriers   bit 3: no MFMAs
+    constexpr int ABL = GDF_ABLATE;
+    rd_ball(smem + A_TILE); rd_aq(smem, 0);
+    auto keep = [&]() {
+#pragma unroll
+      for (int j = 0; j < 5; ++j) { asm volatile("" : "+v"(b10[j][0])); asm volatile("" : "+v"(b10[j][1])); }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) { asm volatile("" : "+v"(a4[i][0])); asm volatile("" : "+v"(a4[i][1])); }
+    };
+    auto xbar = [&]() { if constexpr (!(ABL & 4)) bar(); };
+    auto xmma = [&](auto q) { if constexpr (!(ABL & 8)) mma_q(q); else keep(); };
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = kt & 1;
+      const char* sA = smem + cur * STAGE;
+      const char* sB = sA + A_TILE;
+      if constexpr (!(ABL & 1)) { rd_ball(sB); rd_aq(sA, 0); } else keep();
+      if constexpr (!(ABL & 2)) stage_a(kt + 1, cur ^ 1, 3);
+      lgkm0(); xbar(); xmma(P0); xbar();
+      if constexpr (!(ABL & 1)) rd_aq(sA, 1); else keep();
+      if constexpr (!(ABL & 2)) stage_b(kt + 2, cur, B1);
+      lgkm0(); xbar(); xmma(P1); xbar();
+      if constexpr (!(ABL & 1)) rd_aq(sA, 2); else keep();
+      if constexpr (!(ABL & 2)) { stage_b(kt + 2, cur, B2); stage_a(kt + 2, cur, 0); }
+      lgkm0(); xbar(); xmma(P2); xbar();
+      if constexpr (!(ABL & 1)) rd_aq(sA, 3); else keep();
+      if constexpr (!(ABL & 2)) { stage_a(kt + 2, cur, 1); stage_a(kt + 2, cur, 2); wait_vmcnt<8>(); }
+      lgkm0(); xbar(); xmma(P3); xbar();
+    }
+#endif
     }
     if (!g1) bar();
     wait_vmcnt<0>();                 // the over-staged tiles must not land in the epilogue's staging area
