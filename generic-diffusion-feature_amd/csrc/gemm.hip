@@ -75,15 +75,26 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// exact (erf) GELU.  erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, far below the fp16 output rounding):
-// one v_exp_f32 + one v_rcp_f32 instead of libm's branchy erff (the GEGLU epilogue evaluates 32 of these per lane).
-__device__ __forceinline__ float gelu_erf(float x) {
-  const float z = fabsf(x) * 0.70710678118654752f;
-  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);     // v_rcp_f32 (1 ulp), not the IEEE division sequence
-  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-  const float erf_abs = 1.0f - poly * __expf(-z * z);
-  const float erf_x = copysignf(erf_abs, x);
-  return 0.5f * x * (1.0f + erf_x);
+// exact (erf) GELU, two values at a time (the GEGLU epilogue evaluates 64 per lane; at 2 waves per SIMD the VALU time of the
+// round-1 form — Abramowitz-Stegun 7.1.26 with one v_rcp_f32 + one v_exp_f32 and ~15 scalar-float ops — was 5.4 us of a 37-us
+// tile, tools/trace_gemm.py).  With u = |x| and q(u) = 1 - Phi(u) = erfc(u / sqrt 2) / 2:
+//     gelu(x) = x Phi(x) = max(x, 0) - u q(u),        q(u) = 2^P(u),  P = degree-7 fit of log2 q on [0, 5.5], P(0) = -1
+// ONE transcendental, and the Horner chain + the final ops run as packed fp32 (v_pk_fma_f32: two lanes' worth per issue).
+// |gelu - exact| <= 6.5e-7 absolute and <= 5.4e-6 relative on x > -4.5 (fp16 output rounding: 4.9e-4); u is clamped at 5.5,
+// beyond which q < 2e-8 (coefficients: Lawson-weighted least squares on 4000 Chebyshev nodes, checked on 400k points in fp32).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
+  const f32x2 u = {fminf(fabsf(x[0]), 5.5f), fminf(fabsf(x[1]), 5.5f)};
+  f32x2 P = u * -1.735116371e-06f + 5.974406668e-05f;
+  P = P * u + -9.168680408e-04f;
+  P = P * u + 8.457269520e-03f;
+  P = P * u + -5.386104062e-02f;
+  P = P * u + -4.585619271e-01f;
+  P = P * u + -1.151209950e+00f;
+  P = P * u + -1.0f;
+  const f32x2 q = {__builtin_amdgcn_exp2f(P[0]), __builtin_amdgcn_exp2f(P[1])};
+  const f32x2 r = {fmaxf(x[0], 0.f), fmaxf(x[1], 0.f)};
+  return r - u * q;
 }
 
 // XCD-aware bijective remap: consecutive tiles (which share the same A row-block) land on one XCD's L2.
@@ -107,6 +118,17 @@ __device__ __forceinline__ float gelu_tanh(float x) {
 // QKN: compile the fused RMSNorm(q) / RMSNorm(k) + RoPE epilogue (GemmParams::qkn_*; 256x256 MMDiT QKV projections only).  It is
 // its own instantiation because its live state (cos / sin rows, norm gains) on top of the gated-residual operands pushed the
 // one-size-fits-all MMDiT epilogue over 256 VGPRs (9 spilled, 40 B of scratch per lane in EVERY 256x256 MMDiT GEMM).
+// diagnostics build (tools/trace_gemm.sh, -DGDF_TRACE): workgroup time stamps (100 MHz s_memrealtime) at kernel entry, after the
+// prologue's DMA issue, when K-tile 0 has landed, after the main loop and after the epilogue, + the CU the workgroup ran on
+#if defined(GDF_TRACE)
+__device__ unsigned long long gdf_trace[16384 * 8];
+#define GDF_TR(i) do { if (threadIdx.x == 0) gdf_trace[(vb & 16383) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define GDF_TR_ID() do { if (threadIdx.x == 0) gdf_trace[(vb & 16383) * 8 + 6] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | __builtin_amdgcn_s_getreg(63492); } while (0)
+#else
+#define GDF_TR(i)
+#define GDF_TR_ID()
+#endif
+
 template <int MODE, int BM, int BN, int STAGES, bool GEGLU, bool DIT, bool BF = false, bool QKN = false>
 __device__ __forceinline__ void gemm_body(const GemmParams& p) {
   static_assert(!BF || DIT, "bf16 operands exist on the MMDiT path only");
@@ -133,7 +155,17 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tiles_n = (p.N + BN - 1) / BN;
-  const int nblk = gridDim.x;
+  const int nblk = ((p.M + BM - 1) / BM) * tiles_n;
+  // Persistent form: the launcher may start fewer workgroups than tiles (one per CU for the two-group 256x256 kernels); workgroup b
+  // then walks the tiles b, b + gridDim.x, ... — with gridDim.x a multiple of 8 these are the tiles the hardware would have given the
+  // same XCD round after round, so the super-block order below is unchanged.  Saves the workgroup relaunch between rounds
+  // (tools/trace_gemm.py: 2.6 us from a tile's last instruction to the first of the next tile on that CU, of ~37 us per tile at
+  // K = 1280) and the kernel-argument / descriptor setup.  A plain launch has gridDim.x == nblk: one trip.
+  // Compiled as a loop only where the register budget has room for the loop-carried lane constants (256x320: 9-11 VGPRs spilled).
+  constexpr bool PERSIST = (STAGES == 8);
+  int vb = blockIdx.x;
+  do {
+  GDF_TR(0); GDF_TR_ID();
   int tile_m, tile_n;
   if (p.sb_gn > 0) {
     // 2-D super-block order: the workgroups one XCD runs concurrently cover sb_gm x sb_gn tiles, so its private L2
@@ -146,18 +178,18 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
     const int nsb = (nblk / conc);
     const int grouped = (nsb >> 3) * 8 * conc;            // workgroups covered by whole groups of 8 super-blocks
     int sb, li;
-    if ((int)blockIdx.x < grouped) {
-      const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    if (vb < grouped) {
+      const int xcd = vb & 7, j = vb >> 3;
       sb = (j / conc) * 8 + xcd; li = j - (j / conc) * conc;
     } else {
-      const int t = blockIdx.x - grouped;
+      const int t = vb - grouped;
       sb = (nsb >> 3) * 8 + t / conc; li = t - (t / conc) * conc;
     }
     const int sbr = sb / sbn, sbc = sb - sbr * sbn;
     tile_m = sbr * p.sb_gm + li / p.sb_gn;
     tile_n = sbc * p.sb_gn + li % p.sb_gn;
   } else {
-    const int t = xcd_remap(blockIdx.x, nblk);
+    const int t = xcd_remap(vb, nblk);
     tile_m = t / tiles_n; tile_n = t - tile_m * tiles_n;
   }
   const int m0 = tile_m * BM, n0 = tile_n * BN;
@@ -200,6 +232,9 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
   const int cpb = (MODE == A_CONV3) ? p.Cin / BK : 1;  // K-tiles per filter tap
   const int IH = p.ups ? 2 * p.H : p.H, IW = p.ups ? 2 * p.W : p.W;
 
+  // byte offset of K-tile kt inside a dense row.  The two-group schedules also stage the tiles nk, nk + 1 (so that the counted
+  // waits are the same in every iteration): those get an out-of-range offset — zero fill, no L2 / HBM traffic (scalar select)
+  auto koff = [&](int kt) -> uint32_t { return kt < nk ? (uint32_t)kt * 128u : OOB; };
   int tap = 0, cb = 0;                                 // filter tap / channel block of the NEXT tile to issue
   auto issue = [&](int kt, int buf) {
     char* sA = smem + buf * STAGE;
@@ -340,7 +375,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
         for (int j = 0; j < 2; ++j) {
           uint32_t off;
           if (MODE == A_DENSE) {
-            off = ha[W][j] + (uint32_t)kt * 128u;
+            off = ha[W][j] + koff(kt);
           } else {                                             // K-tiles are tap-major, cpb tiles per filter tap
             const int tp = kt / cpb, cbk = kt - tp * cpb;
             const int ky = tp / 3, kx = tp - ky * 3;
@@ -355,8 +390,8 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
         constexpr int H = W - 2;
         char* base = smem + buf * STAGE + A_TILE + H * (BHALF * 128) + hbq[H] * 1024;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) glds16(rsB, base + j * 1024, hb[H][j] + (uint32_t)kt * 128u);
-        if (B3 && (g1 == (H == 1))) glds16(rsB, base + 2 * 1024, hb[H][2] + (uint32_t)kt * 128u);
+        for (int j = 0; j < 2; ++j) glds16(rsB, base + j * 1024, hb[H][j] + koff(kt));
+        if (B3 && (g1 == (H == 1))) glds16(rsB, base + 2 * 1024, hb[H][2] + koff(kt));
       }
     };
     // DMA instructions of this wave in the three youngest stagings at the phase-4 wait (A-lo, A-hi, B-lo of tile T+2)
@@ -407,8 +442,10 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
 
     stage(0, 0, ALO); stage(0, 0, AHI); stage(0, 0, BLO); stage(0, 0, BHI);
     stage(1, 1, ALO); stage(1, 1, AHI); stage(1, 1, BLO);
+    GDF_TR(1);
     wait_tile();                     // this wave's share of K-tile 0
     bar();                           // ... everyone's
+    GDF_TR(2);
     if (g1) bar();                   // group 1 runs one barrier behind group 0
 #if !defined(GDF_PHASES4)
     // TWO phases of 32 MFMAs per K-tile (round 2; the round-1 schedule below ran four phases of 16).  Per barrier interval one
@@ -499,7 +536,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
       char* dst = smem + buf * STAGE + ((wave >> 2) * 128 + q * 32 + (wave & 3) * 8) * 128;
       uint32_t off;
       if (MODE == A_DENSE) {
-        off = ua[q] + (uint32_t)kt * 128u;
+        off = ua[q] + koff(kt);
       } else {
         const int tp = kt / cpb, cbk = kt - tp * cpb;
         const int ky = tp / 3, kx = tp - ky * 3;
@@ -516,7 +553,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
 #pragma unroll
       for (int j = (PT ? 3 : 0); j < (PT ? 5 : 3); ++j) {
         const int qi = j < 3 ? wave * 3 + j : 24 + wave * 2 + (j - 3);
-        glds16(rsB, base + qi * 1024, ub[j] + (uint32_t)kt * 128u);
+        glds16(rsB, base + qi * 1024, ub[j] + koff(kt));
       }
     };
     constexpr std::integral_constant<int, 0> B1{};
@@ -575,6 +612,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
     constexpr bool TWO_PHASE = (MODE == A_DENSE);
 #endif
     stage_b(0, 0, B1); stage_b(0, 0, B2); stage_a(0, 0, 0); stage_a(0, 0, 1); stage_a(0, 0, 2); stage_a(0, 0, 3);
+    GDF_TR(1);
     if constexpr (TWO_PHASE) {
       stage_b(1, 1, B1); stage_a(1, 1, 0); stage_a(1, 1, 1);
       wait_vmcnt<5>();
@@ -583,6 +621,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
       wait_vmcnt<8>();               // this wave's share of K-tile 0
     }
     bar();                           // ... everyone's
+    GDF_TR(2);
     if (g1) bar();                   // group 1 runs one barrier behind group 0
     if constexpr (TWO_PHASE) {
       f16x8 a8[4][2];
@@ -699,6 +738,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
     }
   }
   __syncthreads();   // all waves finished reading the last tile: LDS is free for epilogue staging
+  GDF_TR(3);
 
   // ---- epilogue: per-wave staging of 32-row slabs through LDS ----
   // epilogue operands; the QKN instantiation (QKV projection: bias -> RMSNorm + RoPE -> 16-bit store) has none of the
@@ -808,12 +848,18 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
     for (int i2 = 0; i2 < FPP; ++i2)
 #pragma unroll
       for (int j = 0; j < FNV; ++j)
+        if constexpr (GEGLU) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float x;
-          if (GEGLU) x = (acc[ps * FPP + i2][2 * j][r] + bh[j]) * gelu_erf(acc[ps * FPP + i2][2 * j + 1][r] + bgt[j]);
-          else x = acc[ps * FPP + i2][j][r] * a_sc;
-          st[(i2 * 16 + fk * 4 + r) * SLD + j * 16 + frow] = x;
+          for (int r = 0; r < 4; r += 2) {
+            const f32x2 hh = {acc[ps * FPP + i2][2 * j][r], acc[ps * FPP + i2][2 * j][r + 1]};
+            const f32x2 gg = {acc[ps * FPP + i2][2 * j + 1][r], acc[ps * FPP + i2][2 * j + 1][r + 1]};
+            const f32x2 x = (hh + bh[j]) * gelu_erf2(gg + bgt[j]);
+            st[(i2 * 16 + fk * 4 + r) * SLD + j * 16 + frow] = x[0];
+            st[(i2 * 16 + fk * 4 + r + 1) * SLD + j * 16 + frow] = x[1];
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) st[(i2 * 16 + fk * 4 + r) * SLD + j * 16 + frow] = acc[ps * FPP + i2][j][r] * a_sc;
         }
     // same-wave LDS RAW across lanes: DS ops of one wave execute in order
     __builtin_amdgcn_wave_barrier();
@@ -966,6 +1012,15 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_sched_barrier(0);                   // keep the next pass's prefetch from being hoisted (VGPR pressure)
   }
+  GDF_TR(4);
+  if constexpr (!PERSIST) break;
+  vb += gridDim.x;
+  if (vb >= nblk) break;
+  // every wave is done with the staging area before the next tile's DMA lands.  Raw barrier + lgkmcnt only: __syncthreads() would
+  // also wait (vmcnt) for this tile's global stores, which may drain under the next tile's prologue
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  } while (true);
 }
 
 template <int MODE, int BM, int BN, int STAGES, bool GEGLU>
@@ -976,6 +1031,22 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_kernel(const GemmParams p) {
 template <int BM, int BN, int STAGES, bool BF, bool QKN>
 __global__ __launch_bounds__(BM * 2, 2) void gemm_dit_kernel(const GemmParams p) {
   gemm_body<A_DENSE, BM, BN, STAGES, false, true, BF, QKN>(p);
+}
+
+// workgroups of a persistent launch of a 1-workgroup-per-CU kernel: the CU count of the current device (a multiple of 8 XCDs);
+// GDF_PERSIST=0 (diagnostics) launches one workgroup per tile instead
+static int persist_wgs() {
+  static const int off = [] { const char* e = getenv("GDF_PERSIST"); return e && atoi(e) == 0; }();
+  if (off) return 1 << 30;
+  static std::atomic<int> cus[16];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 1 << 30;
+  int n = cus[dev].load(std::memory_order_relaxed);
+  if (n == 0) {
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8 || (n & 7)) n = 1 << 30;
+    cus[dev].store(n, std::memory_order_relaxed);
+  }
+  return n;
 }
 
 template <int MODE, int BM, int BN, int STAGES, bool GEGLU, bool DIT = false, bool BF = false, bool QKN = false>
@@ -1003,7 +1074,9 @@ static hipError_t launch_t(const GemmParams& p, hipStream_t s) {
       }
     }
   }
-  const dim3 grid(tiles_m * tiles_n, p.batch > 1 ? p.batch : 1);
+  int gx = tiles_m * tiles_n;
+  if (STAGES == 8 && gx > persist_wgs() && !(p.batch > 1)) gx = persist_wgs();   // persistent: one workgroup per CU walks the tiles
+  const dim3 grid(gx, p.batch > 1 ? p.batch : 1);
   if constexpr (DIT) hipLaunchKernelGGL((gemm_dit_kernel<BM, BN, STAGES, BF, QKN>), grid, dim3(BM * 2), smem, s, q);
   else hipLaunchKernelGGL((gemm_kernel<MODE, BM, BN, STAGES, GEGLU>), grid, dim3(BM * 2), smem, s, q);
   return hipGetLastError();
@@ -1059,7 +1132,11 @@ static int pick_variant(const GemmParams& p) {
   // short-K GEMMs with the fp32 residual epilogue (attention out-projections: 10 B/element of epilogue traffic against
   // 20 K-tiles of MFMA work) fill the chip in ONE round of 256x320 tiles, so main loop and epilogue traffic never overlap;
   // 128x160 tiles run 2 workgroups per CU and 2+ rounds (80 vs 89 us at 16384 x 1280 x 1280)
-  if (p.res32 && p.K <= 1536 && p.N % 160 == 0 && tiles320 <= 512) return 160;
+  // (round 2: with the two-phase main loop the 256x320 tile wins again where its tiles fill whole rounds — 16384 x 1280 x 1280
+  // 64.7 vs 77.7 us, 32768 x 640 x 640 47.0 vs 49.8, 65536 x 640 x 640 equal; it still loses at half-filled rounds, 8192 x 1280 x 1280
+  // 47.3 vs 37.3, and at N = 320, tools/bench_res32.py)
+  if (p.res32 && p.K <= 1536 && p.N % 160 == 0 && tiles320 <= 512 &&
+      !(p.N % 320 == 0 && p.N >= 640 && p.K >= 640 && tiles320 % 256 == 0)) return 160;
   if (p.N % 320 == 0) {                                                    // 8-phase: qkv 1113, ff_out 1088, attn2_q 1045, shortcut 1086 (ring: 1051 / 983 / 980 / 1002)
     const double s932 = 1.00 * round_fill(tiles320, 256), s160 = 0.87 * round_fill((long)((p.M + 127) / 128) * (p.N / 160), 512);
     const double s128 = 0.72 * round_fill((long)((p.M + 127) / 128) * ((p.N + 127) / 128), 512);
@@ -1151,3 +1228,9 @@ hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {
 }
 
 }  // namespace gdf
+
+#if defined(GDF_TRACE)
+extern "C" int gdf_debug_trace(unsigned long long* dst, int n_words) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(gdf::gdf_trace), (size_t)n_words * 8, 0, hipMemcpyDeviceToHost);
+}
+#endif

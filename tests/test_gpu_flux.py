@@ -35,7 +35,9 @@ def _region_major(x_txt, x_img):
 
 @pytest.mark.parametrize("M,N,K,variant", [(300, 256, 192, 128), (1024, 512, 256, 1256), (700, 768, 1280, 1256), (520, 64, 256, 128),
                                             # 8-phase main loop: 1, 3 and 20 K-tiles, ragged M / N tiles
-                                            (512, 512, 64, 8256), (700, 768, 192, 8256), (1030, 520, 1280, 8256), (4096, 1024, 3072, 8256)])
+                                            (512, 512, 64, 8256), (700, 768, 192, 8256), (1030, 520, 1280, 8256), (4096, 1024, 3072, 8256),
+                                            # persistent form: 18 x 18 = 324 tiles walked by 256 workgroups (68 take a second tile), ragged M
+                                            (4500, 4608, 192, 8256)])
 @pytest.mark.parametrize("mode", ["plain", "gelu", "gate_res", "gate_res_seg"])
 @pytest.mark.parametrize("dt", ["float16", "bfloat16"])
 def test_gemm_dit(M, N, K, variant, mode, dt):

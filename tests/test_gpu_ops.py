@@ -63,7 +63,8 @@ def test_gemm_asymmetric_identity():
 
 
 @pytest.mark.parametrize("M,C,variant", [(128, 64, 0), (520, 320, 128), (520, 320, 256), (520, 320, 320), (300, 640, 0),
-                                          (520, 320, 825), (1100, 640, 825)])
+                                          (520, 320, 825), (1100, 640, 825),
+                                          (4200, 640, 825)])       # 17 x 20 = 340 tiles: persistent launch, 84 workgroups take a second tile
 def test_gemm_geglu(M, C, variant):
     group = 16
     L = lib()

@@ -6,10 +6,10 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 from ops_binding import P, lib, ok, stream
 from bench_ops import timeit
 L = lib(); dev = "cuda"
-for (name, M, N, mode, var) in [("geglu320", 16384, 10240, "geglu", 320), ("geglu320 linear", 16384, 10240, "geglu", 320 | (1 << 13)),
-                                ("plain320 N10240", 16384, 10240, "", 320), ("plain320 N3840", 16384, 3840, "", 320),
-                                ("plain320 N3840 lin", 16384, 3840, "", 320 | (1 << 13)),
-                                ("geglu320 640", 65536, 5120, "geglu", 320), ("geglu320 640 lin", 65536, 5120, "geglu", 320 | (1 << 13))]:
+for (name, M, N, mode, var) in [("geglu 825 (256x256 two-group)", 16384, 10240, "geglu", 825), ("geglu 320 ring", 16384, 10240, "geglu", 320),
+                                ("plain 932 N3840 (3 rounds)", 16384, 3840, "", 932), ("plain 932 N1280 (1 round)", 16384, 1280, "", 932),
+                                ("res32 932 N1280", 16384, 1280, "res", 932), ("res32 160 N1280", 16384, 1280, "res", 160),
+                                ("geglu 825 M65536 N5120", 65536, 5120, "geglu", 825), ("plain 932 M65536 N640", 65536, 640, "", 932)]:
     rows = []
     for K in (640, 1280, 2560, 5120):
         A = torch.randn(M, K, device=dev).half(); W = (torch.randn(N, K, device=dev) * K ** -0.5).half()
@@ -24,4 +24,4 @@ for (name, M, N, mode, var) in [("geglu320", 16384, 10240, "geglu", 320), ("gegl
     slope = (t1 - t0) / (k1 - k0)                      # ms per unit K
     fixed = t0 - slope * k0
     rate = 2.0 * M * N / slope / 1e9
-    print(f"{name:20s} " + " ".join(f"K{k}:{t:.4f}ms" for k, t in rows) + f"  main-loop {rate:7.1f} TFLOP/s, fixed {fixed*1e3:7.1f} us/launch")
+    print(f"{name:30s} " + " ".join(f"K{k}:{t:.4f}ms" for k, t in rows) + f"  main-loop {rate:7.1f} TFLOP/s, fixed {fixed*1e3:7.1f} us/launch")

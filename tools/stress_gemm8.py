@@ -39,7 +39,7 @@ for M, N, K in [(4608, 3072, 64), (4608, 9216, 192), (9216, 3072, 3072), (4608, 
     o16 = torch.empty(M, N, device="cuda", dtype=torch.half)
     g = lambda var: (lambda: ok(L.gdf_op_gemm_dit(P(A), K, P(W), P(bias), 1, None, 0, 0, 1, 0, 1, None, 0, None, 0, P(o16), N, None, 0, M, N, K, var, stream()), L))
     run(f"dit 8256 vs 1256   {M}x{N}x{K} (gelu)", g(1256), g(8256), o16)
-for B, H, Ci, Co in [(2, 64, 64, 320), (4, 64, 320, 640), (2, 32, 1280, 1280), (2, 64, 128, 256), (2, 48, 256, 512)]:
+for B, H, Ci, Co in [(2, 64, 64, 320), (4, 64, 320, 640), (2, 32, 1280, 1280), (2, 64, 128, 256), (2, 48, 256, 512), (9, 64, 64, 1024)]:   # last: 144 x 4 = 576 tiles, persistent
     x = torch.randn(B, H, H, Ci, device="cuda").half(); w = (torch.randn(Co, 9 * Ci, device="cuda") * (9 * Ci) ** -0.5).half()
     bias = torch.randn(Co, device="cuda"); o16 = torch.empty(B, H, H, Co, device="cuda", dtype=torch.half)
     var_new, var_ref = (932, 320) if Co % 320 == 0 else (826, 256)
