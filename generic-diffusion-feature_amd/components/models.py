@@ -25,7 +25,7 @@ _HF = {
     "xl": ("stabilityai/stable-diffusion-xl-base-1.0", "StableDiffusionXLImg2ImgPipeline"),
     "pgv2": ("playgroundai/playground-v2-1024px-aesthetic", "StableDiffusionXLImg2ImgPipeline"),
 }
-_LATER = ("pixart-alpha", "if", "hunyuan")       # pixart-alpha-1024 needs the resolution micro-conditioning
+_LATER = ("if", "hunyuan")                       # no BASELINE config (pixel-space UNet / untested DiT)
 
 
 def _fill(model, loader):
@@ -176,8 +176,10 @@ class SyntheticPixartPipe(SyntheticPipe):
     """Offline stand-in for diffusers' PixArtSigmaPipeline as FeatureExtractor uses it: true-architecture DiT
     (NativePixArtTransformer, seeded random weights), native VAE encoder, stand-in T5 embeddings with a ragged mask."""
 
-    def __init__(self, version, device, seed=0, cfg=None, n_txt=300):
+    def __init__(self, version, device, seed=0, cfg=None, n_txt=None):
         cfg = dict(cfg or PIXART_CONFIGS[version])
+        alpha = version == "pixart-alpha"                         # PixArtAlphaPipeline: max_sequence_length 120, sd-vae-ft-ema
+        n_txt = n_txt or (120 if alpha else 300)
         self.version = version
         self.device = device
         self._pcfg = cfg
@@ -185,7 +187,7 @@ class SyntheticPixartPipe(SyntheticPipe):
         self.transformer = _fill(NativePixArtTransformer(cfg, device=device), lambda m: m.init_synthetic(seed))
         self.unet = self.transformer               # reference models.py:91 `pipe.unet = pipe.transformer`
         empty = types.SimpleNamespace(parameters=lambda: iter(()), to=lambda *a, **k: None)
-        self.vae = types.SimpleNamespace(parameters=lambda: iter(()), config=types.SimpleNamespace(scaling_factor=0.13025))
+        self.vae = types.SimpleNamespace(parameters=lambda: iter(()), config=types.SimpleNamespace(scaling_factor=0.18215 if alpha else 0.13025))
         self.native_vae = _fill(NativeVAEEncoder(VAE_CONFIGS["sd"], device=device), lambda m: m.init_synthetic(seed + 1))
         self.text_encoder = empty
         self.scheduler = _Scheduler(euler=False)
@@ -327,8 +329,12 @@ def get_diffusion_model(version, dtype, offline_lora=None, offline_lora_filename
             import diffusers
         except ImportError as e:
             raise RuntimeError("diffusers is not installed and GDF_SYNTHETIC_WEIGHTS is not set (see INTEGRATION.md)") from e
-        repo = "PixArt-alpha/PixArt-Sigma-XL-2-1024-MS" if version == "pixart-sigma" else "PixArt-alpha/PixArt-Sigma-XL-2-512-MS"
-        pipe = diffusers.PixArtSigmaPipeline.from_pretrained(repo, torch_dtype=dt, use_safetensors=True).to(device)
+        if version == "pixart-alpha":                             # reference models.py:103-115 (120-token T5 captions, SD VAE)
+            pipe = diffusers.PixArtAlphaPipeline.from_pretrained("PixArt-alpha/PixArt-XL-2-512x512", torch_dtype=dt, variant="fp16",
+                                                                 use_safetensors=True).to(device)
+        else:
+            repo = "PixArt-alpha/PixArt-Sigma-XL-2-1024-MS" if version == "pixart-sigma" else "PixArt-alpha/PixArt-Sigma-XL-2-512-MS"
+            pipe = diffusers.PixArtSigmaPipeline.from_pretrained(repo, torch_dtype=dt, use_safetensors=True).to(device)
         net = NativePixArtTransformer(PIXART_CONFIGS[version], device=device)
         _fill(net, lambda m: m.load_state_dict({k: v for k, v in pipe.transformer.state_dict().items() if k != "pos_embed.pos_embed"}))
         pipe.transformer = pipe.unet = net

@@ -791,6 +791,11 @@ PIXART_CONFIGS = {
                          patch_size=2, sample_size=128, caption_channels=4096, interpolation_scale=2),
     "pixart-sigma-512": dict(num_attention_heads=16, attention_head_dim=72, in_channels=4, out_channels=8, num_layers=28,
                              patch_size=2, sample_size=64, caption_channels=4096, interpolation_scale=1),
+    # PixArt-alpha/PixArt-XL-2-512x512 (reference models.py:103-115): the same 28-block DiT; at sample_size 64 the checkpoint has no
+    # resolution / aspect-ratio micro-conditioning (`use_additional_conditions` is only set at sample_size 128) and the reference
+    # calls it with added_cond_kwargs = {'resolution': None, 'aspect_ratio': None} (diffusion_feature.py:466-474)
+    "pixart-alpha": dict(num_attention_heads=16, attention_head_dim=72, in_channels=4, out_channels=8, num_layers=28,
+                         patch_size=2, sample_size=64, caption_channels=4096, interpolation_scale=1),
 }
 
 

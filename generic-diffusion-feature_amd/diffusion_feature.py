@@ -22,7 +22,7 @@ from components.feature_extractor import (ATTENTION_CATEGORIES, aggregate_attent
 class FeatureExtractor(nn.Module):
     def __init__(self,
                  layer,            # filename of the layer json, a pre-loaded dict, or None (= all layers)
-                 version,          # '1-5', 'xl', 'pgv2', 'flux', 'pixart-sigma', 'pixart-sigma-512'
+                 version,          # '1-5', '2-1', 'xl', 'pgv2', 'flux', 'pixart-sigma', 'pixart-sigma-512', 'pixart-alpha'
                  device,
                  dtype='float16',
                  img_size=1024,    # 512 for 1-5, 1024 otherwise

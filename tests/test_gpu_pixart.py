@@ -75,8 +75,9 @@ def test_pixart_matches_reference_golden():
             assert hooks[k].shape == ref.shape and rel_l2(hooks[k], ref) < TOL, (k, rel_l2(hooks[k], ref))
 
 
-def test_feature_extractor_api_pixart_synthetic():
-    """FeatureExtractor(version='pixart-sigma') through the drop-in class (reference diffusion_feature.py:277-283, 466-474):
+@pytest.mark.parametrize("version", ["pixart-sigma", "pixart-alpha"])
+def test_feature_extractor_api_pixart_synthetic(version):
+    """FeatureExtractor(version='pixart-sigma' | 'pixart-alpha') through the drop-in class (reference diffusion_feature.py:277-283, 466-474):
     native VAE encode + noise-add, native DiT forward, hooks via FeatureStore."""
     import numpy as np
     from PIL import Image
@@ -84,10 +85,11 @@ def test_feature_extractor_api_pixart_synthetic():
     from components.feature_extractor import dit_layer_ids
     from components.models import SyntheticPixartPipe
     arch = PR.tiny_arch(heads=8, num_layers=2, sample_size=16)
-    pipe = SyntheticPixartPipe("pixart-sigma", "cuda:0", seed=0, cfg=arch, n_txt=20)
+    pipe = SyntheticPixartPipe(version, "cuda:0", seed=0, cfg=arch, n_txt=20)
     assert pipe.transformer.hook_names() == dit_layer_ids(arch) == PR.hook_ids(arch, maps=True)
+    assert pipe.vae.config.scaling_factor == (0.18215 if version == "pixart-alpha" else 0.13025)     # sd-vae-ft-ema vs the SDXL VAE
     layer = {"vit-block1-out": True, "vit-block0-cross-q": True, "vit-block1-ffn-inner": True, "vit-block0-cross-k": True}
-    df = diffusion_feature.FeatureExtractor(layer=layer, version='pixart-sigma', img_size=128, device='cuda:0', external_model=pipe)
+    df = diffusion_feature.FeatureExtractor(layer=layer, version=version, img_size=128, device='cuda:0', external_model=pipe)
     prompt = df.encode_prompt('a photo of a cat')
     img = Image.fromarray((np.random.RandomState(0).rand(90, 70, 3) * 255).astype(np.uint8))
     feats = df.extract(prompt, batch_size=2, image=[img, img], t=100)

@@ -102,10 +102,15 @@ def test_model_registry_error_behaviour(monkeypatch):
     with pytest.raises(NotImplementedError):
         models.get_diffusion_model("no-such-version", "float16")     # reference models.py:173-174
     with pytest.raises(NotImplementedError):
-        models.get_diffusion_model("pixart-alpha", "float16")            # alpha-1024 micro-conditioning: not native
+        models.get_diffusion_model("hunyuan", "float16")             # out of scope, says so
+    from components.native import PIXART_CONFIGS, ARCH_CONFIGS
+    assert PIXART_CONFIGS["pixart-alpha"] == PIXART_CONFIGS["pixart-sigma-512"]      # same DiT at sample_size 64 (models.py:103-115)
+    assert {"1-5", "2-1", "xl", "pgv2"} <= set(ARCH_CONFIGS)
     monkeypatch.delenv("GDF_SYNTHETIC_WEIGHTS", raising=False)
     with pytest.raises(RuntimeError):
         models.get_diffusion_model("1-5", "float16")                 # no diffusers, no synthetic opt-in: loud failure
+    with pytest.raises(RuntimeError):
+        models.get_diffusion_model("pixart-alpha", "float16")
 
 
 def test_bench_flop_model_matches_survey_totals():
