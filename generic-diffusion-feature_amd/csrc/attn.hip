@@ -69,6 +69,29 @@ __device__ __forceinline__ size_t seg_row(int b, int j, int per_b, int seg_T, in
   return j < seg_T ? (size_t)b * seg_T + j : (size_t)B * seg_T + (size_t)b * (S_tot - seg_T) + (j - seg_T);
 }
 
+// diagnostics build (tools/ablate_attn.sh, -DGDF_ATTN_TRACE): shader-clock time per loop phase, summed over the tiles of wave 0 of
+// every workgroup: [QK^T, softmax, PV, stage + barrier + next loads, whole kernel]
+#if defined(GDF_ATTN_TRACE)
+__device__ unsigned long long gdf_attn_trace[8192 * 8];
+#define GDF_AT_DECL unsigned long long at_acc[4] = {0, 0, 0, 0}; unsigned long long at_t = __builtin_readcyclecounter(); const unsigned long long at_t0 = at_t;
+#define GDF_AT(i) do { const unsigned long long n_ = __builtin_readcyclecounter(); at_acc[i] += n_ - at_t; at_t = n_; } while (0)
+#define GDF_AT_END do { if (threadIdx.x == 0 && blockIdx.x < 8192) { for (int i_ = 0; i_ < 4; ++i_) gdf_attn_trace[blockIdx.x * 8 + i_] = at_acc[i_]; \
+    gdf_attn_trace[blockIdx.x * 8 + 4] = __builtin_readcyclecounter() - at_t0; } } while (0)
+#else
+#define GDF_AT_DECL
+#define GDF_AT(i)
+#define GDF_AT_END
+#endif
+#if !defined(GDF_ATTN_PRIO)
+#define GDF_ATTN_PRIO 1
+#endif
+#if GDF_ATTN_PRIO == 1          // MFMA phases at priority 1 (shipped)
+#define GDF_ATTN_PRIO_MFMA(x) __builtin_amdgcn_s_setprio(x)
+#elif GDF_ATTN_PRIO == 2        // experiment: the softmax (VALU) phase at priority 1 instead
+#define GDF_ATTN_PRIO_MFMA(x) __builtin_amdgcn_s_setprio(1 - (x))
+#else                           // experiment: no priorities
+#define GDF_ATTN_PRIO_MFMA(x)
+#endif
 // NW = waves per workgroup (4, or 8: twice the query rows share every staged K / V tile)
 // (Measured and rejected: an explicit ping-pong — 8 waves, the two waves of a SIMD one workgroup barrier apart, iteration =
 // softmax phase | barrier | PV(t) + QK^T(t+1) phase | barrier — which is what lifts the GEMM main loops.  Here the two phases
@@ -88,6 +111,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(const AttnParams p) {
   constexpr int NCH = (KT * CPR + NT - 1) / NT;  // chunks per thread per tile
   constexpr int NS = DQK / 16;                   // k-steps of QK^T
   constexpr int NDB = DV / 32;                   // 32-row blocks of O^T
+  constexpr int PD = 4;                          // fragment reads in flight ahead of the MFMAs that consume them
   constexpr int QBW = 32 * QW;                   // query rows per wave
   constexpr int QBLK = NW * QBW;                 // query rows per workgroup
   constexpr bool PADDED = (DP != D);             // head dims 40 / 80: zero-filled pad chunks
@@ -195,34 +219,103 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(const AttnParams p) {
     }
   };
 
-  gload(0);
+  // Fast tile load (head dims without pad chunks, tiles that lie inside one region and hold KT valid keys): buffer loads with a
+  // per-lane byte offset computed ONCE and the tile's row offset in the scalar operand — no per-tile address arithmetic (the
+  // generic form above spends ~25 VALU instructions per tile on clamping, region select and 64-bit address math, 10 % of the
+  // loop's VALU work; tools/ablate_attn.py: the K / V global loads cost 12-15 % of the kernel, their LDS stores nothing).
+  constexpr bool FASTLD = !PADDED && (KT * CPR) % NT == 0;
+  uint32_t kvo[NCH], vvo[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int idx = tid + c * NT;
+    const int row = idx / CPR, ch = idx - row * CPR;
+    kvo[c] = ((uint32_t)row * ldk + (uint32_t)(ch * 8)) * 2u;
+    vvo[c] = ((uint32_t)row * ldv + (uint32_t)(ch * 8)) * 2u;
+  }
+  const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, 0xffffffffu, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, 0xffffffffu, 0x00020000);
+  const bool seg_aligned = p.seg_T <= 0 || (p.seg_T % KT) == 0;
+  const bool small_off = ((size_t)p.B * (size_t)(p.kv_bstride > p.Sk ? p.kv_bstride : p.Sk) + KT) * (size_t)(ldk > ldv ? ldk : ldv) * 2 < (1ull << 32);   // 32-bit byte offsets
+  auto gload_fast = [&](int t) {
+    const uint32_t r0 = (uint32_t)(t * KT) + ((t * KT) < segT ? c0 : c1);       // first row of the tile (uniform)
+    const uint32_t sk = r0 * ldk * 2u, sv = r0 * ldv * 2u;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      kreg[c] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rsK, kvo[c], sk, 0));
+      vreg[c] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rsV, vvo[c], sv, 0));
+    }
+  };
+  const bool fast_ok = FASTLD && seg_aligned && small_off;
+  auto load_tile = [&](int t) {
+    if (fast_ok && (t + 1) * KT <= Sk) gload_fast(t); else gload(t);
+  };
+  load_tile(0);
   lstore(0);
   __syncthreads();
-  if (ntiles > 1) gload(1);
+#if defined(GDF_ATTN_ABLATE) && (GDF_ATTN_ABLATE & 1)
+  lstore(1);                                   // diagnostics (tools/ablate_attn.sh): no K / V traffic inside the loop
+  __syncthreads();
+#else
+  if (ntiles > 1) load_tile(1);
+#endif
+  GDF_AT_DECL
   for (int t = 0; t < ntiles; ++t) {
     const _Float16* cK = sK[t & 1];
     const _Float16* cV = sV[t & 1];
+    GDF_AT(3);
 
     // ---- S^T = K Q^T : two 32-key blocks; every K fragment feeds QW query blocks ----
+    // Fragment reads run PD steps ahead of the MFMAs that consume them (round 2: the compiler's order — read, wait, multiply —
+    // exposed the LDS latency at every step; tools/trace_attn.py: QK^T 766 and PV 1622 cycles per tile for 512 cycles of MFMA each)
     f32x16 s[QW][2];
-    __builtin_amdgcn_s_setprio(1);
+    constexpr int NQK = NS * 2;                  // K fragments per tile, step i -> (st = i / 2, kb = i % 2): the key blocks alternate
+    auto rdk = [&](int i) -> f16x8 {
+#if defined(GDF_ATTN_ABLATE) && (GDF_ATTN_ABLATE & 64)
+      return qf[0][i % NS];                              // diagnostics: no K fragment reads
+#endif
+      return *(const f16x8*)(cK + ((i & 1) * 32 + lq) * LDR + 16 * (i >> 1) + 8 * lh);
+    };
+    f16x8 kq[PD];
 #pragma unroll
-    for (int st = 0; st < NS; ++st) {
+    for (int i = 0; i < PD; ++i) kq[i] = rdk(i);
+    // the first V^T fragments of this tile are fetched here as well: they land during the softmax
+    auto rdv = [&](int i) -> f16x8 {             // step i -> (s4 = i / NDB, db = i % NDB)
+      const int s4 = i / NDB, db = i - s4 * NDB;
+#if defined(GDF_ATTN_ABLATE) && (GDF_ATTN_ABLATE & 32)
+      return qf[0][(s4 + db) % NS];                      // diagnostics: no V^T fragment reads
+#endif
+      // V^T fragment: lane (d = db*32 + lq, lh) needs V[16 s4 + 4 lh + {0..3}][d] and V[16 s4 + 8 + 4 lh + {0..3}][d]
+      const int i16 = lane & 15;
+      const int c0v = db * 32 + 16 * ((lane >> 4) & 1) + (i16 & 3) * 4;
+      const int r0 = 16 * s4 + 4 * lh + (i16 >> 2);
+      const fp16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((LDS_AS fp16x4_t*)(cV + r0 * LDV + c0v));
+      const fp16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((LDS_AS fp16x4_t*)(cV + (r0 + 8) * LDV + c0v));
+      union { fp16x4_t q[2]; f16x8 h; } vf;              // pure register re-interpretation, no conversion
+      vf.q[0] = lo; vf.q[1] = hi;
+      return vf.h;
+    };
+    GDF_ATTN_PRIO_MFMA(1);
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {           // the two key blocks alternate: no back-to-back dependent MFMAs
-        const f16x8 kf = *(const f16x8*)(cK + (kb * 32 + lq) * LDR + 16 * st + 8 * lh);
+    for (int i = 0; i < NQK; ++i) {
+      const int st = i >> 1, kb = i & 1;
+      const f16x8 kf = kq[i % PD];
 #pragma unroll
-        for (int w = 0; w < QW; ++w) {
-          if (st == 0) {
-            const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            s[w][kb] = mfma32<BF>(kf, qf[w][st], z);
-          } else {
-            s[w][kb] = mfma32<BF>(kf, qf[w][st], s[w][kb]);
-          }
+      for (int w = 0; w < QW; ++w) {
+        if (st == 0) {
+          const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          s[w][kb] = mfma32<BF>(kf, qf[w][st], z);
+        } else {
+          s[w][kb] = mfma32<BF>(kf, qf[w][st], s[w][kb]);
         }
       }
+      if (i + PD < NQK) kq[i % PD] = rdk(i + PD);
     }
-    __builtin_amdgcn_s_setprio(0);
+    constexpr int NPV = 4 * NDB;                 // V^T fragments per tile
+    f16x8 vq[PD];
+#pragma unroll
+    for (int i = 0; i < PD; ++i) vq[i] = rdv(i);
+    GDF_ATTN_PRIO_MFMA(0);
+    GDF_AT(0);
     // ---- mask the tail tile, online softmax (per-lane query column) ----
     if ((t + 1) * KT > Sk) {
 #pragma unroll
@@ -239,11 +332,13 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(const AttnParams p) {
 #pragma unroll
     for (int w = 0; w < QW; ++w) {
       float mx = s[w][0][0];
+#if !(defined(GDF_ATTN_ABLATE) && (GDF_ATTN_ABLATE & 2))
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[w][kb][r]);
       mx = half_max(mx) * sl2;
+#endif
       // lazy rescale: the running max only moves when the new one exceeds it by more than 2^8 (probabilities then stay
       // <= 256 in fp16 and the fp32 accumulators never need the per-tile alpha multiply after the first tiles)
       const float m_new = (mx > m_run[w] + 8.0f) ? mx : m_run[w];
@@ -252,9 +347,18 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(const AttnParams p) {
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
+#if defined(GDF_ATTN_ABLATE) && (GDF_ATTN_ABLATE & 2)
+          const float e0 = s[w][kb][r], e1 = s[w][kb][r + 1];      // diagnostics: no exp / fma / sum
+#else
+#if defined(GDF_ATTN_ABLATE) && (GDF_ATTN_ABLATE & 128)
+          const float e0 = s[w][kb][r] * sl2 - m_new;                  // diagnostics: everything but the v_exp_f32
+          const float e1 = s[w][kb][r + 1] * sl2 - m_new;
+#else
           const float e0 = __builtin_amdgcn_exp2f(s[w][kb][r] * sl2 - m_new);
           const float e1 = __builtin_amdgcn_exp2f(s[w][kb][r + 1] * sl2 - m_new);
+#endif
           psum += e0 + e1;
+#endif
           const f16x2_t h2 = cvt_pair<BF>(e0, e1);
           pf[w][kb * 2 + (r >> 3)][r & 7] = h2[0];
           pf[w][kb * 2 + (r >> 3)][(r & 7) + 1] = h2[1];
@@ -272,32 +376,41 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(const AttnParams p) {
     }
 
     // ---- O^T += V^T P^T : 4 steps of 16 (relabelled) keys; every V^T fragment feeds QW query blocks ----
-    __builtin_amdgcn_s_setprio(1);
+    GDF_AT(1);
+    GDF_ATTN_PRIO_MFMA(1);
 #pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) {
+    for (int i = 0; i < NPV; ++i) {
+      const int s4 = i / NDB, db = i - s4 * NDB;
+      const f16x8 vf = vq[i % PD];
 #pragma unroll
-      for (int db = 0; db < NDB; ++db) {
-        // V^T fragment: lane (d = db*32 + lq, lh) needs V[16 s4 + 4 lh + {0..3}][d] and V[16 s4 + 8 + 4 lh + {0..3}][d]
-        const int i16 = lane & 15;
-        const int c0v = db * 32 + 16 * ((lane >> 4) & 1) + (i16 & 3) * 4;
-        const int r0 = 16 * s4 + 4 * lh + (i16 >> 2);
-        const fp16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((LDS_AS fp16x4_t*)(cV + r0 * LDV + c0v));
-        const fp16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((LDS_AS fp16x4_t*)(cV + (r0 + 8) * LDV + c0v));
-        union { fp16x4_t q[2]; f16x8 h; } vf;            // pure register re-interpretation, no conversion
-        vf.q[0] = lo; vf.q[1] = hi;
-#pragma unroll
-        for (int w = 0; w < QW; ++w)
-          o[w][db] = mfma32<BF>(vf.h, pf[w][s4], o[w][db]);
-      }
+      for (int w = 0; w < QW; ++w)
+        o[w][db] = mfma32<BF>(vf, pf[w][s4], o[w][db]);
+      if (i + PD < NPV) vq[i % PD] = rdv(i + PD);
     }
 
-    __builtin_amdgcn_s_setprio(0);
+    GDF_ATTN_PRIO_MFMA(0);
+    GDF_AT(2);
     // ---- stage tile t+1 into the other buffer (last read during tile t-1, fenced by the previous barrier) ----
+#if defined(GDF_ATTN_ABLATE) && (GDF_ATTN_ABLATE & 1)
+#if !(GDF_ATTN_ABLATE & 4)
+    __syncthreads();
+#endif
+#elif defined(GDF_ATTN_ABLATE) && (GDF_ATTN_ABLATE & 8)
+    if (t + 1 < ntiles) lstore((t + 1) & 1);         // diagnostics: LDS stores of stale registers, no global loads
+    __syncthreads();
+#elif defined(GDF_ATTN_ABLATE) && (GDF_ATTN_ABLATE & 16)
+    __syncthreads();                                 // diagnostics: global loads, no LDS stores
+    if (t + 2 < ntiles) load_tile(t + 2);
+    asm volatile("" :: "v"(kreg[0]), "v"(vreg[0]), "v"(kreg[NCH - 1]), "v"(vreg[NCH - 1]));
+#else
     if (t + 1 < ntiles) lstore((t + 1) & 1);
     __syncthreads();
-    if (t + 2 < ntiles) gload(t + 2);               // HBM latency hides under the next tile's MFMAs
+    if (t + 2 < ntiles) load_tile(t + 2);           // HBM latency hides under the next tile's MFMAs
+#endif
   }
 
+  GDF_AT(3);
+  GDF_AT_END;
   // ---- finalize: O[q][d] = O^T[d][q] / l ----
   // The accumulators hold O^T (lane = query column): stored directly, every lane would write 8 bytes into a different row.
   // Each wave transposes its QBW x D block through the (now idle) K / V staging memory instead, so that the global stores
@@ -803,3 +916,9 @@ hipError_t launch_attention(const AttnParams& p, hipStream_t s) {
 }
 
 }  // namespace gdf
+
+#if defined(GDF_ATTN_TRACE)
+extern "C" int gdf_debug_attn_trace(unsigned long long* dst, int n_words) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(gdf::gdf_attn_trace), (size_t)n_words * 8, 0, hipMemcpyDeviceToHost);
+}
+#endif
