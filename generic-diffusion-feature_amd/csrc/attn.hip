@@ -97,6 +97,12 @@ __device__ unsigned long long gdf_attn_trace[8192 * 8];
 // softmax phase | barrier | PV(t) + QK^T(t+1) phase | barrier — which is what lifts the GEMM main loops.  Here the two phases
 // are data dependent and unequal, and the lock step costs more than the free-running overlap of two independent workgroups
 // per CU gives: D = 128 928 -> 821 TFLOP/s, D = 64 726 -> 573 (32 rows per wave) / 366 (64 rows per wave: 76 VGPRs spilled).)
+// (Round 2, measured and rejected: a software-pipelined D = 64 kernel that issues the PV / QK^T MFMAs of one 32-query block between
+// the softmax instructions of the wave's other block, K / V in rings of three: 770-795 vs 812-829 TFLOP/s.  tools/micro/overlap.hip
+// shows why no such schedule can pay on gfx950: ordinary VALU instructions do not overlap with MFMAs on a SIMD at all — 16 MFMAs +
+// 128 v_fma take 533 + 321 cycles whether they come from one wave, interleaved, or from two waves — only transcendentals do
+// (16 MFMAs + 64 v_exp: 727 cycles against 533 and 644 alone).  The loop's bound is therefore MFMA + plain-VALU + LDS-read issue
+// time, and the lever is the instruction count, not the placement.)
 template <int D, int QW, int NW = 4, bool BF = false>
 __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(const AttnParams p) {
   constexpr int NT = NW * 64;                    // threads per workgroup
