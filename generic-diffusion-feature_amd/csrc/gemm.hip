@@ -235,6 +235,45 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
   // byte offset of K-tile kt inside a dense row.  The two-group schedules also stage the tiles nk, nk + 1 (so that the counted
   // waits are the same in every iteration): those get an out-of-range offset — zero fill, no L2 / HBM traffic (scalar select)
   auto koff = [&](int kt) -> uint32_t { return kt < nk ? (uint32_t)kt * 128u : OOB; };
+  // 3x3-conv rows of the two-group schedules (round 2): per output row ONE byte offset — that of filter tap (0, 0), which may lie
+  // outside the image — and a 9-bit validity mask, so that a K-tile's source offset is `base + scalar tap offset` and one bit test
+  // (4 VALU instructions per row and K-tile instead of ~12: bounds compares, pixel arithmetic and two multiplies; VALU issue time
+  // is not hidden by MFMAs on this hardware).  Nearest-x2 upsampling fused into the conv: source row of tap ky is
+  // (uy + ky) >> 1 = (uy >> 1) + {0, parity, 1}[ky]; the two parities travel in mask bits 9 / 10.
+  auto conv_row = [&](int m, uint32_t& base, uint32_t& mask) {
+    const int hw = p.OH * p.OW;
+    const int n = m / hw;
+    const int rem = m - n * hw;
+    const int oy = rem / p.OW, ox = rem - oy * p.OW;
+    const int uy = oy * p.stride - 1 + p.pad0, ux = ox * p.stride - 1 + p.pad0;      // pad0 = 1: no top / left padding (VAE downsample)
+    const int by = p.ups ? (uy >> 1) : uy, bx = p.ups ? (ux >> 1) : ux;
+    base = (uint32_t)((n * p.H + by) * p.W + bx) * (uint32_t)p.lda * 2u + (uint32_t)chunk * 16u;
+    uint32_t mk = 0;
+    if (m < p.M) {
+#pragma unroll
+      for (int tp = 0; tp < 9; ++tp) {
+        const int iy = uy + tp / 3, ix = ux + tp % 3;
+        if ((iy >= 0) & (iy < IH) & (ix >= 0) & (ix < IW)) mk |= 1u << tp;
+      }
+    }
+    if (p.ups) mk |= ((uint32_t)(uy & 1) << 9) | ((uint32_t)(ux & 1) << 10);
+    mask = mk;
+  };
+  auto conv_off = [&](int kt, uint32_t base, uint32_t mask) -> uint32_t {
+    const int tp = kt / cpb, cbk = kt - tp * cpb;               // K-tiles are tap-major, cpb tiles per filter tap (scalar)
+    const int ky = tp / 3, kx = tp - ky * 3;
+    const uint32_t rowb = (uint32_t)p.W * (uint32_t)p.lda * 2u, pixb = (uint32_t)p.lda * 2u;
+    uint32_t off;
+    if (!p.ups) {
+      off = base + ((uint32_t)ky * rowb + (uint32_t)kx * pixb + (uint32_t)cbk * 128u);
+    } else {
+      off = base + ((ky == 2 ? rowb : 0u) + (kx == 2 ? pixb : 0u) + (uint32_t)cbk * 128u);
+      if (ky == 1 && (mask & 512u)) off += rowb;
+      if (kx == 1 && (mask & 1024u)) off += pixb;
+    }
+    const uint32_t bit = tp < 9 ? (1u << tp) : 0u;               // tiles >= nk (over-staged): zero fill
+    return (mask & bit) ? off : OOB;
+  };
   int tap = 0, cb = 0;                                 // filter tap / channel block of the NEXT tile to issue
   auto issue = [&](int kt, int buf) {
     char* sA = smem + buf * STAGE;
@@ -338,8 +377,8 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
     constexpr int BHALF = BN / 2;                       // rows per B half-tile
     constexpr bool B3 = (BN == 320);
     const bool g1 = wave >= 4;
-    uint32_t ha[2][2], hb[2][3];                        // ha: DENSE byte offset of (row, chunk); CONV pixel base of the sample
-    int hy[2][2], hx[2][2];                             // CONV: top-left input pixel of the 3x3 window
+    uint32_t ha[2][2], hb[2][3];                        // ha: DENSE byte offset of (row, chunk); CONV byte offset of filter tap (0, 0)
+    uint32_t hm[2][2];                                  // CONV: validity mask of the 9 taps (conv_row)
     int hbq[2];                                         // first instruction index of this wave in B half-tile h
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -350,15 +389,9 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
         const int m = m0 + h * 128 + (wave * 2 + j) * 8 + lrow;
         if (MODE == A_DENSE) {
           ha[h][j] = (m < p.M) ? (uint32_t)m * (uint32_t)p.lda * 2u + (uint32_t)chunk * 16u : OOB;
-          hy[h][j] = hx[h][j] = 0;
+          hm[h][j] = 0;
         } else {
-          const int hw = p.OH * p.OW;
-          const int n = m / hw;
-          const int rem = m - n * hw;
-          const int oy = rem / p.OW, ox = rem - oy * p.OW;
-          ha[h][j] = (uint32_t)(n * p.H * p.W);
-          hy[h][j] = (m < p.M) ? oy * p.stride - 1 + p.pad0 : -(1 << 20);
-          hx[h][j] = ox * p.stride - 1 + p.pad0;
+          conv_row(m, ha[h][j], hm[h][j]);
         }
       }
 #pragma unroll
@@ -376,13 +409,8 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
           uint32_t off;
           if (MODE == A_DENSE) {
             off = ha[W][j] + koff(kt);
-          } else {                                             // K-tiles are tap-major, cpb tiles per filter tap
-            const int tp = kt / cpb, cbk = kt - tp * cpb;
-            const int ky = tp / 3, kx = tp - ky * 3;
-            const int iy = hy[W][j] + ky, ix = hx[W][j] + kx;
-            const bool okk = (tp < 9) & (iy >= 0) & (iy < IH) & (ix >= 0) & (ix < IW);
-            const int sy = p.ups ? (iy >> 1) : iy, sx = p.ups ? (ix >> 1) : ix;
-            off = okk ? (ha[W][j] + (uint32_t)(sy * p.W + sx)) * (uint32_t)p.lda * 2u + (uint32_t)(cbk * BK + chunk * 8) * 2u : OOB;
+          } else {
+            off = conv_off(kt, ha[W][j], hm[W][j]);
           }
           glds16(rsA, base + j * 1024, off);
         }
@@ -506,22 +534,16 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
     static_assert((MODE == A_DENSE || MODE == A_CONV3) && BM == 256 && BN == 320 && FM == 8 && FN == 5 && WGN == 4,
                   "8-phase schedule, 2x4 waves of 128x80");
     // A unit q: this wave's instruction covers rows (wave>>2)*128 + q*32 + (wave&3)*8 + lrow
-    uint32_t ua[4];                                     // DENSE: byte offset of (row, chunk); CONV: pixel base of the sample
-    int uy[4], ux[4];
+    uint32_t ua[4];                                     // DENSE: byte offset of (row, chunk); CONV: byte offset of filter tap (0, 0)
+    uint32_t um[4];                                     // CONV: validity mask of the 9 taps (conv_row)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int m = m0 + (wave >> 2) * 128 + q * 32 + (wave & 3) * 8 + lrow;
       if (MODE == A_DENSE) {
         ua[q] = (m < p.M) ? (uint32_t)m * (uint32_t)p.lda * 2u + (uint32_t)chunk * 16u : OOB;
-        uy[q] = ux[q] = 0;
+        um[q] = 0;
       } else {
-        const int hw = p.OH * p.OW;
-        const int n = m / hw;
-        const int rem = m - n * hw;
-        const int oy = rem / p.OW, ox = rem - oy * p.OW;
-        ua[q] = (uint32_t)(n * p.H * p.W);
-        uy[q] = (m < p.M) ? oy * p.stride - 1 + p.pad0 : -(1 << 20);
-        ux[q] = ox * p.stride - 1 + p.pad0;
+        conv_row(m, ua[q], um[q]);
       }
     }
     uint32_t ub[5];                                     // B_1: instructions wave*3 + {0,1,2}; B_2: 24 + wave*2 + {0,1}
@@ -538,12 +560,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
       if (MODE == A_DENSE) {
         off = ua[q] + koff(kt);
       } else {
-        const int tp = kt / cpb, cbk = kt - tp * cpb;
-        const int ky = tp / 3, kx = tp - ky * 3;
-        const int iy = uy[q] + ky, ix = ux[q] + kx;
-        const bool okk = (tp < 9) & (iy >= 0) & (iy < IH) & (ix >= 0) & (ix < IW);
-        const int sy = p.ups ? (iy >> 1) : iy, sx = p.ups ? (ix >> 1) : ix;
-        off = okk ? (ua[q] + (uint32_t)(sy * p.W + sx)) * (uint32_t)p.lda * 2u + (uint32_t)(cbk * BK + chunk * 8) * 2u : OOB;
+        off = conv_off(kt, ua[q], um[q]);
       }
       glds16(rsA, dst, off);
     };
