@@ -10,6 +10,8 @@ shapes = [(16384, 1280, 10240), (8192, 7680, 8192), (16384, 3840, 1280), (16384,
 dev = "cuda"
 only = [int(x) for x in sys.argv[1:]]
 keep = {}
+_w = torch.randn(8192, 8192, device=dev).half()
+for _ in range(150): _w @ _w
 for a in (only or (0, 100, 1, 2, 3, 4, 8, 9, 10, 11, 12)):
     path = (os.path.join(ROOT, "generic-diffusion-feature_amd", "libgdf.so") if a == 0 else
             os.path.join(ROOT, "tools/micro/build", "libgdf_phases4.so" if a == 100 else f"libgdf_abl{a}.so"))
@@ -31,7 +33,7 @@ for a in (only or (0, 100, 1, 2, 3, 4, 8, 9, 10, 11, 12)):
         ms = e0.elapsed_time(e1) / 10
         tag = ""
         if a == 0: keep[(M, N, K)] = (A, W, o.clone())
-        elif a == 100 and (M, N, K) in keep:
+        elif a >= 100 and (M, N, K) in keep:
             A0, W0, o0 = keep[(M, N, K)]
             L.gdf_op_gemm(vp(A0.data_ptr()), K, vp(W0.data_ptr()), None, None, None, N, vp(o.data_ptr()), N, None, N, M, N, K, 932 << 8, s); torch.cuda.synchronize()
             tag = " bit-identical" if torch.equal(o, o0) else f" DIFFERS max {float((o.float() - o0.float()).abs().max()):.3g}"
