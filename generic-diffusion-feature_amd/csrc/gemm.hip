@@ -47,7 +47,6 @@ static constexpr uint32_t OOB = 0x80000000u;   // any offset >= num_records read
 __device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rsrc, char* lds_wave_base, uint32_t voff) {
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (LDS_AS void*)lds_wave_base, 16, voff, 0, 0, 0);
 }
-
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // BF: the 16-byte fragments hold bf16 (MMDiT path of a bf16 model); same MFMA rate, same register layout
 template <bool BF>
@@ -403,20 +402,14 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
     auto stage = [&](int kt, int buf, auto which) {            // which: 0 A-lo, 1 A-hi, 2 B-lo, 3 B-hi
       constexpr int W = decltype(which)::value;
       if constexpr (W < 2) {
-        char* base = smem + buf * STAGE + W * 16384 + wave * 2048;
+        char* base = smem + buf * A_TILE + W * 16384 + wave * 2048;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          uint32_t off;
-          if (MODE == A_DENSE) {
-            off = ha[W][j] + koff(kt);
-          } else {
-            off = conv_off(kt, ha[W][j], hm[W][j]);
-          }
-          glds16(rsA, base + j * 1024, off);
+          glds16(rsA, base + j * 1024, MODE == A_DENSE ? ha[W][j] + koff(kt) : conv_off(kt, ha[W][j], hm[W][j]));
         }
       } else {
         constexpr int H = W - 2;
-        char* base = smem + buf * STAGE + A_TILE + H * (BHALF * 128) + hbq[H] * 1024;
+        char* base = smem + 2 * A_TILE + buf * B_TILE + H * (BHALF * 128) + hbq[H] * 1024;
 #pragma unroll
         for (int j = 0; j < 2; ++j) glds16(rsB, base + j * 1024, hb[H][j] + koff(kt));
         if (B3 && (g1 == (H == 1))) glds16(rsB, base + 2 * 1024, hb[H][2] + koff(kt));
@@ -431,23 +424,27 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
     constexpr std::integral_constant<int, 2> BLO{};
     constexpr std::integral_constant<int, 3> BHI{};
     f16x8 a8[4][2], b8[FNH][2];
-    auto rd_a = [&](const char* sA) {
+    // lane part of a fragment address for k-step kk: (first row of the wave tile + frow) * 128 + swizzled 16-byte chunk; the row of
+    // fragment i and the ring buffer are compile-time constants -> the ds_read's immediate offset (opaque to the optimiser, or it
+    // re-associates them back into per-fragment VGPRs: 26-41 spilled)
+    uint32_t fa[2], fb[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      fa[kk] = (uint32_t)((wm * WTM + frow) * 128 + (((kk * 4 + fk) ^ (frow & 7)) << 4));
+      fb[kk] = (uint32_t)(2 * A_TILE + (wn * WTN + frow) * 128 + (((kk * 4 + fk) ^ (frow & 7)) << 4));
+      asm volatile("" : "+v"(fa[kk]), "+v"(fb[kk]));
+    }
+    auto rd_a = [&](const int cur) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-          const int r = wm * WTM + i * 16 + frow, kc = kk * 4 + fk;
-          a8[i][kk] = *(const f16x8*)(sA + r * 128 + ((kc ^ (r & 7)) << 4));
-        }
+        for (int kk = 0; kk < 2; ++kk) a8[i][kk] = *(const f16x8*)(smem + fa[kk] + (cur * A_TILE + i * 2048));
     };
-    auto rd_b = [&](const char* sB, int half) {
+    auto rd_b = [&](const int cur, int half) {
 #pragma unroll
       for (int j = 0; j < FNH; ++j)
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-          const int r = wn * WTN + (half * FNH + j) * 16 + frow, kc = kk * 4 + fk;
-          b8[j][kk] = *(const f16x8*)(sB + r * 128 + ((kc ^ (r & 7)) << 4));
-        }
+        for (int kk = 0; kk < 2; ++kk) b8[j][kk] = *(const f16x8*)(smem + fb[kk] + (cur * B_TILE + (half * FNH + j) * 2048));
     };
     auto mma_q = [&](auto ah, auto bh) {
       constexpr int AH = decltype(ah)::value, BH = decltype(bh)::value;
@@ -490,32 +487,47 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
     // Slot lifetimes: A-lo is read by group 0 only and A-hi by group 1 only, both in phase 1 — group 1 one barrier after group 0 —
     // and B-lo by both; every read is retired (lgkmcnt) before the reader's next barrier, so all three are free from phase 2's
     // read slot of either group on; B-hi (read in phase 2) is free from the next tile's phase 1 on.
-    for (int kt = 0; kt < nk; ++kt) {
-      const int cur = kt & 1;
-      const char* sA = smem + cur * STAGE;
-      const char* sB = sA + A_TILE;
-      rd_a(sA); rd_b(sB, 0); stage(kt + 1, cur ^ 1, BHI);
+    // Ring layout [A buf 0][A buf 1][B buf 0][B buf 1] and the K loop unrolled by two: the buffer index is a compile-time constant
+    // in each copy of the body, so it lands in the 16-bit immediate offset of the ds_read (A_TILE, B_TILE <= 40 KiB) instead of ~20
+    // v_add per K-tile that rebuild every fragment address from `cur * STAGE` (VALU issue time adds to MFMA time on this hardware).
+    auto ktile = [&](int kt, const int cur) {
+      rd_a(cur); rd_b(cur, 0); stage(kt + 1, cur ^ 1, BHI);
       bar(); lgkm0(); mma_q(Q0, Q0); mma_q(Q1, Q0); bar();
-      rd_b(sB, 1); stage(kt + 2, cur, ALO); stage(kt + 2, cur, AHI); stage(kt + 2, cur, BLO); wait_tile(); lgkm0();
+      rd_b(cur, 1); stage(kt + 2, cur, ALO); stage(kt + 2, cur, AHI); stage(kt + 2, cur, BLO); wait_tile(); lgkm0();
       bar(); mma_q(Q1, Q1); mma_q(Q0, Q1); bar();
+    };
+    {
+      int kt = 0;
+      if constexpr (MODE == A_DENSE) {
+        for (; kt + 1 < nk; kt += 2) { ktile(kt, 0); ktile(kt + 1, 1); }
+        if (kt < nk) ktile(kt, 0);
+      } else {                                                 // conv: the unrolled form spills 6-7 VGPRs; 4 v_add per K-tile instead
+        for (; kt < nk; ++kt) ktile(kt, kt & 1);
+      }
     }
 #else
-    for (int kt = 0; kt < nk; ++kt) {
-      const int cur = kt & 1;
-      const char* sA = smem + cur * STAGE;
-      const char* sB = sA + A_TILE;
+    auto ktile4 = [&](int kt, const int cur) {
       // phase 1
-      rd_a(sA); rd_b(sB, 0); stage(kt + 1, cur ^ 1, BHI);
+      rd_a(cur); rd_b(cur, 0); stage(kt + 1, cur ^ 1, BHI);
       bar(); lgkm0(); mma_q(Q0, Q0); bar();
       // phase 2
       stage(kt + 2, cur, ALO);
       bar(); mma_q(Q1, Q0); bar();
       // phase 3
-      rd_b(sB, 1); stage(kt + 2, cur, AHI); lgkm0();
+      rd_b(cur, 1); stage(kt + 2, cur, AHI); lgkm0();
       bar(); mma_q(Q1, Q1); bar();
       // phase 4
       stage(kt + 2, cur, BLO); wait_tile();
       bar(); mma_q(Q0, Q1); bar();
+    };
+    {
+      int kt = 0;
+      if constexpr (MODE == A_DENSE) {
+        for (; kt + 1 < nk; kt += 2) { ktile4(kt, 0); ktile4(kt + 1, 1); }
+        if (kt < nk) ktile4(kt, 0);
+      } else {
+        for (; kt < nk; ++kt) ktile4(kt, kt & 1);
+      }
     }
 #endif
     if (!g1) bar();
@@ -555,18 +567,12 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
     }
     // filter tap / channel block of K-tile kt (conv): K-tiles are tap-major, cpb tiles per tap
     auto stage_a = [&](int kt, int buf, int q) {
-      char* dst = smem + buf * STAGE + ((wave >> 2) * 128 + q * 32 + (wave & 3) * 8) * 128;
-      uint32_t off;
-      if (MODE == A_DENSE) {
-        off = ua[q] + koff(kt);
-      } else {
-        off = conv_off(kt, ua[q], um[q]);
-      }
-      glds16(rsA, dst, off);
+      char* dst = smem + buf * A_TILE + ((wave >> 2) * 128 + q * 32 + (wave & 3) * 8) * 128;
+      glds16(rsA, dst, MODE == A_DENSE ? ua[q] + koff(kt) : conv_off(kt, ua[q], um[q]));
     };
     auto stage_b = [&](int kt, int buf, auto part) {
       constexpr int PT = decltype(part)::value;           // 0: B_1 (3 instructions), 1: B_2 (2)
-      char* base = smem + buf * STAGE + A_TILE;
+      char* base = smem + 2 * A_TILE + buf * B_TILE;
 #pragma unroll
       for (int j = (PT ? 3 : 0); j < (PT ? 5 : 3); ++j) {
         const int qi = j < 3 ? wave * 3 + j : 24 + wave * 2 + (j - 3);
@@ -576,23 +582,24 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
     constexpr std::integral_constant<int, 0> B1{};
     constexpr std::integral_constant<int, 1> B2{};
     f16x8 a4[2][2], b10[5][2];
-    auto rd_aq = [&](const char* sA, int q) {
+    uint32_t fa[2], fb[2];                              // lane part of a fragment address per k-step (see STAGES == 8)
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      fa[kk] = (uint32_t)((wm * WTM + frow) * 128 + (((kk * 4 + fk) ^ (frow & 7)) << 4));
+      fb[kk] = (uint32_t)(2 * A_TILE + (wn * WTN + frow) * 128 + (((kk * 4 + fk) ^ (frow & 7)) << 4));
+      asm volatile("" : "+v"(fa[kk]), "+v"(fb[kk]));
+    }
+    auto rd_aq = [&](const int cur, int q) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-          const int r = wm * WTM + (q * 2 + i) * 16 + frow, kc = kk * 4 + fk;
-          a4[i][kk] = *(const f16x8*)(sA + r * 128 + ((kc ^ (r & 7)) << 4));
-        }
+        for (int kk = 0; kk < 2; ++kk) a4[i][kk] = *(const f16x8*)(smem + fa[kk] + (cur * A_TILE + (q * 2 + i) * 2048));
     };
-    auto rd_ball = [&](const char* sB) {
+    auto rd_ball = [&](const int cur) {
 #pragma unroll
       for (int j = 0; j < 5; ++j)
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-          const int r = wn * WTN + j * 16 + frow, kc = kk * 4 + fk;
-          b10[j][kk] = *(const f16x8*)(sB + r * 128 + ((kc ^ (r & 7)) << 4));
-        }
+        for (int kk = 0; kk < 2; ++kk) b10[j][kk] = *(const f16x8*)(smem + fb[kk] + (cur * B_TILE + j * 2048));
     };
     auto mma_q = [&](auto qq) {
       constexpr int Q = decltype(qq)::value;
@@ -642,14 +649,11 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
     if (g1) bar();                   // group 1 runs one barrier behind group 0
     if constexpr (TWO_PHASE) {
       f16x8 a8[4][2];
-      auto rd_ah = [&](const char* sA_, int h) {
+      auto rd_ah = [&](const int cur, int h) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int kk = 0; kk < 2; ++kk) {
-            const int r = wm * WTM + (h * 4 + i) * 16 + frow, kc = kk * 4 + fk;
-            a8[i][kk] = *(const f16x8*)(sA_ + r * 128 + ((kc ^ (r & 7)) << 4));
-          }
+          for (int kk = 0; kk < 2; ++kk) a8[i][kk] = *(const f16x8*)(smem + fa[kk] + (cur * A_TILE + (h * 4 + i) * 2048));
       };
       auto mma_h = [&](auto hh) {
         constexpr int H = decltype(hh)::value;
@@ -661,35 +665,41 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
             for (int j = 0; j < 5; ++j)
               acc[H * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a8[i][kk], b10[j][kk], acc[H * 4 + i][j], 0, 0, 0);
       };
-      for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        const char* sA = smem + cur * STAGE;
-        const char* sB = sA + A_TILE;
-        rd_ball(sB); rd_ah(sA, 0); stage_b(kt + 1, cur ^ 1, B2); stage_a(kt + 1, cur ^ 1, 2); stage_a(kt + 1, cur ^ 1, 3); lgkm0();
+      auto ktile = [&](int kt, const int cur) {                 // ring [A0][A1][B0][B1], loop unrolled by two: see STAGES == 8
+        rd_ball(cur); rd_ah(cur, 0); stage_b(kt + 1, cur ^ 1, B2); stage_a(kt + 1, cur ^ 1, 2); stage_a(kt + 1, cur ^ 1, 3); lgkm0();
         bar(); mma_h(P0); bar();
-        rd_ah(sA, 1); stage_b(kt + 2, cur, B1); stage_a(kt + 2, cur, 0); stage_a(kt + 2, cur, 1); wait_vmcnt<5>(); lgkm0();
+        rd_ah(cur, 1); stage_b(kt + 2, cur, B1); stage_a(kt + 2, cur, 0); stage_a(kt + 2, cur, 1); wait_vmcnt<5>(); lgkm0();
         bar(); mma_h(P1); bar();
-      }
+      };
+      int kt = 0;
+      for (; kt + 1 < nk; kt += 2) { ktile(kt, 0); ktile(kt + 1, 1); }
+      if (kt < nk) ktile(kt, 0);
     } else {
 #if !defined(GDF_ABLATE)
-    for (int kt = 0; kt < nk; ++kt) {
-      const int cur = kt & 1;
-      const char* sA = smem + cur * STAGE;
-      const char* sB = sA + A_TILE;
-      rd_ball(sB); rd_aq(sA, 0); stage_a(kt + 1, cur ^ 1, 3); lgkm0();
+    auto ktile4 = [&](int kt, const int cur) {                  // ring [A0][A1][B0][B1]: see STAGES == 8
+      rd_ball(cur); rd_aq(cur, 0); stage_a(kt + 1, cur ^ 1, 3); lgkm0();
       bar(); mma_q(P0); bar();
-      rd_aq(sA, 1); stage_b(kt + 2, cur, B1); lgkm0();
+      rd_aq(cur, 1); stage_b(kt + 2, cur, B1); lgkm0();
       bar(); mma_q(P1); bar();
-      rd_aq(sA, 2); stage_b(kt + 2, cur, B2); stage_a(kt + 2, cur, 0); lgkm0();
+      rd_aq(cur, 2); stage_b(kt + 2, cur, B2); stage_a(kt + 2, cur, 0); lgkm0();
       bar(); mma_q(P2); bar();
-      rd_aq(sA, 3); stage_a(kt + 2, cur, 1); stage_a(kt + 2, cur, 2); wait_vmcnt<8>(); lgkm0();
+      rd_aq(cur, 3); stage_a(kt + 2, cur, 1); stage_a(kt + 2, cur, 2); wait_vmcnt<8>(); lgkm0();
       bar(); mma_q(P3); bar();
+    };
+    {
+      int kt = 0;
+      if constexpr (MODE == A_DENSE) {
+        for (; kt + 1 < nk; kt += 2) { ktile4(kt, 0); ktile4(kt + 1, 1); }
+        if (kt < nk) ktile4(kt, 0);
+      } else {                                                 // conv: the unrolled form spills 6-7 VGPRs; 4 v_add per K-tile instead
+        for (; kt < nk; ++kt) ktile4(kt, kt & 1);
+      }
     }
 #else
     // ---- diagnostics build (tools/ablate_gemm.sh): the same loop with parts compiled out; results are garbage, timing is the point ----
     //   bit 0: no fragment reads   bit 1: no LDS-DMA   bit 2: no workgroup barriers   bit 3: no MFMAs
     constexpr int ABL = GDF_ABLATE;
-    rd_ball(smem + A_TILE); rd_aq(smem, 0);
+    rd_ball(0); rd_aq(0, 0);
     auto keep = [&]() {
 #pragma unroll
       for (int j = 0; j < 5; ++j) { asm volatile("" : "+v"(b10[j][0])); asm volatile("" : "+v"(b10[j][1])); }
@@ -698,22 +708,24 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
     };
     auto xbar = [&]() { if constexpr (!(ABL & 4)) bar(); };
     auto xmma = [&](auto q) { if constexpr (!(ABL & 8)) mma_q(q); else keep(); };
-    for (int kt = 0; kt < nk; ++kt) {
-      const int cur = kt & 1;
-      const char* sA = smem + cur * STAGE;
-      const char* sB = sA + A_TILE;
-      if constexpr (!(ABL & 1)) { rd_ball(sB); rd_aq(sA, 0); } else keep();
+    auto ktile_abl = [&](int kt, const int cur) {
+      if constexpr (!(ABL & 1)) { rd_ball(cur); rd_aq(cur, 0); } else keep();
       if constexpr (!(ABL & 2)) stage_a(kt + 1, cur ^ 1, 3);
       lgkm0(); xbar(); xmma(P0); xbar();
-      if constexpr (!(ABL & 1)) rd_aq(sA, 1); else keep();
+      if constexpr (!(ABL & 1)) rd_aq(cur, 1); else keep();
       if constexpr (!(ABL & 2)) stage_b(kt + 2, cur, B1);
       lgkm0(); xbar(); xmma(P1); xbar();
-      if constexpr (!(ABL & 1)) rd_aq(sA, 2); else keep();
+      if constexpr (!(ABL & 1)) rd_aq(cur, 2); else keep();
       if constexpr (!(ABL & 2)) { stage_b(kt + 2, cur, B2); stage_a(kt + 2, cur, 0); }
       lgkm0(); xbar(); xmma(P2); xbar();
-      if constexpr (!(ABL & 1)) rd_aq(sA, 3); else keep();
+      if constexpr (!(ABL & 1)) rd_aq(cur, 3); else keep();
       if constexpr (!(ABL & 2)) { stage_a(kt + 2, cur, 1); stage_a(kt + 2, cur, 2); wait_vmcnt<8>(); }
       lgkm0(); xbar(); xmma(P3); xbar();
+    };
+    {
+      int kt = 0;
+      for (; kt + 1 < nk; kt += 2) { ktile_abl(kt, 0); ktile_abl(kt + 1, 1); }
+      if (kt < nk) ktile_abl(kt, 0);
     }
 #endif
     }
