@@ -265,9 +265,18 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(const AttnParams p) {
   if (ntiles > 1) load_tile(1);
 #endif
   GDF_AT_DECL
+  // Fragment addresses = one lane-dependent LDS pointer per operand (opaque to the optimiser, which otherwise rebuilds every
+  // fragment address with its own VALU adds: ~30 per tile; VALU issue time adds to MFMA time on this hardware, tools/micro/overlap.hip)
+  // + the ring buffer's offset (one add per tile) + compile-time constants (key block, k-step) in the instruction's immediate.
+  // (Unrolling the tile loop by two to make the buffer a constant as well spills 123 VGPRs at 64 rows per wave.)
+  const int i16 = lane & 15;
+  LDS_AS const char* kl = (LDS_AS const char*)&sK[0][0] + (lq * LDR + 8 * lh) * 2;
+  LDS_AS const char* vl = (LDS_AS const char*)&sV[0][0] + ((4 * lh + (i16 >> 2)) * LDV + 16 * ((lane >> 4) & 1) + (i16 & 3) * 4) * 2;
+  asm volatile("" : "+v"(kl), "+v"(vl));
   for (int t = 0; t < ntiles; ++t) {
-    const _Float16* cK = sK[t & 1];
-    const _Float16* cV = sV[t & 1];
+    const int BUF = t & 1;
+    LDS_AS const char* const klt = kl + BUF * (KT * LDR * 2);
+    LDS_AS const char* const vlt = vl + BUF * (KT * LDV * 2);
     GDF_AT(3);
 
     // ---- S^T = K Q^T : two 32-key blocks; every K fragment feeds QW query blocks ----
@@ -279,7 +288,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(const AttnParams p) {
 #if defined(GDF_ATTN_ABLATE) && (GDF_ATTN_ABLATE & 64)
       return qf[0][i % NS];                              // diagnostics: no K fragment reads
 #endif
-      return *(const f16x8*)(cK + ((i & 1) * 32 + lq) * LDR + 16 * (i >> 1) + 8 * lh);
+      return *(LDS_AS const f16x8*)(klt + ((i & 1) * 32 * LDR + 16 * (i >> 1)) * 2);
     };
     f16x8 kq[PD];
 #pragma unroll
@@ -291,11 +300,10 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(const AttnParams p) {
       return qf[0][(s4 + db) % NS];                      // diagnostics: no V^T fragment reads
 #endif
       // V^T fragment: lane (d = db*32 + lq, lh) needs V[16 s4 + 4 lh + {0..3}][d] and V[16 s4 + 8 + 4 lh + {0..3}][d]
-      const int i16 = lane & 15;
-      const int c0v = db * 32 + 16 * ((lane >> 4) & 1) + (i16 & 3) * 4;
-      const int r0 = 16 * s4 + 4 * lh + (i16 >> 2);
-      const fp16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((LDS_AS fp16x4_t*)(cV + r0 * LDV + c0v));
-      const fp16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((LDS_AS fp16x4_t*)(cV + (r0 + 8) * LDV + c0v));
+      // (row 4 lh + (i16 >> 2), column 16 ((lane >> 4) & 1) + 4 (i16 & 3) are in `vl`)
+      LDS_AS const char* vp = vlt + (16 * s4 * LDV + db * 32) * 2;
+      const fp16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((LDS_AS fp16x4_t*)vp);
+      const fp16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((LDS_AS fp16x4_t*)(vp + 8 * LDV * 2));
       union { fp16x4_t q[2]; f16x8 h; } vf;              // pure register re-interpretation, no conversion
       vf.q[0] = lo; vf.q[1] = hi;
       return vf.h;
@@ -402,14 +410,14 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(const AttnParams p) {
     __syncthreads();
 #endif
 #elif defined(GDF_ATTN_ABLATE) && (GDF_ATTN_ABLATE & 8)
-    if (t + 1 < ntiles) lstore((t + 1) & 1);         // diagnostics: LDS stores of stale registers, no global loads
+    if (t + 1 < ntiles) lstore(BUF ^ 1);         // diagnostics: LDS stores of stale registers, no global loads
     __syncthreads();
 #elif defined(GDF_ATTN_ABLATE) && (GDF_ATTN_ABLATE & 16)
     __syncthreads();                                 // diagnostics: global loads, no LDS stores
     if (t + 2 < ntiles) load_tile(t + 2);
     asm volatile("" :: "v"(kreg[0]), "v"(vreg[0]), "v"(kreg[NCH - 1]), "v"(vreg[NCH - 1]));
 #else
-    if (t + 1 < ntiles) lstore((t + 1) & 1);
+    if (t + 1 < ntiles) lstore(BUF ^ 1);
     __syncthreads();
     if (t + 2 < ntiles) load_tile(t + 2);           // HBM latency hides under the next tile's MFMAs
 #endif
