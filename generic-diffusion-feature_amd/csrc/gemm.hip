@@ -200,13 +200,17 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
   // ---- per-lane load geometry: one wave-instruction moves 8 rows x 128 B ----
   const int lrow = lane >> 3;                         // row inside an 8-row instruction
   const int chunk = (lane & 7) ^ lrow;                // source 16-B chunk (swizzle on the source side)
-  uint32_t a_off[A_PER_WAVE];                         // DENSE: byte offset of (row, chunk); CONV: pixel base of sample
-  int a_oy[A_PER_WAVE], a_ox[A_PER_WAVE];
+  uint32_t a_off[A_PER_WAVE];                         // DENSE: byte offset of (row, chunk); CONV3: byte offset of filter tap (0, 0)
+  uint32_t a_msk[A_PER_WAVE];                         // CONV3: validity mask of the 9 taps (conv_row below)
+  int a_oy[A_PER_WAVE], a_ox[A_PER_WAVE];             // SMALLC: pixel base of the sample in a_off, top-left input pixel here
 #pragma unroll
   for (int j = 0; j < A_PER_WAVE; ++j) {
     const int m = m0 + (wave * A_PER_WAVE + j) * 8 + lrow;
+    a_msk[j] = 0; a_oy[j] = a_ox[j] = 0;
     if (MODE == A_DENSE) {
       a_off[j] = (m < p.M) ? (uint32_t)m * (uint32_t)p.lda * 2u + (uint32_t)chunk * 16u : OOB;
+    } else if (MODE == A_CONV3) {
+      a_off[j] = 0;                                   // filled by conv_row once its scalars are known
     } else {
       const int hw = p.OH * p.OW;
       const int n = m / hw;
@@ -258,8 +262,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
     if (p.ups) mk |= ((uint32_t)(uy & 1) << 9) | ((uint32_t)(ux & 1) << 10);
     mask = mk;
   };
-  auto conv_off = [&](int kt, uint32_t base, uint32_t mask) -> uint32_t {
-    const int tp = kt / cpb, cbk = kt - tp * cpb;               // K-tiles are tap-major, cpb tiles per filter tap (scalar)
+  auto conv_tap_off = [&](int tp, int cbk, uint32_t base, uint32_t mask) -> uint32_t {     // filter tap tp, channel block cbk (scalars)
     const int ky = tp / 3, kx = tp - ky * 3;
     const uint32_t rowb = (uint32_t)p.W * (uint32_t)p.lda * 2u, pixb = (uint32_t)p.lda * 2u;
     uint32_t off;
@@ -273,23 +276,25 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
     const uint32_t bit = tp < 9 ? (1u << tp) : 0u;               // tiles >= nk (over-staged): zero fill
     return (mask & bit) ? off : OOB;
   };
+  auto conv_off = [&](int kt, uint32_t base, uint32_t mask) -> uint32_t {
+    const int tp = kt / cpb;                                    // K-tiles are tap-major, cpb tiles per filter tap (scalar)
+    return conv_tap_off(tp, kt - tp * cpb, base, mask);
+  };
+  if (MODE == A_CONV3 && STAGES < 8) {
+#pragma unroll
+    for (int j = 0; j < A_PER_WAVE; ++j) conv_row(m0 + (wave * A_PER_WAVE + j) * 8 + lrow, a_off[j], a_msk[j]);
+  }
   int tap = 0, cb = 0;                                 // filter tap / channel block of the NEXT tile to issue
   auto issue = [&](int kt, int buf) {
     char* sA = smem + buf * STAGE;
     char* sB = sA + A_TILE;
-    int ky = 0, kx = 0;
-    if (MODE == A_CONV3) { ky = tap / 3; kx = tap - ky * 3; }
 #pragma unroll
     for (int j = 0; j < A_PER_WAVE; ++j) {
       uint32_t off;
       if (MODE == A_DENSE) {
         off = a_off[j] + (uint32_t)kt * 128u;          // OOB stays >= 2^31
       } else if (MODE == A_CONV3) {
-        const int iy = a_oy[j] + ky, ix = a_ox[j] + kx;
-        const bool okk = (iy >= 0) & (iy < IH) & (ix >= 0) & (ix < IW);
-        const int sy = p.ups ? (iy >> 1) : iy, sx = p.ups ? (ix >> 1) : ix;
-        off = okk ? (a_off[j] + (uint32_t)(sy * p.W + sx)) * (uint32_t)p.lda * 2u + (uint32_t)(cb * BK + chunk * 8) * 2u
-                  : OOB;
+        off = conv_tap_off(tap, cb, a_off[j], a_msk[j]);
       } else {  // SMALLC: 8 channels per pixel = one 16-B chunk per tap; chunk index == tap - 8*kt
         const int tp = kt * 8 + chunk;
         const int kyy = tp / 3, kxx = tp - kyy * 3;
@@ -327,20 +332,22 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
   // registers follow the barrier, 929 -> 684 TFLOP/s on the 256x320 GEGLU GEMM; a two-group ping-pong with 2 barriers
   // per K-tile, 1002 -> 903 at 8192^3.)
   f16x8 af[FM], bf[FN];
+  // lane part of a fragment address per k-step (all wave-tile origins are multiples of 16 rows, so the swizzle term depends on
+  // frow only); opaque to the optimiser so that buffer + fragment offsets stay `one add + immediate` instead of an add per fragment
+  uint32_t rfa[2], rfb[2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+    rfa[kk] = (uint32_t)((wm * WTM + frow) * 128 + (((kk * 4 + fk) ^ (frow & 7)) << 4));
+    rfb[kk] = (uint32_t)(A_TILE + (wn * WTN + frow) * 128 + (((kk * 4 + fk) ^ (frow & 7)) << 4));
+    if (STAGES < 8) asm volatile("" : "+v"(rfa[kk]), "+v"(rfb[kk]));
+  }
   auto read_kk = [&](int buf, int kk) {
-    const char* sA = smem + buf * STAGE;
-    const char* sB = sA + A_TILE;
-    const int kc = kk * 4 + fk;
+    const char* pa = smem + buf * STAGE + rfa[kk];
+    const char* pb = smem + buf * STAGE + rfb[kk];
 #pragma unroll
-    for (int i = 0; i < FM; ++i) {
-      const int r = wm * WTM + i * 16 + frow;
-      af[i] = *(const f16x8*)(sA + r * 128 + ((kc ^ (r & 7)) << 4));
-    }
+    for (int i = 0; i < FM; ++i) af[i] = *(const f16x8*)(pa + i * 2048);
 #pragma unroll
-    for (int j = 0; j < FN; ++j) {
-      const int r = wn * WTN + j * 16 + frow;
-      bf[j] = *(const f16x8*)(sB + r * 128 + ((kc ^ (r & 7)) << 4));
-    }
+    for (int j = 0; j < FN; ++j) bf[j] = *(const f16x8*)(pb + j * 2048);
   };
   auto mma = [&]() {
 #pragma unroll
