@@ -313,6 +313,11 @@ struct PlanBuilder {
     const Ref Wr = wt(w.w);
     const int N = w.cout, Bq = Bn;
     GemmParams gk{}; gk.M = (int)M; gk.N = N; gk.K = 9 * Cin; gk.mode = A_CONV3; gk.bn = e.bn;
+    // few output tiles, long K (SD1.5's 8x8 level: 160 tiles of 128x128 walking 180-360 K-tiles each): deterministic split-K
+    const int splitk = gemm_splitk_factor(gk);
+    const size_t ws_b = splitk > 1 ? (size_t)splitk * M * N * 4 : 0;
+    const size_t wsk = splitk > 1 ? tmp(ws_b) : 0;
+    gk.splitk = splitk;
     op(name, 2.0 * (double)M * N * 9 * Cin, [=](const Bind& b, hipStream_t s) {
       GemmParams g{};
       g.A = (const half_t*)b.p(src); g.lda = ld;
@@ -321,8 +326,9 @@ struct PlanBuilder {
       g.stride = stride; g.ups = ups ? 1 : 0; g.Cin = Cin; g.pad0 = e.pad0;
       g.Wt = (const half_t*)b.p(Wr); g.w_bytes = (uint32_t)((size_t)N * 9 * Cin * 2);
       fill_epi(g, e, b);
-      return launch_gemm(g, s);
+      return splitk > 1 ? launch_gemm_splitk(g, splitk, (float*)b.ws(wsk), s) : launch_gemm(g, s);
     }, gemm_kernel_name(gk));
+    if (splitk > 1) untmp(wsk, ws_b);
   }
 
   // ---- ResnetBlock2D ------------------------------------------------------------------------------

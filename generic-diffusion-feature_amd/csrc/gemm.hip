@@ -232,6 +232,12 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
   }
 
   const int nk = (MODE == A_CONV_SMALLC) ? 2 : p.K / BK;
+  // split-K (2-stage ring tiles only): this workgroup accumulates the K-tiles [kt0, kt1) and stores raw partial sums
+  int kt0 = 0, kt1 = nk;
+  if (STAGES == 2 && p.splitk > 1) {
+    kt0 = (int)((long)nk * blockIdx.y / p.splitk);
+    kt1 = (int)((long)nk * (blockIdx.y + 1) / p.splitk);
+  }
   const int cpb = (MODE == A_CONV3) ? p.Cin / BK : 1;  // K-tiles per filter tap
   const int IH = p.ups ? 2 * p.H : p.H, IW = p.ups ? 2 * p.W : p.W;
 
@@ -284,7 +290,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
 #pragma unroll
     for (int j = 0; j < A_PER_WAVE; ++j) conv_row(m0 + (wave * A_PER_WAVE + j) * 8 + lrow, a_off[j], a_msk[j]);
   }
-  int tap = 0, cb = 0;                                 // filter tap / channel block of the NEXT tile to issue
+  int tap = kt0 / cpb, cb = kt0 - (kt0 / cpb) * cpb;   // filter tap / channel block of the NEXT tile to issue
   auto issue = [&](int kt, int buf) {
     char* sA = smem + buf * STAGE;
     char* sB = sA + A_TILE;
@@ -739,16 +745,16 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
     if (!g1) bar();
     wait_vmcnt<0>();                 // the over-staged tiles must not land in the epilogue's staging area
   } else if (STAGES == 2) {
-    issue(0, 0);
-    for (int kt = 0; kt < nk; ++kt) {
+    issue(kt0, kt0 & 1);
+    for (int kt = kt0; kt < kt1; ++kt) {
       // tile kt has landed (all outstanding DMA of this wave) and every wave is done reading buf[(kt+1)&1]
       wait_vmcnt<0>();
       __syncthreads();
       if (early_mma) {
         read_kk(kt & 1, 0); mma();
-        if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+        if (kt + 1 < kt1) issue(kt + 1, (kt + 1) & 1);
       } else {
-        if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+        if (kt + 1 < kt1) issue(kt + 1, (kt + 1) & 1);
         read_kk(kt & 1, 0); mma();
       }
       read_kk(kt & 1, 1); mma();
@@ -783,7 +789,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
   const float* const e_rowvec = QKN ? nullptr : p.rowvec;
   const _Float16* const e_res16 = QKN ? nullptr : p.res16;
   _Float16* const e_aux16 = QKN ? nullptr : p.aux16;
-  float* const e_out32 = QKN ? nullptr : p.out32;
+  float* const e_out32 = QKN ? nullptr : (STAGES == 2 && p.splitk > 1) ? p.out32 + (size_t)blockIdx.y * p.o32_sstride : p.out32;
   // Every epilogue operand (bias, temb row vector, residual) is fetched BEFORE the staging pass that needs
   // it, so the pass itself is LDS + stores only (a dependent global load per iteration made the first
   // version of this epilogue latency bound: ~17k cycles per tile).
@@ -1112,7 +1118,7 @@ static hipError_t launch_t(const GemmParams& p, hipStream_t s) {
   }
   int gx = tiles_m * tiles_n;
   if (STAGES == 8 && gx > persist_wgs() && !(p.batch > 1)) gx = persist_wgs();   // persistent: one workgroup per CU walks the tiles
-  const dim3 grid(gx, p.batch > 1 ? p.batch : 1);
+  const dim3 grid(gx, (STAGES == 2 && p.splitk > 1) ? p.splitk : p.batch > 1 ? p.batch : 1);
   if constexpr (DIT) hipLaunchKernelGGL((gemm_dit_kernel<BM, BN, STAGES, BF, QKN>), grid, dim3(BM * 2), smem, s, q);
   else hipLaunchKernelGGL((gemm_kernel<MODE, BM, BN, STAGES, GEGLU>), grid, dim3(BM * 2), smem, s, q);
   return hipGetLastError();
@@ -1139,6 +1145,7 @@ static int pick_variant(const GemmParams& p) {
     return (p.N % 128 == 0 && (long)((p.M + 255) / 256) * (p.N / 128) >= 256) ? 2128 : 128;   // PixArt: C = 1152 = 9 x 128
   }
   if (p.bn == 16) return 16;
+  if (p.splitk > 1) return (p.N % 160 == 0 && p.N % 128 != 0) ? 160 : 128;      // split-K lives in the 2-stage ring tiles
   if (p.variant) return p.variant;
   const long tiles256 = (long)((p.M + 255) / 256) * ((p.N + 127) / 128);
   const long tiles320 = (long)((p.M + 255) / 256) * ((p.N + 319) / 320);
@@ -1261,6 +1268,88 @@ hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {
       return v == 160 ? launch_t<A_CONV_SMALLC, 128, 160, 2, false>(p, s) : launch_t<A_CONV_SMALLC, 128, 128, 2, false>(p, s);
   }
   return hipErrorInvalidValue;
+}
+
+// ---- split-K: sum the partial slabs in a fixed order (deterministic) and apply the GEMM epilogue of kernels.h ----
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p, const float* ws, int splitk) {
+  const int CH = p.N / 8;
+  const long total = (long)p.M * CH;
+  const float a_sc = p.acc_scale != 0.f ? p.acc_scale : 1.0f, o_sc = p.out16_scale != 0.f ? p.out16_scale : 1.0f;
+  const size_t slab = (size_t)p.M * p.N;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int row = (int)(i / CH), col = (int)(i - (long)row * CH) * 8;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    for (int sp = 0; sp < splitk; ++sp) {
+      const f32x4* q = (const f32x4*)(ws + sp * slab + (size_t)row * p.N + col);
+      const f32x4 a = q[0], b = q[1];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[e] += a[e]; v[4 + e] += b[e]; }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      v[e] *= a_sc;
+      if (p.bias) v[e] += p.bias[col + e];
+      if (p.rowvec) v[e] += p.rowvec[(size_t)(row / p.rows_per_sample) * p.ldrv + col + e];
+    }
+    if (p.aux16) {
+      f16x8 h;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) h[e] = (_Float16)v[e];
+      *(f16x8*)(p.aux16 + (size_t)row * p.ldaux + col) = h;
+    }
+    if (p.res32) {
+      const f32x4* q = (const f32x4*)(p.res32 + (size_t)row * p.ldres + col);
+      const f32x4 a = q[0], b = q[1];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[e] += a[e]; v[4 + e] += b[e]; }
+    } else if (p.res16) {
+      const f16x8 r = *(const f16x8*)(p.res16 + (size_t)row * p.ldres + col);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += (float)r[e];
+    }
+    if (p.out16) {
+      f16x8 h;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) h[e] = (_Float16)(v[e] * o_sc);
+      *(f16x8*)(p.out16 + (size_t)row * p.ldo16 + col) = h;
+    }
+    if (p.out32) {
+      f32x4* q = (f32x4*)(p.out32 + (size_t)row * p.ldo32 + col);
+      q[0] = f32x4{v[0], v[1], v[2], v[3]};
+      q[1] = f32x4{v[4], v[5], v[6], v[7]};
+    }
+  }
+}
+
+// > 1 when splitting K pays: a plain (UNet) GEMM / conv whose 128-row tiles fill less than half of the chip's 512 workgroup slots
+// while every tile walks a long K.  The factor keeps >= 16 K-tiles per range and aims at ~2 workgroups per CU.
+int gemm_splitk_factor(const GemmParams& p) {
+  static const int off = [] { const char* e = getenv("GDF_SPLITK"); return e && atoi(e) == 0; }();     // diagnostics: GDF_SPLITK=0
+  if (off || p.dit || p.geglu || p.bn == 16 || p.batch > 1 || p.mode == A_CONV_SMALLC || p.variant || (p.N % 128) || (p.K % BK)) return 1;
+  const long tiles = (long)((p.M + 127) / 128) * (p.N / 128);
+  const int nk = p.K / BK;
+  if (tiles >= 256 || nk < 64) return 1;
+  int s = (int)(512 / tiles);
+  if (s > nk / 16) s = nk / 16;
+  if (s > 8) s = 8;
+  return s < 2 ? 1 : s;
+}
+
+hipError_t launch_gemm_splitk(const GemmParams& p, int splitk, float* ws, hipStream_t s) {
+  if (splitk <= 1) return launch_gemm(p, s);
+  if (p.dit || p.geglu || p.batch > 1 || (p.N % 8)) return hipErrorInvalidValue;
+  GemmParams g = p;                                       // pass 1: raw partial sums, one slab per K range
+  g.bias = nullptr; g.rowvec = nullptr; g.res32 = nullptr; g.res16 = nullptr; g.aux16 = nullptr; g.out16 = nullptr;
+  g.acc_scale = 0.f; g.out16_scale = 0.f;
+  g.out32 = ws; g.ldo32 = p.N; g.splitk = splitk; g.o32_sstride = (long)p.M * p.N; g.variant = 0;
+  hipError_t e = launch_gemm(g, s);
+  if (e != hipSuccess) return e;
+  long blocks = ((long)p.M * (p.N / 8) + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, (const float*)ws, splitk);
+  return hipGetLastError();
 }
 
 }  // namespace gdf

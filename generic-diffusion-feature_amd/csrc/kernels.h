@@ -82,6 +82,9 @@ struct GemmParams {
   int ldaux;
   int geglu;             // != 0: weight rows / bias are interleaved [16 h | 16 gate]; out = (h) * gelu(gate), N_out = N/2
   int bn;                // 128 (default) or 16 (very narrow N, e.g. conv_out)
+  int splitk;            // > 1 (2-stage ring tiles, batch <= 1): blockIdx.y selects one of `splitk` contiguous K ranges; the launch then
+                         // writes RAW fp32 partial sums to out32 + blockIdx.y * o32_sstride and launch_gemm_splitk() finishes the epilogue
+  long o32_sstride;      // elements between consecutive partial-sum slabs
   int batch;             // > 1: blockIdx.y selects one of `batch` independent problems sharing A (grouped text-K/V projections)
   long w_bstride;        // elements between consecutive weight matrices
   long o_bstride;        // elements between consecutive out16 matrices
@@ -113,6 +116,11 @@ struct GemmParams {
   float acc_scale, out16_scale;
 };
 hipError_t launch_gemm(const GemmParams& p, hipStream_t s);
+// Deterministic split-K for problems with few output tiles and a long K (the 8x8-level 3x3 convs of SD1.5: 160 tiles of 128x128,
+// K = 11520..23040): gemm_splitk_factor() > 1 says it pays; the caller provides `splitk * M * N` floats of workspace, the GEMM
+// launch writes one raw partial-sum slab per K range and splitk_reduce_kernel sums them in a fixed order and applies the epilogue.
+int gemm_splitk_factor(const GemmParams& p);
+hipError_t launch_gemm_splitk(const GemmParams& p, int splitk, float* ws, hipStream_t s);
 const char* gemm_kernel_name(const GemmParams& p);
 bool gemm_qkn_ok(int M, int N, int K);   // kernel symbol launch_gemm would pick (only M,N,K,mode,geglu,bn,variant are read)
 

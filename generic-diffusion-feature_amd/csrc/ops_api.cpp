@@ -52,6 +52,30 @@ int gdf_op_conv3x3(const void* x, int ld, int B, int H, int W, int Cin, const vo
   return fin(launch_gemm(g, (hipStream_t)stream), "conv3x3");
 }
 
+int gdf_op_conv3x3_splitk(const void* x, int ld, int B, int H, int W, int Cin, const void* Wt, int Cout, const float* bias,
+                          const float* rowvec, int stride, int ups, const float* res32, void* aux16, void* out16,
+                          float* out32, int splitk, float* ws, void* stream) {
+  const int IH = ups ? 2 * H : H, IW = ups ? 2 * W : W;
+  const int OH = (IH - 1) / stride + 1, OW = (IW - 1) / stride + 1;
+  GemmParams g{};
+  if (!span_ok(((size_t)B * H * W - 1) * ld * 2 + (size_t)Cin * 2, (size_t)Cout * 9 * Cin * 2, "conv3x3_splitk")) return GDF_ERR_UNSUPPORTED;
+  g.A = (const half_t*)x; g.lda = ld; g.a_bytes = (uint32_t)(((size_t)B * H * W - 1) * ld * 2 + (size_t)Cin * 2);
+  g.M = B * OH * OW; g.N = Cout; g.K = 9 * Cin; g.mode = A_CONV3; g.H = H; g.W = W; g.OH = OH; g.OW = OW;
+  g.stride = stride; g.ups = ups; g.Cin = Cin;
+  g.Wt = (const half_t*)Wt; g.w_bytes = (uint32_t)((size_t)Cout * 9 * Cin * 2);
+  g.bias = bias; g.rowvec = rowvec; g.rows_per_sample = OH * OW; g.ldrv = Cout;
+  g.res32 = res32; g.ldres = Cout;
+  g.aux16 = (half_t*)aux16; g.ldaux = Cout;
+  g.out16 = (half_t*)out16; g.ldo16 = Cout; g.out32 = out32; g.ldo32 = Cout; g.bn = 128;
+  if (splitk == 0) splitk = gemm_splitk_factor(g);          // 0: the plan builder's own choice (returned through *ws[0]? no: see gdf_op_splitk_factor)
+  return fin(launch_gemm_splitk(g, splitk, ws, (hipStream_t)stream), "conv3x3_splitk");
+}
+
+int gdf_op_splitk_factor(int M, int N, int K, int conv) {
+  GemmParams g{}; g.M = M; g.N = N; g.K = K; g.mode = conv ? A_CONV3 : A_DENSE; g.bn = 128;
+  return gemm_splitk_factor(g);
+}
+
 int gdf_op_conv_in(const void* x_nchw, int B, int Cin, int H, int W, const void* w_oihw, const float* bias, int Cout,
                    void* out16, void* scratch, void* stream) {
   hipStream_t s = (hipStream_t)stream;

@@ -27,6 +27,15 @@ int gdf_op_conv3x3(const void* x, int ld, int B, int H, int W, int Cin, const vo
                    const float* rowvec, int stride, int ups, const float* res32, void* aux16, void* out16,
                    float* out32, int narrow /* bit0: BN=16; bits 8..: tile variant */, void* stream);
 
+/* Deterministic split-K form of gdf_op_conv3x3 (few output tiles, long K — the 8x8-level convs of SD1.5): the K range is cut
+ * into `splitk` contiguous parts (0 = the plan builder's heuristic, gdf_op_splitk_factor), every part writes raw fp32 partial
+ * sums to its own slab of `ws` (splitk * M * Cout floats, M = B * OH * OW), a second kernel adds the slabs in a fixed order and
+ * applies the same epilogue as gdf_op_conv3x3.  Same result as the unsplit conv up to fp32 summation order. */
+int gdf_op_conv3x3_splitk(const void* x, int ld, int B, int H, int W, int Cin, const void* Wt, int Cout, const float* bias,
+                          const float* rowvec, int stride, int ups, const float* res32, void* aux16, void* out16,
+                          float* out32, int splitk, float* ws, void* stream);
+int gdf_op_splitk_factor(int M, int N, int K, int conv);
+
 /* conv_in: x NCHW fp16 [B,Cin<=8,H,W] -> NHWC [B,H,W,Cout]; weights in diffusers OIHW fp16 layout.
  * scratch: B*H*W*16 + Cout*256 bytes.                                                                  */
 int gdf_op_conv_in(const void* x_nchw, int B, int Cin, int H, int W, const void* w_oihw, const float* bias, int Cout,

@@ -110,6 +110,46 @@ def test_conv3x3(B, H, W, Cin, Cout, stride, ups, variant):
     assert rel(o16.permute(0, 3, 1, 2), ref) < TOL16
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout,stride,splitk", [(2, 8, 8, 1280, 1280, 1, 0), (3, 8, 8, 640, 256, 1, 4), (2, 12, 10, 320, 384, 2, 3),
+                                                        (1, 8, 8, 2560, 1280, 1, 8)])
+def test_conv3x3_splitk(B, H, W, Cin, Cout, stride, splitk):
+    """Deterministic split-K (include/gdf_ops.h gdf_op_conv3x3_splitk; the plan builder uses it for few-tile, long-K convs —
+    SD1.5's 8x8 level): same epilogue semantics as gdf_op_conv3x3, vs fp32 F.conv2d; two launches are bit-identical."""
+    import ctypes
+    L = lib()
+    L.gdf_op_splitk_factor.restype = ctypes.c_int
+    x = rnd(B, Cin, H, W); w = rnd(Cout, Cin, 3, 3, scale=(9 * Cin) ** -0.5)
+    bias, temb = rnd(Cout).float(), rnd(B, Cout).float()
+    inc = F.conv2d(x.float(), w.float(), bias, stride=stride, padding=1) + temb[:, :, None, None]
+    OH, OW = inc.shape[2], inc.shape[3]
+    res = rnd(B, Cout, OH, OW, seed=5).float()
+    ref = inc + res
+    M = B * OH * OW
+    heur = L.gdf_op_splitk_factor(M, Cout, 9 * Cin, 1)
+    if splitk == 0:
+        assert heur > 1                                          # the SD1.5 8x8 shape class must take the split path
+    S = splitk or heur
+    x_nhwc = x.permute(0, 2, 3, 1).contiguous().cuda()
+    wd = torch.empty(Cout, 9 * Cin, dtype=torch.half, device="cuda")
+    ws_, bd, td = w.cuda(), bias.cuda(), temb.cuda()
+    ok(L.gdf_op_relayout_conv3(P(ws_), P(wd), Cout, Cin, stream()), L)
+    res_nhwc = res.permute(0, 2, 3, 1).contiguous().cuda()
+    work = torch.empty(S * M * Cout, device="cuda")
+    outs = []
+    for rep in range(2):
+        aux = torch.zeros(B, OH, OW, Cout, dtype=torch.half, device="cuda")
+        o16 = torch.zeros_like(aux); o32 = torch.zeros(B, OH, OW, Cout, device="cuda")
+        ok(L.gdf_op_conv3x3_splitk(P(x_nhwc), Cin, B, H, W, Cin, P(wd), Cout, P(bd), P(td), stride, 0,
+                                   P(res_nhwc), P(aux), P(o16), P(o32), splitk, P(work), stream()), L)
+        torch.cuda.synchronize()
+        outs.append((aux, o16, o32))
+    aux, o16, o32 = outs[0]
+    assert rel(aux.permute(0, 3, 1, 2), inc) < TOL16
+    assert rel(o32.permute(0, 3, 1, 2), ref) < TOL32
+    assert rel(o16.permute(0, 3, 1, 2), ref) < TOL16
+    assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[1]))                  # fixed summation order: run-to-run bit-identical
+
+
 def test_conv3x3_narrow_cout4():
     L = lib()
     B, H, W, Cin, Cout = 2, 8, 8, 64, 4
