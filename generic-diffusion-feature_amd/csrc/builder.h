@@ -261,14 +261,20 @@ struct PlanBuilder {
     const Ref W = wt(w.w + w_off_bytes);
     GemmParams gk{}; gk.M = (int)M; gk.N = N; gk.K = K; gk.mode = A_DENSE; gk.geglu = e.geglu; gk.bn = e.bn; gk.dit = e.dit; gk.bf16 = e.bf16;
     gk.res32 = e.has_r32 ? (const float*)1 : nullptr;      // tile selection looks at the epilogue form (never dereferenced)
+    // few output tiles, long K (small batches: ff_out at 1024-2048 rows): deterministic split-K (see conv3)
+    const int splitk = gemm_splitk_factor(gk);
+    const size_t ws_b = splitk > 1 ? (size_t)splitk * M * N * 4 : 0;
+    const size_t wsk = splitk > 1 ? tmp(ws_b) : 0;
+    gk.splitk = splitk;
     op(name, 2.0 * (double)M * N * K, [=](const Bind& b, hipStream_t s) {
       GemmParams g{};
       g.A = (const half_t*)b.p(A); g.lda = lda; g.a_bytes = (uint32_t)(((size_t)M - 1) * lda * 2 + (size_t)K * 2);
       g.M = (int)M; g.N = N; g.K = K; g.mode = A_DENSE;
       g.Wt = (const half_t*)b.p(W); g.w_bytes = (uint32_t)((size_t)N * K * 2);
       fill_epi(g, e, b);
-      return launch_gemm(g, s);
+      return splitk > 1 ? launch_gemm_splitk(g, splitk, (float*)b.ws(wsk), s) : launch_gemm(g, s);
     }, gemm_kernel_name(gk));
+    if (splitk > 1) untmp(wsk, ws_b);
   }
 
   Ref temb_all{};     // [B][temb_total] f32: every resnet's time_emb_proj(silu(emb)) (UNet only)
