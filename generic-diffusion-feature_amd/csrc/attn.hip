@@ -73,12 +73,17 @@ __device__ __forceinline__ size_t seg_row(int b, int j, int per_b, int seg_T, in
 // every workgroup: [QK^T, softmax, PV, stage + barrier + next loads, whole kernel]
 #if defined(GDF_ATTN_TRACE)
 __device__ unsigned long long gdf_attn_trace[8192 * 8];
-#define GDF_AT_DECL unsigned long long at_acc[4] = {0, 0, 0, 0}; unsigned long long at_t = __builtin_readcyclecounter(); const unsigned long long at_t0 = at_t;
+#define GDF_AT_ENTRY const unsigned long long at_entry = __builtin_readcyclecounter();
+#define GDF_AT_DECL unsigned long long at_acc[4] = {0, 0, 0, 0}; unsigned long long at_t = __builtin_readcyclecounter(); const unsigned long long at_t0 = at_t; \
+    if (threadIdx.x == 0 && blockIdx.x < 8192) gdf_attn_trace[blockIdx.x * 8 + 5] = at_t0 - at_entry;
+#define GDF_AT_EXIT do { if (threadIdx.x == 0 && blockIdx.x < 8192) gdf_attn_trace[blockIdx.x * 8 + 6] = __builtin_readcyclecounter() - at_entry; } while (0)
 #define GDF_AT(i) do { const unsigned long long n_ = __builtin_readcyclecounter(); at_acc[i] += n_ - at_t; at_t = n_; } while (0)
 #define GDF_AT_END do { if (threadIdx.x == 0 && blockIdx.x < 8192) { for (int i_ = 0; i_ < 4; ++i_) gdf_attn_trace[blockIdx.x * 8 + i_] = at_acc[i_]; \
     gdf_attn_trace[blockIdx.x * 8 + 4] = __builtin_readcyclecounter() - at_t0; } } while (0)
 #else
+#define GDF_AT_ENTRY
 #define GDF_AT_DECL
+#define GDF_AT_EXIT
 #define GDF_AT(i)
 #define GDF_AT_END
 #endif
@@ -105,6 +110,7 @@ __device__ unsigned long long gdf_attn_trace[8192 * 8];
 // time, and the lever is the instruction count, not the placement.)
 template <int D, int QW, int NW = 4, bool BF = false>
 __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(const AttnParams p) {
+  GDF_AT_ENTRY
   constexpr int NT = NW * 64;                    // threads per workgroup
   constexpr int DQK = (D + 15) / 16 * 16;        // contraction length of QK^T, padded
   constexpr int DV = (D + 31) / 32 * 32;         // output rows of O^T, padded
@@ -454,6 +460,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(const AttnParams p) {
       if (lane < RPIO * LPRO && r < QBW && q < p.Sq)
         *(f16x8*)(p.o + seg_row(b, q, p.Sq, p.seg_T, p.B, p.Sq) * p.ldo + head * D + oc) = *(const f16x8*)(stg + r * RSH + oc);
     }
+    GDF_AT_EXIT;
     return;
   }
 #pragma unroll
