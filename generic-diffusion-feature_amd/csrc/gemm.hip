@@ -745,7 +745,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
     if (!g1) bar();
     wait_vmcnt<0>();                 // the over-staged tiles must not land in the epilogue's staging area
   } else if (STAGES == 2) {
-    issue(kt0, kt0 & 1);
+    if (kt0 < kt1) issue(kt0, kt0 & 1);                    // (an empty split-K range stores zeros)
     for (int kt = kt0; kt < kt1; ++kt) {
       // tile kt has landed (all outstanding DMA of this wave) and every wave is done reading buf[(kt+1)&1]
       wait_vmcnt<0>();
@@ -1339,7 +1339,9 @@ int gemm_splitk_factor(const GemmParams& p) {
 
 hipError_t launch_gemm_splitk(const GemmParams& p, int splitk, float* ws, hipStream_t s) {
   if (splitk <= 1) return launch_gemm(p, s);
-  if (p.dit || p.geglu || p.batch > 1 || (p.N % 8)) return hipErrorInvalidValue;
+  if (p.dit || p.geglu || p.batch > 1 || (p.N % 8) || p.mode == A_CONV_SMALLC || (p.K % BK)) return hipErrorInvalidValue;
+  if (splitk > p.K / BK) splitk = p.K / BK;
+  if (splitk <= 1) return launch_gemm(p, s);
   GemmParams g = p;                                       // pass 1: raw partial sums, one slab per K range
   g.bias = nullptr; g.rowvec = nullptr; g.res32 = nullptr; g.res16 = nullptr; g.aux16 = nullptr; g.out16 = nullptr;
   g.acc_scale = 0.f; g.out16_scale = 0.f;
