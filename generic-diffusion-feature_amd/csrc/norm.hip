@@ -235,7 +235,10 @@ int gn_fused_slab(int B, int HW, int C, int G) {
   while (L % 8) L += cpg;                                      // lcm(cpg, 8)
   int SC = L;
   while (SC < 64 && C % (SC * 2) == 0) SC *= 2;
-  if (C % SC || SC > 256 || (long)B * (C / SC) < 64) return 0;
+  if (C % SC || SC > 256) return 0;
+  // fewer than 64 workgroups cannot stream a LARGE tensor at full bandwidth; a small one (small batches: <= 8 MiB) is latency bound
+  // and one launch beats the three of the statistics + apply path (batch 2: 44 GroupNorms, 7.5 % of the step in gn_stats alone)
+  if ((long)B * (C / SC) < 64 && (long)B * HW * C * 2 > (8L << 20)) return 0;
   return SC;
 }
 
