@@ -294,8 +294,24 @@ def main():
         d = by_label.setdefault(lab, [0.0, 0.0, 0])
         d[0] += ms; d[1] += fl; d[2] += 1
     dominant = max(by_label, key=lambda k: by_label[k][0])
+    TIMING_STRIDE = 8        # every 8th launch of the dominant kernel carries an event pair (an event node costs ~3.5 us inside a graph)
+    rc = lib.gdf_plan_set_timing_stride(plan.handle, TIMING_STRIDE)
+    assert rc == 0, lib.gdf_last_error()
     rc = lib.gdf_plan_set_timing(plan.handle, dominant.encode())
     assert rc == 0, lib.gdf_last_error()
+    # The timed region below is the PRODUCT path: one hipGraphLaunch per step.  With timing switched on the library replays graphs
+    # that carry event-record nodes around every launch of the dominant kernel (gdf.h gdf_plan_set_timing; one graph per timing
+    # event set), so `roofline.achieved` is measured live inside the same K steps that give `value`.  Those graphs are captured
+    # here, before the clock starts; then the accumulators are reset.  (Results are dropped before each step so that the plan
+    # reuses one hook-buffer set: a stable binding, no capture inside the timed region — asserted below.)
+    out = None
+    for _ in range(4):
+        out = None
+        out = step()
+    torch.cuda.synchronize()
+    rc = lib.gdf_plan_set_timing(plan.handle, dominant.encode())
+    assert rc == 0, lib.gdf_last_error()
+    cap_before = plan.graph_stats()[0]
 
     def barrier():
         if world > 1:
@@ -303,9 +319,11 @@ def main():
     barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
+        out = None
         out = step()
     torch.cuda.synchronize(); barrier()
     dt = time.perf_counter() - t0
+    cap_in_region = plan.graph_stats()[0] - cap_before
     if world > 1:
         tt = torch.tensor([dt], device="cpu" if share_gpu else dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -342,6 +360,8 @@ def main():
             "value": round(ips, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "timed_region": {"path": "hipGraph replay (product default), event-record nodes around the dominant kernel" if plan.graph
+                             else "eager launches (GDF_HIP_GRAPH=0)", "graph_captures_inside": int(cap_in_region)},
             "config": {"workload": f"{'SDXL' if args.version == 'xl' else 'SD1.5'} UNet {img}x{img} (latent {lat}x{lat}), "
                                    f"batch {B}/GPU, t=100, hooks=config_{'xl' if args.version == 'xl' else '15'}_practical "
                                    f"({len(ids)} ids, {hook_bytes / B / 1e6:.2f} MB/img), full forward"
@@ -354,6 +374,8 @@ def main():
             "roofline": {"bound": "mfma", "kernel": dominant, "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                          "launches": int(launches.value), "avg_launch_ms": round(ms_tot.value / max(1, launches.value), 4),
+                         "sampling": f"HIP events around every {TIMING_STRIDE}th launch of the kernel in program order, all K steps "
+                                     f"({int(launches.value)} of {TIMING_STRIDE * int(launches.value)} launches)",
                          "flops_per_launch_g": round(fl_tot.value / max(1, launches.value) / 1e9, 2),
                          "share_of_step_time": round(by_label[dominant][0] / sum(v[0] for v in by_label.values()), 3),
                          # the same kernel symbol serves several op classes of the plan: TFLOP/s and ms per class (synchronising
@@ -398,9 +420,8 @@ def main():
                             "frac": round(2 * copied / 1e6 / max(h_ms, 1e-9) / HBM_PEAK_GBS, 4) if h_ms > 0 else None,
                             "bytes_per_step": copied, "ms_per_step": round(h_ms, 4)},
         }
-        # ---- product path (extra, N = 1): forward_raw as FeatureExtractor.extract drives it — private stream, stable buffers,
-        # the op program replayed as ONE hipGraphLaunch per step (gdf.h gdf_plan_set_graph).  `value` above stays the eagerly
-        # launched, event-instrumented region the roofline contract asks for; this leg shows the host cost the graph removes.
+        # ---- extra legs (N = 1): the same steps WITHOUT the timing nodes (`hipgraph.value`: what FeatureExtractor.extract runs) and
+        # eagerly launched (`eager_host_cpu_ms_per_step`: the host cost the graph removes)
         if world == 1:
             def leg():
                 for _ in range(3):

@@ -71,6 +71,7 @@ SIGNATURES = {
     "gdf_plan_num_kernel_labels": (C.c_int, [C.c_void_p]),
     "gdf_plan_kernel_label": (C.c_char_p, [C.c_void_p, C.c_int]),
     "gdf_plan_set_timing": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "gdf_plan_set_timing_stride": (C.c_int, [C.c_void_p, C.c_int]),
     "gdf_plan_read_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_long), C.POINTER(C.c_double)]),
 }
 

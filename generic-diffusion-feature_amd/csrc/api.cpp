@@ -244,6 +244,13 @@ int gdf_plan_set_timing(gdf_plan* p, const char* kernel_label) {
   if (!p) { set_error("null plan"); return GDF_ERR_ARG; }
   return plan_set_timing(p->p, kernel_label);
 }
+int gdf_plan_set_timing_stride(gdf_plan* p, int stride) {
+  if (!p) { set_error("null plan"); return GDF_ERR_ARG; }
+  if (stride < 1) { set_error("timing stride must be >= 1"); return GDF_ERR_ARG; }
+  if (p->p.timing_label >= 0) { set_error("set the stride before gdf_plan_set_timing"); return GDF_ERR_STATE; }
+  p->p.timing_stride = stride;
+  return GDF_OK;
+}
 int gdf_plan_read_timing(gdf_plan* p, double* ms_total, long* launches, double* flops_total) {
   if (!p) { set_error("null plan"); return GDF_ERR_ARG; }
   return plan_read_timing(p->p, ms_total, launches, flops_total);

@@ -636,8 +636,10 @@ static void timing_collect(Plan& P, int set) {
   if (!P.ev_used[set]) return;
   auto& v = P.ev[set];
   size_t k = 0;
+  long nlab = 0;
   for (auto& op : P.ops) {
     if (op.label != P.timing_label) continue;
+    if ((nlab++ % P.timing_stride) != 0) continue;
     float ms = 0.f;
     hipEventSynchronize(v[k + 1]);
     if (hipEventElapsedTime(&ms, v[k], v[k + 1]) == hipSuccess) { P.t_ms += ms; P.t_flops += op.flops; P.t_launches++; }
@@ -653,7 +655,7 @@ int plan_set_timing(Plan& P, const char* label) {
   for (size_t i = 0; i < P.labels.size(); ++i) if (P.labels[i] == label) P.timing_label = (int)i;
   if (P.timing_label < 0) { set_error(std::string("no op with kernel label ") + label); return GDF_ERR_ARG; }
   size_t n = 0;
-  for (auto& op : P.ops) n += op.label == P.timing_label;
+  for (auto& op : P.ops) n += op.label == P.timing_label;          // (an upper bound with a stride > 1)
   for (int s = 0; s < Plan::EV_RING; ++s)
     while (P.ev[s].size() < 2 * n) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) { set_error("hipEventCreate"); return GDF_ERR_HIP; } P.ev[s].push_back(e); }
   return GDF_OK;
@@ -683,9 +685,46 @@ int plan_forward(Plan& P, const Model& m, const void* lat, const float* t, const
   return plan_run(P, b, s, ms, names, flops, cap);
 }
 
-static int run_ops_eager(Plan& P, const Bind& b, hipStream_t s) {
+// An event-record NODE at the current point of the capture on `s` (fires at every replay).  Spelled with the graph API — current
+// capture dependencies -> hipGraphAddEventRecordNode -> make the node the capture's dependency set — because
+// hipEventRecordWithFlags(..., hipEventRecordExternal) returns "invalid argument" under the HIP runtime PyTorch 2.10 bundles
+// (ROCm 7.0), while it works under /opt/rocm 7.2 (tools/micro/graph_events.hip).
+static hipError_t record_in_capture(hipEvent_t ev, hipStream_t s) {
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  hipGraph_t graph = nullptr;
+  const hipGraphNode_t* deps = nullptr;
+  size_t ndeps = 0;
+  hipError_t e = hipStreamGetCaptureInfo_v2(s, &st, nullptr, &graph, &deps, &ndeps);
+  if (e != hipSuccess) return e;
+  if (st != hipStreamCaptureStatusActive || !graph) return hipErrorStreamCaptureInvalidated;
+  hipGraphNode_t node = nullptr;
+  e = hipGraphAddEventRecordNode(&node, graph, deps, ndeps, ev);
+  if (e != hipSuccess) return e;
+  return hipStreamUpdateCaptureDependencies(s, &node, 1, hipStreamSetCaptureDependencies);
+}
+
+// evset >= 0: record the timing events of set `evset` around every op of the timed label; `external` = inside a stream capture
+// (event-record nodes that fire at every replay)
+static int run_ops_eager(Plan& P, const Bind& b, hipStream_t s, int evset = -1, bool external = false) {
+  size_t evk = 0;
+  long nlab = 0;
   for (auto& op : P.ops) {
+    const bool timed = evset >= 0 && op.label == P.timing_label && (nlab++ % P.timing_stride) == 0;
+    if (timed) {
+      const hipError_t ee = external ? record_in_capture(P.ev[evset][evk], s) : hipEventRecord(P.ev[evset][evk], s);
+      if (ee != hipSuccess) {
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone; (void)hipStreamIsCapturing(s, &st);
+        char buf[160]; snprintf(buf, sizeof buf, "hipEventRecord failed: %s (event %p, stream %p, capture status %d, evk %zu of %zu, external %d)",
+                                hipGetErrorString(ee), (void*)P.ev[evset][evk], (void*)s, (int)st, evk, P.ev[evset].size(), (int)external);
+        set_error(buf); return GDF_ERR_HIP;
+      }
+    }
     hipError_t e = op.fn(b, s);
+    if (timed) {
+      const hipError_t ee = external ? record_in_capture(P.ev[evset][evk + 1], s) : hipEventRecord(P.ev[evset][evk + 1], s);
+      if (ee != hipSuccess && e == hipSuccess) { set_error("hipEventRecord failed"); return GDF_ERR_HIP; }
+      evk += 2;
+    }
     if (e != hipSuccess) { set_error(std::string("op '") + op.name + "' failed: " + hipGetErrorString(e)); return GDF_ERR_HIP; }
   }
   return GDF_OK;
@@ -693,10 +732,12 @@ static int run_ops_eager(Plan& P, const Bind& b, hipStream_t s) {
 
 // hipGraph path: the op program is captured once per distinct binding table on the caller's (non-default) stream and
 // replayed with one hipGraphLaunch; ~2400 kernel launches per SDXL forward become one host call.
-static int run_ops_graph(Plan& P, const Bind& b, hipStream_t s) {
+static int run_ops_graph(Plan& P, const Bind& b, hipStream_t s, int evset = -1) {
   const size_t nh = P.hooks.size();
+  const int label = evset >= 0 ? P.timing_label : -1;
   for (auto& g : P.graphs) {
-    bool same = memcmp(g.key.base, b.base, sizeof b.base) == 0 && memcmp(g.key.f, b.f, sizeof b.f) == 0 && g.hook_ptrs.size() == nh;
+    bool same = g.evset == evset && g.label == label && memcmp(g.key.base, b.base, sizeof b.base) == 0 && memcmp(g.key.f, b.f, sizeof b.f) == 0 &&
+                g.hook_ptrs.size() == nh;
     for (size_t i = 0; same && i < nh; ++i) same = g.hook_ptrs[i] == b.hooks[i];
     if (same) {
       g.stamp = ++P.graph_clock; ++P.graph_launches;
@@ -705,33 +746,35 @@ static int run_ops_graph(Plan& P, const Bind& b, hipStream_t s) {
     }
   }
   Plan::GraphEntry g;
-  g.key = b; g.key.hooks = nullptr;
+  g.key = b; g.key.hooks = nullptr; g.evset = evset; g.label = label;
   for (size_t i = 0; i < nh; ++i) g.hook_ptrs.push_back(b.hooks[i]);
   // Relaxed mode: the op program only launches kernels (no allocation, no synchronisation), and in this mode HIP neither lists
   // the stream for its "unsafe call during capture" checks nor lets an unrelated call invalidate the capture — other host
   // threads (one extractor per thread: aggregation_network.py:67-95) keep allocating, synchronising and capturing freely.
   if (hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) != hipSuccess) {
     (void)hipGetLastError();
-    return run_ops_eager(P, b, s);                       // e.g. the legacy default stream cannot be captured
+    return run_ops_eager(P, b, s, evset);                // e.g. the legacy default stream cannot be captured
   }
-  const int rc = run_ops_eager(P, b, s);
+  const int rc = run_ops_eager(P, b, s, evset, true);
   hipError_t e = hipStreamEndCapture(s, &g.graph);
+  static const bool dbg = getenv("GDF_DEBUG_GRAPH") != nullptr;
+  if (dbg) fprintf(stderr, "[gdf] capture evset=%d rc=%d end=%s graph=%p (%s)\n", evset, rc, hipGetErrorString(e), (void*)g.graph, rc ? last_error() : "");
   if (rc != GDF_OK || e != hipSuccess || !g.graph) {
     // a capture that failed or was invalidated has executed nothing: drop it and run this forward eagerly (the ops are pure
     // functions of their inputs); the next call tries to capture again
     if (g.graph) hipGraphDestroy(g.graph);
     (void)hipGetLastError();
     ++P.graph_capture_failures;
-    return run_ops_eager(P, b, s);
+    return run_ops_eager(P, b, s, evset);
   }
   if (hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0) != hipSuccess) {
     hipGraphDestroy(g.graph);
     (void)hipGetLastError();
     ++P.graph_capture_failures;
-    return run_ops_eager(P, b, s);
+    return run_ops_eager(P, b, s, evset);
   }
   ++P.graph_captures;
-  if (P.graphs.size() >= 4) {                            // evict the least recently used entry
+  if (P.graphs.size() >= 12) {                           // evict the least recently used entry (timed replays: one graph per event set)
     size_t lru = 0;
     for (size_t i = 1; i < P.graphs.size(); ++i) if (P.graphs[i].stamp < P.graphs[lru].stamp) lru = i;
     hipGraphExecDestroy(P.graphs[lru].exec); hipGraphDestroy(P.graphs[lru].graph);
@@ -744,9 +787,19 @@ static int run_ops_graph(Plan& P, const Bind& b, hipStream_t s) {
 }
 
 int plan_run(Plan& P, const Bind& b, hipStream_t s, float* ms, const char** names, double* flops, int cap) {
-  if (P.graph_mode && !ms && P.timing_label < 0 && s != nullptr) {
+  if (P.graph_mode && !ms && s != nullptr) {
     if (!P.warmed) { P.warmed = true; return run_ops_eager(P, b, s); }
-    return run_ops_graph(P, b, s);
+    if (P.timing_label < 0) return run_ops_graph(P, b, s);
+    // timed replay: this forward uses event set `evset`; its results are collected when the set comes round again (or on read)
+    if (!P.timed_graph_broken) {
+      const int evset = P.ev_next; P.ev_next = (P.ev_next + 1) % Plan::EV_RING;
+      timing_collect(P, evset);
+      const long fails = P.graph_capture_failures;
+      const int rc = run_ops_graph(P, b, s, evset);
+      if (P.graph_capture_failures != fails) P.timed_graph_broken = true;     // ran eagerly (with plain events); stay eager from now on
+      if (rc == GDF_OK) P.ev_used[evset] = true;
+      return rc;
+    }
   }
   P.warmed = true;
   hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -758,9 +811,10 @@ int plan_run(Plan& P, const Bind& b, hipStream_t s, float* ms, const char** name
     timing_collect(P, evset);           // results of the forward that used this set EV_RING calls ago
     P.ev_used[evset] = true;
   }
+  long nlab = 0;
   for (auto& op : P.ops) {
     if (ms && i < cap) hipEventRecord(e0, s);
-    const bool timed = evset >= 0 && op.label == P.timing_label;
+    const bool timed = evset >= 0 && op.label == P.timing_label && (nlab++ % P.timing_stride) == 0;
     if (timed) hipEventRecord(P.ev[evset][evk], s);
     hipError_t e = op.fn(b, s);
     if (timed) { hipEventRecord(P.ev[evset][evk + 1], s); evk += 2; }

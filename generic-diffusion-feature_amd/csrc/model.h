@@ -142,12 +142,16 @@ struct Plan {
   std::vector<hipEvent_t> ev[EV_RING];
   bool ev_used[EV_RING] = {false, false, false, false};
   int ev_next = 0;
+  int timing_stride = 1;                      // time every timing_stride-th launch of the label
   double t_ms = 0, t_flops = 0; long t_launches = 0;
   // hipGraph replay of the op program (gdf_plan_set_graph): one captured + instantiated graph per distinct binding table
   // (the op program is static, only the caller's buffer addresses vary), small LRU
-  struct GraphEntry { Bind key; std::vector<void*> hook_ptrs; hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; long stamp = 0; };
+  // evset >= 0: the capture carries event-record nodes (hipEventRecordExternal) of timing event set `evset` around every launch of the
+  // timed kernel label, so that gdf_plan_set_timing measures the graph REPLAY (the product path) and not an eager re-launch
+  struct GraphEntry { Bind key; std::vector<void*> hook_ptrs; hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; long stamp = 0; int evset = -1; int label = -1; };
   int graph_mode = 0;
   bool warmed = false;                        // first forward runs eagerly (lazy one-time kernel attribute setup)
+  bool timed_graph_broken = false;            // a capture with event-record nodes failed once: timed forwards run eagerly
   long graph_clock = 0, graph_launches = 0, graph_captures = 0, graph_capture_failures = 0;
   std::vector<GraphEntry> graphs;
   ~Plan();
