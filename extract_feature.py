@@ -142,6 +142,8 @@ def init_data_parallel():
         dist.init_process_group("gloo", rank=rank, world_size=world)
     else:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"))
+    from components import dist as D
+    D.enable_weight_broadcast()       # every rank builds the same extractor below: rank 0 loads, the others receive the arena
     return rank, world, f"cuda:{local}"
 
 

@@ -8,7 +8,32 @@ the image batch; there is NO collective in the hot loop.
 import torch
 import torch.distributed as dist
 
-BUCKET_ELEMS = 1 << 28          # 512 MiB of fp16 per broadcast: few, large collectives
+import os
+
+# Data-parallel weight sharing is OPT-IN: a host program that merely has a torch.distributed group initialised (a DDP trainer using
+# the extractor as a frozen backbone on some ranks, one extractor per thread, ...) must not be dragged into collectives by the
+# model constructors.  extract_feature.py / bench.py (the launches that build the same model on EVERY rank, in the same order)
+# call enable_weight_broadcast(); GDF_DP_BROADCAST=1 does the same from the environment.
+_broadcast_enabled = os.environ.get("GDF_DP_BROADCAST", "0") not in ("", "0")
+
+
+def enable_weight_broadcast(on=True):
+    global _broadcast_enabled
+    _broadcast_enabled = bool(on)
+
+
+def weight_broadcast_enabled():
+    return _broadcast_enabled and rank_world()[1] > 1
+
+
+def broadcast_object(obj, src=0):
+    """Small picklable object (a config dict) from rank `src` to every rank; identity without a process group."""
+    rank, world = rank_world()
+    if world == 1:
+        return obj
+    box = [obj if rank == src else None]
+    dist.broadcast_object_list(box, src=src)
+    return box[0]
 
 
 def shard_range(n_items, rank, world):
@@ -16,37 +41,6 @@ def shard_range(n_items, rank, world):
     base, rem = divmod(n_items, world)
     lo = rank * base + min(rank, rem)
     return lo, lo + base + (1 if rank < rem else 0)
-
-
-def broadcast_state_dict(shapes, make_tensor, consume, device, src=0, bucket_elems=BUCKET_ELEMS, dtype=torch.float16):
-    """Stream a state dict from rank `src` to all ranks in flat buckets.
-
-    shapes: ordered {name: shape};  make_tensor(name, shape) -> tensor (called on `src` only);
-    consume(dict name -> tensor view) is called on EVERY rank once per bucket (views die with the bucket)."""
-    rank = dist.get_rank() if dist.is_initialized() else 0
-    names = list(shapes)
-    i = 0
-    while i < len(names):
-        j, tot = i, 0
-        while j < len(names) and (tot == 0 or tot + _numel(shapes[names[j]]) <= bucket_elems):
-            tot += _numel(shapes[names[j]])
-            j += 1
-        flat = torch.empty(tot, dtype=dtype, device=device)
-        if rank == src:
-            off = 0
-            for n in names[i:j]:
-                k = _numel(shapes[n])
-                flat[off:off + k] = make_tensor(n, shapes[n]).reshape(-1).to(dtype)
-                off += k
-        if dist.is_initialized() and dist.get_world_size() > 1:
-            dist.broadcast(flat, src=src)
-        off, sd = 0, {}
-        for n in names[i:j]:
-            k = _numel(shapes[n])
-            sd[n] = flat[off:off + k].view(shapes[n])
-            off += k
-        consume(sd)
-        i = j
 
 
 def rank_world():
@@ -65,6 +59,12 @@ def broadcast_model_weights(model, src=0, chunk_bytes=1 << 29):
         return model
     blob = model.weight_blob()
     via_host = dist.get_backend() == "gloo"            # CPU-side test backend (two ranks on one GPU): stage through host memory
+    # every rank must hold an arena of the same size (same architecture descriptor) before any piece moves
+    n = torch.tensor([blob.numel(), -blob.numel()], dtype=torch.int64, device="cpu" if via_host else blob.device)
+    dist.all_reduce(n, op=dist.ReduceOp.MAX)
+    if int(n[0]) != blob.numel() or int(-n[1]) != blob.numel():
+        raise RuntimeError(f"weight arenas differ across ranks ({blob.numel()} bytes here, {int(-n[1])}..{int(n[0])} in the group): "
+                           "the ranks did not build the same model")
     for off in range(0, blob.numel(), chunk_bytes):
         piece = blob[off:off + chunk_bytes]
         if via_host:
@@ -79,26 +79,3 @@ def broadcast_model_weights(model, src=0, chunk_bytes=1 << 29):
     return model
 
 
-def synthetic_param(name, shape, gen, device):
-    """Seeded synthetic weight (no checkpoints offline): W ~ N(0,1/fan_in), bias 0.05 N, gamma 1+0.1 N, beta 0.1 N."""
-    is_norm = ".norm" in name or name.startswith("conv_norm_out")
-    t = torch.randn(shape, generator=gen, device=device, dtype=torch.float32)
-    if name.endswith(".weight") and not is_norm:
-        fan = 1
-        for s in shape[1:]:
-            fan *= s
-        t.mul_(fan ** -0.5)
-    elif name.endswith(".weight"):
-        t.mul_(0.1).add_(1.0)
-    elif is_norm:
-        t.mul_(0.1)
-    else:
-        t.mul_(0.05)
-    return t.half()
-
-
-def _numel(shape):
-    n = 1
-    for s in shape:
-        n *= s
-    return n

@@ -29,10 +29,14 @@ _LATER = ("if", "hunyuan")                       # no BASE
 
 
 def _fill(model, loader):
-    """Weights of a native model in a data-parallel launch (one process per GPU, extract_feature.py under torchrun):
-    rank 0 runs `loader(model)` (checkpoint re-layout or synthetic init), every other rank receives the flat device arena
-    over RCCL (components/dist.py broadcast_model_weights).  Single process: just the loader."""
+    """Weights of a native model.  Single process — or a process group the launch did not opt in with (components/dist.py
+    enable_weight_broadcast: extract_feature.py / bench.py under torchrun do) —: just `loader(model)` (checkpoint re-layout or
+    synthetic init).  Data-parallel launch: rank 0 runs the loader, every other rank receives the flat device arena over RCCL
+    (broadcast_model_weights; the arena sizes are checked to agree first)."""
     from . import dist as D
+    if not D.weight_broadcast_enabled():
+        loader(model)
+        return model
     rank, _world = D.rank_world()
     if rank == 0:
         loader(model)
@@ -204,12 +208,18 @@ class SyntheticPixartPipe(SyntheticPipe):
 
 
 class SyntheticFluxPipe:
-    """Offline stand-in for diffusers' FluxImg2ImgPipeline as the reference drives it
+    """Offline stand-in for the reference's PATCHED FluxImg2ImgPipeline as `FeatureExtractor.extract` drives it
     (`pipe(image=..., prompt=..., strength=t/1000, guidance_scale=1)`, diffusion_feature.py:246-254): true-architecture
     MMDiT (NativeFluxTransformer, seeded random weights) + deterministic stand-ins for the T5/CLIP encoders and the
-    16-channel VAE, flow-matching sigmas, 2x2 latent packing and the img2img strength -> timestep rule."""
+    16-channel VAE, flow-matching sigmas with the resolution-dependent shift, 2x2 latent packing and the img2img
+    strength -> timestep rule.  Like the reference's pipeline (feature/diffusers/pipelines/flux/pipeline_flux_img2img.py:
+    804-841: `return` at the end of the FIRST loop iteration) one call runs EXACTLY ONE transformer forward, at
+    sigmas[t_start], and returns None."""
 
     num_inference_steps = 28                      # FluxImg2ImgPipeline.__call__ default
+    returns_after_first_forward = True            # like the reference's patched pipeline (:841)
+    # FlowMatchEulerDiscreteScheduler config of black-forest-labs/FLUX.1-dev (scheduler/scheduler_config.json) [memory]
+    sched_cfg = dict(base_image_seq_len=256, max_image_seq_len=4096, base_shift=0.5, max_shift=1.15)
 
     def __init__(self, device, seed=0, cfg=None, n_txt=512):
         self.device = device
@@ -223,10 +233,21 @@ class SyntheticFluxPipe:
         self.text_encoder_2 = empty
         self.scheduler = types.SimpleNamespace()
         self.image_processor = types.SimpleNamespace(preprocess=SyntheticPipe._preprocess.__get__(self))
+        self.last_call = None                      # (sigma, packed latents, prompt embeds, ...) of the last call: test / debugging aid
 
     def _embeds(self, text, shape):
         seed = int.from_bytes(hashlib.sha256(text.encode()).digest()[:4], "little")
         return torch.randn(shape, generator=torch.Generator().manual_seed(seed)).to(self.device, torch.float16)
+
+    def sigmas(self, n_steps, image_seq_len):
+        """pipeline_flux_img2img.py:744-760: sigmas = linspace(1, 1/N, N), shifted by mu = calculate_shift(image_seq_len, ...)
+        (`time_shift`: exp(mu) / (exp(mu) + (1/sigma - 1)), FlowMatchEulerDiscreteScheduler with dynamic shifting), + final 0."""
+        c = self.sched_cfg
+        m = (c["max_shift"] - c["base_shift"]) / (c["max_image_seq_len"] - c["base_image_seq_len"])
+        mu = image_seq_len * m + (c["base_shift"] - m * c["base_image_seq_len"])
+        s = torch.linspace(1.0, 1.0 / n_steps, n_steps, dtype=torch.float64)
+        s = math.exp(mu) / (math.exp(mu) + (1.0 / s - 1.0))
+        return s.tolist() + [0.0]
 
     def __call__(self, image=None, prompt=None, strength=0.6, guidance_scale=7.0, num_inference_steps=None, **kw):
         dev = self.device
@@ -243,9 +264,9 @@ class SyntheticFluxPipe:
         Bc, Cc, H, W = lat.shape
         gh, gw = H // 2, W // 2
         pack = lambda z: z.view(Bc, Cc, gh, 2, gw, 2).permute(0, 2, 4, 1, 3, 5).reshape(Bc, gh * gw, Cc * 4)
-        # img2img schedule: sigmas 1 .. 1/N, the last int(N * strength) steps are run (get_timesteps)
+        # img2img schedule (get_timesteps, :606-616): the last int(N * strength) steps remain; only the FIRST of them is run
         N = num_inference_steps or self.num_inference_steps
-        sigmas = torch.linspace(1.0, 1.0 / N, N).tolist() + [0.0]
+        sigmas = self.sigmas(N, gh * gw)
         init = min(N * strength, N)
         t_start = int(max(N - init, 0))
         if N - t_start < 1:
@@ -259,16 +280,14 @@ class SyntheticFluxPipe:
         img_ids = img_ids.reshape(gh * gw, 3)
         txt_ids = torch.zeros(self.n_txt, 3, device=dev)
         guidance = torch.full((B,), float(guidance_scale), device=dev) if self._cfg["guidance_embeds"] else None
-        for i in range(t_start, N):
-            t = torch.full((B,), sigmas[i], device=dev)               # the pipeline passes timestep / 1000 = sigma
-            out = self.transformer.forward_raw(z, enc, pooled, t, img_ids, txt_ids, guidance=guidance,
-                                               hook_ids=self.transformer.requested_ids(), grid=(gh, gw))
-            v, hooks = out
-            if self.transformer.feature_store is not None:
-                for hid, tens in hooks.items():
-                    self.transformer.feature_store.store(tens, hid)
-            z = (z.float() + (sigmas[i + 1] - sigmas[i]) * v.float()).half()
-        return types.SimpleNamespace(images=None, latents=z)
+        t = torch.full((B,), s0, device=dev)                          # the pipeline passes timestep / 1000 = sigma (:816)
+        self.last_call = dict(sigma=s0, t_start=t_start, hidden_states=z, encoder_hidden_states=enc, pooled_projections=pooled,
+                              img_ids=img_ids, txt_ids=txt_ids, guidance=guidance, grid=(gh, gw))
+        # ONE denoiser forward through the model's __call__ (it delivers the hooks to the FeatureStore), then return like the
+        # reference's patched loop does (:841) — no scheduler.step, no further steps, no VAE decode
+        self.transformer(hidden_states=z, timestep=t, guidance=guidance, pooled_projections=pooled, encoder_hidden_states=enc,
+                         txt_ids=txt_ids, img_ids=img_ids, joint_attention_kwargs=None, return_dict=False, grid=(gh, gw))
+        return None
 
 
 def _native_flux_from_diffusers(pipe, device):
@@ -287,8 +306,8 @@ def _native_flux_from_diffusers(pipe, device):
 
 def _native_from_diffusers(pipe, device):
     """Swap pipe.unet (diffusers UNet2DConditionModel) for the native implementation with the same weights."""
-    ucfg = pipe.unet.config if pipe.unet is not None else pipe._gdf_unet_config      # ranks > 0 skip the UNet checkpoint
-    unet = NativeUNet(config_from_diffusers(ucfg), device=device)
+    cfg = getattr(pipe, "_gdf_unet_config", None) or config_from_diffusers(pipe.unet.config)   # ranks > 0 may have no UNet module
+    unet = NativeUNet(cfg, device=device)
     _fill(unet, lambda m: m.load_state_dict(pipe.unet.state_dict()))
     pipe.unet = unet
     # the step before the hot path (SURVEY.md §8f rank 1): VAE encode + sample + noise-add in libgdf.so as well.
@@ -352,16 +371,23 @@ def get_diffusion_model(version, dtype, offline_lora=None, offline_lora_filename
     kw = dict(variant="fp16") if (version in ("xl", "pgv2") and dt == torch.float16) else {}      # reference models.py:51-53
     from . import dist as D
     rank, world = D.rank_world()
-    ucfg = None
-    if world > 1 and rank != 0:          # data-parallel launch: only rank 0 reads the 5 GB UNet checkpoint, the rest receive it (_fill)
-        ucfg = types.SimpleNamespace(**diffusers.UNet2DConditionModel.load_config(repo, subfolder="unet"))
+    # data-parallel launch (opt-in, see _fill): only rank 0 reads the 5 GB UNet checkpoint, the other ranks receive the re-laid-out
+    # arena.  With an offline LoRA every rank loads its own UNet instead: load_lora_weights / fuse_lora need the module, and each
+    # rank fuses the same weights (the broadcast then only overwrites them with rank 0's identical arena).
+    skip_unet = D.weight_broadcast_enabled() and rank != 0 and not offline_lora
+    if skip_unet:
         kw["unet"] = None
     pipe = getattr(diffusers, cls).from_pretrained(repo, torch_dtype=dt, use_safetensors=True, **kw)
-    pipe._gdf_unet_config = ucfg
     if version != "1-5":
         pipe.scheduler = diffusers.EulerDiscreteScheduler.from_config(pipe.scheduler.config)
     if offline_lora:
         pipe.load_lora_weights(offline_lora, weight_name=offline_lora_filename)
         pipe.fuse_lora()
+    # the architecture descriptor comes from rank 0's LOADED module (constructor defaults filled in: the raw config.json of SD1.5 /
+    # SD2.1 lacks `transformer_layers_per_block`, SD1.5's also `use_linear_projection`) and is sent to the ranks without a UNet
+    cfg = config_from_diffusers(pipe.unet.config) if pipe.unet is not None else None
+    if D.weight_broadcast_enabled():
+        cfg = D.broadcast_object(cfg, src=0)
+    pipe._gdf_unet_config = cfg
     pipe = pipe.to(device)
     return _native_from_diffusers(pipe, device)

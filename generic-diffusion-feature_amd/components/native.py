@@ -67,6 +67,7 @@ SIGNATURES = {
                                    C.POINTER(C.c_float), C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.c_int]),
     "gdf_plan_set_graph": (C.c_int, [C.c_void_p, C.c_int]),
     "gdf_plan_graph_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_long), C.POINTER(C.c_long)]),
+    "gdf_plan_graph_failures": (C.c_long, [C.c_void_p]),
     "gdf_plan_op_kernel": (C.c_char_p, [C.c_void_p, C.c_int]),
     "gdf_plan_num_kernel_labels": (C.c_int, [C.c_void_p]),
     "gdf_plan_kernel_label": (C.c_char_p, [C.c_void_p, C.c_int]),
@@ -195,26 +196,31 @@ def arch_desc(cfg):
 
 
 def config_from_diffusers(uc):
-    """Map a diffusers UNet2DConditionModel.config onto ARCH_CONFIGS fields."""
+    """Map a diffusers UNet2DConditionModel.config (or a raw config.json namespace: fields the constructor defaults are read with
+    those defaults) onto ARCH_CONFIGS fields."""
     boc = tuple(uc.block_out_channels)
     n = len(boc)
-    tl = uc.transformer_layers_per_block
+    tl = getattr(uc, "transformer_layers_per_block", 1)
     tl = tuple(tl) if isinstance(tl, (list, tuple)) else (tl,) * n
     ahd = uc.attention_head_dim
     ahd = tuple(ahd) if isinstance(ahd, (list, tuple)) else (ahd,) * n
     text_time = getattr(uc, "addition_embed_type", None) == "text_time"
     return dict(in_channels=uc.in_channels, out_channels=uc.out_channels, block_out_channels=boc,
                 has_attn=tuple(int("CrossAttn" in t) for t in uc.down_block_types), transformer_layers=tl, heads=ahd,
-                layers_per_block=uc.layers_per_block, cross_attention_dim=uc.cross_attention_dim,
-                use_linear_projection=int(bool(uc.use_linear_projection)), time_embed_dim=boc[0] * 4,
+                layers_per_block=getattr(uc, "layers_per_block", 2), cross_attention_dim=uc.cross_attention_dim,
+                use_linear_projection=int(bool(getattr(uc, "use_linear_projection", False))), time_embed_dim=boc[0] * 4,
                 addition_embed_text_time=int(text_time),
-                addition_time_embed_dim=(uc.addition_time_embed_dim or 0) if text_time else 0,
-                add_in_dim=(uc.projection_class_embeddings_input_dim or 0) if text_time else 0)
+                addition_time_embed_dim=(getattr(uc, "addition_time_embed_dim", None) or 0) if text_time else 0,
+                add_in_dim=(getattr(uc, "projection_class_embeddings_input_dim", None) or 0) if text_time else 0)
 
 
 def _use_count(t):
-    """References to the storage of tensor `t` (views handed to callers included) — the liveness test of a hook-buffer set."""
-    return torch._C._storage_Use_Count(t.untyped_storage()._cdata)
+    """References to the storage of tensor `t` (views handed to callers included) — the liveness test of a hook-buffer set.
+    Private torch API; when a torch build lacks it, sets are never pooled (fresh buffers per forward, eager launches)."""
+    try:
+        return torch._C._storage_Use_Count(t.untyped_storage()._cdata)
+    except Exception:
+        return None
 
 
 class _HookSet:
@@ -237,7 +243,14 @@ class _HookSet:
         self.base_count = _use_count(self.buf)
 
     def free(self):
-        return _use_count(self.buf) == self.base_count
+        """Reusable once the caller dropped every view.  Reuse is STREAM-ORDERED, not event-guarded: the next forward runs on the
+        plan's stream after `side.wait_stream(current)`, so everything the caller enqueued on its current stream before calling
+        the next forward (a D2H copy of the hooks, a consumer kernel) is ordered before the buffers are overwritten, and the host
+        can keep queueing forwards without waiting for the GPU.
+        CONTRACT (differs from the caching allocator, where record_stream() on a view protects it): a consumer that reads the
+        returned tensors on ANOTHER stream must keep them referenced until that stream's work has been ordered before its next
+        extract() call (e.g. current_stream.wait_stream(other)), exactly as for any buffer it would hand back to a producer."""
+        return self.base_count is not None and _use_count(self.buf) == self.base_count
 
 
 class _Plan:
@@ -245,6 +258,11 @@ class _Plan:
     hook-buffer sets and a private non-default stream.  Stable addresses are what lets gdf_plan_set_graph replay one captured
     hipGraph per set instead of re-capturing (the graph cache of the library is keyed on the buffer addresses)."""
     MAX_SETS = 3
+    # Forwards queued ahead of the GPU.  An SDXL forward is ~1000 kernel nodes; with an unbounded queue the AQL ring fills and the
+    # host thread SPINS inside hipGraphLaunch waiting for ring space (BENCH_r02: 35 ms of host CPU per step with 20 steps
+    # queued).  Bounding the depth and waiting on a blocking-sync event makes the host SLEEP instead; two forwards ahead is more
+    # than enough to keep the GPU fed (a forward is 10..500 ms of GPU work, its launch 0.4 ms).
+    MAX_INFLIGHT = int(os.environ.get("GDF_MAX_INFLIGHT", "2"))
 
     def __init__(self, lib, handle):
         self.lib, self.handle = lib, handle
@@ -260,6 +278,7 @@ class _Plan:
         self.stream = None
         self.staged = {}
         self.sets = []
+        self.inflight = []
 
     def __del__(self):
         try:
@@ -268,9 +287,10 @@ class _Plan:
             pass
 
     def graph_stats(self):
+        """(captures, graph launches, forwards that fell back to eager launching after a failed capture)"""
         cap, lau = C.c_long(), C.c_long()
         self.lib.gdf_plan_graph_stats(self.handle, C.byref(cap), C.byref(lau))
-        return cap.value, lau.value
+        return cap.value, lau.value, int(self.lib.gdf_plan_graph_failures(self.handle))
 
     def _stage(self, name, t, dtype, dev):
         """copy `t` into the persistent staging buffer of input `name` (dtype conversion + layout in the same copy)"""
@@ -291,6 +311,8 @@ class _Plan:
         if self.stream is None:
             self.stream = torch.cuda.Stream(device=dev)
         side = self.stream
+        while len(self.inflight) >= max(1, self.MAX_INFLIGHT):
+            self.inflight.pop(0).synchronize()     # blocking-sync event: the thread sleeps, it does not spin
         side.wait_stream(cur)
         n_out = 1
         for d in out_shape:
@@ -315,6 +337,9 @@ class _Plan:
                 if no_graph:
                     self.lib.gdf_plan_set_graph(self.handle, 1)
             hs.buf.record_stream(cur)
+            done = torch.cuda.Event(blocking=True)
+            done.record(side)
+            self.inflight.append(done)
         cur.wait_stream(side)
         feats = {}
         for off, (hid, shape, stride, _) in zip(hs.offs, self.hooks):
@@ -591,6 +616,15 @@ def flux_desc(cfg):
     return d
 
 
+class SingleForwardDone(Exception):
+    """Raised by NativeFluxTransformer.__call__ (single_forward=True) after its first forward of a pipeline call; carries the
+    model output.  See FeatureExtractor.extract (flux branch)."""
+
+    def __init__(self, sample):
+        super().__init__("single denoiser forward done")
+        self.sample = sample
+
+
 class NativeFluxTransformer(_NativeModel):
     """FluxTransformer2DModel replacement running entirely in libgdf.so (hand-written HIP, gfx950).
 
@@ -621,6 +655,8 @@ class NativeFluxTransformer(_NativeModel):
         self.handle = h
         self.early_exit = bool(early_exit)
         self.feature_store = None
+        self.single_forward = False      # True: __call__ raises SingleForwardDone after one forward (stock diffusers pipelines)
+        self.calls = 0                   # number of __call__ forwards so far (tests count one per pipe(...) call)
         self._plans = {}
         self.io_dtype = torch.bfloat16 if self.cfg["compute_dtype"] == "bfloat16" else torch.float16   # inputs / `out` of libgdf
         self.dtype = self.io_dtype
@@ -684,15 +720,22 @@ class NativeFluxTransformer(_NativeModel):
 
     def __call__(self, hidden_states, encoder_hidden_states=None, pooled_projections=None, timestep=None, img_ids=None,
                  txt_ids=None, guidance=None, joint_attention_kwargs=None, controlnet_block_samples=None,
-                 controlnet_single_block_samples=None, return_dict=True, **kwargs):
+                 controlnet_single_block_samples=None, return_dict=True, grid=None, **kwargs):
         if controlnet_block_samples is not None or controlnet_single_block_samples is not None or joint_attention_kwargs:
             raise NotImplementedError("ControlNet residuals / IP-adapter kwargs are outside the native hot path")
         ids = self.requested_ids()
         out, hooks = self.forward_raw(hidden_states, encoder_hidden_states, pooled_projections, timestep, img_ids, txt_ids,
-                                      guidance=guidance, hook_ids=ids)
+                                      guidance=guidance, hook_ids=ids, grid=grid)
+        self.calls += 1
         if self.feature_store is not None:
             for hid, t in hooks.items():
                 self.feature_store.store(t, hid)
+        if self.single_forward:
+            # The reference's patched pipeline returns right after its FIRST transformer call
+            # (feature/diffusers/pipelines/flux/pipeline_flux_img2img.py:804-841): one pipe(...) call = one denoiser forward at
+            # sigmas[t_start].  A stock (un-patched) diffusers FluxImg2ImgPipeline would go on to scheduler.step, the remaining
+            # steps and the VAE decode; FeatureExtractor.extract sets this flag and catches the exception instead.
+            raise SingleForwardDone(out)
         if return_dict:
             return types.SimpleNamespace(sample=out)
         return (out,)

@@ -240,6 +240,7 @@ int gdf_plan_graph_stats(const gdf_plan* p, long* captures, long* launches) {
   if (launches) *launches = p->p.graph_launches;
   return GDF_OK;
 }
+long gdf_plan_graph_failures(const gdf_plan* p) { return p ? p->p.graph_capture_failures : -1; }
 int gdf_plan_set_timing(gdf_plan* p, const char* kernel_label) {
   if (!p) { set_error("null plan"); return GDF_ERR_ARG; }
   return plan_set_timing(p->p, kernel_label);

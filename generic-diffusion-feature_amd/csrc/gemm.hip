@@ -238,7 +238,10 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
     kt0 = (int)((long)nk * blockIdx.y / p.splitk);
     kt1 = (int)((long)nk * (blockIdx.y + 1) / p.splitk);
   }
-  const int cpb = (MODE == A_CONV3) ? p.Cin / BK : 1;  // K-tiles per filter tap
+  // 3x3 conv: K-tiles are channel-block-major with the nine filter taps innermost (K-tile kt = tap kt % 9 of channel block kt / 9;
+  // weights laid out [Cout][Cin / 64][tap][64] by launch_relayout_conv).  Round 2 walked them tap-major: the nine shifted reads of
+  // one 64-channel slab were Cin / 64 K-tiles apart, times all resident workgroups of the XCD >> its 4 MB L2, and rocprofv3 counted
+  // 1.38 GB of fabric fetches per launch for 134 MB of input + weights (profiles/r02_final_pmc_traffic.json).
   const int IH = p.ups ? 2 * p.H : p.H, IW = p.ups ? 2 * p.W : p.W;
 
   // byte offset of K-tile kt inside a dense row.  The two-group schedules also stage the tiles nk, nk + 1 (so that the counted
@@ -268,7 +271,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
     if (p.ups) mk |= ((uint32_t)(uy & 1) << 9) | ((uint32_t)(ux & 1) << 10);
     mask = mk;
   };
-  auto conv_tap_off = [&](int tp, int cbk, uint32_t base, uint32_t mask) -> uint32_t {     // filter tap tp, channel block cbk (scalars)
+  auto conv_tap_off = [&](int tp, int cbk, uint32_t base, uint32_t mask, bool live = true) -> uint32_t {     // filter tap tp, channel block cbk (scalars)
     const int ky = tp / 3, kx = tp - ky * 3;
     const uint32_t rowb = (uint32_t)p.W * (uint32_t)p.lda * 2u, pixb = (uint32_t)p.lda * 2u;
     uint32_t off;
@@ -279,18 +282,18 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
       if (ky == 1 && (mask & 512u)) off += rowb;
       if (kx == 1 && (mask & 1024u)) off += pixb;
     }
-    const uint32_t bit = tp < 9 ? (1u << tp) : 0u;               // tiles >= nk (over-staged): zero fill
+    const uint32_t bit = live ? (1u << tp) : 0u;                 // tiles >= nk (over-staged): zero fill
     return (mask & bit) ? off : OOB;
   };
   auto conv_off = [&](int kt, uint32_t base, uint32_t mask) -> uint32_t {
-    const int tp = kt / cpb;                                    // K-tiles are tap-major, cpb tiles per filter tap (scalar)
-    return conv_tap_off(tp, kt - tp * cpb, base, mask);
+    const int cbk = kt / 9;                                     // scalar: channel block, then filter tap
+    return conv_tap_off(kt - cbk * 9, cbk, base, mask, kt < nk);
   };
   if (MODE == A_CONV3 && STAGES < 8) {
 #pragma unroll
     for (int j = 0; j < A_PER_WAVE; ++j) conv_row(m0 + (wave * A_PER_WAVE + j) * 8 + lrow, a_off[j], a_msk[j]);
   }
-  int tap = kt0 / cpb, cb = kt0 - (kt0 / cpb) * cpb;   // filter tap / channel block of the NEXT tile to issue
+  int cb = kt0 / 9, tap = kt0 - (kt0 / 9) * 9;         // channel block / filter tap of the NEXT tile to issue
   auto issue = [&](int kt, int buf) {
     char* sA = smem + buf * STAGE;
     char* sB = sA + A_TILE;
@@ -317,7 +320,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
         glds16(rsB, sB + (wave * B_PER_WAVE + j) * 1024, off);
       }
     }
-    if (MODE == A_CONV3) { if (++cb == cpb) { cb = 0; ++tap; } }
+    if (MODE == A_CONV3) { if (++tap == 9) { tap = 0; ++cb; } }
   };
 
   // ---- accumulators ----
@@ -578,7 +581,6 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
       const int n = n0 + qi * 8 + lrow;
       ub[j] = (n < p.N) ? (uint32_t)n * (uint32_t)p.K * 2u + (uint32_t)chunk * 16u : OOB;
     }
-    // filter tap / channel block of K-tile kt (conv): K-tiles are tap-major, cpb tiles per tap
     auto stage_a = [&](int kt, int buf, int q) {
       char* dst = smem + buf * A_TILE + ((wave >> 2) * 128 + q * 32 + (wave & 3) * 8) * 128;
       glds16(rsA, dst, MODE == A_DENSE ? ua[q] + koff(kt) : conv_off(kt, ua[q], um[q]));

@@ -59,7 +59,7 @@ struct GemmParams {
   int ups;               // 1: source is nearest-upsampled x2 before the conv (Upsample2D fused)
   int pad0;              // 0: zero padding 1 on every side; 1: pad right / bottom only (F.pad (0,1,0,1), Downsample2D padding=0)
   int Cin;
-  // ---- B operand: weights [N][K] fp16, K contiguous (conv: K index = tap*Cin + c)
+  // ---- B operand: weights [N][K] fp16, K contiguous (conv3: K index = ((c / 64) * 9 + tap) * 64 + c % 64, launch_relayout_conv cblk = 64)
   const half_t* Wt;
   uint32_t w_bytes;
   // ---- epilogue:  v = acc + bias[col] + rowvec[row / rows_per_sample][col]
@@ -232,8 +232,9 @@ hipError_t launch_maps_mean(const half_t* const* maps, int n, int B, int heads, 
 // ------------------------------------------------------------------------------------------------
 // `src_f32` is the source dtype code of gdf_model_set_param: 0 fp16, 1 fp32, 2 bf16
 // generic: dst[o][t][i] = src[o][i][t]  (OIHW -> OHWI with T = kh*kw); i padded to ipad, t to tpad
+// cblk > 0: dst[o][i / cblk][t][i % cblk] (the 3x3-conv K order of gemm_kernel<A_CONV3>: K index = ((c / 64) * 9 + tap) * 64 + c % 64)
 hipError_t launch_relayout_conv(const void* src, int src_f32, half_t* dst, int O, int I, int T, int ipad, int tpad,
-                                hipStream_t s);
+                                hipStream_t s, int cblk = 0);
 // rows: dst[rowmap(r)][k] = src[r][k] for r in [0,R); rowmap: 0 identity+row_off, 1 GEGLU interleave (half = R/2)
 hipError_t launch_relayout_rows(const void* src, int src_f32, half_t* dst, int R, int K, int row_off, int geglu /*0 or interleave group (16)*/,
                                 hipStream_t s, int dst_bf16 = 0);

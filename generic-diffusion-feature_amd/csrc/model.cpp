@@ -212,7 +212,7 @@ int model_set_param(Model* m, const char* name, const void* src, int dtype, hipS
     case PK_VEC: e = launch_relayout_vec(src, f32, (float*)(base + p.dst), (int)p.shape[0], 0, 0, s); break;
     case PK_VEC_OFF: e = launch_relayout_vec(src, f32, (float*)(base + p.dst), p.a0, p.a1, 0, s); break;
     case PK_VEC_GEGLU: e = launch_relayout_vec(src, f32, (float*)(base + p.dst), p.a0, 0, geglu_group(p.a0), s); break;
-    case PK_CONV3: e = launch_relayout_conv(src, f32, (half_t*)(base + p.dst), p.a0, p.a1, 9, p.a1, 9, s); break;
+    case PK_CONV3: e = launch_relayout_conv(src, f32, (half_t*)(base + p.dst), p.a0, p.a1, 9, p.a1, 9, s, 64); break;
     case PK_CONV_IN: e = launch_relayout_conv(src, f32, (half_t*)(base + p.dst), p.a0, p.a1, 9, 8, 16, s); break;
     case PK_ROWS: e = launch_relayout_rows(src, f32, (half_t*)(base + p.dst), p.a0, p.a1, p.a2, 0, s, m->bf16); break;
     case PK_ROWS_PADK: e = launch_relayout_rows_padk(src, f32, (half_t*)(base + p.dst), p.a0, p.a1, p.a2, s); break;
@@ -759,18 +759,24 @@ static int run_ops_graph(Plan& P, const Bind& b, hipStream_t s, int evset = -1) 
   hipError_t e = hipStreamEndCapture(s, &g.graph);
   static const bool dbg = getenv("GDF_DEBUG_GRAPH") != nullptr;
   if (dbg) fprintf(stderr, "[gdf] capture evset=%d rc=%d end=%s graph=%p (%s)\n", evset, rc, hipGetErrorString(e), (void*)g.graph, rc ? last_error() : "");
+  auto failed = [&](const char* what, hipError_t err) {
+    // reported once per plan: a persistently failing capture would otherwise silently turn every forward into ~1000 eager launches
+    if (P.graph_capture_failures++ == 0)
+      fprintf(stderr, "[gdf] hipGraph %s failed (%s%s%s): this forward runs eagerly; gdf_plan_graph_failures() counts such calls\n", what,
+              hipGetErrorString(err), rc != GDF_OK ? "; " : "", rc != GDF_OK ? last_error() : "");
+  };
   if (rc != GDF_OK || e != hipSuccess || !g.graph) {
     // a capture that failed or was invalidated has executed nothing: drop it and run this forward eagerly (the ops are pure
     // functions of their inputs); the next call tries to capture again
     if (g.graph) hipGraphDestroy(g.graph);
     (void)hipGetLastError();
-    ++P.graph_capture_failures;
+    failed("capture", e);
     return run_ops_eager(P, b, s, evset);
   }
-  if (hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0) != hipSuccess) {
+  if (const hipError_t ie = hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0); ie != hipSuccess) {
     hipGraphDestroy(g.graph);
     (void)hipGetLastError();
-    ++P.graph_capture_failures;
+    failed("instantiate", ie);
     return run_ops_eager(P, b, s, evset);
   }
   ++P.graph_captures;

@@ -578,24 +578,37 @@ __device__ __forceinline__ int geglu_row(int r, int half, int g) {
   return (rr / g) * 2 * g + (is_gate ? g : 0) + (rr % g);
 }
 
-__global__ void relayout_conv_kernel(const void* src, int f32, half_t* dst, int O, int I, int T, int ipad, int tpad,
+// cblk == 0: dst[o][t][i];  cblk > 0 (3x3 convs, cblk = 64 = one K-tile): dst[o][i / cblk][t][i % cblk] — channel-block-major with
+// the filter taps INNERMOST, so that the implicit GEMM walks the nine shifted windows of one 64-channel slab of the input in nine
+// CONSECUTIVE K-tiles (they overlap in all but one image row / column: the re-reads hit the XCD's L2 instead of the fabric)
+__global__ void relayout_conv_kernel(const void* src, int f32, half_t* dst, int O, int I, int T, int ipad, int tpad, int cblk,
                                      long total) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int ci = (int)(i % ipad);
-    const int t = (int)((i / ipad) % tpad);
-    const int o = (int)(i / ((long)ipad * tpad));
+    int ci, t, o;
+    if (cblk > 0) {
+      const int cl = (int)(i % cblk);
+      t = (int)((i / cblk) % tpad);
+      const int cb = (int)((i / ((long)cblk * tpad)) % (ipad / cblk));
+      o = (int)(i / ((long)ipad * tpad));
+      ci = cb * cblk + cl;
+    } else {
+      ci = (int)(i % ipad);
+      t = (int)((i / ipad) % tpad);
+      o = (int)(i / ((long)ipad * tpad));
+    }
     float v = 0.f;
     if (ci < I && t < T) v = ldsrc(src, f32, ((size_t)o * I + ci) * T + t);
     dst[i] = (_Float16)v;
   }
 }
 hipError_t launch_relayout_conv(const void* src, int src_f32, half_t* dst, int O, int I, int T, int ipad, int tpad,
-                                hipStream_t s) {
+                                hipStream_t s, int cblk) {
+  if (cblk > 0 && (ipad % cblk) != 0) return hipErrorInvalidValue;
   const long total = (long)O * ipad * tpad;
   long blocks = (total + 255) / 256;
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(relayout_conv_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src, src_f32, dst, O, I, T, ipad,
-                     tpad, total);
+                     tpad, cblk, total);
   return hipGetLastError();
 }
 

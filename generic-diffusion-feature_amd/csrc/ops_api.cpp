@@ -127,7 +127,7 @@ int gdf_op_copy2d(const void* s16, const float* s32, int lds, void* dst, int ldd
 }
 
 int gdf_op_relayout_conv3(const void* w, void* dst, int O, int I, void* stream) {
-  return fin(launch_relayout_conv(w, 0, (half_t*)dst, O, I, 9, I, 9, (hipStream_t)stream), "relayout_conv3");
+  return fin(launch_relayout_conv(w, 0, (half_t*)dst, O, I, 9, I, 9, (hipStream_t)stream, 64), "relayout_conv3");
 }
 int gdf_op_relayout_geglu(const void* w, const float* bias, void* w_dst, float* bias_dst, int R, int K, int group, void* stream) {
   hipError_t e = launch_relayout_rows(w, 0, (half_t*)w_dst, R, K, 0, group, (hipStream_t)stream);

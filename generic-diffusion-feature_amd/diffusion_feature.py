@@ -121,8 +121,22 @@ class FeatureExtractor(nn.Module):
         self.feature_store.reset()
         device = self.device
         if self.version == 'flux':                                                       # reference :246-254
-            self.pipe(image=[i.resize((self.img_size, self.img_size)).convert("RGB") for i in image],
-                      prompt=prompts, strength=t / 1000, guidance_scale=1)
+            # ONE denoiser forward per call, at sigmas[t_start]: the reference's patched pipeline returns after its first
+            # transformer call (feature/diffusers/pipelines/flux/pipeline_flux_img2img.py:804-841).  The synthetic pipe does
+            # the same by construction; a stock diffusers pipeline is stopped by the native transformer (SingleForwardDone).
+            from components.native import SingleForwardDone
+            tr = getattr(self.pipe, 'transformer', None)
+            stock = tr is not None and hasattr(tr, 'single_forward') and not getattr(self.pipe, 'returns_after_first_forward', False)
+            if stock:
+                tr.single_forward = True
+            try:
+                self.pipe(image=[i.resize((self.img_size, self.img_size)).convert("RGB") for i in image],
+                          prompt=prompts, strength=t / 1000, guidance_scale=1)
+            except SingleForwardDone:
+                pass
+            finally:
+                if stock:
+                    tr.single_forward = False
             return self.feature_store.stored_feats
 
         is_dit = self.version.startswith('pixart')

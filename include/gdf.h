@@ -129,6 +129,10 @@ int gdf_forward(gdf_plan* p, const void* latents, const float* timesteps, const 
  * per timing event set (LRU of 12), so the timing measures the replay itself.  Applies to UNet, Flux, PixArt and VAE plans alike. */
 int gdf_plan_set_graph(gdf_plan* p, int enable);
 int gdf_plan_graph_stats(const gdf_plan* p, long* captures, long* launches);
+/* Forwards that had to run EAGERLY although graph replay was enabled, because a capture / instantiate failed (each such call retries
+ * the capture; the first failure of a plan is also reported once on stderr).  0 on a healthy plan: a measurement that labels its
+ * timed region "graph replay" must check this together with the launch count of gdf_plan_graph_stats. */
+long gdf_plan_graph_failures(const gdf_plan* p);
 
 /* Per-op timing of the last plan (diagnostics; synchronises the stream). Fills up to cap entries
  * with milliseconds per op, returns the op count. names[i] points into plan-owned storage. */

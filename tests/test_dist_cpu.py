@@ -1,5 +1,6 @@
-"""N>1 path on CPU: world_size-2 gloo — bucketed weight broadcast reproduces rank 0's state dict on every rank,
-and the image sharding covers the batch exactly once with no data-path collective."""
+"""N>1 path on CPU: world_size-2 gloo — the flat weight-arena broadcast reproduces rank 0's bytes on every rank (opt-in, size
+checked), the architecture descriptor travels from rank 0, and the image sharding covers the batch exactly once with no
+data-path collective."""
 import os
 import sys
 
@@ -16,17 +17,14 @@ def _worker(rank, world, port, out):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from components import dist as D
-    shapes = {"a.weight": (7, 5, 3, 3), "a.bias": (7,), "b.norm.weight": (33,), "c.weight": (129, 65), "d.bias": (3,)}
-    gen = torch.Generator().manual_seed(123 + rank)          # different seeds: only rank 0's values may survive
-    got = {}
-    D.broadcast_state_dict(shapes, lambda n, s: D.synthetic_param(n, s, gen, "cpu"),
-                           lambda sd: got.update({k: v.clone() for k, v in sd.items()}), "cpu", bucket_elems=400)
+    from components import models as M
     lo, hi = D.shard_range(11, rank, world)
 
     class Arena:                                             # stand-in for a native model's flat device weight arena
-        def __init__(self):
-            self.blob = torch.randint(0, 255, (1000,), dtype=torch.uint8, generator=torch.Generator().manual_seed(7 + rank))
+        def __init__(self, n=1000):
+            self.blob = torch.randint(0, 255, (n,), dtype=torch.uint8, generator=torch.Generator().manual_seed(7 + rank))
             self.ready = rank == 0
+            self.loaded = False
 
         def weight_blob(self):
             return self.blob
@@ -35,7 +33,25 @@ def _worker(rank, world, port, out):
             self.ready = True
     ar = Arena()
     D.broadcast_model_weights(ar, chunk_bytes=300)           # 4 pieces
-    torch.save({"sd": got, "range": (lo, hi), "blob": ar.blob, "ready": ar.ready, "rw": D.rank_world()}, os.path.join(out, f"r{rank}.pt"))
+    # the architecture descriptor travels from rank 0 (only rank 0 has the loaded UNet module: components/models.py)
+    cfg = D.broadcast_object(dict(block_out_channels=(320, 640), heads=(5, 10)) if rank == 0 else None)
+    # models._fill: a process group alone does NOT drag a constructor into collectives (opt-in) ...
+    solo = Arena()
+    assert not D.weight_broadcast_enabled()
+    M._fill(solo, lambda m: setattr(m, "loaded", True))
+    solo_ok = solo.loaded and torch.equal(solo.blob, Arena().blob)
+    # ... after enable_weight_broadcast() rank 0 loads and the others receive
+    D.enable_weight_broadcast()
+    dp = Arena()
+    M._fill(dp, lambda m: setattr(m, "loaded", True))
+    # arenas of different sizes (ranks built different models) are refused before any byte moves
+    mismatch = None
+    try:
+        D.broadcast_model_weights(Arena(1000 + 8 * rank))
+    except RuntimeError as e:
+        mismatch = str(e)
+    torch.save({"range": (lo, hi), "blob": ar.blob, "ready": ar.ready, "rw": D.rank_world(), "cfg": cfg, "solo_ok": solo_ok,
+                "dp_loaded": dp.loaded, "dp_blob": dp.blob, "dp_ready": dp.ready, "mismatch": mismatch}, os.path.join(out, f"r{rank}.pt"))
     dist.destroy_process_group()
 
 
@@ -43,16 +59,31 @@ def test_broadcast_and_shard_gloo(tmp_path):
     world, port = 2, 29500 + os.getpid() % 2000
     mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     r0, r1 = torch.load(tmp_path / "r0.pt"), torch.load(tmp_path / "r1.pt")
-    from components import dist as D
-    gen = torch.Generator().manual_seed(123)
-    for n, s in {"a.weight": (7, 5, 3, 3), "a.bias": (7,), "b.norm.weight": (33,), "c.weight": (129, 65), "d.bias": (3,)}.items():
-        ref = D.synthetic_param(n, s, gen, "cpu")
-        assert torch.equal(r0["sd"][n], ref) and torch.equal(r1["sd"][n], ref), n     # bit-exact on both ranks
     assert r0["range"] == (0, 6) and r1["range"] == (6, 11)
     # flat-arena broadcast (what extract_feature.py / bench.py use): rank 1 ends up with rank 0's bytes and is marked ready
     want = torch.randint(0, 255, (1000,), dtype=torch.uint8, generator=torch.Generator().manual_seed(7))
     assert torch.equal(r0["blob"], want) and torch.equal(r1["blob"], want) and r0["ready"] and r1["ready"]
     assert r0["rw"] == (0, 2) and r1["rw"] == (1, 2)
+    assert r0["cfg"] == r1["cfg"] == dict(block_out_channels=(320, 640), heads=(5, 10))
+    assert r0["solo_ok"] and r1["solo_ok"]                                   # no collective without the opt-in: both ranks loaded
+    assert r0["dp_loaded"] and not r1["dp_loaded"]                           # opt-in: only rank 0 runs the loader
+    assert torch.equal(r0["dp_blob"], want) and torch.equal(r1["dp_blob"], want) and r1["dp_ready"]
+    assert r0["mismatch"] and r1["mismatch"] and "differ across ranks" in r1["mismatch"]
+
+
+def test_config_from_diffusers_fills_constructor_defaults():
+    """The raw unet/config.json of SD1.5 has neither `transformer_layers_per_block` nor `use_linear_projection`."""
+    import types
+    from components.native import config_from_diffusers, ARCH_CONFIGS
+    raw15 = types.SimpleNamespace(in_channels=4, out_channels=4, block_out_channels=[320, 640, 1280, 1280], attention_head_dim=8,
+                                  down_block_types=["CrossAttnDownBlock2D"] * 3 + ["DownBlock2D"], layers_per_block=2,
+                                  cross_attention_dim=768)
+    assert config_from_diffusers(raw15) == ARCH_CONFIGS["1-5"]
+    xl = types.SimpleNamespace(in_channels=4, out_channels=4, block_out_channels=[320, 640, 1280], attention_head_dim=[5, 10, 20],
+                               down_block_types=["DownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D"], layers_per_block=2,
+                               cross_attention_dim=2048, transformer_layers_per_block=[1, 2, 10], use_linear_projection=True,
+                               addition_embed_type="text_time", addition_time_embed_dim=256, projection_class_embeddings_input_dim=2816)
+    assert config_from_diffusers(xl) == ARCH_CONFIGS["xl"]
 
 
 def test_shard_range_partitions():

@@ -289,12 +289,70 @@ def test_feature_extractor_api_flux_synthetic():
     layer = {"vit-block0-out": True, "vit-block1-q": True, "vit-block3-out": True, "vit-block2-attn-out": True, "nope": True}
     df = diffusion_feature.FeatureExtractor(layer=layer, version='flux', img_size=128, device='cuda:0', external_model=pipe)
     img = Image.fromarray((np.random.RandomState(0).rand(90, 70, 3) * 255).astype(np.uint8))
-    feats = df.extract("a photo of a cat", batch_size=2, image=[img, img], t=100)     # strength 0.1 -> 2 of 28 steps
+    tr = pipe.transformer
+    feats = df.extract("a photo of a cat", batch_size=2, image=[img, img], t=100)     # strength 0.1 -> steps 26, 27 remain; ONE is run
+    # the reference's patched pipeline returns after its first transformer call (pipeline_flux_img2img.py:804-841)
+    assert tr.calls == 1 and pipe.last_call["t_start"] == 26
     assert list(feats.keys()) == ["vit-block0-out", "vit-block1-q", "vit-block2-attn-out", "vit-block3-out"]
     for v in feats.values():
         assert v.shape == (2, 256, 8, 8) and v.dtype == torch.float16 and v.is_cuda and torch.isfinite(v.float()).all()
+    # ... and what it stored is that forward's hooks: forward_raw on the same packed latents at sigmas[t_start]
+    lc = pipe.last_call
+    sig = pipe.sigmas(28, 64)
+    assert lc["sigma"] == sig[26] and 0.0 < sig[27] < sig[26] < sig[0] == 1.0
+    _, hooks = tr.forward_raw(lc["hidden_states"], lc["encoder_hidden_states"], lc["pooled_projections"],
+                              torch.full((2,), lc["sigma"], device="cuda:0"), lc["img_ids"], lc["txt_ids"], guidance=lc["guidance"],
+                              hook_ids=list(feats.keys()), grid=lc["grid"])
+    for k in feats:
+        assert torch.equal(hooks[k], feats[k]), k
     f1 = df.extract("x", batch_size=1, image=[img], t=10)                                # strength 0.01 -> the last step only
+    assert tr.calls == 2 and pipe.last_call["t_start"] == 27
     assert list(f1.keys()) == list(feats.keys()) and f1["vit-block0-out"].shape == (1, 256, 8, 8)
+    f0 = df.extract("x", batch_size=1, image=[img], t=1000)                              # strength 1 -> starts at sigma 1 (pure noise)
+    assert tr.calls == 3 and pipe.last_call["t_start"] == 0 and pipe.last_call["sigma"] == 1.0 and list(f0.keys()) == list(feats.keys())
+
+
+def test_feature_extractor_flux_stock_pipeline_is_stopped_after_one_forward():
+    """A STOCK (un-patched) diffusers FluxImg2ImgPipeline loops over every remaining step and then decodes; the reference's vendored
+    copy returns after the first transformer call (pipeline_flux_img2img.py:841).  With the native transformer swapped in,
+    FeatureExtractor.extract reproduces the reference: the transformer raises SingleForwardDone after its first forward and the
+    hooks of THAT forward (the noisiest remaining step) are what is returned."""
+    import numpy as np
+    from PIL import Image
+    import diffusion_feature
+    from components.models import SyntheticFluxPipe
+    arch = FR.tiny_arch(num_layers=1, num_single_layers=1)
+
+    class StockLikePipe(SyntheticFluxPipe):
+        returns_after_first_forward = False
+
+        def __call__(self, image=None, prompt=None, strength=0.6, guidance_scale=7.0, **kw):
+            self.steps = 0
+            sig = self.sigmas(28, 64)
+            t_start = int(max(28 - min(28 * strength, 28), 0))
+            SyntheticFluxPipe.__call__(self, image=image, prompt=prompt, strength=strength, guidance_scale=guidance_scale)   # step t_start
+            lc = self.last_call
+            for i in range(t_start + 1, 28):                            # the rest of the stock denoising loop
+                self.steps += 1
+                self.transformer(hidden_states=lc["hidden_states"], timestep=torch.full((1,), sig[i], device=self.device),
+                                 guidance=lc["guidance"], pooled_projections=lc["pooled_projections"],
+                                 encoder_hidden_states=lc["encoder_hidden_states"], txt_ids=lc["txt_ids"], img_ids=lc["img_ids"],
+                                 return_dict=False, grid=lc["grid"])
+            raise AssertionError("the stock loop ran to its end (VAE decode would follow)")
+
+    pipe = StockLikePipe("cuda:0", seed=0, cfg=arch, n_txt=16)
+    df = diffusion_feature.FeatureExtractor(layer={"vit-block0-out": True, "vit-block1-out": True}, version='flux', img_size=128,
+                                            device='cuda:0', external_model=pipe)
+    img = Image.fromarray((np.random.RandomState(0).rand(90, 70, 3) * 255).astype(np.uint8))
+    feats = df.extract("a photo of a cat", batch_size=1, image=[img], t=500)            # 14 steps remain in a stock pipeline
+    assert pipe.transformer.calls == 1 and pipe.steps == 0 and pipe.transformer.single_forward is False
+    lc = pipe.last_call
+    assert lc["t_start"] == 14
+    _, hooks = pipe.transformer.forward_raw(lc["hidden_states"], lc["encoder_hidden_states"], lc["pooled_projections"],
+                                            torch.full((1,), lc["sigma"], device="cuda:0"), lc["img_ids"], lc["txt_ids"],
+                                            guidance=lc["guidance"], hook_ids=list(feats.keys()), grid=lc["grid"])
+    for k in feats:
+        assert torch.equal(hooks[k], feats[k]), k
 
 
 def test_flux_early_exit_matches_full_run():

@@ -133,7 +133,9 @@ def main():
                       "tflop_per_image": round(fl_img / 1e12, 2), "model_tflops_per_s": round(ips * fl_img / 1e12, 1),
                       "weights_gb": round(lib.gdf_model_weight_bytes(net.handle) / 1e9, 2), "weights_init_s": round(t_w, 1),
                       "workspace_gb": round(plan.ws_bytes / 1e9, 2),
-                      "arithmetic": "fp16 MFMA operands, fp32 accumulate, fp32 residual stream (reference: bf16)"},
+                      "arithmetic": ("bf16 MFMA operands / weights / activations (the reference's dtype, components/models.py:158-169)"
+                                     if args.dtype == "bfloat16" else "fp16 MFMA operands / weights / activations (reference: bf16)")
+                                    + ", fp32 accumulate, fp32 residual stream, fp16 hooks (saturating)"},
            "roofline": {"bound": "mfma", "kernel": dominant, "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS,
                         "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
                         "launches": int(launches.value), "avg_launch_ms": round(ms_tot.value / max(1, launches.value), 4),
