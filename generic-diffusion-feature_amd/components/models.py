@@ -16,7 +16,7 @@ import types
 import torch
 
 from .native import (ARCH_CONFIGS, FLUX_CONFIGS, PIXART_CONFIGS, VAE_CONFIGS, NativeFluxTransformer, NativePixArtTransformer,
-                     NativeUNet, NativeVAEEncoder, config_from_diffusers)
+                     NativeUNet, NativeVAEDecoder, NativeVAEEncoder, config_from_diffusers)
 
 # version -> (HF repo id, pipeline class name) exactly as the reference selects them (models.py:18-70)
 _HF = {
@@ -78,6 +78,27 @@ class _Scheduler:
         a, b = self.noise_scalars(t)
         return a * x + b * noise
 
+    def step_scalars(self, t):
+        """(c_sample, c_eps) with step(eps, t, x).prev_sample = c_sample x + c_eps eps for the FIRST step after set_timesteps:
+        PNDM's first step_plms call (eq. 9 of the PNDM paper with the model output as is) for '1-5', the Euler step
+        x + (sigma_next - sigma) eps otherwise (epsilon prediction; un-vendored diffusers schedulers, oracle/vae_ref.py)."""
+        ti = int(t.flatten()[0])
+        if self.euler:
+            idx = int((self.timesteps == ti).nonzero()[0]) if self.timesteps is not None else None
+            nxt = int(self.timesteps[idx + 1]) if idx is not None and idx + 1 < len(self.timesteps) else -1
+            acn = float(self.alphas_cumprod[nxt]) if nxt >= 0 else 1.0
+            sig_next = ((1 - acn) / acn) ** 0.5 if nxt >= 0 else 0.0
+            return 1.0, sig_next - self._sigma(t)
+        step = 1000 // len(self.timesteps) if self.timesteps is not None else 1
+        a_t = float(self.alphas_cumprod[ti])
+        a_p = float(self.alphas_cumprod[ti - step]) if ti - step >= 0 else float(self.alphas_cumprod[0])
+        den = a_t * (1 - a_p) ** 0.5 + (a_t * (1 - a_t) * a_p) ** 0.5
+        return (a_p / a_t) ** 0.5, -(a_p - a_t) / den
+
+    def step(self, model_output, t, sample, return_dict=False):
+        a, b = self.step_scalars(t)
+        return (a * sample + b * model_output,)
+
     def noise_scalars(self, t):
         """(noise_a, noise_b) with add_noise(x, n, t) = a x + b n."""
         ac = float(self.alphas_cumprod[int(t.flatten()[0])])
@@ -97,6 +118,47 @@ def scheduler_noise_scalars(scheduler, timestep):
         return 1.0, sigma
     ac = float(scheduler.alphas_cumprod[int(t)])
     return ac ** 0.5, (1 - ac) ** 0.5
+
+
+def scheduler_step_scalars(scheduler, timestep):
+    """(c_sample, c_eps) such that `scheduler.step(noise_pred, timestep, latents)[0] == c_sample * latents + c_eps * noise_pred` for the
+    call the reference makes at feature/diffusion_feature.py:478-480 (the first step after set_timesteps).  Schedulers that say so
+    themselves (`step_scalars`) are asked; for a diffusers scheduler the two coefficients are PROBED on a deep copy with two
+    one-element CPU tensors — (x, eps) = (1, 0) and (0, 1) — because the first PNDM / Euler step is linear in both (epsilon / v
+    prediction without thresholding or clipping), which the probe verifies on a third point."""
+    if hasattr(scheduler, "step_scalars"):
+        return scheduler.step_scalars(timestep)
+    import copy
+    t = timestep.flatten()[0].cpu() if torch.is_tensor(timestep) else timestep
+
+    def probe(x, e):
+        sch = copy.deepcopy(scheduler)
+        out = sch.step(torch.full((1, 1, 1, 1), float(e), dtype=torch.float64), t, torch.full((1, 1, 1, 1), float(x), dtype=torch.float64),
+                       return_dict=False)[0]
+        return float(out.flatten()[0])
+    a, b = probe(1.0, 0.0), probe(0.0, 1.0)
+    chk = probe(0.5, -2.0)
+    if abs(chk - (0.5 * a - 2.0 * b)) > 1e-6 * (1.0 + abs(chk)):
+        raise NotImplementedError("scheduler.step is not linear in (sample, model_output) for this scheduler configuration; "
+                                  "'vae-out' needs a linear first step (PNDM / EulerDiscrete as the reference configures them)")
+    return a, b
+
+
+def native_vae_decoder(pipe, device):
+    """The pipe's native AutoencoderKL decoder, created on first use (only a config that asks for 'vae-out' needs it)."""
+    dec = getattr(pipe, "_native_vae_decoder", None)
+    if dec is None:
+        if getattr(pipe, "native_vae", None) is not None and not hasattr(pipe.vae, "state_dict"):      # synthetic pipe
+            dec = _fill(NativeVAEDecoder(VAE_CONFIGS["sd"], device=device), lambda m: m.init_synthetic(getattr(pipe, "_seed", 0) + 2))
+        else:
+            vc = pipe.vae.config
+            dec = NativeVAEDecoder(dict(in_channels=vc.in_channels, latent_channels=vc.latent_channels,
+                                        block_out_channels=tuple(vc.block_out_channels), layers_per_block=vc.layers_per_block,
+                                        use_quant_conv=int(getattr(vc, "use_post_quant_conv", getattr(vc, "use_quant_conv", True)))),
+                                   device=device)
+            _fill(dec, lambda m: m.load_vae_state_dict(pipe.vae.state_dict()))
+        pipe._native_vae_decoder = dec
+    return dec
 
 
 def native_prepare_latents(pipe, image, timestep, batch_size, num_images_per_prompt, dtype, device, generator=None):
@@ -121,6 +183,7 @@ class SyntheticPipe:
         cfg = ARCH_CONFIGS[version]
         self.version = version
         self.device = device
+        self._seed = seed
         self.unet = _fill(NativeUNet(cfg, device=device, stream_fp32=stream_fp32), lambda m: m.init_synthetic(seed))
         empty = types.SimpleNamespace(parameters=lambda: iter(()), to=lambda *a, **k: None)
         self.vae = types.SimpleNamespace(parameters=lambda: iter(()), config=types.SimpleNamespace(

@@ -163,6 +163,42 @@ int gdf_vae_plan_profile(gdf_plan* p, const void* image, const void* eps, const 
   return (int)p->p.ops.size();
 }
 
+// ---- VAE decoder: the optional `vae-out` feature (include/gdf_vae.h) ----
+int gdf_vae_decoder_create(const gdf_vae_desc* desc, gdf_model** out) {
+  if (!desc || !out) { set_error("null argument"); return GDF_ERR_ARG; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { set_error("no HIP device: libgdf has no CPU fallback"); return GDF_ERR_HIP; }
+  Model* m = vae_decoder_create(*desc);
+  if (!m) return GDF_ERR_ARG;
+  *out = new gdf_model{m};
+  return GDF_OK;
+}
+int gdf_vae_decode_plan_create(gdf_model* m, int batch, int lat_h, int lat_w, gdf_plan** out) {
+  if (!m || !out) { set_error("null argument"); return GDF_ERR_ARG; }
+  gdf_plan* p = new gdf_plan();
+  p->owner = m;
+  p->p.model = m->m;
+  const int rc = vae_dec_plan_build(*m->m, p->p, batch, lat_h, lat_w, false);
+  if (rc != GDF_OK) { delete p; return rc; }
+  *out = p;
+  return GDF_OK;
+}
+int gdf_vae_decode(gdf_plan* p, const void* latents, const void* noise_pred, float step_c_sample, float step_c_eps, float inv_scaling,
+                   void* image_out, void* workspace, void* stream) {
+  if (!p) { set_error("null plan"); return GDF_ERR_ARG; }
+  return vae_decode(p->p, *p->p.model, latents, noise_pred, step_c_sample, step_c_eps, inv_scaling, image_out, workspace,
+                    (hipStream_t)stream, nullptr, nullptr, nullptr, 0);
+}
+int gdf_vae_decode_plan_profile(gdf_plan* p, const void* latents, const void* noise_pred, float step_c_sample, float step_c_eps,
+                                float inv_scaling, void* image_out, void* workspace, void* stream, float* ms, const char** names,
+                                double* flops, int cap) {
+  if (!p || !ms) { set_error("null argument"); return -1; }
+  const int rc = vae_decode(p->p, *p->p.model, latents, noise_pred, step_c_sample, step_c_eps, inv_scaling, image_out, workspace,
+                            (hipStream_t)stream, ms, names, flops, cap);
+  if (rc != GDF_OK) return -1;
+  return (int)p->p.ops.size();
+}
+
 // ---- MMDiT / Flux front end (include/gdf_flux.h) ----
 int gdf_flux_model_create(const gdf_flux_desc* desc, gdf_model** out) {
   if (!desc || !out) { set_error("null argument"); return GDF_ERR_ARG; }

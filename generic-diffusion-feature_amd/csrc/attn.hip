@@ -460,6 +460,34 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(const AttnParams p) {
       if (lane < RPIO * LPRO && r < QBW && q < p.Sq)
         *(f16x8*)(p.o + seg_row(b, q, p.Sq, p.seg_T, p.B, p.Sq) * p.ldo + head * D + oc) = *(const f16x8*)(stg + r * RSH + oc);
     }
+    if (!BF && p.o_lo > 0) {
+      // split operand for the out-projection of a "precise" plan: lo = fp16(O - fp16(O)), staged and stored like the hi half
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int w = 0; w < QW; ++w) {
+        const float inv = 1.0f / half_sum(l_run[w]);
+#pragma unroll
+        for (int db = 0; db < NDB; ++db)
+#pragma unroll
+          for (int rq = 0; rq < 4; ++rq) {
+            const int d0 = db * 32 + 8 * rq + 4 * lh;
+            if (d0 < D) {
+              f16x4 lv;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) { const float x = o[w][db][rq * 4 + e] * inv; lv[e] = (_Float16)(x - (float)(_Float16)x); }
+              *(f16x4*)(stg + (w * 32 + lq) * RSH + d0) = lv;
+            }
+          }
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int it = 0; it < (QBW + RPIO - 1) / RPIO; ++it) {
+        const int r = it * RPIO + orow;
+        const int q = qb * QBLK + wave * QBW + r;
+        if (lane < RPIO * LPRO && r < QBW && q < p.Sq)
+          *(f16x8*)(p.o + seg_row(b, q, p.Sq, p.seg_T, p.B, p.Sq) * p.ldo + head * D + oc + p.o_lo) = *(const f16x8*)(stg + r * RSH + oc);
+      }
+    }
     GDF_AT_EXIT;
     return;
   }
@@ -479,6 +507,12 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(const AttnParams p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) hv[e] = out16<BF>(o[w][db][rq * 4 + e] * inv);
             *(f16x4*)(op + d0) = hv;
+            if (!BF && p.o_lo > 0) {
+              f16x4 lv;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) lv[e] = (_Float16)(o[w][db][rq * 4 + e] * inv - (float)hv[e]);
+              *(f16x4*)(op + d0 + p.o_lo) = lv;
+            }
           }
         }
     }
@@ -877,6 +911,12 @@ __global__ __launch_bounds__(LW ? 320 : 256, OCC) void attn_map_kernel(const Att
 #pragma unroll
           for (int e = 0; e < 4; ++e) hv[e] = out16<BF>(o[db][rq * 4 + e]);
           *(f16x4*)(op + d0) = hv;
+          if (!BF && p.o_lo > 0) {
+            f16x4 lv;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) lv[e] = (_Float16)(o[db][rq * 4 + e] - (float)hv[e]);
+            *(f16x4*)(op + d0 + p.o_lo) = lv;
+          }
         }
       }
   }

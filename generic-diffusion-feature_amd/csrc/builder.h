@@ -97,6 +97,7 @@ struct Arena {   // plan-time first-fit allocator with coalescing free list
 struct Act {
   float hscale = 1.0f;        // the fp16 image holds value * hscale (a power of two; 1 everywhere but in the VAE encoder)
   Ref h{}; int ld = 0;        // fp16 [rows][C] with leading dimension ld
+  int lo = 0;                 // > 0 ("precise" plans): the image is a split pair, hi = fp16(v) at h, lo = fp16(v - hi) `lo` elements further
   Ref f{}; bool has_f = false;
   int C = 0, H = 0, W = 0;
   size_t h_alloc = NPOS, h_bytes = 0;   // workspace block owned by h (NPOS: lives in a concat buffer / elsewhere)
@@ -116,8 +117,18 @@ struct PlanBuilder {
   // undo it exactly (GEMM: acc_scale; GroupNorm is scale invariant once eps is scaled by hscale^2).  Residual adds use the
   // fp32 master, which always holds the true values.
   float act_scale = 1.0f;
+  // "precise" plans (gdf_plan_opts.reserved[1], UNet only): every 16-bit activation that feeds an MFMA contraction or a GroupNorm is
+  // stored as a split pair (hi, lo) = 22 mantissa bits, and the contraction runs over [hi | lo] against the weights read twice
+  // (GemmParams::k_w): the fp16-OPERAND rounding of DESIGN.md §4 disappears, at twice the MFMA work.  Attention internals (q, k,
+  // v, P) stay fp16.  px = 2 in such a plan: width factor of every 16-bit image.
+  bool precise = false;
+  int px = 1;
 
-  PlanBuilder(const Model& mm, Plan& pp, bool d, const PlanOpts& o) : m(mm), P(pp), dry(d), opt(o) {}
+  PlanBuilder(const Model& mm, Plan& pp, bool d, const PlanOpts& o) : m(mm), P(pp), dry(d), opt(o) {
+    precise = o.reserved[1] != 0 && mm.kind == 0;        // the UNet op program only
+    px = precise ? 2 : 1;
+  }
+  size_t img_bytes(size_t nrows, int C) const { return nrows * (size_t)C * 2 * px; }     // a contiguous 16-bit image (split: [hi | lo])
 
   Ref ws(size_t off) const { return Ref{BUF_WS, off}; }
   Ref wt(size_t off) const { return Ref{BUF_WT, off}; }
@@ -137,8 +148,8 @@ struct PlanBuilder {
   size_t rows(const Act& a) const { return (size_t)Bn * a.H * a.W; }
 
   Act new_act(int C, int H, int W, bool master) {
-    Act a; a.C = C; a.H = H; a.W = W; a.ld = C; a.hscale = act_scale;
-    a.h_bytes = (size_t)Bn * H * W * C * 2;
+    Act a; a.C = C; a.H = H; a.W = W; a.ld = C * px; a.lo = precise ? C : 0; a.hscale = act_scale;
+    a.h_bytes = (size_t)Bn * H * W * C * 2 * px;
     a.h_alloc = dry ? 0 : ar.alloc(a.h_bytes);
     a.h = ws(a.h_alloc);
     if (master && opt.stream_fp32) add_master(a);
@@ -150,8 +161,8 @@ struct PlanBuilder {
     a.f = ws(a.f_alloc); a.has_f = true;
   }
   // activation whose fp16 image lives inside someone else's buffer (concat slice)
-  Act view_act(Ref h, int ld, int C, int H, int W, bool master) {
-    Act a; a.C = C; a.H = H; a.W = W; a.ld = ld; a.h = h;
+  Act view_act(Ref h, int ld, int C, int H, int W, bool master, int lo = 0) {
+    Act a; a.C = C; a.H = H; a.W = W; a.ld = ld; a.h = h; a.lo = lo;
     if (master && opt.stream_fp32) add_master(a);
     return a;
   }
@@ -214,6 +225,7 @@ struct PlanBuilder {
     Ref out16{}; bool has_o16 = false; int ldo16 = 0;
     Ref out32{}; bool has_o32 = false; int ldo32 = 0;
     int aux_slot = -1; int ldaux = 0;
+    int o16_lo = 0;                                                       // out16 is a split (hi, lo) pair, lo at +o16_lo elements
     int geglu = 0; int bn = 128;
     int dit = 0, act = 0, rv_mul = 0, rv_seg_rows = 0, rv_rps2 = 0;     // MMDiT epilogue (kernels.h)
     int bf16 = 0;                                                         // bf16 operands / activations (set by gemm() from the model)
@@ -226,14 +238,18 @@ struct PlanBuilder {
   };
   void residual_from(Epi& e, const Act& x) {
     if (x.has_f) { e.res32 = x.f; e.has_r32 = true; e.ldres = x.C; }
-    else { e.res16 = x.h; e.has_r16 = true; e.ldres = x.ld; }      // (a scaled fp16 image always comes with an fp32 master)
+    else {
+      e.res16 = x.h; e.has_r16 = true; e.ldres = x.ld;             // (a scaled fp16 image always comes with an fp32 master)
+      if (x.lo && !dry) { set_error("precise plan: residual source without an fp32 master"); bad = true; }
+    }
   }
+  bool bad = false;           // the op program could not be built (reported by plan_build)
   // A operand = the fp16 image of activation x: undo its storage scale on the accumulators
   static void reads_image(Epi& e, const Act& x) { if (x.hscale != 1.0f) e.acc_scale = 1.0f / x.hscale; }
   // need_shadow = false: the fp16 image of a stream tensor is not stored when its only consumers read the fp32
   // master (LayerNorm + the next residual add): saves one 2-byte/element write per residual GEMM
   void out_to(Epi& e, const Act& y, bool need_shadow = true) {
-    if (need_shadow || !y.has_f) { e.out16 = y.h; e.has_o16 = true; e.ldo16 = y.ld; if (y.hscale != 1.0f) e.out16_scale = y.hscale; }
+    if (need_shadow || !y.has_f) { e.out16 = y.h; e.has_o16 = true; e.ldo16 = y.ld; e.o16_lo = y.lo; if (y.hscale != 1.0f) e.out16_scale = y.hscale; }
     if (y.has_f) { e.out32 = y.f; e.has_o32 = true; e.ldo32 = y.C; }
   }
   static void fill_epi(GemmParams& g, const Epi& e, const Bind& b) {
@@ -244,7 +260,7 @@ struct PlanBuilder {
     g.out16 = e.has_o16 ? (half_t*)b.p(e.out16) : nullptr; g.ldo16 = e.ldo16;
     g.out32 = e.has_o32 ? (float*)b.p(e.out32) : nullptr; g.ldo32 = e.ldo32;
     g.aux16 = e.aux_slot >= 0 ? (half_t*)b.hook(e.aux_slot) : nullptr; g.ldaux = e.ldaux;
-    g.geglu = e.geglu; g.bn = e.bn; g.bf16 = e.bf16; g.acc_scale = e.acc_scale; g.out16_scale = e.out16_scale;
+    g.geglu = e.geglu; g.bn = e.bn; g.bf16 = e.bf16; g.acc_scale = e.acc_scale; g.out16_scale = e.out16_scale; g.o16_lo = e.o16_lo;
     g.dit = e.dit; g.act = e.act; g.rv_mul = e.rv_mul; g.rv_seg_rows = e.rv_seg_rows; g.rv_rps2 = e.rv_rps2; g.rv_tok = e.rv_tok;
     g.qkn_nq = e.qkn_nq;
     if (e.qkn_nq) {
@@ -254,11 +270,13 @@ struct PlanBuilder {
     }
   }
 
-  // dense GEMM: A (fp16 [M][K], lda) x W[N][K]
-  void gemm(const char* name, Ref A, int lda, size_t M, const LinW& w, int N, int K, size_t w_off_bytes, const Epi& e0) {
+  // dense GEMM: A (fp16 [M][K], lda) x W[N][K].  a_lo > 0: A is a split pair (lo columns a_lo elements after the hi columns):
+  // the contraction runs over [hi | lo] (2K) against W read twice (GemmParams::k_w)
+  void gemm(const char* name, Ref A, int lda, size_t M, const LinW& w, int N, int Kw, size_t w_off_bytes, const Epi& e0, int a_lo = 0) {
     Epi e = e0;
     e.bf16 = (e.dit && m.bf16) ? 1 : 0;
     const Ref W = wt(w.w + w_off_bytes);
+    const int K = a_lo > 0 ? 2 * Kw : Kw;
     GemmParams gk{}; gk.M = (int)M; gk.N = N; gk.K = K; gk.mode = A_DENSE; gk.geglu = e.geglu; gk.bn = e.bn; gk.dit = e.dit; gk.bf16 = e.bf16;
     gk.res32 = e.has_r32 ? (const float*)1 : nullptr;      // tile selection looks at the epilogue form (never dereferenced)
     // few output tiles, long K (small batches: ff_out at 1024-2048 rows): deterministic split-K (see conv3)
@@ -266,11 +284,12 @@ struct PlanBuilder {
     const size_t ws_b = splitk > 1 ? (size_t)splitk * M * N * 4 : 0;
     const size_t wsk = splitk > 1 ? tmp(ws_b) : 0;
     gk.splitk = splitk;
-    op(name, 2.0 * (double)M * N * K, [=](const Bind& b, hipStream_t s) {
+    op(name, 2.0 * (double)M * N * Kw, [=](const Bind& b, hipStream_t s) {      // algorithmic FLOPs (the split doubles the MFMA work, not these)
       GemmParams g{};
-      g.A = (const half_t*)b.p(A); g.lda = lda; g.a_bytes = (uint32_t)(((size_t)M - 1) * lda * 2 + (size_t)K * 2);
+      g.A = (const half_t*)b.p(A); g.lda = lda; g.a_bytes = (uint32_t)(((size_t)M - 1) * lda * 2 + (size_t)(a_lo + Kw) * 2);
       g.M = (int)M; g.N = N; g.K = K; g.mode = A_DENSE;
-      g.Wt = (const half_t*)b.p(W); g.w_bytes = (uint32_t)((size_t)N * K * 2);
+      if (a_lo > 0) { g.k_w = Kw; g.a_lo_bytes = (uint32_t)a_lo * 2u; }
+      g.Wt = (const half_t*)b.p(W); g.w_bytes = (uint32_t)((size_t)N * Kw * 2);
       fill_epi(g, e, b);
       return splitk > 1 ? launch_gemm_splitk(g, splitk, (float*)b.ws(wsk), s) : launch_gemm(g, s);
     }, gemm_kernel_name(gk));
@@ -284,41 +303,44 @@ struct PlanBuilder {
   size_t groupnorm(const Act& x, const NormW& w, float eps_true, bool silu) {
     const float eps = eps_true * x.hscale * x.hscale;      // GN(s x, s^2 eps) == GN(x, eps): the scaled fp16 image normalises identically
     const size_t n = rows(x);
-    const size_t y = tmp(n * x.C * 2);
+    const size_t y = tmp(img_bytes(n, x.C));
+    // precise plans: the input is the fp32 master where there is one, else the split image; the output is a split image
+    const bool from_f = precise && x.has_f;
+    const Ref xh = x.h, xf = x.f; const int ld = from_f ? x.C : x.ld, C = x.C, HW = x.H * x.W, Bq = Bn;
+    const int x_lo = from_f ? 0 : x.lo, ldy = C * px, y_lo = precise ? C : 0;
+    const Ref g = wt(w.g), bt = wt(w.b);
     if (gn_fused_slab(Bn, x.H * x.W, x.C, 32)) {            // small feature map: statistics + apply in one launch
-      const Ref xh = x.h; const int ld = x.ld, C = x.C, HW = x.H * x.W, Bq = Bn;
-      const Ref g = wt(w.g), bt = wt(w.b);
       op(silu ? "gn_fused_silu" : "gn_fused", 0, [=](const Bind& b, hipStream_t s) {
-        return launch_gn_fused((const half_t*)b.p(xh), nullptr, ld, Bq, HW, C, 32, eps, (const float*)b.p(g), (const float*)b.p(bt),
-                               silu ? 1 : 0, (half_t*)b.ws(y), s);
+        return launch_gn_fused(from_f ? nullptr : (const half_t*)b.p(xh), from_f ? (const float*)b.p(xf) : nullptr, ld, Bq, HW, C, 32, eps,
+                               (const float*)b.p(g), (const float*)b.p(bt), silu ? 1 : 0, (half_t*)b.ws(y), s, x_lo, ldy, y_lo);
       });
       return y;
     }
     const size_t part_b = gn_partial_floats(Bn, x.H * x.W, x.C) * 4, ab_b = (size_t)Bn * x.C * 8;
     const size_t part = tmp(part_b), ab = tmp(ab_b);
-    const Ref xh = x.h; const int ld = x.ld, C = x.C, HW = x.H * x.W, Bq = Bn;
-    const Ref g = wt(w.g), bt = wt(w.b);
     op("gn_stats", 0, [=](const Bind& b, hipStream_t s) {
-      return launch_gn_stats((const half_t*)b.p(xh), nullptr, ld, Bq, HW, C, 32, eps, (const float*)b.p(g),
-                             (const float*)b.p(bt), (float*)b.ws(part), (float*)b.ws(ab), s);
+      return launch_gn_stats(from_f ? nullptr : (const half_t*)b.p(xh), from_f ? (const float*)b.p(xf) : nullptr, ld, Bq, HW, C, 32, eps,
+                             (const float*)b.p(g), (const float*)b.p(bt), (float*)b.ws(part), (float*)b.ws(ab), s, x_lo);
     });
     op(silu ? "gn_apply_silu" : "gn_apply", 0, [=](const Bind& b, hipStream_t s) {
-      return launch_gn_apply((const half_t*)b.p(xh), nullptr, ld, Bq, HW, C, (const float*)b.ws(ab), silu ? 1 : 0,
-                             (half_t*)b.ws(y), s);
+      return launch_gn_apply(from_f ? nullptr : (const half_t*)b.p(xh), from_f ? (const float*)b.p(xf) : nullptr, ld, Bq, HW, C,
+                             (const float*)b.ws(ab), silu ? 1 : 0, (half_t*)b.ws(y), s, x_lo, ldy, y_lo);
     });
     untmp(part, part_b); untmp(ab, ab_b);
     return y;
   }
 
   // 3x3 conv as implicit GEMM over NHWC `src` (Bn, H, W, ld>=Cin)
-  void conv3(const char* name, Ref src, int ld, int Cin, int H, int W, int stride, bool ups, const ConvW& w, const Epi& e0) {
+  // a_lo > 0: the source pixels are split pairs (lo channels a_lo elements after the hi channels), see gemm()
+  void conv3(const char* name, Ref src, int ld, int Cin, int H, int W, int stride, bool ups, const ConvW& w, const Epi& e0, int a_lo = 0) {
     Epi e = e0;
+    const int kx = a_lo > 0 ? 2 : 1;
     const int IH = ups ? 2 * H : H, IW = ups ? 2 * W : W;
     const int OH = (IH + 2 - 3) / stride + 1, OW = (IW + 2 - 3) / stride + 1;
     const size_t M = (size_t)Bn * OH * OW;
     const Ref Wr = wt(w.w);
     const int N = w.cout, Bq = Bn;
-    GemmParams gk{}; gk.M = (int)M; gk.N = N; gk.K = 9 * Cin; gk.mode = A_CONV3; gk.bn = e.bn;
+    GemmParams gk{}; gk.M = (int)M; gk.N = N; gk.K = 9 * Cin * kx; gk.mode = A_CONV3; gk.bn = e.bn;
     // few output tiles, long K (SD1.5's 8x8 level: 160 tiles of 128x128 walking 180-360 K-tiles each): deterministic split-K
     const int splitk = gemm_splitk_factor(gk);
     const size_t ws_b = splitk > 1 ? (size_t)splitk * M * N * 4 : 0;
@@ -327,8 +349,9 @@ struct PlanBuilder {
     op(name, 2.0 * (double)M * N * 9 * Cin, [=](const Bind& b, hipStream_t s) {
       GemmParams g{};
       g.A = (const half_t*)b.p(src); g.lda = ld;
-      g.a_bytes = (uint32_t)(((size_t)Bq * H * W - 1) * ld * 2 + (size_t)Cin * 2);
-      g.M = (int)M; g.N = N; g.K = 9 * Cin; g.mode = A_CONV3; g.H = H; g.W = W; g.OH = OH; g.OW = OW;
+      g.a_bytes = (uint32_t)(((size_t)Bq * H * W - 1) * ld * 2 + (size_t)(a_lo + Cin) * 2);
+      g.M = (int)M; g.N = N; g.K = 9 * Cin * kx; g.mode = A_CONV3; g.H = H; g.W = W; g.OH = OH; g.OW = OW;
+      if (a_lo > 0) { g.k_w = 9 * Cin; g.a_lo_bytes = (uint32_t)a_lo * 2u; }
       g.stride = stride; g.ups = ups ? 1 : 0; g.Cin = Cin; g.pad0 = e.pad0;
       g.Wt = (const half_t*)b.p(Wr); g.w_bytes = (uint32_t)((size_t)N * 9 * Cin * 2);
       fill_epi(g, e, b);
@@ -344,7 +367,7 @@ struct PlanBuilder {
     const size_t n = rows(x);
     const int HW = x.H * x.W;
     const size_t n1 = groupnorm(x, w.n1, w.eps, true);
-    const size_t h1_b = n * w.cout * 2;
+    const int slo = precise ? 1 : 0;                     // GroupNorm outputs of a precise plan: [rows][2C], lo at +C
     Act h1 = new_act(w.cout, x.H, x.W, false);
     {
       Epi e; e.bias = wt(w.c1.b); e.has_bias = true;
@@ -352,19 +375,18 @@ struct PlanBuilder {
         e.rowvec = Ref{temb_all.buf, temb_all.off + (size_t)w.temb_off * 4}; e.has_rv = true; e.rps = HW; e.ldrv = m.temb_total;
       }
       out_to(e, h1);
-      conv3("res_conv1", ws(n1), x.C, x.C, x.H, x.W, 1, false, w.c1, e);
+      conv3("res_conv1", ws(n1), x.C * px, x.C, x.H, x.W, 1, false, w.c1, e, slo * x.C);
     }
-    untmp(n1, n * x.C * 2);
+    untmp(n1, img_bytes(n, x.C));
     const size_t n2 = groupnorm(h1, w.n2, w.eps, true);
     free_act(h1);
-    (void)h1_b;
     // shortcut: 1x1 conv of x into an fp32 residual buffer
     size_t sc = NPOS; const size_t sc_b = n * w.cout * 4;
     if (w.has_sc) {
       sc = tmp(sc_b);
       Epi e; e.bias = wt(w.sc.b); e.has_bias = true; e.out32 = ws(sc); e.has_o32 = true; e.ldo32 = w.cout;
       reads_image(e, x);
-      gemm("res_shortcut", x.h, x.ld, n, w.sc, w.cout, x.C, 0, e);
+      gemm("res_shortcut", x.h, x.ld, n, w.sc, w.cout, x.C, 0, e, x.lo);
     }
     {
       Epi e; e.bias = wt(w.c2.b); e.has_bias = true;
@@ -372,10 +394,10 @@ struct PlanBuilder {
       if (w.has_sc) { e.res32 = ws(sc); e.has_r32 = true; e.ldres = w.cout; }
       else residual_from(e, x);
       out_to(e, y);
-      conv3("res_conv2", ws(n2), w.cout, w.cout, x.H, x.W, 1, false, w.c2, e);
+      conv3("res_conv2", ws(n2), w.cout * px, w.cout, x.H, x.W, 1, false, w.c2, e, slo * w.cout);
       if (e.aux_slot >= 0) hook_done();
     }
-    untmp(n2, n * w.cout * 2);
+    untmp(n2, img_bytes(n, w.cout));
     if (w.has_sc) untmp(sc, sc_b);
     gather(id + "-res-out", y);                                                           // resnet.py:376-377
   }

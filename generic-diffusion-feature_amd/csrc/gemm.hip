@@ -245,8 +245,14 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
   const int IH = p.ups ? 2 * p.H : p.H, IW = p.ups ? 2 * p.W : p.W;
 
   // byte offset of K-tile kt inside a dense row.  The two-group schedules also stage the tiles nk, nk + 1 (so that the counted
-  // waits are the same in every iteration): those get an out-of-range offset — zero fill, no L2 / HBM traffic (scalar select)
-  auto koff = [&](int kt) -> uint32_t { return kt < nk ? (uint32_t)kt * 128u : OOB; };
+  // waits are the same in every iteration): those get an out-of-range offset — zero fill, no L2 / HBM traffic (scalar select).
+  // Split operands (GemmParams::k_w): the lo half of A starts a_lo_bytes after the hi half, the weight K-tiles repeat.
+  const int nkw = (p.k_w > 0) ? p.k_w / BK : nk;               // K-tiles of the weight matrix (== nk without a split)
+  const uint32_t a_lo = p.a_lo_bytes;
+  auto koffA = [&](int kt) -> uint32_t { return kt < nkw ? (uint32_t)kt * 128u : (kt < nk ? a_lo + (uint32_t)(kt - nkw) * 128u : OOB); };
+  auto koffB = [&](int kt) -> uint32_t { return kt < nk ? (uint32_t)(kt < nkw ? kt : kt - nkw) * 128u : OOB; };
+  const int cbw = nkw / 9;                                      // conv3: 64-channel blocks of the weight matrix
+  auto chanb = [&](int cbk) -> uint32_t { return cbk < cbw ? (uint32_t)cbk * 128u : a_lo + (uint32_t)(cbk - cbw) * 128u; };
   // 3x3-conv rows of the two-group schedules (round 2): per output row ONE byte offset — that of filter tap (0, 0), which may lie
   // outside the image — and a 9-bit validity mask, so that a K-tile's source offset is `base + scalar tap offset` and one bit test
   // (4 VALU instructions per row and K-tile instead of ~12: bounds compares, pixel arithmetic and two multiplies; VALU issue time
@@ -276,9 +282,9 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
     const uint32_t rowb = (uint32_t)p.W * (uint32_t)p.lda * 2u, pixb = (uint32_t)p.lda * 2u;
     uint32_t off;
     if (!p.ups) {
-      off = base + ((uint32_t)ky * rowb + (uint32_t)kx * pixb + (uint32_t)cbk * 128u);
+      off = base + ((uint32_t)ky * rowb + (uint32_t)kx * pixb + chanb(cbk));
     } else {
-      off = base + ((ky == 2 ? rowb : 0u) + (kx == 2 ? pixb : 0u) + (uint32_t)cbk * 128u);
+      off = base + ((ky == 2 ? rowb : 0u) + (kx == 2 ? pixb : 0u) + chanb(cbk));
       if (ky == 1 && (mask & 512u)) off += rowb;
       if (kx == 1 && (mask & 1024u)) off += pixb;
     }
@@ -286,14 +292,24 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
     return (mask & bit) ? off : OOB;
   };
   auto conv_off = [&](int kt, uint32_t base, uint32_t mask) -> uint32_t {
+#if defined(GDF_CONV_TAP_MAJOR)                                   // diagnostics build (tools/build_variant.sh): the round-2 K order, for same-box A/Bs
+    const int cpb = p.Cin / BK, tp = kt / cpb;
+    return conv_tap_off(tp < 9 ? tp : 0, kt - tp * cpb, base, mask, tp < 9);
+#else
     const int cbk = kt / 9;                                     // scalar: channel block, then filter tap
     return conv_tap_off(kt - cbk * 9, cbk, base, mask, kt < nk);
+#endif
   };
   if (MODE == A_CONV3 && STAGES < 8) {
 #pragma unroll
     for (int j = 0; j < A_PER_WAVE; ++j) conv_row(m0 + (wave * A_PER_WAVE + j) * 8 + lrow, a_off[j], a_msk[j]);
   }
+#if defined(GDF_CONV_TAP_MAJOR)
+  const int cpb_ = (MODE == A_CONV3) ? p.Cin / BK : 1;
+  int tap = kt0 / cpb_, cb = kt0 - (kt0 / cpb_) * cpb_;
+#else
   int cb = kt0 / 9, tap = kt0 - (kt0 / 9) * 9;         // channel block / filter tap of the NEXT tile to issue
+#endif
   auto issue = [&](int kt, int buf) {
     char* sA = smem + buf * STAGE;
     char* sB = sA + A_TILE;
@@ -301,7 +317,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
     for (int j = 0; j < A_PER_WAVE; ++j) {
       uint32_t off;
       if (MODE == A_DENSE) {
-        off = a_off[j] + (uint32_t)kt * 128u;          // OOB stays >= 2^31
+        off = a_off[j] + koffA(kt);                    // OOB stays >= 2^31
       } else if (MODE == A_CONV3) {
         off = conv_tap_off(tap, cb, a_off[j], a_msk[j]);
       } else {  // SMALLC: 8 channels per pixel = one 16-B chunk per tap; chunk index == tap - 8*kt
@@ -316,11 +332,15 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
 #pragma unroll
     for (int j = 0; j < B_PER_WAVE; ++j) {
       if (b_act[j]) {
-        const uint32_t off = b_off[j] + (uint32_t)kt * 128u;
+        const uint32_t off = b_off[j] + (MODE == A_CONV_SMALLC ? (uint32_t)kt * 128u : koffB(kt));
         glds16(rsB, sB + (wave * B_PER_WAVE + j) * 1024, off);
       }
     }
+#if defined(GDF_CONV_TAP_MAJOR)
+    if (MODE == A_CONV3) { if (++cb == cpb_) { cb = 0; ++tap; } }
+#else
     if (MODE == A_CONV3) { if (++tap == 9) { tap = 0; ++cb; } }
+#endif
   };
 
   // ---- accumulators ----
@@ -421,14 +441,14 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
         char* base = smem + buf * A_TILE + W * 16384 + wave * 2048;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          glds16(rsA, base + j * 1024, MODE == A_DENSE ? ha[W][j] + koff(kt) : conv_off(kt, ha[W][j], hm[W][j]));
+          glds16(rsA, base + j * 1024, MODE == A_DENSE ? ha[W][j] + koffA(kt) : conv_off(kt, ha[W][j], hm[W][j]));
         }
       } else {
         constexpr int H = W - 2;
         char* base = smem + 2 * A_TILE + buf * B_TILE + H * (BHALF * 128) + hbq[H] * 1024;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) glds16(rsB, base + j * 1024, hb[H][j] + koff(kt));
-        if (B3 && (g1 == (H == 1))) glds16(rsB, base + 2 * 1024, hb[H][2] + koff(kt));
+        for (int j = 0; j < 2; ++j) glds16(rsB, base + j * 1024, hb[H][j] + koffB(kt));
+        if (B3 && (g1 == (H == 1))) glds16(rsB, base + 2 * 1024, hb[H][2] + koffB(kt));
       }
     };
     // DMA instructions of this wave in the three youngest stagings at the phase-4 wait (A-lo, A-hi, B-lo of tile T+2)
@@ -583,7 +603,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
     }
     auto stage_a = [&](int kt, int buf, int q) {
       char* dst = smem + buf * A_TILE + ((wave >> 2) * 128 + q * 32 + (wave & 3) * 8) * 128;
-      glds16(rsA, dst, MODE == A_DENSE ? ua[q] + koff(kt) : conv_off(kt, ua[q], um[q]));
+      glds16(rsA, dst, MODE == A_DENSE ? ua[q] + koffA(kt) : conv_off(kt, ua[q], um[q]));
     };
     auto stage_b = [&](int kt, int buf, auto part) {
       constexpr int PT = decltype(part)::value;           // 0: B_1 (3 instructions), 1: B_2 (2)
@@ -591,7 +611,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
 #pragma unroll
       for (int j = (PT ? 3 : 0); j < (PT ? 5 : 3); ++j) {
         const int qi = j < 3 ? wave * 3 + j : 24 + wave * 2 + (j - 3);
-        glds16(rsB, base + qi * 1024, ub[j] + koff(kt));
+        glds16(rsB, base + qi * 1024, ub[j] + koffB(kt));
       }
     };
     constexpr std::integral_constant<int, 0> B1{};
@@ -1027,6 +1047,16 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
             for (int e = 0; e < 8; ++e) hv[e] = act16<DIT, BF>(v[it][e] * o_sc);
             *(f16x8*)(out16 + (size_t)rowi[it] * p.ldo16 + col) = hv;
           }
+        if (!DIT && p.o16_lo > 0) {                      // split operand for the consumer GEMM: lo = fp16(v - hi)
+#pragma unroll
+          for (int it = 0; it < NIT; ++it)
+            if (okr[it]) {
+              f16x8 lv;
+#pragma unroll
+              for (int e = 0; e < 8; ++e) { const float x = v[it][e] * o_sc; lv[e] = (_Float16)(x - (float)(_Float16)x); }
+              *(f16x8*)(out16 + (size_t)rowi[it] * p.ldo16 + col + p.o16_lo) = lv;
+            }
+        }
       }
       if (e_out32) {
 #pragma unroll
@@ -1222,6 +1252,9 @@ hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {
   if (p.M <= 0 || p.N <= 0) return hipSuccess;
   if (p.mode != A_CONV_SMALLC && (p.K % BK) != 0) return hipErrorInvalidValue;
   if (p.mode == A_CONV3 && (p.Cin % BK) != 0) return hipErrorInvalidValue;
+  if (p.k_w > 0 && (p.K != 2 * p.k_w || (p.k_w % BK) != 0 || p.mode == A_CONV_SMALLC || p.dit || (p.mode == A_CONV3 && (p.k_w % (9 * BK)) != 0)))
+    return hipErrorInvalidValue;                                                         // split operands: K = [hi | lo] over one weight matrix
+  if (p.o16_lo > 0 && (p.dit || p.bn == 16 || (p.o16_lo % 8) != 0)) return hipErrorInvalidValue;
   const int v = pick_variant(p);
   if (v != 16 && ((p.geglu ? p.N / 2 : p.N) % 8) != 0) return hipErrorInvalidValue;   // ragged N only in the BN = 16 variant
   if (p.bf16 && !p.dit) return hipErrorInvalidValue;                                      // bf16 exists on the MMDiT path only
@@ -1316,6 +1349,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p, 
 #pragma unroll
       for (int e = 0; e < 8; ++e) h[e] = (_Float16)(v[e] * o_sc);
       *(f16x8*)(p.out16 + (size_t)row * p.ldo16 + col) = h;
+      if (p.o16_lo > 0) {
+        f16x8 l;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) l[e] = (_Float16)(v[e] * o_sc - (float)h[e]);
+        *(f16x8*)(p.out16 + (size_t)row * p.ldo16 + col + p.o16_lo) = l;
+      }
     }
     if (p.out32) {
       f32x4* q = (f32x4*)(p.out32 + (size_t)row * p.ldo32 + col);

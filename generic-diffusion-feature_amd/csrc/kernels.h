@@ -114,6 +114,14 @@ struct GemmParams {
   // fp32).  v = acc * acc_scale + bias ...; out16 = fp16(v * out16_scale).  A tensor whose fp16 image is stored with
   // out16_scale = 2^-k is read back by its consumer GEMM with acc_scale = 2^k (exact: powers of two).  0 means 1.
   float acc_scale, out16_scale;
+  // SPLIT OPERANDS ("precise" plans, gdf_plan_opts.precise): an activation is stored as two fp16 numbers hi = fp16(v), lo = fp16(v - hi)
+  // (22 mantissa bits) and the contraction runs over [hi | lo] against [W | W]:  A.W = hi.W + lo.W with K doubled, the weights read
+  // twice from the SAME matrix.  k_w > 0: K of the weight matrix (K == 2 k_w); K-tile kt >= k_w / 64 of A starts a_lo_bytes after the
+  // hi columns (conv3: per pixel) and reads weight K-tile kt - k_w / 64.  o16_lo > 0: out16 is written as such a pair, lo at
+  // out16 + o16_lo elements (same row).  0 everywhere = plain fp16 operands (the default plans).
+  int k_w;
+  uint32_t a_lo_bytes;
+  int o16_lo;
 };
 hipError_t launch_gemm(const GemmParams& p, hipStream_t s);
 // Deterministic split-K for problems with few output tiles and a long K (the 8x8-level 3x3 convs of SD1.5: 160 tiles of 128x128,
@@ -141,6 +149,7 @@ struct AttnParams {
   const int* kv_len;     // optional [B]: keys [kv_len[b], Sk) of sample b are masked out (prefix text mask)
   int seg_T;             // > 0: MMDiT joint sequence, region-major rows [B x seg_T text][B x (Sq - seg_T) image] (Sq == Sk)
   int bf16;              // D = 128 only: q, k, v, o are bf16 (mfma_f32_32x32x16_bf16, P rounded to bf16); maps stay fp16
+  int o_lo;              // > 0 ("precise" plans): o is written as a split (hi, lo) pair, lo at o + o_lo elements in the same row
 };
 hipError_t launch_attention(const AttnParams& p, hipStream_t s);
 
@@ -152,17 +161,19 @@ hipError_t launch_attention(const AttnParams& p, hipStream_t s);
 //              (`partial` is scratch of gn_partial_floats(B, HW, C) floats)
 //   gn_apply : y = act(x*a + b) as contiguous fp16 [B*HW][C]; silu=1 applies v*sigmoid(v)
 size_t gn_partial_floats(int B, int HW, int C);
+// split operands ("precise" plans): x_lo > 0 = the fp16 source is a (hi, lo) pair with lo x_lo elements after hi in the row;
+// y_lo > 0 = y is written as such a pair (rows of ldy elements, lo at column offset y_lo); ldy = 0 means C
 hipError_t launch_gn_stats(const half_t* x16, const float* x32, int ld, int B, int HW, int C, int G, float eps,
-                           const float* gamma, const float* beta, float* partial, float* ab, hipStream_t s);
+                           const float* gamma, const float* beta, float* partial, float* ab, hipStream_t s, int x_lo = 0);
 hipError_t launch_gn_apply(const half_t* x16, const float* x32, int ld, int B, int HW, int C,
-                           const float* ab, int silu, half_t* y, hipStream_t s);
+                           const float* ab, int silu, half_t* y, hipStream_t s, int x_lo = 0, int ldy = 0, int y_lo = 0);
 // single-launch GroupNorm (+SiLU) for small feature maps; gn_fused_slab(...) != 0 says whether it applies
 int gn_fused_slab(int B, int HW, int C, int G);
 hipError_t launch_gn_fused(const half_t* x16, const float* x32, int ld, int B, int HW, int C, int G, float eps, const float* gamma,
-                           const float* beta, int silu, half_t* y, hipStream_t s);
+                           const float* beta, int silu, half_t* y, hipStream_t s, int x_lo = 0, int ldy = 0, int y_lo = 0);
 // LayerNorm over the last dim (C), rows x [R][ld]; y contiguous fp16 [R][C]
 hipError_t launch_layernorm(const half_t* x16, const float* x32, int ld, int R, int C, float eps,
-                            const float* gamma, const float* beta, half_t* y, hipStream_t s);
+                            const float* gamma, const float* beta, half_t* y, hipStream_t s, int ldy = 0, int y_lo = 0);
 // LayerNorm without affine + adaLN modulation (AdaLayerNormZero / ZeroSingle / Continuous and the norm2 modulate of
 // the MMDiT blocks): y = LN(x, eps) * (1 + scale[s][c]) + shift[s][c]; s = row / rps for row < seg_rows (or
 // seg_rows == 0), else (row - seg_rows) / rps2.  x fp32 (or fp16) [R][ld], y fp16 [R][C], scale/shift fp32 rows of ldm.
@@ -185,6 +196,10 @@ hipError_t launch_softmax_rows(half_t* x, int ld, int R, int n, float scale, hip
 hipError_t launch_vae_finish(const float* h, int B, int HW, int L, const half_t* wq, const float* bq, const half_t* eps,
                              const half_t* noise, float scaling, float noise_a, float noise_b, float in_scale, half_t* out,
                              hipStream_t s);
+// VAE decoder head: z = (c_sample * latents + c_eps * noise_pred) * inv_scaling; y = post_quant_conv(z) (wq == NULL: identity)
+// -> NHWC fp16 padded to 8 channels.  latents / noise_pred NCHW fp16 (B, L, H, W); noise_pred may be NULL (plain decode)
+hipError_t launch_vae_dec_prepare(const half_t* lat, const half_t* eps, int B, int HW, int L, float ca, float cb, float inv_sf,
+                                  const half_t* wq, const float* bq, half_t* nhwc8, hipStream_t s);
 // PatchEmbed positional table (embeddings.get_2d_sincos_pos_embed as PatchEmbed calls it): out fp32 [gh*gw][C]
 hipError_t launch_sincos_pos_embed(float* out, int C, int gh, int gw, int base_size, float interpolation_scale, hipStream_t s);
 // out[b][i] = table[i] + vec[b][i % period]   (ada_norm_single: scale_shift_table + timestep embedding, all blocks at once)

@@ -236,7 +236,7 @@ struct B : PlanBuilder {   // UNet op program
 
   // ---- attention helper ---------------------------------------------------------------------------
   void attention(const char* name, Ref q, int ldq, Ref k, int ldk, Ref v, int ldv, Ref o, int ldo, int heads, int Sq,
-                 int Sk, int D, int map_slot, int kv_rows_per_batch = -1) {
+                 int Sk, int D, int map_slot, int kv_rows_per_batch = -1, int o_lo = 0) {
     if (kv_rows_per_batch < 0) kv_rows_per_batch = Sk;
     const int Bq = Bn;
     const double fl = 4.0 * (double)Bn * heads * Sq * Sk * D;
@@ -245,7 +245,7 @@ struct B : PlanBuilder {   // UNet op program
       a.q = (const half_t*)b.p(q); a.ldq = ldq; a.k = (const half_t*)b.p(k); a.ldk = ldk;
       a.v = (const half_t*)b.p(v); a.ldv = ldv; a.o = (half_t*)b.p(o); a.ldo = ldo;
       a.B = Bq; a.heads = heads; a.Sq = Sq; a.Sk = Sk; a.D = D; a.scale = 1.0f / sqrtf((float)D);
-      a.kv_bstride = kv_rows_per_batch;
+      a.kv_bstride = kv_rows_per_batch; a.o_lo = o_lo;
       a.map = map_slot >= 0 ? (half_t*)b.hook(map_slot) : nullptr;
       return launch_attention(a, s);
     });
@@ -259,33 +259,36 @@ struct B : PlanBuilder {   // UNet op program
     const int C = x.C, S = x.H * x.W, heads = w.heads, D = C / heads;
     const bool maps = P.want_maps;
     // GroupNorm(eps 1e-6) -> proj_in  (conv1x1 == linear in NHWC)
+    // precise plans: every GEMM A operand below is a split image [hi | lo] (row width 2K, lo at +K): builder.h gemm(..., a_lo)
+    const int sp = precise ? 1 : 0;
     const size_t gn = groupnorm(x, w.gn, 1e-6f, false);
     Act tok = new_act(C, x.H, x.W, true);
     {
       Epi e; e.bias = wt(w.pin.b); e.has_bias = true; out_to(e, tok, /*need_shadow=*/w.blocks.empty());
-      gemm("proj_in", ws(gn), C, n, w.pin, C, C, 0, e);
+      gemm("proj_in", ws(gn), C * px, n, w.pin, C, C, 0, e, sp * C);
     }
-    untmp(gn, n * C * 2);
+    untmp(gn, img_bytes(n, C));
     for (size_t bi = 0; bi < w.blocks.size() && !stop; ++bi) {
       const BlockW& bw = w.blocks[bi];
       const std::string bid = id + "-block" + std::to_string(bi);
-      const size_t nb = n * C * 2;
+      const size_t nb = n * C * 2;            // a plain fp16 [n][C] tensor (q, hooks)
+      const size_t nbx = img_bytes(n, C);     // an MFMA A operand [n][C] (split in a precise plan)
       // --- self attention ---
       size_t ln = layernorm(tok, bw.ln1);
       const size_t qkv = tmp(n * 3 * C * 2);
-      { Epi e; e.out16 = ws(qkv); e.has_o16 = true; e.ldo16 = 3 * C; gemm("attn1_qkv", ws(ln), C, n, bw.qkv, 3 * C, C, 0, e); }
-      untmp(ln, nb);
+      { Epi e; e.out16 = ws(qkv); e.has_o16 = true; e.ldo16 = 3 * C; gemm("attn1_qkv", ws(ln), C * px, n, bw.qkv, 3 * C, C, 0, e, sp * C); }
+      untmp(ln, nbx);
       hook_copy(want(bid + "-self-q", C, x.H, x.W), ws(qkv), 3 * C, n, C);                 // attention_processor.py:3291-3294
       hook_copy(want(bid + "-self-k", C, x.H, x.W), ws(qkv + (size_t)C * 2), 3 * C, n, C);
       hook_copy(want(bid + "-self-v", C, x.H, x.W), ws(qkv + (size_t)2 * C * 2), 3 * C, n, C);
-      size_t ao = tmp(nb);
+      size_t ao = tmp(nbx);
       const int ms = maps ? want_map(bid + "-self-map", heads, S, S) : (dry_map(bid + "-self-map"), -1);
-      attention("attn1", ws(qkv), 3 * C, ws(qkv + (size_t)C * 2), 3 * C, ws(qkv + (size_t)2 * C * 2), 3 * C, ws(ao), C, heads,
-                S, S, D, ms);
+      attention("attn1", ws(qkv), 3 * C, ws(qkv + (size_t)C * 2), 3 * C, ws(qkv + (size_t)2 * C * 2), 3 * C, ws(ao), C * px, heads,
+                S, S, D, ms, -1, sp * C);
       untmp(qkv, n * 3 * C * 2);
       { Epi e; e.bias = wt(bw.o1.b); e.has_bias = true; residual_from(e, tok); out_to(e, tok, false);
-        gemm("attn1_out", ws(ao), C, n, bw.o1, C, C, 0, e); }
-      untmp(ao, nb);
+        gemm("attn1_out", ws(ao), C * px, n, bw.o1, C, C, 0, e, sp * C); }
+      untmp(ao, nbx);
       if (stop) break;
       // --- cross attention ---
       ln = layernorm(tok, bw.ln2);
@@ -294,41 +297,46 @@ struct B : PlanBuilder {   // UNet op program
       const int hq = want(bid + "-cross-q", C, x.H, x.W);
       const size_t q2 = hq >= 0 ? 0 : tmp(nb);
       const Ref q2r = hq >= 0 ? Ref{BUF_HOOK0 + hq, 0} : ws(q2);
-      { Epi e; e.out16 = q2r; e.has_o16 = true; e.ldo16 = C; gemm("attn2_q", ws(ln), C, n, bw.q2, C, C, 0, e); }
-      untmp(ln, nb);
+      { Epi e; e.out16 = q2r; e.has_o16 = true; e.ldo16 = C; gemm("attn2_q", ws(ln), C * px, n, bw.q2, C, C, 0, e, sp * C); }
+      untmp(ln, nbx);
       if (hq >= 0) hook_done();
       // text K/V: precomputed for all blocks by the grouped GEMM at the head of the plan; with one prompt repeated over
       // the batch (reference diffusion_feature.py:272, opts.reserved[0]) there is a single K/V set per block
       const bool shared = opt.reserved[0] != 0;
       const size_t kv = dry ? 0 : kv_bufs[bw.kv_group].first + (size_t)bw.kv_index * kv_bufs[bw.kv_group].second;
-      ao = tmp(nb);
+      ao = tmp(nbx);
       const int mc = maps ? want_map(bid + "-cross-map", heads, S, n_ctx) : (dry_map(bid + "-cross-map"), -1);
-      attention("attn2", q2r, C, ws(kv), 2 * C, ws(kv + (size_t)C * 2), 2 * C, ws(ao), C, heads, S, n_ctx, D, mc,
-                shared ? 0 : n_ctx);
+      attention("attn2", q2r, C, ws(kv), 2 * C, ws(kv + (size_t)C * 2), 2 * C, ws(ao), C * px, heads, S, n_ctx, D, mc,
+                shared ? 0 : n_ctx, sp * C);
       if (hq < 0) untmp(q2, nb);
       { Epi e; e.bias = wt(bw.o2.b); e.has_bias = true; residual_from(e, tok); out_to(e, tok, false);
-        gemm("attn2_out", ws(ao), C, n, bw.o2, C, C, 0, e); }
-      untmp(ao, nb);
+        gemm("attn2_out", ws(ao), C * px, n, bw.o2, C, C, 0, e, sp * C); }
+      untmp(ao, nbx);
       if (stop) break;
       // --- feed forward (GEGLU) ---
       ln = layernorm(tok, bw.ln3);
       const int hi = want(bid + "-ffn-inner", 4 * C, x.H, x.W);                             // attention.py:1255-1257
-      const size_t inner = hi >= 0 ? 0 : tmp(n * 4 * C * 2);
-      const Ref innr = hi >= 0 ? Ref{BUF_HOOK0 + hi, 0} : ws(inner);
-      { Epi e; e.bias = wt(bw.ff1.b); e.has_bias = true; e.geglu = geglu_group(8 * C); e.out16 = innr; e.has_o16 = true; e.ldo16 = 4 * C;
-        gemm("ff_geglu", ws(ln), C, n, bw.ff1, 8 * C, C, 0, e); }
-      untmp(ln, nb);
-      if (hi >= 0) hook_done();
+      // (precise plans: the inner tensor is a split pair in workspace; a hooked `ffn-inner` is then a copy of its hi half)
+      const bool direct = hi >= 0 && !precise;
+      const size_t inner_b = img_bytes(n, 4 * C);
+      const size_t inner = direct ? 0 : tmp(inner_b);
+      const Ref innr = direct ? Ref{BUF_HOOK0 + hi, 0} : ws(inner);
+      { Epi e; e.bias = wt(bw.ff1.b); e.has_bias = true; e.geglu = geglu_group(8 * C); e.out16 = innr; e.has_o16 = true; e.ldo16 = 4 * C * px;
+        e.o16_lo = sp * 4 * C;
+        gemm("ff_geglu", ws(ln), C * px, n, bw.ff1, 8 * C, C, 0, e, sp * C); }
+      untmp(ln, nbx);
+      if (direct) hook_done();
+      else if (hi >= 0) hook_copy(hi, innr, 4 * C * px, n, 4 * C);
       { // the fp16 image of the block output is only needed by the `blockN-out` hook and by proj_out (last block)
         const bool shadow = (bi + 1 == w.blocks.size()) || (!dry && P.requested.count(bid + "-out"));
         Epi e; e.bias = wt(bw.ff2.b); e.has_bias = true; residual_from(e, tok); out_to(e, tok, shadow);
-        gemm("ff_out", innr, 4 * C, n, bw.ff2, C, 4 * C, 0, e); }
-      if (hi < 0) untmp(inner, n * 4 * C * 2);
+        gemm("ff_out", innr, 4 * C * px, n, bw.ff2, C, 4 * C, 0, e, sp * 4 * C); }
+      if (!direct) untmp(inner, inner_b);
       gather(bid + "-out", tok);                                                           // attention.py:589-590
     }
     if (!stop) {
       Epi e; e.bias = wt(w.pout.b); e.has_bias = true; residual_from(e, x); out_to(e, y);
-      gemm("proj_out", tok.h, tok.ld, n, w.pout, C, C, 0, e);
+      gemm("proj_out", tok.h, tok.ld, n, w.pout, C, C, 0, e, tok.lo);
     }
     free_act(tok);
     gather(id + "-out", y);                                                                // transformer_2d.py:474-475
@@ -337,12 +345,14 @@ struct B : PlanBuilder {   // UNet op program
 
   size_t layernorm(const Act& x, const NormW& w) {
     const size_t n = rows(x);
-    const size_t y = tmp(n * x.C * 2);
+    const size_t y = tmp(img_bytes(n, x.C));
     const Ref xh = x.h, xf = x.f; const bool hf = x.has_f; const int ld = x.ld, C = x.C;
     const Ref g = wt(w.g), bt = wt(w.b);
+    const int ldy = C * px, y_lo = precise ? C : 0;       // precise plans: split output [hi | lo]
+    if (precise && !hf && !dry) { set_error("precise plan: LayerNorm input without an fp32 master"); bad = true; }
     op("layernorm", 0, [=](const Bind& b, hipStream_t s) {
       return launch_layernorm(hf ? nullptr : (const half_t*)b.p(xh), hf ? (const float*)b.p(xf) : nullptr, hf ? C : ld,
-                              (int)n, C, 1e-5f, (const float*)b.p(g), (const float*)b.p(bt), (half_t*)b.ws(y), s);
+                              (int)n, C, 1e-5f, (const float*)b.p(g), (const float*)b.p(bt), (half_t*)b.ws(y), s, ldy, y_lo);
     });
     return y;
   }
@@ -432,7 +442,7 @@ struct B : PlanBuilder {   // UNet op program
         const int lv = L - 1 - i, co = boc[lv], cin_skip = boc[std::max(lv - 1, 0)];
         for (int r = 0; r < nl + 1; ++r) {
           Cat c; c.ch = (r == 0) ? prev : co; c.cs = (r == nl) ? cin_skip : co; c.H = hh; c.W = ww;
-          c.bytes = (size_t)Bn * hh * ww * (c.ch + c.cs) * 2;
+          c.bytes = (size_t)Bn * hh * ww * (c.ch + c.cs) * 2 * px;          // precise plans: [h_hi | skip_hi | h_lo | skip_lo]
           c.off = tmp(c.bytes);
           cats.push_back(c);
         }
@@ -443,7 +453,7 @@ struct B : PlanBuilder {   // UNet op program
     int skip_idx = 0;                 // k-th produced skip is consumed by cats[n_skips-1-k]
     auto skip_dst = [&](int C, int hh, int ww) -> Act {
       const Cat& c = cats[n_skips - 1 - skip_idx++];
-      return view_act(ws(c.off + (size_t)c.ch * 2), c.ch + c.cs, C, hh, ww, true);
+      return view_act(ws(c.off + (size_t)c.ch * 2), (c.ch + c.cs) * px, C, hh, ww, true, precise ? c.ch + c.cs : 0);
     };
 
     // ---- conv_in ----
@@ -501,7 +511,7 @@ struct B : PlanBuilder {   // UNet op program
       if (lw.has_sampler && !stop) {
         Act nxt = skip_dst(boc[lv], hh / 2, ww / 2);
         Epi e; e.bias = wt(lw.sampler.b); e.has_bias = true; out_to(e, nxt);
-        conv3("downsample", cur.h, cur.ld, cur.C, hh, ww, 2, false, lw.sampler, e);          // downsampling.py:132-152
+        conv3("downsample", cur.h, cur.ld, cur.C, hh, ww, 2, false, lw.sampler, e, cur.lo);  // downsampling.py:132-152
         free_master(cur);
         cur = nxt; hh /= 2; ww /= 2;
         gather("down-level" + std::to_string(lv) + "-downsampler-out", cur);
@@ -516,7 +526,7 @@ struct B : PlanBuilder {   // UNet op program
       vit("mid-vit", m.mid_vit, a0, a1);
       free_act(a0);
       // mid output feeds cats[0] channel slice [0, ch)
-      Act a2 = view_act(ws(cats[0].off), cats[0].ch + cats[0].cs, boc[L - 1], hh, ww, false);
+      Act a2 = view_act(ws(cats[0].off), (cats[0].ch + cats[0].cs) * px, boc[L - 1], hh, ww, false, precise ? cats[0].ch + cats[0].cs : 0);
       resnet("mid-repeat1", m.mid_res1, a1, a2);
       free_act(a1);
       cur = a2;
@@ -529,14 +539,14 @@ struct B : PlanBuilder {   // UNet op program
       for (int r = 0; r < nl + 1 && !stop; ++r, ++ci) {
         const std::string id = "up-level" + std::to_string(i) + "-repeat" + std::to_string(r);
         const Cat& c = cats[ci];
-        Act cat = view_act(ws(c.off), c.ch + c.cs, c.ch + c.cs, c.H, c.W, false);            // torch.cat([h, skip], 1)
+        Act cat = view_act(ws(c.off), (c.ch + c.cs) * px, c.ch + c.cs, c.H, c.W, false, precise ? c.ch + c.cs : 0);   // torch.cat([h, skip], 1)
         // destination: the h-slice of the next concat buffer, or a fresh tensor at the end of a level
         const bool last_in_level = (r == nl);
         const bool attn = a.has_attn[lv];
         auto make_dst = [&](bool master) -> Act {
           if (!last_in_level) {
             const Cat& nc = cats[ci + 1];
-            return view_act(ws(nc.off), nc.ch + nc.cs, boc[lv], c.H, c.W, master);
+            return view_act(ws(nc.off), (nc.ch + nc.cs) * px, boc[lv], c.H, c.W, master, precise ? nc.ch + nc.cs : 0);
           }
           return new_act(boc[lv], c.H, c.W, master);
         };
@@ -556,9 +566,9 @@ struct B : PlanBuilder {   // UNet op program
       }
       if (lw.has_sampler && !stop) {
         const Cat& nc = cats[ci];
-        Act nxt = view_act(ws(nc.off), nc.ch + nc.cs, boc[lv], cur.H * 2, cur.W * 2, false);
+        Act nxt = view_act(ws(nc.off), (nc.ch + nc.cs) * px, boc[lv], cur.H * 2, cur.W * 2, false, precise ? nc.ch + nc.cs : 0);
         Epi e; e.bias = wt(lw.sampler.b); e.has_bias = true; out_to(e, nxt);
-        conv3("upsample", cur.h, cur.ld, cur.C, cur.H, cur.W, 1, true, lw.sampler, e);       // upsampling.py:176-193
+        conv3("upsample", cur.h, cur.ld, cur.C, cur.H, cur.W, 1, true, lw.sampler, e, cur.lo);   // upsampling.py:176-193
         free_act(cur);
         cur = nxt;
         gather("up-level" + std::to_string(i) + "-upsampler-out", cur);
@@ -571,8 +581,8 @@ struct B : PlanBuilder {   // UNet op program
       Epi e; e.bias = wt(m.conv_out.b); e.has_bias = true; e.bn = 16;
       e.out16 = Ref{BUF_NOISE, 0}; e.has_o16 = true; e.ldo16 = a.out_channels;
       P.writes_noise = true;
-      conv3("conv_out", ws(no), cur.C, cur.C, cur.H, cur.W, 1, false, m.conv_out, e);
-      untmp(no, n * cur.C * 2);
+      conv3("conv_out", ws(no), cur.C * px, cur.C, cur.H, cur.W, 1, false, m.conv_out, e, precise ? cur.C : 0);
+      untmp(no, img_bytes(n, cur.C));
       const int slot = want("unet-out", a.out_channels, cur.H, cur.W);                       // :1309-1310
       hook_copy(slot, Ref{BUF_NOISE, 0}, a.out_channels, n, a.out_channels);
       free_act(cur);
@@ -589,9 +599,11 @@ int plan_build(const Model& m, Plan& P, int batch, int H, int W, int n_ctx, cons
   if (batch < 1 || H < 1 || W < 1 || (H % (1 << (L - 1))) || (W % (1 << (L - 1)))) {
     set_error("latent size must be a positive multiple of 2^(levels-1)"); return GDF_ERR_ARG;
   }
+  const bool precise = opts.reserved[1] != 0;
+  if (precise && !opts.stream_fp32) { set_error("a precise plan needs the fp32 master stream (stream_fp32 = 1)"); return GDF_ERR_ARG; }
   for (int lv = 0; lv < L; ++lv) {   // 32-bit buffer offsets: the widest row (concat / GEGLU inner / qkv) must stay < 2 GiB
     const size_t r = (size_t)batch * (H >> lv) * (W >> lv), c = m.arch.block_out_channels[lv];
-    if (r * c * 4 * 2 >= (1ull << 31)) {
+    if (r * c * 4 * 2 * (precise ? 2 : 1) >= (1ull << 31)) {
       set_error("batch*H*W too large for 32-bit buffer offsets; split the batch"); return GDF_ERR_UNSUPPORTED;
     }
   }
@@ -607,6 +619,7 @@ int plan_build(const Model& m, Plan& P, int batch, int H, int W, int n_ctx, cons
     if (opts.early_exit && b.remaining == 0) b.stop = true;
   }
   b.build(H, W);
+  if (b.bad) return GDF_ERR_UNSUPPORTED;
   P.ws_bytes = b.ar.peak + 256;
   return GDF_OK;
 }

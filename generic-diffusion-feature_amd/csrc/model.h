@@ -75,16 +75,21 @@ struct PixartW {
 struct VaeW {
   gdf_vae_desc d{};
   ConvW conv_in, conv_out;
-  std::vector<std::vector<ResnetW>> down;      // [level][layer]
+  std::vector<std::vector<ResnetW>> down;      // [level][layer]   (encoder)
   std::vector<ConvW> downsamplers;             // level < L-1
   ResnetW mid0, mid1;
   NormW attn_gn, norm_out;
   LinW q, k, v, o, quant;
+  // decoder half (Model::kind 4): up blocks of layers_per_block + 1 resnets over the REVERSED channel list, Upsample2D on all but the
+  // last block, post_quant_conv ([L][L], fp16 rows + fp32 bias)
+  std::vector<std::vector<ResnetW>> up;
+  std::vector<ConvW> upsamplers;
+  LinW post_quant;
 };
 
 struct Model {
   int bf16 = 0;                                // 16-bit element type of weights / activations: 0 fp16, 1 bf16 (Flux only)
-  int kind = 0;                                // 0: UNet2DConditionModel, 1: FluxTransformer2DModel, 2: AutoencoderKL encoder
+  int kind = 0;                                // 0: UNet2DConditionModel, 1: FluxTransformer2DModel, 2: AutoencoderKL encoder, 3: PixArt DiT, 4: AutoencoderKL decoder
   FluxW flux;
   VaeW vae;
   PixartW pix;                                 // kind 3
@@ -176,6 +181,12 @@ Model* vae_model_create(const gdf_vae_desc& d);
 int vae_plan_build(const Model& m, Plan& P, int batch, int img_h, int img_w, bool dry);
 int vae_encode(Plan& P, const Model& m, const void* image, const void* eps, const void* noise, float scaling, float noise_a,
                float noise_b, float in_scale, void* out, void* ws, hipStream_t s, float* ms, const char** names, double* flops, int cap);
+
+// ---- VAE decoder (`vae-out`, include/gdf_vae.h) ----
+Model* vae_decoder_create(const gdf_vae_desc& d);
+int vae_dec_plan_build(const Model& m, Plan& P, int batch, int lat_h, int lat_w, bool dry);
+int vae_decode(Plan& P, const Model& m, const void* latents, const void* noise_pred, float c_sample, float c_eps, float inv_scaling,
+               void* image_out, void* ws, hipStream_t s, float* ms, const char** names, double* flops, int cap);
 
 // ---- PixArt DiT front end (include/gdf_pixart.h) ----
 Model* pixart_model_create(const gdf_pixart_desc& d);

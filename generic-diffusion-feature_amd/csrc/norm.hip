@@ -26,7 +26,8 @@ static int gn_slab(int B, int HW) {
   return slab;
 }
 
-__device__ __forceinline__ void load8(const half_t* x16, const float* x32, size_t idx, float v[8]) {
+// x_lo > 0: the fp16 source is a split (hi, lo) pair, lo stored x_lo elements after hi in the same row ("precise" plans, kernels.h)
+__device__ __forceinline__ void load8(const half_t* x16, const float* x32, size_t idx, float v[8], int x_lo = 0) {
   if (x32) {
     const f32x4 a = *(const f32x4*)(x32 + idx), b = *(const f32x4*)(x32 + idx + 4);
 #pragma unroll
@@ -35,6 +36,24 @@ __device__ __forceinline__ void load8(const half_t* x16, const float* x32, size_
     const f16x8 a = *(const f16x8*)(x16 + idx);
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = (float)a[e];
+    if (x_lo > 0) {
+      const f16x8 l = *(const f16x8*)(x16 + idx + x_lo);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += (float)l[e];
+    }
+  }
+}
+// fp16 store of 8 values, optionally as a split (hi, lo) pair (lo at y + y_lo)
+__device__ __forceinline__ void store8(half_t* y, const float t[8], int y_lo) {
+  f16x8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = (_Float16)t[e];
+  *(f16x8*)y = o;
+  if (y_lo > 0) {
+    f16x8 l;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) l[e] = (_Float16)(t[e] - (float)o[e]);
+    *(f16x8*)(y + y_lo) = l;
   }
 }
 
@@ -46,7 +65,7 @@ size_t gn_partial_floats(int B, int HW, int C) {
 
 // stage 1: per (sample, slab) block: per-channel sum / sum of squares over the slab's pixel rows
 __global__ __launch_bounds__(256) void gn_partial_kernel(const half_t* x16, const float* x32, int ld, int HW, int C,
-                                                         float* partial, int slab_rows) {
+                                                         float* partial, int slab_rows, int x_lo) {
   extern __shared__ float red[];                  // [rgroups][C][2]
   const int b = blockIdx.y, slab = blockIdx.x, nslab = gridDim.x;
   const int CH = C / 8;
@@ -61,7 +80,7 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const half_t* x16, cons
     if (tr < rgroups) {
       for (int r = r0 + tr; r < r1; r += rgroups) {
         float v[8];
-        load8(x16, x32, ((size_t)b * HW + r) * ld + c * 8, v);
+        load8(x16, x32, ((size_t)b * HW + r) * ld + c * 8, v, x_lo);
 #pragma unroll
         for (int e = 0; e < 8; ++e) { s[e] += v[e]; q[e] += v[e] * v[e]; }
       }
@@ -106,19 +125,20 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const float* partial, i
 }
 
 hipError_t launch_gn_stats(const half_t* x16, const float* x32, int ld, int B, int HW, int C, int G, float eps,
-                           const float* gamma, const float* beta, float* partial, float* ab, hipStream_t s) {
+                           const float* gamma, const float* beta, float* partial, float* ab, hipStream_t s, int x_lo) {
   if (C % 8 || C % G) return hipErrorInvalidValue;
   const int slab = gn_slab(B, HW);
   const int nslab = (HW + slab - 1) / slab;
   const int CH = C / 8, cht = CH < 256 ? CH : 256, rgroups = 256 / cht;
   const size_t smem = (size_t)rgroups * C * 2 * sizeof(float);
-  hipLaunchKernelGGL(gn_partial_kernel, dim3(nslab, B), dim3(256), smem, s, x16, x32, ld, HW, C, partial, slab);
+  hipLaunchKernelGGL(gn_partial_kernel, dim3(nslab, B), dim3(256), smem, s, x16, x32, ld, HW, C, partial, slab, x_lo);
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(G, B), dim3(64), 0, s, partial, nslab, HW, C, G, eps, gamma, beta, ab);
   return hipGetLastError();
 }
 
 __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* x16, const float* x32, int ld, int HW, int C,
-                                                       const float* ab, int silu, half_t* y, int rows_per_block) {
+                                                       const float* ab, int silu, half_t* y, int rows_per_block, int x_lo, int ldy,
+                                                       int y_lo) {
   const int b = blockIdx.y;
   const int CH = C / 8;
   const int cht = CH < 256 ? CH : 256, rgroups = 256 / cht;
@@ -134,25 +154,24 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* x16, const 
     }
     for (int r = r0 + tr; r < r1; r += rgroups) {
       float v[8];
-      load8(x16, x32, ((size_t)b * HW + r) * ld + c * 8, v);
-      f16x8 o;
+      load8(x16, x32, ((size_t)b * HW + r) * ld + c * 8, v, x_lo);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         float t = v[e] * a[e] + bb[e];
         if (silu) t = t / (1.0f + __expf(-t));
-        o[e] = (_Float16)t;
+        v[e] = t;
       }
-      *(f16x8*)(y + ((size_t)b * HW + r) * C + c * 8) = o;
+      store8(y + ((size_t)b * HW + r) * ldy + c * 8, v, y_lo);
     }
   }
 }
 
 hipError_t launch_gn_apply(const half_t* x16, const float* x32, int ld, int B, int HW, int C, const float* ab, int silu,
-                           half_t* y, hipStream_t s) {
+                           half_t* y, hipStream_t s, int x_lo, int ldy, int y_lo) {
   if (C % 8) return hipErrorInvalidValue;
   const int rpb = 64;
   hipLaunchKernelGGL(gn_apply_kernel, dim3((HW + rpb - 1) / rpb, B), dim3(256), 0, s, x16, x32, ld, HW, C, ab, silu, y,
-                     rpb);
+                     rpb, x_lo, ldy > 0 ? ldy : C, y_lo);
   return hipGetLastError();
 }
 
@@ -161,7 +180,8 @@ hipError_t launch_gn_apply(const half_t* x16, const float* x32, int ld, int B, i
 // slab's HW x SC block, the slab's group statistics are combined in double in LDS, pass 2 re-reads the block (L2 / MALL
 // resident: it was just read), applies the affine (+SiLU) and writes fp16.  One launch, same 6 B/element.
 __global__ __launch_bounds__(256) void gn_fused_kernel(const half_t* x16, const float* x32, int ld, int HW, int C, int G, float eps,
-                                                       const float* gamma, const float* beta, int silu, half_t* y, int SC) {
+                                                       const float* gamma, const float* beta, int silu, half_t* y, int SC, int x_lo,
+                                                       int ldy, int y_lo) {
   extern __shared__ float red[];                  // [RPP][SC][2] floats, then reused: double chan[SC][2], float ab[SC][2]
   const int b = blockIdx.y, c0 = blockIdx.x * SC;
   const int LPR = SC / 8, RPP = 256 / LPR;
@@ -174,7 +194,7 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(const half_t* x16, const 
   if (act) {
     for (int r = tr; r < HW; r += RPP) {
       float v[8];
-      load8(x16, x32, (rowbase + r) * ld + c0 + lc * 8, v);
+      load8(x16, x32, (rowbase + r) * ld + c0 + lc * 8, v, x_lo);
 #pragma unroll
       for (int e = 0; e < 8; ++e) { s[e] += v[e]; q[e] += v[e] * v[e]; }
     }
@@ -215,15 +235,14 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(const half_t* x16, const 
   for (int e = 0; e < 8; ++e) { a[e] = ab[(lc * 8 + e) * 2]; bb[e] = ab[(lc * 8 + e) * 2 + 1]; }
   for (int r = tr; r < HW; r += RPP) {
     float v[8];
-    load8(x16, x32, (rowbase + r) * ld + c0 + lc * 8, v);
-    f16x8 o;
+    load8(x16, x32, (rowbase + r) * ld + c0 + lc * 8, v, x_lo);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       float t = v[e] * a[e] + bb[e];
       if (silu) t = t / (1.0f + __expf(-t));
-      o[e] = (_Float16)t;
+      v[e] = t;
     }
-    *(f16x8*)(y + (rowbase + r) * C + c0 + lc * 8) = o;
+    store8(y + (rowbase + r) * ldy + c0 + lc * 8, v, y_lo);
   }
 }
 
@@ -243,19 +262,20 @@ int gn_fused_slab(int B, int HW, int C, int G) {
 }
 
 hipError_t launch_gn_fused(const half_t* x16, const float* x32, int ld, int B, int HW, int C, int G, float eps, const float* gamma,
-                           const float* beta, int silu, half_t* y, hipStream_t s) {
+                           const float* beta, int silu, half_t* y, hipStream_t s, int x_lo, int ldy, int y_lo) {
   const int SC = gn_fused_slab(B, HW, C, G);
   if (!SC) return hipErrorInvalidValue;
   const int LPR = SC / 8, RPP = 256 / LPR;
   const size_t smem = (size_t)RPP * SC * 2 * 4 + (size_t)SC * 2 * 8 + (size_t)SC * 2 * 4;
-  hipLaunchKernelGGL(gn_fused_kernel, dim3(C / SC, B), dim3(256), smem, s, x16, x32, ld, HW, C, G, eps, gamma, beta, silu, y, SC);
+  hipLaunchKernelGGL(gn_fused_kernel, dim3(C / SC, B), dim3(256), smem, s, x16, x32, ld, HW, C, G, eps, gamma, beta, silu, y, SC, x_lo,
+                     ldy > 0 ? ldy : C, y_lo);
   return hipGetLastError();
 }
 
 // LayerNorm: one wave per row, row kept in registers (C <= 64*8*MAXC), exact two-pass statistics.
 template <int MAXC>
 __global__ __launch_bounds__(256) void layernorm_kernel(const half_t* x16, const float* x32, int ld, int R, int C,
-                                                        float eps, const float* gamma, const float* beta, half_t* y) {
+                                                        float eps, const float* gamma, const float* beta, half_t* y, int ldy, int y_lo) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= R) return;
@@ -292,25 +312,26 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const half_t* x16, const
     if (c < CH) {
       const f32x4 g0 = *(const f32x4*)(gamma + c * 8), g1 = *(const f32x4*)(gamma + c * 8 + 4);
       const f32x4 b0 = *(const f32x4*)(beta + c * 8), b1 = *(const f32x4*)(beta + c * 8 + 4);
-      f16x8 o;
+      float t[8];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        o[e] = (_Float16)((v[i][e] - mean) * rstd * g0[e] + b0[e]);
-        o[4 + e] = (_Float16)((v[i][4 + e] - mean) * rstd * g1[e] + b1[e]);
+        t[e] = (v[i][e] - mean) * rstd * g0[e] + b0[e];
+        t[4 + e] = (v[i][4 + e] - mean) * rstd * g1[e] + b1[e];
       }
-      *(f16x8*)(y + (size_t)row * C + c * 8) = o;
+      store8(y + (size_t)row * ldy + c * 8, t, y_lo);
     }
   }
 }
 
 hipError_t launch_layernorm(const half_t* x16, const float* x32, int ld, int R, int C, float eps, const float* gamma,
-                            const float* beta, half_t* y, hipStream_t s) {
+                            const float* beta, half_t* y, hipStream_t s, int ldy, int y_lo) {
   if (C % 8 || C > 64 * 8 * 4) return hipErrorInvalidValue;
   const int CH = C / 8;
+  if (ldy <= 0) ldy = C;
   dim3 grid((R + 3) / 4), blk(256);
-  if (CH <= 64) hipLaunchKernelGGL(layernorm_kernel<1>, grid, blk, 0, s, x16, x32, ld, R, C, eps, gamma, beta, y);
-  else if (CH <= 128) hipLaunchKernelGGL(layernorm_kernel<2>, grid, blk, 0, s, x16, x32, ld, R, C, eps, gamma, beta, y);
-  else hipLaunchKernelGGL(layernorm_kernel<4>, grid, blk, 0, s, x16, x32, ld, R, C, eps, gamma, beta, y);
+  if (CH <= 64) hipLaunchKernelGGL(layernorm_kernel<1>, grid, blk, 0, s, x16, x32, ld, R, C, eps, gamma, beta, y, ldy, y_lo);
+  else if (CH <= 128) hipLaunchKernelGGL(layernorm_kernel<2>, grid, blk, 0, s, x16, x32, ld, R, C, eps, gamma, beta, y, ldy, y_lo);
+  else hipLaunchKernelGGL(layernorm_kernel<4>, grid, blk, 0, s, x16, x32, ld, R, C, eps, gamma, beta, y, ldy, y_lo);
   return hipGetLastError();
 }
 
@@ -578,6 +599,48 @@ __device__ __forceinline__ int geglu_row(int r, int half, int g) {
   return (rr / g) * 2 * g + (is_gate ? g : 0) + (rr % g);
 }
 
+// VAE decoder head (`vae-out`, reference diffusion_feature.py:477-485): z = (c_sample * latents + c_eps * noise_pred) * inv_scaling
+// (scheduler.step on the un-scaled latents, then `/ vae.config.scaling_factor`), y = post_quant_conv(z) (1x1, [L][L] fp16 weights,
+// fp32 bias; wq == NULL: identity) -> NHWC fp16 padded to 8 channels (the conv_in operand).  latents / noise_pred: NCHW fp16.
+__global__ __launch_bounds__(256) void vae_dec_prepare_kernel(const half_t* lat, const half_t* eps, int HW, int L, long total, float ca,
+                                                              float cb, float inv_sf, const half_t* wq, const float* bq, half_t* nhwc8) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long b = i / HW;
+    const int pix = (int)(i - b * HW);
+    float z[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      z[c] = 0.f;
+      if (c < L) {
+        const size_t idx = ((size_t)b * L + c) * HW + pix;
+        z[c] = (ca * (float)lat[idx] + (eps ? cb * (float)eps[idx] : 0.f)) * inv_sf;
+      }
+    }
+    f16x8 o = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int oc = 0; oc < 8; ++oc) {
+      if (oc < L) {
+        float y = z[oc];
+        if (wq) {
+          y = bq ? bq[oc] : 0.f;
+          for (int c = 0; c < L; ++c) y += (float)wq[oc * L + c] * z[c];
+        }
+        o[oc] = (_Float16)y;
+      }
+    }
+    *(f16x8*)(nhwc8 + (size_t)i * 8) = o;
+  }
+}
+hipError_t launch_vae_dec_prepare(const half_t* lat, const half_t* eps, int B, int HW, int L, float ca, float cb, float inv_sf,
+                                  const half_t* wq, const float* bq, half_t* nhwc8, hipStream_t s) {
+  if (L < 1 || L > 8) return hipErrorInvalidValue;
+  const long total = (long)B * HW;
+  long blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(vae_dec_prepare_kernel, dim3((unsigned)blocks), dim3(256), 0, s, lat, eps, HW, L, total, ca, cb, inv_sf, wq, bq, nhwc8);
+  return hipGetLastError();
+}
+
 // cblk == 0: dst[o][t][i];  cblk > 0 (3x3 convs, cblk = 64 = one K-tile): dst[o][i / cblk][t][i % cblk] — channel-block-major with
 // the filter taps INNERMOST, so that the implicit GEMM walks the nine shifted windows of one 64-channel slab of the input in nine
 // CONSECUTIVE K-tiles (they overlap in all but one image row / column: the re-reads hit the XCD's L2 instead of the fabric)
@@ -603,6 +666,9 @@ __global__ void relayout_conv_kernel(const void* src, int f32, half_t* dst, int 
 }
 hipError_t launch_relayout_conv(const void* src, int src_f32, half_t* dst, int O, int I, int T, int ipad, int tpad,
                                 hipStream_t s, int cblk) {
+#if defined(GDF_CONV_TAP_MAJOR)
+  cblk = 0;
+#endif
   if (cblk > 0 && (ipad % cblk) != 0) return hipErrorInvalidValue;
   const long total = (long)O * ipad * tpad;
   long blocks = (total + 255) / 256;

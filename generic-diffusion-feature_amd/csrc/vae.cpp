@@ -62,6 +62,40 @@ struct VaeModelBuilder : WeightBuilder {
     if (d.use_quant_conv) v.quant = lin("quant_conv", 2 * d.latent_channels, 2 * d.latent_channels, true, true);
     m.weight_bytes = cur;
   }
+
+  // decoder half: `vae.state_dict()` names "post_quant_conv.*" and "decoder.*" (AutoencoderKL.decode, un-vendored diffusers==0.32.2:
+  // post_quant_conv -> Decoder(conv_in, UNetMidBlock2D, UpDecoderBlock2D x L, conv_norm_out + SiLU, conv_out); oracle/vae_ref.py decode)
+  void build_decoder() {
+    VaeW& v = m.vae;
+    const gdf_vae_desc& d = v.d;
+    const int L = d.n_levels, nl = d.layers_per_block;
+    const int* boc = d.block_out_channels;
+    if (d.use_quant_conv) v.post_quant = lin("post_quant_conv", d.latent_channels, d.latent_channels, true, true);
+    const int c = boc[L - 1];
+    v.conv_in.cin = d.latent_channels; v.conv_in.cout = c;
+    v.conv_in.w = take((size_t)c * 128 * 2); v.conv_in.b = take(c * 4);
+    reg("decoder.conv_in.weight", {c, d.latent_channels, 3, 3}, PK_CONV_IN, v.conv_in.w, c, d.latent_channels);
+    reg("decoder.conv_in.bias", {c}, PK_VEC, v.conv_in.b);
+    v.mid0 = resnet("decoder.mid_block.resnets.0", c, c);
+    const std::string a = "decoder.mid_block.attentions.0";
+    v.attn_gn = norm(a + ".group_norm", c);
+    v.q = lin(a + ".to_q", c, c); v.k = lin(a + ".to_k", c, c); v.v = lin(a + ".to_v", c, c); v.o = lin(a + ".to_out.0", c, c);
+    v.mid1 = resnet("decoder.mid_block.resnets.1", c, c);
+    int ci = c;
+    for (int i = 0; i < L; ++i) {
+      const int co = boc[L - 1 - i];
+      std::vector<ResnetW> rs;
+      for (int r = 0; r < nl + 1; ++r) {
+        rs.push_back(resnet("decoder.up_blocks." + std::to_string(i) + ".resnets." + std::to_string(r), ci, co));
+        ci = co;
+      }
+      v.up.push_back(rs);
+      if (i != L - 1) v.upsamplers.push_back(conv3("decoder.up_blocks." + std::to_string(i) + ".upsamplers.0.conv", co, co));
+    }
+    v.norm_out = norm("decoder.conv_norm_out", boc[0]);
+    v.conv_out = conv3("decoder.conv_out", d.in_channels, boc[0]);
+    m.weight_bytes = cur;
+  }
 };
 
 struct VB : PlanBuilder {
@@ -180,6 +214,69 @@ struct VB : PlanBuilder {
     }
     untmp(mo, mo_b);
   }
+
+  // ---- decoder op program (`vae-out`): latents + noise_pred -> image ----
+  // BUF_LAT = latents (B, L, h, w) fp16 NCHW, BUF_CTX = noise_pred (same shape) or NULL, BUF_NOISE = image out (B, H, W, 3) fp16
+  // channels-last; Bind::f = {c_sample, c_eps, 1 / scaling_factor}
+  void build_decoder(int h, int w) {
+    const gdf_vae_desc& d = v.d;
+    const int L = d.n_levels, nl = d.layers_per_block, Bq = Bn;
+    const int* boc = d.block_out_channels;
+    const int c = boc[L - 1];
+    const size_t x8_b = (size_t)Bn * h * w * 16, x8 = tmp(x8_b);
+    {
+      const int Lc = d.latent_channels, HW = h * w;
+      const bool pq = d.use_quant_conv != 0;
+      const Ref qw = wt(v.post_quant.w), qb = wt(v.post_quant.b);
+      op("vae_dec_prepare", 0, [=](const Bind& b, hipStream_t s) {
+        return launch_vae_dec_prepare((const half_t*)b.base[BUF_LAT], (const half_t*)b.base[BUF_CTX], Bq, HW, Lc, b.f[0], b.f[1], b.f[2],
+                                      pq ? (const half_t*)b.p(qw) : nullptr, pq ? (const float*)b.p(qb) : nullptr, (half_t*)b.ws(x8), s);
+      });
+    }
+    Act cur = new_act(c, h, w, true);
+    {
+      Epi e; e.bias = wt(v.conv_in.b); e.has_bias = true; out_to(e, cur);
+      const Ref Wr = wt(v.conv_in.w); const int N = c;
+      const size_t M = (size_t)Bn * h * w;
+      op("vae_dec_conv_in", 2.0 * (double)M * N * 9 * d.latent_channels, [=](const Bind& b, hipStream_t s) {
+        GemmParams g{};
+        g.A = (const half_t*)b.ws(x8); g.lda = 8; g.a_bytes = (uint32_t)(M * 16);
+        g.M = (int)M; g.N = N; g.K = 128; g.mode = A_CONV_SMALLC; g.H = h; g.W = w; g.OH = h; g.OW = w; g.stride = 1; g.Cin = 8;
+        g.Wt = (const half_t*)b.p(Wr); g.w_bytes = (uint32_t)((size_t)N * 128 * 2);
+        fill_epi(g, e, b);
+        return launch_gemm(g, s);
+      });
+    }
+    untmp(x8, x8_b);
+    { Act nxt = new_act(c, h, w, true); resnet("", v.mid0, cur, nxt); free_act(cur); cur = nxt; }
+    { Act nxt = new_act(c, h, w, true); mid_attention(cur, nxt); free_act(cur); cur = nxt; }
+    { Act nxt = new_act(c, h, w, true); resnet("", v.mid1, cur, nxt); free_act(cur); cur = nxt; }
+    int hh = h, ww = w;
+    for (int i = 0; i < L; ++i) {
+      const int co = boc[L - 1 - i];
+      for (int r = 0; r < nl + 1; ++r) {
+        Act nxt = new_act(co, hh, ww, true);
+        resnet("", v.up[i][r], cur, nxt);
+        free_act(cur);
+        cur = nxt;
+      }
+      if (i != L - 1) {                                                                      // Upsample2D: nearest x2 fused into the conv
+        Act nxt = new_act(co, hh * 2, ww * 2, true);
+        Epi e; e.bias = wt(v.upsamplers[i].b); e.has_bias = true; out_to(e, nxt);
+        reads_image(e, cur);
+        conv3("vae_upsample", cur.h, cur.ld, cur.C, hh, ww, 1, true, v.upsamplers[i], e);    // upsampling.py:176-193
+        free_act(cur);
+        cur = nxt; hh *= 2; ww *= 2;
+      }
+    }
+    const size_t n = rows(cur);
+    const size_t no = groupnorm(cur, v.norm_out, 1e-6f, true);
+    { Epi e; e.bias = wt(v.conv_out.b); e.has_bias = true; e.bn = 16;
+      e.out16 = Ref{BUF_NOISE, 0}; e.has_o16 = true; e.ldo16 = d.in_channels;
+      conv3("vae_dec_conv_out", ws(no), cur.C, cur.C, hh, ww, 1, false, v.conv_out, e); }
+    untmp(no, n * cur.C * 2);
+    free_act(cur);
+  }
 };
 
 }  // namespace
@@ -247,6 +344,82 @@ int vae_encode(Plan& P, const Model& m, const void* image, const void* eps, cons
     b.base[BUF_CTX] = noise ? (char*)noise + (size_t)c0 * lat_b : nullptr;
     b.base[BUF_NOISE] = (char*)out + (size_t)c0 * lat_b;
     b.f[0] = scaling; b.f[1] = noise_a; b.f[2] = noise_b; b.f[3] = in_scale;
+    const int rc = plan_run(P, b, s, ms, names, flops, cap);
+    if (rc != GDF_OK) return rc;
+    if (ms) break;                                                                  // profile: one sub-batch pass
+  }
+  return GDF_OK;
+}
+
+}  // namespace gdf
+
+// =====================================================================================================================
+// VAE decoder (`vae-out`): reference feature/diffusion_feature.py:60, :477-485
+// =====================================================================================================================
+namespace gdf {
+
+Model* vae_decoder_create(const gdf_vae_desc& d) {
+  if (d.n_levels < 1 || d.n_levels > GDF_MAX_LEVELS || d.in_channels < 1 || d.in_channels > 8 || d.latent_channels < 1 ||
+      d.latent_channels > 8 || d.layers_per_block < 1) { set_error("bad vae desc"); return nullptr; }
+  for (int i = 0; i < d.n_levels; ++i)
+    if (d.block_out_channels[i] % 64) { set_error("block_out_channels must be multiples of 64"); return nullptr; }
+  Model* m = new Model();
+  m->kind = 4;
+  m->vae.d = d;
+  VaeModelBuilder b(*m);
+  b.build_decoder();
+  if (hipMalloc(&m->weights, m->weight_bytes) != hipSuccess) { set_error("hipMalloc(weights) failed"); delete m; return nullptr; }
+  (void)hipMemset(m->weights, 0, m->weight_bytes);
+  return m;
+}
+
+int vae_dec_plan_build(const Model& m, Plan& P, int batch, int lat_h, int lat_w, bool dry) {
+  if (m.kind != 4) { set_error("not a VAE decoder model"); return GDF_ERR_ARG; }
+  const int L = m.vae.d.n_levels, upf = 1 << (L - 1);
+  if (batch < 1 || lat_h < 8 || lat_w < 8 || (lat_h % 8) || (lat_w % 8)) {                     // latent grid multiple of 8: S % 64 == 0
+    set_error("latent size must be a positive multiple of 8"); return GDF_ERR_ARG;
+  }
+  const size_t S = (size_t)lat_h * lat_w;
+  if (S > 16384) { set_error("mid-block attention supports up to 16384 latent tokens (1024^2 images)"); return GDF_ERR_UNSUPPORTED; }
+  // sub-batch: largest divisor of `batch` whose widest fp16 activation stays below the 32-bit buffer-offset limit.  Up block i works
+  // at (lat << i) with boc[L-1-i] channels; its upsampler's OUTPUT has the same channels at twice the size
+  size_t widest = 0;
+  for (int i = 0; i < L; ++i) {
+    const size_t hw = (size_t)(lat_h << i) * (lat_w << i), c = m.vae.d.block_out_channels[L - 1 - i];
+    widest = std::max(widest, hw * c * 2 * (i != L - 1 ? 4 : 1));
+  }
+  if (widest >= (1ull << 31)) { set_error("image too large for 32-bit buffer offsets"); return GDF_ERR_UNSUPPORTED; }
+  int chunk = 1;
+  for (int c = 1; c <= batch; ++c)
+    if (batch % c == 0 && (size_t)c * widest < (1ull << 31)) chunk = c;
+  P.batch = batch; P.chunk = chunk; P.H = lat_h; P.W = lat_w;
+  (void)upf;
+  PlanOpts o{}; o.stream_fp32 = 1;
+  P.opts = o;
+  VB b(m, P, dry, P.opts);
+  b.Bn = chunk;
+  b.act_scale = 1.0f / 64.0f;          // fp16 range control of the stream images, as in the encoder (vae_plan_build)
+  b.build_decoder(lat_h, lat_w);
+  P.ws_bytes = b.ar.peak + 256;
+  return GDF_OK;
+}
+
+int vae_decode(Plan& P, const Model& m, const void* latents, const void* noise_pred, float c_sample, float c_eps, float inv_scaling,
+               void* image_out, void* ws, hipStream_t s, float* ms, const char** names, double* flops, int cap) {
+  if (m.kind != 4) { set_error("gdf_vae_decode on a model that is not a VAE decoder"); return GDF_ERR_STATE; }
+  if (m.n_set != (int)m.params.size()) { set_error("model weights incomplete"); return GDF_ERR_STATE; }
+  if (!latents || !image_out || !ws) { set_error("null input pointer"); return GDF_ERR_ARG; }
+  const gdf_vae_desc& d = m.vae.d;
+  const int f = 1 << (d.n_levels - 1);
+  const size_t lat_b = (size_t)d.latent_channels * P.H * P.W * 2;                    // bytes per latent
+  const size_t img_b = (size_t)d.in_channels * (P.H * f) * (P.W * f) * 2;            // bytes per image
+  for (int c0 = 0; c0 < P.batch; c0 += P.chunk) {
+    Bind b;
+    b.base[BUF_WS] = (char*)ws; b.base[BUF_WT] = (char*)m.weights;
+    b.base[BUF_LAT] = (char*)latents + (size_t)c0 * lat_b;
+    b.base[BUF_CTX] = noise_pred ? (char*)noise_pred + (size_t)c0 * lat_b : nullptr;
+    b.base[BUF_NOISE] = (char*)image_out + (size_t)c0 * img_b;
+    b.f[0] = c_sample; b.f[1] = c_eps; b.f[2] = inv_scaling;
     const int rc = plan_run(P, b, s, ms, names, flops, cap);
     if (rc != GDF_OK) return rc;
     if (ms) break;                                                                  // profile: one sub-batch pass

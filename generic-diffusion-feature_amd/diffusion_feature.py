@@ -49,9 +49,11 @@ class FeatureExtractor(nn.Module):
             pipe = get_diffusion_model(version, dtype, offline_lora, offline_lora_filename, device=device)
 
         self.feature_store = prepare_feature_extractor(version, pipe, layer, feature_resize, train_unet)
-        self.store_vae_output = bool(self.feature_store.to_store.get('vae-out', False))
-        if self.store_vae_output:
-            raise NotImplementedError("'vae-out' needs the VAE decoder, which is upstream plumbing (SURVEY.md §8f)")
+        self.store_vae_output = bool(self.feature_store.to_store.get('vae-out', False))          # reference :60
+        if self.store_vae_output and (version == 'flux' or version.startswith('pixart')):
+            # reference: the flux branch returns before the decode (:246-254); for PixArt `scheduler.step` would receive the
+            # transformer's 8-channel output (learned sigma) against 4-channel latents (:466-480) — there is no working behaviour to match
+            raise NotImplementedError("'vae-out' exists for the UNet versions ('1-5', '2-1', 'xl', 'pgv2') only")
 
         self.pipe = pipe
         self.control_pipe = None
@@ -205,9 +207,14 @@ class FeatureExtractor(nn.Module):
         # ---- the hot path: native UNet forward, hooks written by the kernels (:445-465) ----
         if hasattr(self.pipe.unet, 'shared_ctx'):
             self.pipe.unet.shared_ctx = True      # prompt_embeds.repeat(batch_size, 1, 1) above: one prompt for the whole batch
-        self.pipe.unet(latent_model_input, timestep=t, encoder_hidden_states=prompt_embeds.to(device),
-                       added_cond_kwargs=added_cond_kwargs, down_block_additional_residuals=None,
-                       mid_block_additional_residual=None, return_dict=False)
+        noise_pred = self.pipe.unet(latent_model_input, timestep=t, encoder_hidden_states=prompt_embeds.to(device),
+                                    added_cond_kwargs=added_cond_kwargs, down_block_additional_residuals=None,
+                                    mid_block_additional_residual=None, return_dict=False)[0]
+        if self.store_vae_output:                                                        # reference :477-485
+            from components.models import native_vae_decoder, scheduler_step_scalars
+            a, b = scheduler_step_scalars(self.pipe.scheduler, t)                         # scheduler.step(noise_pred, t, latents)[0]
+            self.feature_store.stored_feats['vae-out'] = native_vae_decoder(self.pipe, device).decode(
+                latents, noise_pred, c_sample=a, c_eps=b, scaling_factor=float(self.pipe.vae.config.scaling_factor))
         if attn_ids is not None:
             extra = self.pipe.unet.last_extra
             maps = {c: [extra[i] for i in ids if i in extra] for c, ids in attn_ids.items()}

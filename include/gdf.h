@@ -88,7 +88,12 @@ typedef struct gdf_plan_opts {
   int stream_fp32;     /* 1: fp32 master copy of the residual stream (default), 0: fp16 only */
   int early_exit;      /* 1: stop after the last requested hook (opt-in; noise_pred is then not produced) */
   int reserved[6];     /* reserved[0] = shared_ctx: every sample uses ctx row-block 0 (one prompt repeated over the batch,
-                          reference diffusion_feature.py:272): text K/V projections are computed once, not per sample */
+                          reference diffusion_feature.py:272): text K/V projections are computed once, not per sample.
+                          reserved[1] = precise (opt-in, UNet plans, needs stream_fp32): every activation operand of an MFMA
+                          contraction and every GroupNorm input is kept as a split fp16 pair hi + lo (22 mantissa bits) and
+                          multiplied as [hi | lo] x [W | W] (K doubled, weights read twice) — removes the fp16-operand rounding
+                          that bounds the default plans at ~1.0-1.3e-3 on `ffn-inner` / `unet-out`;
+                          about twice the GEMM / conv time.  Attention internals (q, k, v, P) stay fp16. */
 } gdf_plan_opts;
 
 int gdf_plan_create(gdf_model* m, int batch, int lat_h, int lat_w, int n_ctx,

@@ -55,6 +55,28 @@ int gdf_vae_plan_profile(gdf_plan* p, const void* image, const void* eps, const 
                          float noise_a, float noise_b, float input_scale, void* latents_out, void* workspace, void* stream,
                          float* ms, const char** names, double* flops, int cap);
 
+/* ---- `vae-out`: the optional last id of the reference's layer grammar (feature/diffusion_feature.py:60, :477-485) -------------
+ *     latents    = self.pipe.scheduler.step(noise_pred, t, latents, return_dict=False)[0]
+ *     vae_output = self.pipe.vae.decode(latents / self.pipe.vae.config.scaling_factor, return_dict=False)[0]
+ * One native call on the decoder half of the same AutoencoderKL (parameter names "post_quant_conv.*", "decoder.*"; the model is
+ * created from the same gdf_vae_desc; Decoder / UpDecoderBlock2D are un-vendored diffusers, built from ResnetBlock2D(temb=None),
+ * the single-head Attention and Upsample2D — nearest x2 + conv3x3, feature/diffusers/models/upsampling.py:142-195 — which ARE in
+ * the reference tree).  The scheduler step of the first call after set_timesteps is linear in (latents, noise_pred) for the
+ * schedulers the reference uses, so it travels as two scalars:
+ *     z = (step_c_sample * latents + step_c_eps * noise_pred) * inv_scaling;      image = decode(z)
+ *   PNDM (SD1.5), first step_plms call:  c_sample = sqrt(a_prev / a_t),  c_eps = -(a_prev - a_t) / (a_t sqrt(1 - a_prev) + sqrt(a_t (1 - a_t) a_prev))
+ *   EulerDiscrete (SD2.1 / SDXL):        c_sample = 1,                   c_eps = sigma_next - sigma_t
+ * noise_pred == NULL decodes step_c_sample * latents * inv_scaling (plain vae.decode).
+ * latents / noise_pred (B,L,h,w) fp16 NCHW; image_out (B, h*f, w*f, 3) fp16 CHANNELS-LAST (the logical (B,3,H,W) tensor with strides
+ * (H*W*3, 1, W*3, 3)); h, w multiples of 8, h*w <= 16384.  Sub-batching as in gdf_vae_plan_create. */
+int gdf_vae_decoder_create(const gdf_vae_desc* desc, gdf_model** out);
+int gdf_vae_decode_plan_create(gdf_model* m, int batch, int lat_h, int lat_w, gdf_plan** out);
+int gdf_vae_decode(gdf_plan* p, const void* latents, const void* noise_pred, float step_c_sample, float step_c_eps, float inv_scaling,
+                   void* image_out, void* workspace, void* stream);
+int gdf_vae_decode_plan_profile(gdf_plan* p, const void* latents, const void* noise_pred, float step_c_sample, float step_c_eps,
+                                float inv_scaling, void* image_out, void* workspace, void* stream, float* ms, const char** names,
+                                double* flops, int cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -290,16 +290,16 @@ def test_feature_extractor_api_flux_synthetic():
     df = diffusion_feature.FeatureExtractor(layer=layer, version='flux', img_size=128, device='cuda:0', external_model=pipe)
     img = Image.fromarray((np.random.RandomState(0).rand(90, 70, 3) * 255).astype(np.uint8))
     tr = pipe.transformer
-    feats = df.extract("a photo of a cat", batch_size=2, image=[img, img], t=100)     # strength 0.1 -> steps 26, 27 remain; ONE is run
-    # the reference's patched pipeline returns after its first transformer call (pipeline_flux_img2img.py:804-841)
-    assert tr.calls == 1 and pipe.last_call["t_start"] == 26
+    feats = df.extract("a photo of a cat", batch_size=2, image=[img, img], t=100)     # strength 0.1 -> t_start = int(28 - 2.8) = 25:
+    # steps 25..27 remain and ONE is run: the reference's patched pipeline returns after its first transformer call (:804-841)
+    assert tr.calls == 1 and pipe.last_call["t_start"] == 25
     assert list(feats.keys()) == ["vit-block0-out", "vit-block1-q", "vit-block2-attn-out", "vit-block3-out"]
     for v in feats.values():
         assert v.shape == (2, 256, 8, 8) and v.dtype == torch.float16 and v.is_cuda and torch.isfinite(v.float()).all()
     # ... and what it stored is that forward's hooks: forward_raw on the same packed latents at sigmas[t_start]
     lc = pipe.last_call
     sig = pipe.sigmas(28, 64)
-    assert lc["sigma"] == sig[26] and 0.0 < sig[27] < sig[26] < sig[0] == 1.0
+    assert lc["sigma"] == sig[25] and 0.0 < sig[27] < sig[25] < sig[0] == 1.0
     _, hooks = tr.forward_raw(lc["hidden_states"], lc["encoder_hidden_states"], lc["pooled_projections"],
                               torch.full((2,), lc["sigma"], device="cuda:0"), lc["img_ids"], lc["txt_ids"], guidance=lc["guidance"],
                               hook_ids=list(feats.keys()), grid=lc["grid"])

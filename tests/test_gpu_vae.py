@@ -81,3 +81,95 @@ def test_vae_encode_range_beyond_fp16():
     torch.cuda.synchronize()
     assert torch.isfinite(got.float()).all()
     assert rel_l2(got, ref) < 3e-3, rel_l2(got, ref)
+
+
+# ---- `vae-out`: scheduler step + AutoencoderKL decoder (include/gdf_vae.h, reference diffusion_feature.py:60, :477-485) ----
+@pytest.mark.parametrize("channels,lat,batch", [((64, 128, 128), 16, 2), ((64, 128, 256, 256), 16, 3)])
+def test_vae_decode_matches_oracle(channels, lat, batch):
+    """decode((c_sample * latents + c_eps * noise_pred) / scaling_factor) against oracle/vae_ref.py: plain decode, an Euler step and
+    a PNDM-style step.  Stated tolerance: relative L2 <= 3e-3 on the image (shrunken widths; 1e-3 at full size, test_gpu_fullsize)."""
+    from components.native import NativeVAEDecoder
+    arch = VR.tiny_arch(channels)
+    P = VR.synth_dec_params(arch, seed=0)
+    g = torch.Generator().manual_seed(1)
+    z = torch.randn(batch, 4, lat, lat, generator=g).half().float()
+    eps = torch.randn(batch, 4, lat, lat, generator=g).half().float()
+    cfg = dict(in_channels=3, latent_channels=4, block_out_channels=channels, layers_per_block=2, use_quant_conv=1)
+    dec = NativeVAEDecoder(cfg, device="cuda:0")
+    assert dec.param_shapes() == {k: tuple(v) for k, v in VR.dec_param_shapes(arch).items()}
+    dec.load_vae_state_dict({k: v.half() for k, v in P.items()})
+    assert dec.ready()
+    f = 1 << (len(channels) - 1)
+    for (a, b, sf, with_eps) in ((1.0, 0.0, 1.0, False), (1.0, -0.35, 0.13025, True), (1.02, -0.21, 0.18215, True)):
+        ref = VR.vae_out(P, arch, z, eps if with_eps else torch.zeros_like(z), a, b if with_eps else 0.0, sf)
+        got = dec.decode(z, eps if with_eps else None, c_sample=a, c_eps=b, scaling_factor=sf)
+        torch.cuda.synchronize()
+        assert tuple(got.shape) == tuple(ref.shape) == (batch, 3, lat * f, lat * f) and got.dtype == torch.float16
+        e = rel_l2(got, ref)
+        assert e < 3e-3, ((a, b, sf), e)
+
+
+def test_vae_decode_range_beyond_fp16():
+    """The decoder stream pushed past the fp16 range (conv2 of the first mid resnet x 1e5) must still match the fp32 oracle: fp32
+    masters + 2^-6-scaled fp16 images as in the encoder."""
+    from components.native import NativeVAEDecoder
+    channels = (64, 128, 128)
+    arch = VR.tiny_arch(channels)
+    P = VR.synth_dec_params(arch, seed=0)
+    k = "decoder.mid_block.resnets.0.conv2."
+    P[k + "weight"] = (P[k + "weight"] * 1.0e5).half().float()
+    P[k + "bias"] = P[k + "bias"] * 1.0e5
+    z = torch.randn(2, 4, 16, 16, generator=torch.Generator().manual_seed(1)).half().float()
+    cfg = dict(in_channels=3, latent_channels=4, block_out_channels=channels, layers_per_block=2, use_quant_conv=1)
+    dec = NativeVAEDecoder(cfg, device="cuda:0")
+    dec.load_vae_state_dict({k: v.float() for k, v in P.items()})
+    ref = VR.decode(P, arch, z)
+    got = dec.decode(z, None, scaling_factor=1.0)
+    torch.cuda.synchronize()
+    assert torch.isfinite(got.float()).all()
+    assert rel_l2(got, ref) < 3e-3, rel_l2(got, ref)
+
+
+@pytest.mark.parametrize("version,img", [("1-5", 256), ("xl", 256)])
+def test_feature_extractor_vae_out(version, img, monkeypatch):
+    """FeatureExtractor(layer={'vae-out': True, ...}) returns the decoded image next to the hooks (reference :60, :477-485): it equals
+    the native decoder applied to (latents, noise_pred) with the scheduler's first-step coefficients, which in turn are the oracle's
+    PNDM / Euler formulas."""
+    monkeypatch.setenv("GDF_SYNTHETIC_WEIGHTS", "1")
+    import diffusion_feature
+    from components.models import native_vae_decoder, scheduler_step_scalars
+    hook = "up-level1-repeat1-vit-block0-cross-q" if version == "1-5" else "up-level1-repeat0-vit-block0-out"
+    df = diffusion_feature.FeatureExtractor(layer={hook: True, "vae-out": True}, version=version, img_size=img, device='cuda')
+    assert df.store_vae_output
+    prompt = df.encode_prompt('a photo of a cat')
+    lat = torch.randn(2, 4, img // 8, img // 8, generator=torch.Generator().manual_seed(0)).half()
+    feats = df.extract(prompt, batch_size=2, image=lat, image_type='latents', t=100)
+    assert list(feats.keys()) == [hook, "vae-out"]
+    out = feats["vae-out"]
+    assert tuple(out.shape) == (2, 3, img, img) and out.dtype == torch.float16 and torch.isfinite(out.float()).all()
+    # the same numbers from the pieces
+    import copy
+    s2 = copy.deepcopy(df.scheduler_backup); s2.set_timesteps(1000, device='cuda')
+    ts, _ = df.pipe.get_timesteps(1000, 100 / 1000, 'cuda')
+    a, b = scheduler_step_scalars(s2, ts[:1])
+    ti = int(ts[0])
+    if version == "1-5":
+        ra, rb = VR.pndm_first_step_scalars(s2.alphas_cumprod, ti, ti - 1)
+    else:
+        ac = s2.alphas_cumprod
+        sig = lambda i: float(((1 - ac[i]) / ac[i]) ** 0.5)
+        ra, rb = VR.euler_step_scalars(sig(ti), sig(ti - 1))
+    assert abs(a - ra) < 1e-6 and abs(b - rb) < 1e-6
+    unet = df.pipe.unet
+    lin = df.pipe.scheduler.scale_model_input(lat.cuda(), ts[:1])
+    emb, _, pooled, _ = prompt
+    kw = {}
+    if version == "xl":
+        kw = dict(text_embeds=pooled.repeat(2, 1, 1).squeeze(1).cuda(),
+                  time_ids=torch.tensor([[img, img, 0, 0, img, img]], dtype=torch.float32).repeat(2, 1).cuda())
+    noise, _ = unet.forward_raw(lin, ts[:1], emb.repeat(2, 1, 1).cuda(), kw.get("text_embeds"), kw.get("time_ids"), hook_ids=[hook],
+                                shared_ctx=True)
+    img2 = native_vae_decoder(df.pipe, 'cuda').decode(lat.cuda(), noise, c_sample=a, c_eps=b,
+                                                       scaling_factor=float(df.pipe.vae.config.scaling_factor))
+    torch.cuda.synchronize()
+    assert torch.equal(img2, out)

@@ -251,3 +251,71 @@ def test_aggregated_attention_matches_reference_golden():
                   for c in sel}
         prod = aggregate_attention(by_cat, meta["out_size"])
         assert prod.dtype == torch.float16 and torch.allclose(prod.float(), want, atol=1e-3)
+
+
+def test_scheduler_step_scalars_probe_and_formulas():
+    """`vae-out` (reference diffusion_feature.py:478-480): scheduler.step(noise_pred, t, latents)[0] travels to libgdf as two scalars.
+    A diffusers-style scheduler is probed on a deep copy (state untouched, linearity verified); the synthetic pipe's scheduler states
+    its own coefficients, which are the oracle's PNDM-first-step / Euler formulas."""
+    import torch
+    from components.models import _Scheduler, scheduler_step_scalars
+    from oracle import vae_ref as VR
+
+    class Lin:                                   # a stateful, linear scheduler: what PNDM's first step_plms call / Euler's step are
+        def __init__(self):
+            self.calls = 0
+
+        def step(self, model_output, timestep, sample, return_dict=True):
+            self.calls += 1
+            return (0.97 * sample - 0.125 * float(timestep) * model_output,)
+
+    sch = Lin()
+    a, b = scheduler_step_scalars(sch, torch.tensor([4.0]))
+    assert abs(a - 0.97) < 1e-12 and abs(b + 0.5) < 1e-12 and sch.calls == 0
+
+    class Clipped(Lin):
+        def step(self, model_output, timestep, sample, return_dict=True):
+            return ((sample - model_output).clamp(-1, 1),)
+    with pytest.raises(NotImplementedError):
+        scheduler_step_scalars(Clipped(), torch.tensor([4.0]))
+
+    for euler in (False, True):
+        s = _Scheduler(euler=euler)
+        s.set_timesteps(1000)
+        for ti in (999, 100, 1, 0):
+            a, b = scheduler_step_scalars(s, torch.tensor([ti]))
+            if euler:
+                ac = s.alphas_cumprod
+                sig = lambda i: float(((1 - ac[i]) / ac[i]) ** 0.5) if i >= 0 else 0.0
+                ra, rb = VR.euler_step_scalars(sig(ti), sig(ti - 1))
+            else:
+                ra, rb = VR.pndm_first_step_scalars(s.alphas_cumprod, ti, ti - 1)
+            assert abs(a - ra) < 1e-6 and abs(b - rb) < 1e-6, (euler, ti, a, b, ra, rb)
+        x, e = torch.randn(2, 4, 8, 8), torch.randn(2, 4, 8, 8)
+        assert torch.allclose(s.step(e, torch.tensor([100]), x)[0], a * 0 + scheduler_step_scalars(s, torch.tensor([100]))[0] * x
+                              + scheduler_step_scalars(s, torch.tensor([100]))[1] * e)
+
+
+def test_vae_decoder_oracle_structure():
+    """Structural pins of the decoder restatement (the wiring is un-vendored diffusers): parameter count of the published SD VAE
+    (83,653,863 = 34,163,664 encoder + quant_conv, 49,490,199 decoder + post_quant_conv) and the output geometry."""
+    import torch
+    from oracle import vae_ref as VR
+    assert sum(math_prod(s) for s in VR.dec_param_shapes(VR.ARCH_SD_VAE).values()) == 49490199
+    assert sum(math_prod(s) for s in VR.param_shapes(VR.ARCH_SD_VAE).values()) == 34163664
+    a = VR.tiny_arch()
+    P = VR.synth_dec_params(a)
+    with torch.no_grad():
+        y = VR.decode(P, a, torch.randn(2, 4, 8, 8))
+    assert tuple(y.shape) == (2, 3, 32, 32) and torch.isfinite(y).all()
+    # decode is what vae_out applies after the linear scheduler step
+    z, e = torch.randn(1, 4, 8, 8), torch.randn(1, 4, 8, 8)
+    with torch.no_grad():
+        assert torch.allclose(VR.vae_out(P, a, z, e, 1.0, -0.3, 0.5), VR.decode(P, a, (z - 0.3 * e) / 0.5))
+
+
+def math_prod(shape):
+    n = 1
+    for s in shape:
+        n *= s
+    return n

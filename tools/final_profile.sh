@@ -3,8 +3,9 @@
 # (HBM traffic: FETCH_SIZE / WRITE_SIZE in separate runs; attention: MFMA / VALU / LDS counters), all stamped with csrc_sha.
 #   gpurun -- 'bash tools/final_profile.sh <tag>'     -> gpurun_out/final_<tag>/   (then copy into profiles/)
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT; TAG=${1:-r02}; O=$R/gpurun_out/final_$TAG; mkdir -p $O
-python3 $R/bench.py --steps 10 --warmup 3 > $O/bench_line.json 2> $O/bench.err
+R=$GRAFT_REPO_ROOT; TAG=${1:-r03}; O=$R/gpurun_out/final_$TAG; mkdir -p $O
+python3 $R/bench.py --steps 20 --warmup 3 > $O/bench_line.json 2> $O/bench.err
+python3 $R/bench.py --steps 10 --warmup 3 --precise --no-cpu-baseline > $O/bench_line_precise.json 2>> $O/bench.err
 rocprofv3 --kernel-trace --stats -d $O/trace -o bench -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_line_rocprof_run.json 2> $O/rocprof.err
 python3 $R/tools/rocpd_stats.py $O/trace/bench_results.db > $O/kernel_stats.txt 2>> $O/rocprof.err
 rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch -o r --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>> $O/rocprof.err
