@@ -269,11 +269,14 @@ class _Plan:
     hook-buffer sets and a private non-default stream.  Stable addresses are what lets gdf_plan_set_graph replay one captured
     hipGraph per set instead of re-capturing (the graph cache of the library is keyed on the buffer addresses)."""
     MAX_SETS = 3
-    # Forwards queued ahead of the GPU.  An SDXL forward is ~1000 kernel nodes; with an unbounded queue the AQL ring fills and the
-    # host thread SPINS inside hipGraphLaunch waiting for ring space (BENCH_r02: 35 ms of host CPU per step with 20 steps
-    # queued).  Bounding the depth and sleep-polling the oldest forward's event makes the host SLEEP instead; two forwards ahead is
-    # more than enough to keep the GPU fed (a forward is 10..500 ms of GPU work, its launch 0.4 ms).
-    MAX_INFLIGHT = int(os.environ.get("GDF_MAX_INFLIGHT", "2"))
+    # Forwards queued ahead of the GPU (GDF_MAX_INFLIGHT, 0 = unbounded = the default).  With many forwards queued the AQL ring fills
+    # and the launching thread SPINS inside hipGraphLaunch (BENCH_r02: 35 ms of host CPU per 114-ms step with 20 steps queued; 0.4 ms
+    # with 5).  Round 3 measured the alternatives on the same box (bench.py `hipgraph.host_cpu_ms_per_step`, 20 steps): a bound of 2 with
+    # a blocking-sync event.synchronize() 204 ms (every wait of this runtime spins, also with hipDeviceScheduleBlockingSync:
+    # tools/micro/sync_cpu.py), a bound of 2 with a 0.5-ms sleep-poll on event.query() 102 ms (a runtime helper thread spins while
+    # the event is polled), unbounded 35 ms — identical throughput (141.6 / 141.9 img/s).  So the queue stays unbounded; the knob
+    # remains for hosts that prefer a shallow queue.
+    MAX_INFLIGHT = int(os.environ.get("GDF_MAX_INFLIGHT", "0"))
 
     def __init__(self, lib, handle):
         self.lib, self.handle = lib, handle
@@ -322,7 +325,7 @@ class _Plan:
         if self.stream is None:
             self.stream = torch.cuda.Stream(device=dev)
         side = self.stream
-        while len(self.inflight) >= max(1, self.MAX_INFLIGHT):
+        while self.MAX_INFLIGHT > 0 and len(self.inflight) >= self.MAX_INFLIGHT:
             ev = self.inflight.pop(0)
             while not ev.query():                  # sleep-poll: hipEventSynchronize / hipStreamSynchronize SPIN on this runtime even with
                 time.sleep(0.0005)                 # blocking-sync events or hipDeviceScheduleBlockingSync (tools/micro/sync_cpu.py:
@@ -351,9 +354,10 @@ class _Plan:
                 if no_graph:
                     self.lib.gdf_plan_set_graph(self.handle, 1)
             hs.buf.record_stream(cur)
-            done = torch.cuda.Event()
-            done.record(side)
-            self.inflight.append(done)
+            if self.MAX_INFLIGHT > 0:
+                done = torch.cuda.Event()
+                done.record(side)
+                self.inflight.append(done)
         cur.wait_stream(side)
         feats = {}
         for off, (hid, shape, stride, _) in zip(hs.offs, self.hooks):

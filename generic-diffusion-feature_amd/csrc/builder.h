@@ -278,6 +278,7 @@ struct PlanBuilder {
     const Ref W = wt(w.w + w_off_bytes);
     const int K = a_lo > 0 ? 2 * Kw : Kw;
     GemmParams gk{}; gk.M = (int)M; gk.N = N; gk.K = K; gk.mode = A_DENSE; gk.geglu = e.geglu; gk.bn = e.bn; gk.dit = e.dit; gk.bf16 = e.bf16;
+    gk.k_w = a_lo > 0 ? Kw : 0; gk.o16_lo = e.has_o16 ? e.o16_lo : 0;      // split operands: their own kernel instantiations / tile set
     gk.res32 = e.has_r32 ? (const float*)1 : nullptr;      // tile selection looks at the epilogue form (never dereferenced)
     // few output tiles, long K (small batches: ff_out at 1024-2048 rows): deterministic split-K (see conv3)
     const int splitk = gemm_splitk_factor(gk);
@@ -341,6 +342,7 @@ struct PlanBuilder {
     const Ref Wr = wt(w.w);
     const int N = w.cout, Bq = Bn;
     GemmParams gk{}; gk.M = (int)M; gk.N = N; gk.K = 9 * Cin * kx; gk.mode = A_CONV3; gk.bn = e.bn;
+    gk.k_w = a_lo > 0 ? 9 * Cin : 0; gk.o16_lo = e.has_o16 ? e.o16_lo : 0;
     // few output tiles, long K (SD1.5's 8x8 level: 160 tiles of 128x128 walking 180-360 K-tiles each): deterministic split-K
     const int splitk = gemm_splitk_factor(gk);
     const size_t ws_b = splitk > 1 ? (size_t)splitk * M * N * 4 : 0;

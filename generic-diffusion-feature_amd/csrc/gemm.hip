@@ -128,7 +128,10 @@ __device__ unsigned long long gdf_trace[16384 * 8];
 #define GDF_TR_ID()
 #endif
 
-template <int MODE, int BM, int BN, int STAGES, bool GEGLU, bool DIT, bool BF = false, bool QKN = false>
+// SPLIT: split fp16 hi + lo operands of the opt-in "precise" plans (GemmParams::k_w / a_lo_bytes / o16_lo, kernels.h).  A compile-time
+// switch with its own instantiations (gemm_split_kernel): compiled into the default kernels, its few extra live values pushed
+// the 256x320 dense kernel from 253 VGPRs to 139 spilled (140 -> 100 img/s on the SDXL step).
+template <int MODE, int BM, int BN, int STAGES, bool GEGLU, bool DIT, bool BF = false, bool QKN = false, bool SPLIT = false>
 __device__ __forceinline__ void gemm_body(const GemmParams& p) {
   static_assert(!BF || DIT, "bf16 operands exist on the MMDiT path only");
   constexpr int NW = BM / 32;                    // waves per workgroup (4 or 8)
@@ -221,6 +224,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
       a_ox[j] = ox * p.stride - 1 + p.pad0;
     }
   }
+  const uint32_t ldb = (uint32_t)((SPLIT && p.k_w > 0) ? p.k_w : p.K) * 2u;   // bytes per weight row (split operands: the matrix holds k_w columns, read twice)
   uint32_t b_off[B_PER_WAVE];
   bool b_act[B_PER_WAVE];
 #pragma unroll
@@ -228,7 +232,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
     const int q = wave * B_PER_WAVE + j;              // instruction index inside the B tile
     b_act[j] = q < B_INSTR;
     const int n = n0 + q * 8 + lrow;
-    b_off[j] = (n < p.N) ? (uint32_t)n * (uint32_t)p.K * 2u + (uint32_t)chunk * 16u : OOB;
+    b_off[j] = (n < p.N) ? (uint32_t)n * ldb + (uint32_t)chunk * 16u : OOB;
   }
 
   const int nk = (MODE == A_CONV_SMALLC) ? 2 : p.K / BK;
@@ -247,12 +251,21 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
   // byte offset of K-tile kt inside a dense row.  The two-group schedules also stage the tiles nk, nk + 1 (so that the counted
   // waits are the same in every iteration): those get an out-of-range offset — zero fill, no L2 / HBM traffic (scalar select).
   // Split operands (GemmParams::k_w): the lo half of A starts a_lo_bytes after the hi half, the weight K-tiles repeat.
-  const int nkw = (p.k_w > 0) ? p.k_w / BK : nk;               // K-tiles of the weight matrix (== nk without a split)
-  const uint32_t a_lo = p.a_lo_bytes;
-  auto koffA = [&](int kt) -> uint32_t { return kt < nkw ? (uint32_t)kt * 128u : (kt < nk ? a_lo + (uint32_t)(kt - nkw) * 128u : OOB); };
-  auto koffB = [&](int kt) -> uint32_t { return kt < nk ? (uint32_t)(kt < nkw ? kt : kt - nkw) * 128u : OOB; };
+  const int nkw = (SPLIT && p.k_w > 0) ? p.k_w / BK : nk;      // K-tiles of the weight matrix (== nk without a split)
+  const uint32_t a_lo = SPLIT ? p.a_lo_bytes : 0u;
+  auto koffA = [&](int kt) -> uint32_t {
+    if constexpr (!SPLIT) return kt < nk ? (uint32_t)kt * 128u : OOB;
+    else return kt < nkw ? (uint32_t)kt * 128u : (kt < nk ? a_lo + (uint32_t)(kt - nkw) * 128u : OOB);
+  };
+  auto koffB = [&](int kt) -> uint32_t {
+    if constexpr (!SPLIT) return kt < nk ? (uint32_t)kt * 128u : OOB;
+    else return kt < nk ? (uint32_t)(kt < nkw ? kt : kt - nkw) * 128u : OOB;
+  };
   const int cbw = nkw / 9;                                      // conv3: 64-channel blocks of the weight matrix
-  auto chanb = [&](int cbk) -> uint32_t { return cbk < cbw ? (uint32_t)cbk * 128u : a_lo + (uint32_t)(cbk - cbw) * 128u; };
+  auto chanb = [&](int cbk) -> uint32_t {
+    if constexpr (!SPLIT) return (uint32_t)cbk * 128u;
+    else return cbk < cbw ? (uint32_t)cbk * 128u : a_lo + (uint32_t)(cbk - cbw) * 128u;
+  };
   // 3x3-conv rows of the two-group schedules (round 2): per output row ONE byte offset — that of filter tap (0, 0), which may lie
   // outside the image — and a 9-bit validity mask, so that a K-tile's source offset is `base + scalar tap offset` and one bit test
   // (4 VALU instructions per row and K-tile instead of ~12: bounds compares, pixel arithmetic and two multiplies; VALU issue time
@@ -317,7 +330,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
     for (int j = 0; j < A_PER_WAVE; ++j) {
       uint32_t off;
       if (MODE == A_DENSE) {
-        off = a_off[j] + koffA(kt);                    // OOB stays >= 2^31
+        off = a_off[j] + (SPLIT ? koffA(kt) : (uint32_t)kt * 128u);   // OOB stays >= 2^31
       } else if (MODE == A_CONV3) {
         off = conv_tap_off(tap, cb, a_off[j], a_msk[j]);
       } else {  // SMALLC: 8 channels per pixel = one 16-B chunk per tap; chunk index == tap - 8*kt
@@ -332,7 +345,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
 #pragma unroll
     for (int j = 0; j < B_PER_WAVE; ++j) {
       if (b_act[j]) {
-        const uint32_t off = b_off[j] + (MODE == A_CONV_SMALLC ? (uint32_t)kt * 128u : koffB(kt));
+        const uint32_t off = b_off[j] + ((MODE == A_CONV_SMALLC || !SPLIT) ? (uint32_t)kt * 128u : koffB(kt));
         glds16(rsB, sB + (wave * B_PER_WAVE + j) * 1024, off);
       }
     }
@@ -432,7 +445,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
         const int r = h * BHALF + (hbq[h] + j) * 8 + lrow;
-        hb[h][j] = (n0 + r < p.N) ? (uint32_t)(n0 + r) * (uint32_t)p.K * 2u + (uint32_t)chunk * 16u : OOB;
+        hb[h][j] = (n0 + r < p.N) ? (uint32_t)(n0 + r) * ldb + (uint32_t)chunk * 16u : OOB;
       }
     }
     auto stage = [&](int kt, int buf, auto which) {            // which: 0 A-lo, 1 A-hi, 2 B-lo, 3 B-hi
@@ -599,7 +612,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
     for (int j = 0; j < 5; ++j) {
       const int qi = j < 3 ? wave * 3 + j : 24 + wave * 2 + (j - 3);
       const int n = n0 + qi * 8 + lrow;
-      ub[j] = (n < p.N) ? (uint32_t)n * (uint32_t)p.K * 2u + (uint32_t)chunk * 16u : OOB;
+      ub[j] = (n < p.N) ? (uint32_t)n * ldb + (uint32_t)chunk * 16u : OOB;
     }
     auto stage_a = [&](int kt, int buf, int q) {
       char* dst = smem + buf * A_TILE + ((wave >> 2) * 128 + q * 32 + (wave & 3) * 8) * 128;
@@ -668,7 +681,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
 #if defined(GDF_PHASES4) || defined(GDF_ABLATE)
     constexpr bool TWO_PHASE = false;
 #else
-    constexpr bool TWO_PHASE = (MODE == A_DENSE);
+    constexpr bool TWO_PHASE = (MODE == A_DENSE) && !SPLIT;      // (the split-operand form of the two-phase loop spills 139 VGPRs)
 #endif
     stage_b(0, 0, B1); stage_b(0, 0, B2); stage_a(0, 0, 0); stage_a(0, 0, 1); stage_a(0, 0, 2); stage_a(0, 0, 3);
     GDF_TR(1);
@@ -1047,7 +1060,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
             for (int e = 0; e < 8; ++e) hv[e] = act16<DIT, BF>(v[it][e] * o_sc);
             *(f16x8*)(out16 + (size_t)rowi[it] * p.ldo16 + col) = hv;
           }
-        if (!DIT && p.o16_lo > 0) {                      // split operand for the consumer GEMM: lo = fp16(v - hi)
+        if (SPLIT && p.o16_lo > 0) {                     // split operand for the consumer GEMM: lo = fp16(v - hi)
 #pragma unroll
           for (int it = 0; it < NIT; ++it)
             if (okr[it]) {
@@ -1101,6 +1114,11 @@ template <int MODE, int BM, int BN, int STAGES, bool GEGLU>
 __global__ __launch_bounds__(BM * 2, 2) void gemm_kernel(const GemmParams p) {
   gemm_body<MODE, BM, BN, STAGES, GEGLU, false>(p);
 }
+// the same tiles with split fp16 hi + lo operands ("precise" plans)
+template <int MODE, int BM, int BN, int STAGES, bool GEGLU>
+__global__ __launch_bounds__(BM * 2, 2) void gemm_split_kernel(const GemmParams p) {
+  gemm_body<MODE, BM, BN, STAGES, GEGLU, false, false, false, true>(p);
+}
 // dense GEMM with the MMDiT epilogue (tanh-GELU / per-sample gate / two-region sample map); BF: bf16 operands and activations
 template <int BM, int BN, int STAGES, bool BF, bool QKN>
 __global__ __launch_bounds__(BM * 2, 2) void gemm_dit_kernel(const GemmParams p) {
@@ -1123,7 +1141,7 @@ static int persist_wgs() {
   return n;
 }
 
-template <int MODE, int BM, int BN, int STAGES, bool GEGLU, bool DIT = false, bool BF = false, bool QKN = false>
+template <int MODE, int BM, int BN, int STAGES, bool GEGLU, bool DIT = false, bool BF = false, bool QKN = false, bool SPLIT = false>
 static hipError_t launch_t(const GemmParams& p, hipStream_t s) {
   const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
   const int smem = (STAGES >= 8 ? 2 : STAGES) * (BM * 128 + BN * 128);
@@ -1131,6 +1149,7 @@ static hipError_t launch_t(const GemmParams& p, hipStream_t s) {
   {
     const void* fn;
     if constexpr (DIT) fn = (const void*)gemm_dit_kernel<BM, BN, STAGES, BF, QKN>;
+    else if constexpr (SPLIT) fn = (const void*)gemm_split_kernel<MODE, BM, BN, STAGES, GEGLU>;
     else fn = (const void*)gemm_kernel<MODE, BM, BN, STAGES, GEGLU>;
     const hipError_t e = ensure_dyn_smem(attr_mask, fn, smem);
     if (e != hipSuccess) return e;
@@ -1152,6 +1171,7 @@ static hipError_t launch_t(const GemmParams& p, hipStream_t s) {
   if (STAGES == 8 && gx > persist_wgs() && !(p.batch > 1)) gx = persist_wgs();   // persistent: one workgroup per CU walks the tiles
   const dim3 grid(gx, (STAGES == 2 && p.splitk > 1) ? p.splitk : p.batch > 1 ? p.batch : 1);
   if constexpr (DIT) hipLaunchKernelGGL((gemm_dit_kernel<BM, BN, STAGES, BF, QKN>), grid, dim3(BM * 2), smem, s, q);
+  else if constexpr (SPLIT) hipLaunchKernelGGL((gemm_split_kernel<MODE, BM, BN, STAGES, GEGLU>), grid, dim3(BM * 2), smem, s, q);
   else hipLaunchKernelGGL((gemm_kernel<MODE, BM, BN, STAGES, GEGLU>), grid, dim3(BM * 2), smem, s, q);
   return hipGetLastError();
 }
@@ -1167,7 +1187,18 @@ static double round_fill(long tiles, int slots) {
   return (double)tiles / (double)(rounds * slots);
 }
 
+static int pick_variant_any(const GemmParams& p);
+// split-operand launches ("precise" plans) are instantiated for a reduced set of tiles: dense / conv 256x320 two-group, 128x160,
+// 128x128; GEGLU 256x256 two-group and 128x128; the narrow-N tile
+static bool is_split(const GemmParams& p) { return !p.dit && (p.k_w > 0 || p.o16_lo > 0); }
 static int pick_variant(const GemmParams& p) {
+  const int v = pick_variant_any(p);
+  if (!is_split(p) || v == 16) return v;
+  if (p.geglu) return v == 825 ? 825 : 128;
+  if (p.mode == A_CONV_SMALLC) return v == 160 ? 160 : 128;
+  return (v == 932 || v == 160) ? v : 128;
+}
+static int pick_variant_any(const GemmParams& p) {
   if (p.dit) {   // MMDiT widths are multiples of 256 (3072 = 24 x 128): 256x256 tiles (128 KiB ring, 1 workgroup / CU)
     const long t256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
     if (p.variant == 128 || p.variant == 1256 || p.variant == 2128 || p.variant == 8256) return p.variant;
@@ -1238,7 +1269,7 @@ const char* gemm_kernel_name(const GemmParams& p) {
   if (p.mode == A_CONV_SMALLC && v != 160) { bm = 128; bn = 128; st = 2; }
   char tmp[64];
   if (p.dit) snprintf(tmp, sizeof tmp, "gemm_dit_kernel<%d, %d, %d, %s, %s>", v == 128 ? 128 : 256, (v == 1256 || v == 8256) ? 256 : 128, v == 8256 ? 8 : v == 2128 ? 3 : 2, p.bf16 ? "true" : "false", p.qkn_nq ? "true" : "false");
-  else snprintf(tmp, sizeof tmp, "gemm_kernel<%d, %d, %d, %d, %s>", p.mode, bm, bn, st, p.geglu ? "true" : "false");
+  else snprintf(tmp, sizeof tmp, "%s<%d, %d, %d, %d, %s>", is_split(p) ? "gemm_split_kernel" : "gemm_kernel", p.mode, bm, bn, st, p.geglu ? "true" : "false");
   // interned: the returned pointer stays valid for the life of the library (plan build time only, mutex-protected)
   static std::mutex mu;
   static std::deque<std::string> names;
@@ -1272,6 +1303,31 @@ hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {
     if (v == 1256) return p.qkn_nq ? launch_t<A_DENSE, 256, 256, 2, false, true, false, true>(p, s) : launch_t<A_DENSE, 256, 256, 2, false, true>(p, s);
     if (v == 2128) return launch_t<A_DENSE, 256, 128, 3, false, true>(p, s);
     return launch_t<A_DENSE, 128, 128, 2, false, true>(p, s);
+  }
+  if (is_split(p)) {                                                                      // "precise" plans: the reduced tile set of pick_variant
+    if (p.geglu) {
+      if (p.mode != A_DENSE || (p.N % 32) != 0) return hipErrorInvalidValue;
+      return v == 825 ? launch_t<A_DENSE, 256, 256, 8, true, false, false, false, true>(p, s)
+                      : launch_t<A_DENSE, 128, 128, 2, true, false, false, false, true>(p, s);
+    }
+    if (v == 16) {
+      if (p.mode == A_CONV3) return launch_t<A_CONV3, 128, 16, 2, false, false, false, false, true>(p, s);   // conv_out
+      return hipErrorInvalidValue;
+    }
+    switch (p.mode) {
+      case A_DENSE:
+        if (v == 160) return launch_t<A_DENSE, 128, 160, 2, false, false, false, false, true>(p, s);
+        if (v == 932) return launch_t<A_DENSE, 256, 320, 9, false, false, false, false, true>(p, s);
+        return launch_t<A_DENSE, 128, 128, 2, false, false, false, false, true>(p, s);
+      case A_CONV3:
+        if (v == 160) return launch_t<A_CONV3, 128, 160, 2, false, false, false, false, true>(p, s);
+        if (v == 932) return launch_t<A_CONV3, 256, 320, 9, false, false, false, false, true>(p, s);
+        return launch_t<A_CONV3, 128, 128, 2, false, false, false, false, true>(p, s);
+      case A_CONV_SMALLC:
+        return v == 160 ? launch_t<A_CONV_SMALLC, 128, 160, 2, false, false, false, false, true>(p, s)
+                        : launch_t<A_CONV_SMALLC, 128, 128, 2, false, false, false, false, true>(p, s);
+    }
+    return hipErrorInvalidValue;
   }
   if (p.geglu) {
     // weight rows / bias interleaved [16 h | 16 gate] (launch_relayout_rows geglu = 16)

@@ -474,14 +474,15 @@ struct B : PlanBuilder {   // UNet op program
       Epi ee = e;
       const Ref Wr = wt(m.conv_in.w); const int N = boc[0];
       const size_t M = (size_t)Bn * H * W;
-        op("conv_in", 2.0 * (double)M * N * 9 * a.in_channels, [=](const Bind& b, hipStream_t s) {
+      GemmParams gk{}; gk.M = (int)M; gk.N = N; gk.K = 128; gk.mode = A_CONV_SMALLC; gk.bn = ee.bn; gk.o16_lo = ee.has_o16 ? ee.o16_lo : 0;
+      op("conv_in", 2.0 * (double)M * N * 9 * a.in_channels, [=](const Bind& b, hipStream_t s) {
         GemmParams g{};
         g.A = (const half_t*)b.ws(lat8); g.lda = 8; g.a_bytes = (uint32_t)(M * 16);
         g.M = (int)M; g.N = N; g.K = 128; g.mode = A_CONV_SMALLC; g.H = H; g.W = W; g.OH = H; g.OW = W; g.stride = 1; g.Cin = 8;
         g.Wt = (const half_t*)b.p(Wr); g.w_bytes = (uint32_t)((size_t)N * 128 * 2);
         fill_epi(g, ee, b);
         return launch_gemm(g, s);
-      });
+      }, precise ? gemm_kernel_name(gk) : nullptr);
     }
     untmp(lat8, lat8_b);
     gather("unet-after-conv-in", cur);                                                      // :1172-1173

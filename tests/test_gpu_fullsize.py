@@ -271,7 +271,9 @@ def test_flux_dev_full_depth_config_c5_error_vs_depth():
     rep = lambda t: t[:1].expand(B, *t.shape[1:]).contiguous().cuda()
     lines = [f"FLUX.1-dev full depth ({nd} double + {ns} single blocks), 4096 + 512 tokens, GPU batch {B} vs fp32 oracle batch 1 "
              f"(oracle {t_oracle:.0f} s on {torch.get_num_threads()} threads); relative L2 error, worst sample"]
-    bounds = {"bfloat16": 8.0e-3, "float16": 1.0e-3}
+    # measured (profiles/r03_flux_depth_parity.txt): the error saturates with depth — block `out` 1.7e-3 (block 0) -> 2.65e-3 (block 56) in
+    # bf16, 1.3e-4 -> 4.3e-4 in fp16; worst hook (q of the last block) 3.4e-3 / 4.6e-4
+    bounds = {"bfloat16": 4.0e-3, "float16": 6.0e-4}
     for dt, tdt in (("bfloat16", torch.bfloat16), ("float16", torch.float16)):
         net = NativeFluxTransformer(arch, device="cuda:0", compute_dtype=dt)
         net.load_state_dict(_DeviceView(P, tdt))

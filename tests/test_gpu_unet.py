@@ -83,12 +83,14 @@ def test_precise_plan_split_operands_all_hooks(base, lat, batch):
     assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:8]
     assert rel_l2(noise, ref["unet-out"]) < 6e-4
     assert mp < 0.6 * md
-    # selected hooks + early exit + shared ctx go through the same emitters
+    # selected hooks (no maps: the flash attention kernel instead of the map-materialising one) with and without early exit
     sel = [i for i in ids if i.endswith(("ffn-inner", "cross-q", "res-increment", "vit-out"))][:6]
+    _, hs = run_native(up, I, sel)
     ue = native(arch, P, precise=True, early_exit=True)
     _, he = run_native(ue, I, sel)
     for k in sel:
-        assert torch.equal(he[k], hooks[k]), k
+        assert torch.equal(he[k], hs[k]), k
+        assert rel_l2(hs[k], ref[k]) < 6e-4, k
 
 
 def test_fp16_stream_option_and_selected_hooks():
