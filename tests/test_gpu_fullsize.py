@@ -366,6 +366,41 @@ def test_pixart_sigma_full_width_batch4():
     assert errs[worst] <= 6.0e-4, (worst, errs[worst])
 
 
+def test_pixart_sigma_full_depth_batch4():
+    """PixArt-Sigma-XL-2-1024 at FULL DEPTH (28 blocks, 16 heads x 72, 4096 image + 300 caption tokens, ragged caption mask), batch 4 on
+    two samples: the `out` hook of every block (error vs depth) + the q / ffn-inner hooks of a few blocks + the model output vs
+    oracle/pixart_ref.py (reference contract: Transformer2DModel.forward ada_norm_single path, transformer_2d.py:404-475)."""
+    _threads()
+    from oracle import pixart_ref as PR
+    from components.native import NativePixArtTransformer
+    arch = dict(PR.ARCH_PIXART_SIGMA)
+    nl = arch["num_layers"]
+    assert nl == 28
+    P = PR.synth_params(arch, seed=0)
+    I = PR.synth_inputs(arch, 2, 128, 300, seed=1, valid=[300, 117])
+    all_ids = PR.hook_ids(arch)
+    ids = [i for i in all_ids if i.endswith("-out") or (i.split("-")[1] in ("block0", "block13", "block27") and i.endswith(("self-q", "cross-q", "ffn-inner")))]
+    st = PR.Store({k: True for k in ids})
+    with torch.no_grad():
+        y = PR.pixart_forward(P, arch, I["hidden_states"], I["encoder_hidden_states"], I["timestep"], I["encoder_attention_mask"], st,
+                              want_map=False)
+    assert list(st.feats.keys()) == ids
+    net = NativePixArtTransformer(arch, device="cuda:0")
+    net.load_state_dict({k: v.half() for k, v in P.items()})
+    rep = lambda t: torch.cat([t, t], 0).cuda()                       # batch 4 = the two samples twice
+    out, hooks = net.forward_raw(rep(I["hidden_states"]), rep(I["encoder_hidden_states"]), rep(I["timestep"]),
+                                 rep(I["encoder_attention_mask"]), hook_ids=ids)
+    torch.cuda.synchronize()
+    assert list(hooks.keys()) == ids
+    errs = {k: max(_rel_each(hooks[k], st.feats[k])) for k in ids}
+    errs["output"] = max(_rel_each(out, y))
+    depth = [errs[f"vit-block{b}-out"] for b in range(nl)]
+    worst = max(errs, key=errs.get)
+    print(f"\n[pixart-sigma full depth B=4, {len(ids)} hooks] block `out` by depth: " + " ".join(f"{b}:{e:.2e}" for b, e in enumerate(depth)))
+    print(f"[pixart-sigma full depth] worst {worst} = {errs[worst]:.2e}; output {errs['output']:.2e}")
+    assert errs[worst] <= 1.0e-3, (worst, errs[worst])
+
+
 def test_vae_encode_1024_batch2():
     """The step before the hot path at its BASELINE size: SD / SDXL AutoencoderKL encoder (128-256-512-512) on two 1024^2 images,
     posterior sample + Euler noise-add (SDXL scalars) vs oracle/vae_ref.py."""

@@ -35,3 +35,27 @@ for name, ms, f_, k in prof:
 print("# per-op profile of ONE sub-batch pass:")
 for name, r in sorted(rows.items(), key=lambda kv: -kv[1][0]):
     print(f"# {name:18s} n={r[2]:4d} {r[0]:9.3f} ms  {r[1] / 1e9 / max(r[0], 1e-9):8.1f} TFLOP/s")
+
+# ---- `vae-out`: scheduler step + decoder (include/gdf_vae.h decoder half) at the same shape ----
+from components.native import NativeVAEDecoder
+from oracle.vae_ref import dec_flops_per_image
+dec = NativeVAEDecoder(VAE_CONFIGS["sd"], device="cuda:0").init_synthetic(1)
+lat = torch.randn(a.batch, 4, a.img // 8, a.img // 8, device="cuda", generator=g).half(); npred = torch.randn_like(lat)
+dkw = dict(c_sample=1.0, c_eps=-0.4, scaling_factor=0.13025)
+dec.decode(lat, npred, **dkw); torch.cuda.synchronize()
+_, dprof = dec.decode(lat, npred, profile=True, **dkw)
+t0 = time.perf_counter()
+for _ in range(a.steps):
+    img = dec.decode(lat, npred, **dkw)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / a.steps
+fl = dec_flops_per_image(ARCH_SD_VAE, a.img)
+dplan = dec._plan(a.batch, a.img // 8, a.img // 8)
+print(f"VAE step+decode (vae-out): batch {a.batch} x {a.img}^2: {dt * 1e3:.1f} ms/batch = {a.batch / dt:.1f} img/s, "
+      f"{fl / 1e12:.2f} TFLOP/img -> {a.batch * fl / dt / 1e12:.0f} TFLOP/s; workspace {dplan.ws_bytes / 1e9:.2f} GB; finite={bool(torch.isfinite(img.float()).all())}")
+rows = {}
+for name, ms, f_, k in dprof:
+    r = rows.setdefault(name, [0.0, 0.0, 0]); r[0] += ms; r[1] += f_; r[2] += 1
+print("# per-op profile of ONE sub-batch pass (decoder):")
+for name, r in sorted(rows.items(), key=lambda kv: -kv[1][0]):
+    print(f"# {name:18s} n={r[2]:4d} {r[0]:9.3f} ms  {r[1] / 1e9 / max(r[0], 1e-9):8.1f} TFLOP/s")
