@@ -322,3 +322,25 @@ def test_aggregated_attention_feature_matches_oracle():
     assert e < 1e-3, e
     for k in layer:
         assert rel_l2(feats[k], st.feats[k]) < TOL, k
+
+
+def test_feature_extractor_precise_env(monkeypatch):
+    """GDF_PRECISE=1 switches an unmodified FeatureExtractor caller to split-operand plans: same ids, same shapes,
+    values within the fp16-operand distance of the default plans'."""
+    monkeypatch.setenv("GDF_SYNTHETIC_WEIGHTS", "1")
+    import diffusion_feature
+    layer = {"up-level1-repeat1-vit-block0-cross-q": True, "up-level1-repeat2-res-out": True, "up-level2-repeat1-vit-block0-ffn-inner": True}
+    lat = torch.randn(2, 4, 32, 32, generator=torch.Generator().manual_seed(0)).half()
+    out = {}
+    for tag, val in (("default", "0"), ("precise", "1")):
+        monkeypatch.setenv("GDF_PRECISE", val)
+        df = diffusion_feature.FeatureExtractor(layer=layer, version='1-5', img_size=256, device='cuda')
+        assert df.pipe.unet.precise == (val == "1")
+        prompt = df.encode_prompt('a photo of a cat')
+        out[tag] = {k: v.clone() for k, v in df.extract(prompt, batch_size=2, image=lat, image_type='latents', t=100).items()}
+    assert list(out["default"].keys()) == list(out["precise"].keys())
+    for k in out["default"]:
+        a, b = out["default"][k], out["precise"][k]
+        assert a.shape == b.shape and a.dtype == b.dtype == torch.float16
+        e = rel_l2(a, b)
+        assert 0.0 < e < 2.5e-3, (k, e)              # different arithmetic (not bit-equal), same function
