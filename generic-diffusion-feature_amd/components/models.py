@@ -129,13 +129,22 @@ def scheduler_step_scalars(scheduler, timestep):
     if hasattr(scheduler, "step_scalars"):
         return scheduler.step_scalars(timestep)
     import copy
-    t = timestep.flatten()[0].cpu() if torch.is_tensor(timestep) else timestep
+    t0 = timestep.flatten()[0] if torch.is_tensor(timestep) else timestep
+
+    def probe_on(dev, x, e):
+        sch = copy.deepcopy(scheduler)
+        t = t0.to(dev) if torch.is_tensor(t0) else t0
+        out = sch.step(torch.full((1, 1, 1, 1), float(e), dtype=torch.float64, device=dev), t,
+                       torch.full((1, 1, 1, 1), float(x), dtype=torch.float64, device=dev), return_dict=False)[0]
+        return float(out.flatten()[0])
 
     def probe(x, e):
-        sch = copy.deepcopy(scheduler)
-        out = sch.step(torch.full((1, 1, 1, 1), float(e), dtype=torch.float64), t, torch.full((1, 1, 1, 1), float(x), dtype=torch.float64),
-                       return_dict=False)[0]
-        return float(out.flatten()[0])
+        try:
+            return probe_on("cpu", x, e)                 # diffusers keeps sigmas / alphas_cumprod on the CPU
+        except (RuntimeError, TypeError):
+            if torch.is_tensor(t0) and t0.device.type != "cpu":
+                return probe_on(t0.device, x, e)         # a scheduler whose tables live on the timestep's device
+            raise
     a, b = probe(1.0, 0.0), probe(0.0, 1.0)
     chk = probe(0.5, -2.0)
     if abs(chk - (0.5 * a - 2.0 * b)) > 1e-6 * (1.0 + abs(chk)):
