@@ -52,6 +52,65 @@ int gdf_op_conv3x3(const void* x, int ld, int B, int H, int W, int Cin, const vo
   return fin(launch_gemm(g, (hipStream_t)stream), "conv3x3");
 }
 
+// ---- split-operand forms of the "precise" plans (kernels.h GemmParams::k_w / a_lo_bytes / o16_lo) ----
+int gdf_op_gemm_split(const void* A, int lda, int a_lo, const void* W, const float* bias, const float* res32, int ldres, void* out16,
+                      int ldo16, int o16_lo, float* out32, int ldo32, int M, int N, int Kw, int flags, void* stream) {
+  GemmParams g{};
+  const size_t a_bytes = ((size_t)M - 1) * lda * 2 + (size_t)(a_lo + Kw) * 2;
+  if (!span_ok(a_bytes, (size_t)N * Kw * 2, "gemm_split")) return GDF_ERR_UNSUPPORTED;
+  g.A = (const half_t*)A; g.lda = lda; g.a_bytes = (uint32_t)a_bytes;
+  g.M = M; g.N = N; g.K = a_lo > 0 ? 2 * Kw : Kw; g.mode = A_DENSE;
+  if (a_lo > 0) { g.k_w = Kw; g.a_lo_bytes = (uint32_t)a_lo * 2u; }
+  g.Wt = (const half_t*)W; g.w_bytes = (uint32_t)((size_t)N * Kw * 2);
+  g.bias = bias; g.res32 = res32; g.ldres = ldres;
+  g.out16 = (half_t*)out16; g.ldo16 = ldo16; g.o16_lo = o16_lo; g.out32 = out32; g.ldo32 = ldo32;
+  g.geglu = (flags & 1) ? 16 : 0; g.bn = 128; g.rows_per_sample = 1;
+  return fin(launch_gemm(g, (hipStream_t)stream), "gemm_split");
+}
+
+int gdf_op_conv3x3_split(const void* x, int ld, int a_lo, int B, int H, int W, int Cin, const void* Wt, int Cout, const float* bias,
+                         int stride, int ups, const float* res32, void* out16, int ldo16, int o16_lo, float* out32, void* stream) {
+  const int IH = ups ? 2 * H : H, IW = ups ? 2 * W : W;
+  const int OH = (IH - 1) / stride + 1, OW = (IW - 1) / stride + 1;
+  GemmParams g{};
+  const size_t a_bytes = ((size_t)B * H * W - 1) * ld * 2 + (size_t)(a_lo + Cin) * 2;
+  if (!span_ok(a_bytes, (size_t)Cout * 9 * Cin * 2, "conv3x3_split")) return GDF_ERR_UNSUPPORTED;
+  g.A = (const half_t*)x; g.lda = ld; g.a_bytes = (uint32_t)a_bytes;
+  g.M = B * OH * OW; g.N = Cout; g.K = 9 * Cin * (a_lo > 0 ? 2 : 1); g.mode = A_CONV3; g.H = H; g.W = W; g.OH = OH; g.OW = OW;
+  if (a_lo > 0) { g.k_w = 9 * Cin; g.a_lo_bytes = (uint32_t)a_lo * 2u; }
+  g.stride = stride; g.ups = ups; g.Cin = Cin;
+  g.Wt = (const half_t*)Wt; g.w_bytes = (uint32_t)((size_t)Cout * 9 * Cin * 2);
+  g.bias = bias; g.rows_per_sample = OH * OW; g.res32 = res32; g.ldres = Cout;
+  g.out16 = (half_t*)out16; g.ldo16 = ldo16; g.o16_lo = o16_lo; g.out32 = out32; g.ldo32 = Cout; g.bn = 128;
+  return fin(launch_gemm(g, (hipStream_t)stream), "conv3x3_split");
+}
+
+int gdf_op_layernorm_split(const float* x32, int ld, int R, int C, float eps, const float* gamma, const float* beta, void* y, int ldy,
+                           int y_lo, void* stream) {
+  return fin(launch_layernorm(nullptr, x32, ld, R, C, eps, gamma, beta, (half_t*)y, (hipStream_t)stream, ldy, y_lo), "layernorm_split");
+}
+
+int gdf_op_groupnorm_split(const void* x16, int x_lo, const float* x32, int ld, int B, int HW, int C, int G, float eps, const float* gamma,
+                           const float* beta, int silu, void* y, int ldy, int y_lo, void* scratch, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (gn_fused_slab(B, HW, C, G))
+    return fin(launch_gn_fused((const half_t*)x16, x32, ld, B, HW, C, G, eps, gamma, beta, silu, (half_t*)y, s, x_lo, ldy, y_lo), "gn_fused_split");
+  float* partial = (float*)scratch;
+  float* ab = partial + (gn_partial_floats(B, HW, C) + 63) / 64 * 64;
+  hipError_t e = launch_gn_stats((const half_t*)x16, x32, ld, B, HW, C, G, eps, gamma, beta, partial, ab, s, x_lo);
+  if (e != hipSuccess) return fin(e, "gn_stats_split");
+  return fin(launch_gn_apply((const half_t*)x16, x32, ld, B, HW, C, ab, silu, (half_t*)y, s, x_lo, ldy, y_lo), "gn_apply_split");
+}
+
+int gdf_op_attention_split(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* o, int ldo, int o_lo, int B,
+                           int heads, int Sq, int Sk, int D, void* map, void* stream) {
+  AttnParams a{};
+  a.q = (const half_t*)q; a.ldq = ldq; a.k = (const half_t*)k; a.ldk = ldk; a.v = (const half_t*)v; a.ldv = ldv;
+  a.o = (half_t*)o; a.ldo = ldo; a.o_lo = o_lo; a.B = B; a.heads = heads; a.Sq = Sq; a.Sk = Sk; a.D = D; a.kv_bstride = Sk;
+  a.scale = 1.0f / sqrtf((float)D); a.map = (half_t*)map;
+  return fin(launch_attention(a, (hipStream_t)stream), "attention_split");
+}
+
 int gdf_op_conv3x3_splitk(const void* x, int ld, int B, int H, int W, int Cin, const void* Wt, int Cout, const float* bias,
                           const float* rowvec, int stride, int ups, const float* res32, void* aux16, void* out16,
                           float* out32, int splitk, float* ws, void* stream) {

@@ -20,12 +20,30 @@ int gdf_op_gemm(const void* A, int lda, const void* W, const float* bias, const 
                 int ldres, void* out16, int ldo16, float* out32, int ldo32, int M, int N, int K, int flags,
                 void* stream);
 
-/* 3x3 convolution, padding 1, NHWC fp16 x[B,H,W,ld>=Cin], weights [Cout][3][3][Cin] fp16; stride 1|2;
+/* 3x3 convolution, padding 1, NHWC fp16 x[B,H,W,ld>=Cin], weights in the layout gdf_op_relayout_conv3 produces
+ * ([Cout][Cin/64][tap][64] fp16: channel-block-major, the nine taps innermost); stride 1|2;
  * ups=1 fuses a nearest x2 upsample of x in front of the conv.  rowvec: optional [B][Cout] fp32 added per sample.
  * Replaces nn.Conv2d in resnet.py:269,285, downsampling.py:115-118, upsampling.py:131-134,176-193.       */
 int gdf_op_conv3x3(const void* x, int ld, int B, int H, int W, int Cin, const void* Wt, int Cout, const float* bias,
                    const float* rowvec, int stride, int ups, const float* res32, void* aux16, void* out16,
                    float* out32, int narrow /* bit0: BN=16; bits 8..: tile variant */, void* stream);
+
+/* SPLIT-OPERAND forms (the opt-in "precise" plans, gdf.h gdf_plan_opts.reserved[1]): an activation is a pair of fp16 numbers
+ * hi = fp16(v), lo = fp16(v - hi) stored in ONE row, lo `a_lo` (input) / `o16_lo` / `y_lo` / `o_lo` (output) elements after hi, and a
+ * contraction runs over [hi | lo] against the weight matrix read twice: out = (hi + lo) W^T to fp32 accuracy.  a_lo = 0 / *_lo = 0:
+ * the plain form.  Kw / Cin are the WEIGHT matrix's contraction sizes.  They replace the same reference call sites as their
+ * plain counterparts; the reference itself has no such mode (it rounds more: fp16 activations AND an fp16 residual stream). */
+int gdf_op_gemm_split(const void* A, int lda, int a_lo, const void* W, const float* bias, const float* res32, int ldres, void* out16,
+                      int ldo16, int o16_lo, float* out32, int ldo32, int M, int N, int Kw, int flags /* bit0 GEGLU */, void* stream);
+int gdf_op_conv3x3_split(const void* x, int ld, int a_lo, int B, int H, int W, int Cin, const void* Wt, int Cout, const float* bias,
+                         int stride, int ups, const float* res32, void* out16, int ldo16, int o16_lo, float* out32, void* stream);
+int gdf_op_layernorm_split(const float* x32, int ld, int R, int C, float eps, const float* gamma, const float* beta, void* y, int ldy,
+                           int y_lo, void* stream);
+/* x: fp32 (x32, ld) or a split fp16 pair (x16, ld, x_lo) */
+int gdf_op_groupnorm_split(const void* x16, int x_lo, const float* x32, int ld, int B, int HW, int C, int G, float eps, const float* gamma,
+                           const float* beta, int silu, void* y, int ldy, int y_lo, void* scratch, void* stream);
+int gdf_op_attention_split(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* o, int ldo, int o_lo, int B,
+                           int heads, int Sq, int Sk, int D, void* map, void* stream);
 
 /* Deterministic split-K form of gdf_op_conv3x3 (few output tiles, long K — the 8x8-level convs of SD1.5): the K range is cut
  * into `splitk` contiguous parts (0 = the plan builder's heuristic, gdf_op_splitk_factor), every part writes raw fp32 partial

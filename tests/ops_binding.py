@@ -14,6 +14,11 @@ OPS = {
     "gdf_op_gemm": (ci, [vp, ci, vp, vp, vp, vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, vp]),
     "gdf_op_conv3x3": (ci, [vp, ci, ci, ci, ci, ci, vp, ci, vp, vp, ci, ci, vp, vp, vp, vp, ci, vp]),
     "gdf_op_conv_in": (ci, [vp, ci, ci, ci, ci, vp, vp, ci, vp, vp, vp]),
+    "gdf_op_gemm_split": (ci, [vp, ci, ci, vp, vp, vp, ci, vp, ci, ci, vp, ci, ci, ci, ci, ci, vp]),
+    "gdf_op_conv3x3_split": (ci, [vp, ci, ci, ci, ci, ci, ci, vp, ci, vp, ci, ci, vp, vp, ci, ci, vp, vp]),
+    "gdf_op_layernorm_split": (ci, [vp, ci, ci, ci, fp, vp, vp, vp, ci, ci, vp]),
+    "gdf_op_groupnorm_split": (ci, [vp, ci, vp, ci, ci, ci, ci, ci, fp, vp, vp, ci, vp, ci, ci, vp, vp]),
+    "gdf_op_attention_split": (ci, [vp, ci, vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, ci, ci, vp, vp]),
     "gdf_op_attention": (ci, [vp, ci, vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, ci, vp, vp]),
     "gdf_op_groupnorm_scratch_bytes": (C.c_size_t, [ci, ci, ci]),
     "gdf_op_groupnorm": (ci, [vp, vp, ci, ci, ci, ci, ci, fp, vp, vp, ci, vp, vp, vp]),

@@ -312,3 +312,145 @@ def test_postproc_kernels_vs_torch():
                   for c in sel}
         out = aggregate_maps(by_cat, meta["out_size"])
         assert out.is_cuda and out.dtype == torch.float16 and torch.allclose(out.float().cpu(), want, atol=1e-3)
+
+
+# ---- split fp16 hi + lo operands (the opt-in "precise" plans): kernel-level checks through include/gdf_ops.h ----
+def _split(x32):
+    hi = x32.half()
+    lo = (x32 - hi.float()).half()
+    return hi, lo
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 320, 320), (200, 640, 1280), (1232, 1280, 640), (300, 160, 2560)])
+def test_gemm_split_operands(M, N, K):
+    """A = [hi | lo] (lo K + 32 columns further: a gap like the skip-concat buffers have), contraction over 2K against W read twice.
+    Against fp64 of (hi + lo) W^T: fp32-accumulation accuracy (< 3e-6), where the plain fp16-operand GEMM of the same data is at the
+    operand rounding (~2.9e-4); the output pair hi + lo reproduces the fp32 result to 2^-21."""
+    L = lib()
+    g = torch.Generator().manual_seed(M + N + K)
+    a32 = torch.randn(M, K, generator=g)
+    W = (torch.randn(N, K, generator=g) * K ** -0.5).half()
+    bias, res = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    hi, lo = _split(a32)
+    a_lo = K + 32
+    A = torch.zeros(M, a_lo + K + 8, dtype=torch.half)
+    A[:, :K] = hi; A[:, a_lo:a_lo + K] = lo
+    ref = ((hi.double() + lo.double()) @ W.double().t() + bias.double() + res.double())
+    Ad, Wd, bd, rd = A.cuda(), W.cuda(), bias.cuda(), res.cuda()
+    o_lo = N + 8
+    o16 = torch.zeros(M, o_lo + N, dtype=torch.half, device="cuda"); o32 = torch.zeros(M, N, device="cuda")
+    ok(L.gdf_op_gemm_split(P(Ad), A.shape[1], a_lo, P(Wd), P(bd), P(rd), N, P(o16), o16.shape[1], o_lo, P(o32), N, M, N, K, 0, stream()), L)
+    torch.cuda.synchronize()
+    e32 = float((o32.double().cpu() - ref).norm() / ref.norm())
+    assert e32 < 3e-6, e32
+    pair = o16[:, :N].double().cpu() + o16[:, o_lo:o_lo + N].double().cpu()
+    assert float((pair - ref).norm() / ref.norm()) < 3e-6
+    assert torch.equal(o16[:, :N].cpu(), o32.cpu().half())                       # hi = fp16(v): what a hook of this tensor stores
+    # the plain fp16-operand GEMM of the same activation, for scale
+    o32p = torch.zeros(M, N, device="cuda")
+    hid = hi.cuda()
+    ok(L.gdf_op_gemm(P(hid), K, P(Wd), P(bd), P(rd), None, N, None, 0, P(o32p), N, M, N, K, 0, stream()), L)
+    torch.cuda.synchronize()
+    ref_true = a32.double() @ W.double().t() + bias.double() + res.double()
+    ep = float((o32p.double().cpu() - ref_true).norm() / ref_true.norm())
+    es = float((o32.double().cpu() - ref_true).norm() / ref_true.norm())
+    assert es < 0.02 * ep, (es, ep)
+
+
+def test_gemm_split_geglu():
+    L = lib()
+    M, C = 512, 320
+    g = torch.Generator().manual_seed(3)
+    a32 = torch.randn(M, C, generator=g)
+    W = (torch.randn(8 * C, C, generator=g) * C ** -0.5).half(); b = torch.randn(8 * C, generator=g) * 0.1
+    hi, lo = _split(a32)
+    A = torch.cat([hi, lo], 1).cuda()
+    Wi = torch.empty_like(W).cuda(); bi = torch.empty(8 * C, device="cuda")
+    Wd, bd = W.cuda(), b.cuda()
+    ok(L.gdf_op_relayout_geglu(P(Wd), P(bd), P(Wi), P(bi), 8 * C, C, 16, stream()), L)
+    y = (hi.double() + lo.double()) @ W.double().t() + b.double()
+    h, gate = y.chunk(2, -1)
+    ref = h * F.gelu(gate)
+    o16 = torch.zeros(M, 8 * C, dtype=torch.half, device="cuda")                # [hi(4C) | lo(4C)]
+    ok(L.gdf_op_gemm_split(P(A), 2 * C, C, P(Wi), P(bi), None, 0, P(o16), 8 * C, 4 * C, None, 0, M, 8 * C, C, 1, stream()), L)
+    torch.cuda.synchronize()
+    pair = o16[:, :4 * C].double().cpu() + o16[:, 4 * C:].double().cpu()
+    e = float((pair - ref).norm() / ref.norm())
+    assert e < 2e-5, e                                                          # the single-exp GELU's own error (5e-6 relative)
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,stride,ups", [(2, 8, 8, 64, 64, 1, 0), (1, 16, 16, 320, 320, 1, 0), (2, 12, 10, 128, 320, 2, 0),
+                                                        (1, 10, 10, 192, 640, 1, 1), (2, 32, 32, 320, 320, 1, 0)])
+def test_conv3x3_split_operands(B, H, W, Cin, Cout, stride, ups):
+    L = lib()
+    g = torch.Generator().manual_seed(B + H + Cin + Cout)
+    x32 = torch.randn(B, Cin, H, W, generator=g)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) * (9 * Cin) ** -0.5).half()
+    bias = torch.randn(Cout, generator=g)
+    hi, lo = _split(x32)
+    xs = hi.double() + lo.double()
+    xi = F.interpolate(xs, scale_factor=2.0, mode="nearest") if ups else xs
+    ref = F.conv2d(xi, w.double(), bias.double(), stride=stride, padding=1)
+    OH, OW = ref.shape[2], ref.shape[3]
+    a_lo = Cin + 64                                                              # a gap between the halves (concat buffers)
+    xn = torch.zeros(B, H, W, a_lo + Cin, dtype=torch.half)
+    xn[..., :Cin] = hi.permute(0, 2, 3, 1); xn[..., a_lo:] = lo.permute(0, 2, 3, 1)
+    xd, ws, bd = xn.cuda(), w.cuda(), bias.cuda()
+    wd = torch.empty(Cout, 9 * Cin, dtype=torch.half, device="cuda")
+    ok(L.gdf_op_relayout_conv3(P(ws), P(wd), Cout, Cin, stream()), L)
+    o16 = torch.zeros(B, OH, OW, 2 * Cout, dtype=torch.half, device="cuda"); o32 = torch.zeros(B, OH, OW, Cout, device="cuda")
+    ok(L.gdf_op_conv3x3_split(P(xd), xn.shape[-1], a_lo, B, H, W, Cin, P(wd), Cout, P(bd), stride, ups, None, P(o16), 2 * Cout, Cout,
+                              P(o32), stream()), L)
+    torch.cuda.synchronize()
+    e = float((o32.permute(0, 3, 1, 2).double().cpu() - ref).norm() / ref.norm())
+    assert e < 3e-6, e
+    pair = (o16[..., :Cout].double() + o16[..., Cout:].double()).permute(0, 3, 1, 2).cpu()
+    assert float((pair - ref).norm() / ref.norm()) < 3e-6
+
+
+def test_norms_and_attention_split_outputs():
+    """LayerNorm / GroupNorm (+SiLU) / attention outputs as split pairs: hi + lo reproduces the fp32 result to ~2^-21 (the plain fp16
+    output: 2^-12); GroupNorm reads a split pair or the fp32 tensor alike."""
+    L = lib()
+    g = torch.Generator().manual_seed(11)
+    R, C = 300, 640
+    x = torch.randn(R, C, generator=g) * 3 + 0.5
+    gam, bet = 1 + 0.1 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    ref = F.layer_norm(x.double(), (C,), gam.double(), bet.double(), 1e-5)
+    xd, gd, bd = x.cuda(), gam.cuda(), bet.cuda()
+    y = torch.zeros(R, 2 * C, dtype=torch.half, device="cuda")
+    ok(L.gdf_op_layernorm_split(P(xd), C, R, C, 1e-5, P(gd), P(bd), P(y), 2 * C, C, stream()), L)
+    torch.cuda.synchronize()
+    pair = y[:, :C].double().cpu() + y[:, C:].double().cpu()
+    assert rel(pair, ref) < 3e-6 and rel(y[:, :C], ref) > 1e-4
+    # GroupNorm: fp32 input and split-pair input, split output
+    B, HW, Cg = 2, 24 * 24, 320
+    xg = torch.randn(B, HW, Cg, generator=g) * 2 + 0.3
+    gam2, bet2 = 1 + 0.1 * torch.randn(Cg, generator=g), 0.1 * torch.randn(Cg, generator=g)
+    refg = F.silu(F.group_norm(xg.permute(0, 2, 1).double(), 32, gam2.double(), bet2.double(), 1e-5)).permute(0, 2, 1)
+    hi, lo = _split(xg)
+    xp = torch.cat([hi, lo], -1).cuda()                                          # [hi | lo], ld = 2C
+    x32d, g2, b2 = xg.cuda(), gam2.cuda(), bet2.cuda()
+    scratch = torch.empty(L.gdf_op_groupnorm_scratch_bytes(B, HW, Cg) + 1024, dtype=torch.uint8, device="cuda")
+    for src16, x_lo, src32, ld in ((None, 0, x32d, Cg), (xp, Cg, None, 2 * Cg)):
+        yg = torch.zeros(B, HW, 2 * Cg, dtype=torch.half, device="cuda")
+        ok(L.gdf_op_groupnorm_split(P(src16), x_lo, P(src32), ld, B, HW, Cg, 32, 1e-5, P(g2), P(b2), 1, P(yg), 2 * Cg, Cg, P(scratch), stream()), L)
+        torch.cuda.synchronize()
+        pg = yg[..., :Cg].double().cpu() + yg[..., Cg:].double().cpu()
+        assert rel(pg, refg) < 5e-6, rel(pg, refg)
+    # attention: split output
+    Bq, heads, S, D = 2, 5, 512, 64
+    Ca = heads * D
+    qkv = torch.randn(Bq * S, 3 * Ca, generator=g).half()
+    q, k, v = [t.float().view(Bq, S, heads, D).transpose(1, 2) for t in qkv.split(Ca, -1)]
+    refa = F.scaled_dot_product_attention(q.double(), k.double(), v.double()).transpose(1, 2).reshape(Bq * S, Ca)
+    qd = qkv.cuda()
+    o = torch.zeros(Bq * S, 2 * Ca, dtype=torch.half, device="cuda")
+    ok(L.gdf_op_attention_split(P(qd), 3 * Ca, C_off(qd, Ca), 3 * Ca, C_off(qd, 2 * Ca), 3 * Ca, P(o), 2 * Ca, Ca, Bq, heads, S, S, D, None, stream()), L)
+    torch.cuda.synchronize()
+    o1 = torch.zeros(Bq * S, Ca, dtype=torch.half, device="cuda")
+    ok(L.gdf_op_attention(P(qd), 3 * Ca, C_off(qd, Ca), 3 * Ca, C_off(qd, 2 * Ca), 3 * Ca, P(o1), Ca, Bq, heads, S, S, D, None, stream()), L)
+    torch.cuda.synchronize()
+    assert torch.equal(o[:, :Ca], o1)                                            # the hi half IS the plain output
+    pa = o[:, :Ca].double().cpu() + o[:, Ca:].double().cpu()
+    assert rel(pa, refa) < rel(o1, refa)                                         # the pair removes the output rounding (P stays fp16)
