@@ -59,6 +59,8 @@ def parse_args(argv=None):
     p.add_argument('--split', type=str, default='train')
     p.add_argument('--sample_name_first', action='store_true')
     p.add_argument('--show_all_layers', action='store_true')
+    p.add_argument('--precise', action='store_true',
+                   help='native extension (not in the reference CLI): split-operand plans, every feature within 1e-3 of the fp32 reference at ~1.6x the time (= GDF_PRECISE=1)')
     return p.parse_args(argv)
 
 
@@ -150,6 +152,8 @@ def init_data_parallel():
 def main(argv=None):
     from PIL import Image
     args = parse_args(argv)
+    if args.precise:
+        os.environ['GDF_PRECISE'] = '1'                       # read by NativeUNet at construction (components/native.py)
     rank, world, device = init_data_parallel()
     os.makedirs(args.output_dir, exist_ok=True)
     if rank == 0:

@@ -47,6 +47,24 @@ def test_cli_layouts(tmp_path, monkeypatch):
         tmp_path / "o1" / "up-level3-repeat0-vit-block0-self-k" / "b.npy"))
 
 
+def test_cli_precise_flag(tmp_path, monkeypatch):
+    """--precise (native extension): the same files, written from split-operand plans — close to, not equal to, the default run's."""
+    monkeypatch.setenv("GDF_SYNTHETIC_WEIGHTS", "1")
+    monkeypatch.setenv("GDF_PRECISE", "0")
+    sys.path.insert(0, ROOT)
+    import extract_feature as cli
+    layers = _setup(tmp_path)
+    base = ["--layer", str(tmp_path / "layers.json"), "--version", "1-5", "--img_size", "256", "--t", "100", "-b", "2",
+            "--input_dir", str(tmp_path / "imgs" / "*.png"), "--prompt_file", str(tmp_path / "prompt.txt"), "--use_original_filename"]
+    cli.main(base + ["--output_dir", str(tmp_path / "d")])
+    cli.main(base + ["--output_dir", str(tmp_path / "p"), "--precise"])
+    monkeypatch.setenv("GDF_PRECISE", "0")
+    for k in layers:
+        a = np.load(tmp_path / "d" / k / "a.npy").astype(np.float32); b = np.load(tmp_path / "p" / k / "a.npy").astype(np.float32)
+        e = np.linalg.norm(a - b) / np.linalg.norm(b)
+        assert a.shape == b.shape and 0.0 < e < 2.5e-3, (k, e)
+
+
 def test_output_stage_matches_reference_files_on_gpu(tmp_path):
     """(f)2 on device tensors: nearest resize + concat on the GPU, pinned async D2H, byte-identical to the reference's files."""
     from test_host_cpu import _run_output_stage, check_output_stage
