@@ -31,6 +31,9 @@ PRACTICAL = {
             "up-level2-repeat1-vit-block0-cross-q", "up-level3-repeat0-vit-block0-self-k"],
 }
 MFMA_PEAK_TFLOPS = 2500.0      # dense fp16/bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+# what a loop of nothing but independent mfma_f32_16x16x32_f16 sustains on uniform-random operands (2 waves per SIMD, 128 accumulators):
+# the chip is power-limited under MFMA load, zero operands reach 2440-2460 (tools/micro/mfma_shape.hip, profiles/r03_mfma_shape_ceiling.txt)
+MFMA_RANDOM_DATA_CEILING_TFLOPS = 1930.0
 HBM_PEAK_GBS = 8000.0
 
 
@@ -434,6 +437,8 @@ def main():
                        "per_rank_ms_per_step": {"min": round(per_rank_ms[0], 3), "max": round(per_rank_ms[-1], 3)}},
             "roofline": {"bound": "mfma", "kernel": dominant, "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                         "frac_of_random_operand_mfma_ceiling": round(achieved / MFMA_RANDOM_DATA_CEILING_TFLOPS, 4),
+                         "random_operand_mfma_ceiling": MFMA_RANDOM_DATA_CEILING_TFLOPS,
                          "launches": int(launches.value), "avg_launch_ms": round(ms_tot.value / max(1, launches.value), 4),
                          "sampling": f"HIP events around every {TIMING_STRIDE}th launch of the kernel in program order, all K steps "
                                      f"({int(launches.value)} of {TIMING_STRIDE * int(launches.value)} launches)",
