@@ -137,7 +137,7 @@ def cpu_baseline(version, lat_full, budget_s=60.0):
         rate = n * cal_flops / (time.time() - t)
         if nt == cores:
             all_rate = rate                            # every host CPU (BASELINE.md §3's nominal setting): reported, not selected —
-        if rate > best[0] and (nt < cores or cores <= 16):   # a full forward on 256 OpenMP threads ran 0.003 img/s (330 s / image)
+        if rate > best[0] and (nt < cores or cores <= 128):  # only the oversubscribed case is excluded: a full forward on 256 OpenMP threads ran 0.003 img/s (330 s / image)
             best = (rate, nt)
     rate, threads = best
     torch.set_num_threads(threads)
@@ -183,7 +183,7 @@ def cpu_baseline(version, lat_full, budget_s=60.0):
     lat = lat_full
     for cand in (lat_full, lat_full // 2, lat_full // 4):
         lat = cand
-        if 4.0 * fl[cand] / eff <= budget_s:           # warm-up + 2 reps at B = 1 and one B = 2 pair's worth of work, roughly
+        if 9.0 * fl[cand] / eff <= budget_s:           # (1 warm-up + 2 reps) x (batch 1 + batch 2) = 9 image-forwards
             break
 
     def run_b(batch, reps):
@@ -216,7 +216,7 @@ def cpu_baseline(version, lat_full, budget_s=60.0):
                            "calibration_gflops": round(all_rate / 1e9, 1)} if all_ips else None,
                 sample=f"oracle/unet_ref.py fp32 at {how}; 1 warm-up + 2 timed repetitions each at batch 1 ({t1:.1f} s/img) and "
                        f"batch 2 ({t2:.1f} s/img), best = batch {best_b} on {threads} threads; ~{spent:.0f} s of CPU work "
-                       f"(of {cores} host CPUs; thread count = best of 16/32/64/128 on one level-0 ResnetBlock2D + one C=1280 "
+                       f"(of {cores} host CPUs; thread count = best of 16/32/64/128 (and the host CPU count up to 128) on one level-0 ResnetBlock2D + one C=1280 "
                        f"BasicTransformerBlock of the oracle, {rate / 1e9:.0f} GFLOP/s there; on all {cores} CPUs the same two blocks run "
                        f"{(all_rate or 0) / 1e9:.0f} GFLOP/s)")
 

@@ -59,8 +59,11 @@ def parse_args(argv=None):
     p.add_argument('--split', type=str, default='train')
     p.add_argument('--sample_name_first', action='store_true')
     p.add_argument('--show_all_layers', action='store_true')
-    p.add_argument('--precise', action='store_true',
-                   help='native extension (not in the reference CLI): split-operand plans, every feature within 1e-3 of the fp32 reference at ~1.6x the time (= GDF_PRECISE=1)')
+    p.add_argument('--precise', nargs='?', const='precise', default=None,
+                   help="native extension (not in the reference CLI), UNet versions only: operand plan.  Default (flag absent) = 'auto': the cheapest "
+                        "plan that keeps every requested layer within 1e-3 of the fp32 reference (plain fp16 operands, the selective split or the "
+                        "full split).  --precise = the full split (every feature <= 5e-4, ~1.6x the time); --precise selective | plain | "
+                        "a class list such as stream,attn_out")
     return p.parse_args(argv)
 
 
@@ -152,8 +155,8 @@ def init_data_parallel():
 def main(argv=None):
     from PIL import Image
     args = parse_args(argv)
-    if args.precise:
-        os.environ['GDF_PRECISE'] = '1'                       # read by NativeUNet at construction (components/native.py)
+    if args.precise is not None and (args.version == 'flux' or args.version.startswith('pixart')):
+        raise SystemExit("--precise: split-operand plans exist for the UNet versions ('1-5', '2-1', 'xl', 'pgv2') only")
     rank, world, device = init_data_parallel()
     os.makedirs(args.output_dir, exist_ok=True)
     if rank == 0:
@@ -163,7 +166,8 @@ def main(argv=None):
     df = diffusion_feature.FeatureExtractor(
         args.layer, args.version, device=device, dtype=args.dtype, offline_lora=args.offline_lora,
         offline_lora_filename=args.offline_lora_filename, feature_resize=args.feature_resize, control=args.control,
-        attention=args.attention, img_size=args.img_size)
+        attention=args.attention, img_size=args.img_size,
+        precise=None if args.precise is None else (False if args.precise == 'plain' else args.precise))
 
     paths = sorted(glob.glob(args.input_dir, recursive=True))
     lo, hi = 0, len(paths)

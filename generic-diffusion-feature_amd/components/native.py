@@ -75,6 +75,10 @@ SIGNATURES = {
     "gdf_plan_set_timing": (C.c_int, [C.c_void_p, C.c_char_p]),
     "gdf_plan_set_timing_stride": (C.c_int, [C.c_void_p, C.c_int]),
     "gdf_plan_read_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_long), C.POINTER(C.c_double)]),
+    "gdf_stream_create_cu_mask": (C.c_int, [C.POINTER(C.c_uint32), C.c_int, C.POINTER(C.c_void_p)]),
+    "gdf_stream_destroy": (C.c_int, [C.c_void_p]),
+    "gdf_device_cu_count": (C.c_int, []),
+    "gdf_cu_census": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
 }
 
 
@@ -138,6 +142,112 @@ SIGNATURES.update({
 })
 
 _lib = None
+
+# Operand classes of a UNet plan that can be kept as split fp16 pairs hi + lo (csrc/builder.h SP_*, include/gdf.h gdf_plan_opts.reserved[1]).
+SPLIT_CLASSES = {"stream": 1, "gnv": 2, "ln_attn": 4, "attn_out": 8, "ln_ff": 16, "ff_inner": 32, "res": 64, "out": 128}
+SPLIT_ALL = 255
+# The SELECTIVE preset: the main-path roundings (fp16 images of the residual stream, the GroupNorm output in front of proj_in, conv_out's operand)
+# plus the attention outputs — the cheapest subset whose CPU-emulated worst hook stays below 8.5e-4 on SDXL and SD1.5 (tools/operand_subsets.py,
+# profiles/r04_operand_subsets_*.txt)
+SPLIT_SELECTIVE = SPLIT_CLASSES["stream"] | SPLIT_CLASSES["gnv"] | SPLIT_CLASSES["attn_out"] | SPLIT_CLASSES["out"]
+# per architecture family: SD1.5 / SD2.1 (one transformer block per level) do not need the attention outputs
+SELECTIVE_BY_ARCH = {"xl": SPLIT_SELECTIVE, "1-5": SPLIT_CLASSES["stream"] | SPLIT_CLASSES["gnv"] | SPLIT_CLASSES["out"]}
+AUTO_BOUND = 9.5e-4      # emulated error above which the next plan level is chosen (the HIP path sits 0-7 % above the emulation)
+_ERR_TABLE = None
+
+
+def arch_family(cfg):
+    """'xl' (3 levels, deep transformers: SDXL / Playground-v2), '1-5' (4 levels, one block per level: SD1.5 / SD2.1) or None (anything else)"""
+    boc, tl = tuple(cfg["block_out_channels"]), tuple(cfg["transformer_layers"])
+    if boc == (320, 640, 1280) and tl[:3] == (1, 2, 10):
+        return "xl"
+    if boc == (320, 640, 1280, 1280) and set(tl) == {1}:
+        return "1-5"
+    return None
+
+
+def choose_split(cfg, hook_ids):
+    """The cheapest operand-class mask under which every requested hook stays within BASELINE.json's 1e-3 of the fp32 reference:
+    0 (plain fp16 operands) -> the architecture's selective preset -> SPLIT_ALL.  Decided from components/operand_error_table.json (per-hook
+    error of the CPU oracle with exactly the plan's operand classes rounded to fp16, tools/operand_subsets.py): a level is accepted when
+    every requested hook's emulated error is <= AUTO_BOUND.  `*-map` hooks (not in the table: too large to emulate per class) and unknown
+    architectures / hook ids fall back to kind rules: maps, `ffn-inner`, `unet-out` need the selective preset."""
+    global _ERR_TABLE
+    ids = [h for h in hook_ids]
+    if not ids:
+        return 0
+    fam = arch_family(cfg)
+    if _ERR_TABLE is None:
+        import json
+        try:
+            _ERR_TABLE = json.load(open(os.path.join(_HERE, "operand_error_table.json")))
+        except Exception:
+            _ERR_TABLE = {}
+    tab = _ERR_TABLE.get(fam, {}).get("hooks") if fam else None
+    sel = SELECTIVE_BY_ARCH.get(fam, SPLIT_SELECTIVE)
+    level = 0
+    for h in ids:
+        if h.endswith("-map"):
+            level = max(level, 1)
+            continue
+        row = tab.get(h) if tab else None
+        if row is None:                                  # unknown architecture or id: conservative kind rule
+            risky = h.endswith(("ffn-inner", "unet-out", "-q", "-k", "-v")) or (fam != "xl" and h.endswith(("-out", "res-increment")))
+            level = max(level, 1 if risky else 0)
+            continue
+        if row[0] <= AUTO_BOUND:
+            continue
+        level = max(level, 1 if row[1] <= AUTO_BOUND else 2)
+        if level == 2:
+            break
+    return (0, sel, SPLIT_ALL)[level]
+
+
+def split_mask(spec):
+    """None / False / 0 -> 0 (plain fp16 operands); True / 'precise' / 'all' -> every class; 'selective' -> SPLIT_SELECTIVE;
+    'stream,attn_out' -> those classes; an int is taken as the mask itself."""
+    if spec is None or spec is False:
+        return 0
+    if spec is True:
+        return SPLIT_ALL
+    if isinstance(spec, int):
+        return spec & SPLIT_ALL
+    m = 0
+    for tok in str(spec).replace("+", ",").split(","):
+        tok = tok.strip().lower()
+        if not tok or tok in ("0", "none", "default", "plain"):
+            continue
+        if tok in ("1", "all", "precise", "full"):
+            m |= SPLIT_ALL
+        elif tok == "selective":
+            m |= SPLIT_SELECTIVE
+        elif tok in SPLIT_CLASSES:
+            m |= SPLIT_CLASSES[tok]
+        else:
+            raise ValueError(f"unknown split-operand class {tok!r}; known: {sorted(SPLIT_CLASSES)} + 'selective', 'precise'")
+    return m
+
+
+def make_cu_partition_streams(dev, parts=2, layout="interleave"):
+    """`parts` HIP streams restricted to disjoint, equal sets of CUs of `dev` (hipExtStreamCreateWithCUMask through
+    gdf_stream_create_cu_mask) -> ([torch.cuda.ExternalStream], CUs per partition).
+    layout "interleave": CU i belongs to partition i % parts; "block": contiguous ranges of the mask."""
+    lib = load_library()
+    with torch.cuda.device(dev):
+        n = lib.gdf_device_cu_count()
+        if n <= 0 or n % (8 * parts):
+            raise RuntimeError(f"cannot split {n} CUs into {parts} partitions of a multiple of 8")
+        per = n // parts
+        out = []
+        for k in range(parts):
+            words = (C.c_uint32 * ((n + 31) // 32))()
+            for i in range(n):
+                if (i % parts == k) if layout == "interleave" else (i // per == k):
+                    words[i // 32] |= (1 << (i % 32))
+            h = C.c_void_p()
+            _check(lib.gdf_stream_create_cu_mask(words, len(words), C.byref(h)), "stream_create_cu_mask")
+            out.append(torch.cuda.ExternalStream(h.value, device=dev))
+    return out, per
 
 
 def lib_path():
@@ -277,6 +387,7 @@ class _Plan:
     # the event is polled), unbounded 35 ms — identical throughput (141.6 / 141.9 img/s).  So the queue stays unbounded; the knob
     # remains for hosts that prefer a shallow queue.
     MAX_INFLIGHT = int(os.environ.get("GDF_MAX_INFLIGHT", "0"))
+    _warned_no_use_count = False
 
     def __init__(self, lib, handle):
         self.lib, self.handle = lib, handle
@@ -342,9 +453,16 @@ class _Plan:
             pooled = True
             if hs is None:
                 hs = _HookSet(self, n_out, dev)
-                pooled = len(self.sets) < self.MAX_SETS        # more live result sets than that: one-off buffers, run eagerly
+                # more live result sets than MAX_SETS — or a torch build without the storage use count (sets can never be recycled):
+                # one-off buffers, eager launches
+                pooled = len(self.sets) < self.MAX_SETS and hs.base_count is not None
                 if pooled:
                     self.sets.append(hs)
+                elif hs.base_count is None and not _Plan._warned_no_use_count:
+                    _Plan._warned_no_use_count = True
+                    import warnings
+                    warnings.warn("torch._C._storage_Use_Count is unavailable: hook-buffer sets cannot be recycled, every forward allocates "
+                                  "fresh buffers and launches eagerly (no hipGraph replay)")
             no_graph = self.graph and (eager or profile or not pooled)
             if no_graph:
                 self.lib.gdf_plan_set_graph(self.handle, 0)
@@ -372,6 +490,7 @@ class _NativeModel:
     lib = None
     handle = None
     device = None
+    split = 0          # split-operand classes of the plans (UNet only; see NativeUNet)
 
     def _is_norm(self, name):
         """True for norm parameters (synthetic init: weight 1 + 0.1 N, bias 0.1 N)."""
@@ -527,7 +646,13 @@ class NativeUNet(_NativeModel):
         self.handle = h
         self.stream_fp32 = bool(stream_fp32)
         self.early_exit = bool(early_exit)
-        self.precise = bool(os.environ.get("GDF_PRECISE", "0") not in ("", "0")) if precise is None else bool(precise)
+        # split-operand classes of the plans: `precise` = None / 'auto' (default: chosen per hook set, choose_split) | False (plain fp16
+        # operands) | True | 'selective' | 'stream,attn_out' | mask.  GDF_PRECISE in the environment supplies the default.
+        env = os.environ.get("GDF_PRECISE")
+        self.set_precise(precise if precise is not None else (env if env not in (None, "") else "auto"))
+        self.last_split = 0
+        self.cus = 0                     # > 0: plans are sized for a CU partition of that many CUs and run on `self.partition_stream`
+        self.partition_stream = None     # torch.cuda.ExternalStream over a CU-masked HIP stream (make_cu_partition_streams)
         self.feature_store = None
         self.shared_ctx = False          # set by FeatureExtractor.extract (it repeats one prompt over the batch)
         self.extra_hook_ids = []         # hooks FeatureExtractor needs internally (aggregated `attention=` feature)
@@ -540,22 +665,44 @@ class NativeUNet(_NativeModel):
             sample_size=None, cross_attention_dim=cfg["cross_attention_dim"])
         self.add_embedding = types.SimpleNamespace(linear_1=types.SimpleNamespace(in_features=cfg["add_in_dim"]))
 
+    @property
+    def precise(self):
+        """True when the plans keep EVERY operand class split (the round-3 `precise` plans)"""
+        return (not getattr(self, "auto_split", False)) and self.split == SPLIT_ALL
+
+    @precise.setter
+    def precise(self, v):
+        self.set_precise(v)
+
+    def set_precise(self, spec):
+        """'auto': the cheapest plan level that keeps every REQUESTED hook within 1e-3 (choose_split); anything else: split_mask(spec)"""
+        self.auto_split = isinstance(spec, str) and spec.strip().lower() == "auto"
+        self.split = 0 if self.auto_split else split_mask(spec)
+        return self
+
+    def split_for(self, hook_ids):
+        return choose_split(self.cfg, hook_ids) if getattr(self, "auto_split", False) else self.split
+
     def _is_norm(self, name):
         return ".norm" in name or name.startswith("conv_norm_out")
 
     # ---- plans ------------------------------------------------------------------------------------
-    def _plan(self, batch, h, w, n_ctx, hook_ids, shared_ctx=False):
-        key = (batch, h, w, n_ctx, tuple(hook_ids), self.stream_fp32, self.early_exit, bool(shared_ctx), self.precise)
+    def _plan(self, batch, h, w, n_ctx, hook_ids, shared_ctx=False, split=None):
+        split = self.split_for(hook_ids) if split is None else split
+        key = (batch, h, w, n_ctx, tuple(hook_ids), self.stream_fp32, self.early_exit, bool(shared_ctx), split, self.cus)
         p = self._plans.get(key)
         if p is None:
             ids = (C.c_char_p * max(1, len(hook_ids)))(*[s.encode() for s in hook_ids])
             opts = PlanOpts(int(self.stream_fp32), int(self.early_exit))
             opts.reserved[0] = int(bool(shared_ctx))
-            opts.reserved[1] = int(self.precise)
+            opts.reserved[1] = 1 if split == SPLIT_ALL else (split << 8)
+            opts.reserved[2] = int(self.cus)
             ph = C.c_void_p()
             _check(self.lib.gdf_plan_create(self.handle, batch, h, w, n_ctx, ids, len(hook_ids), C.byref(opts),
                                             C.byref(ph)), "plan_create")
             p = _Plan(self.lib, ph)
+            if self.partition_stream is not None:
+                p.stream = self.partition_stream
             if len(self._plans) >= 8:
                 self._plans.pop(next(iter(self._plans)))
             self._plans[key] = p
@@ -585,7 +732,8 @@ class NativeUNet(_NativeModel):
         if ctx.shape[0] != B or ctx.shape[2] != self.cfg["cross_attention_dim"]:
             raise ValueError("encoder_hidden_states shape mismatch")
         ids = list(hook_ids) if hook_ids is not None else self.requested_ids()
-        plan = self._plan(B, H, W, ctx.shape[1], ids, shared_ctx)
+        self.last_split = self.split_for(ids)
+        plan = self._plan(B, H, W, ctx.shape[1], ids, shared_ctx, self.last_split)
         f16, f32 = torch.float16, torch.float32
         call = self._launch(plan, self.lib.gdf_forward, self.lib.gdf_plan_profile, "forward", profile)
         noise, out, prof = plan.run(dev, [("sample", sample, f16), ("t", t, f32), ("ctx", ctx, f16), ("txt", txt, f16),

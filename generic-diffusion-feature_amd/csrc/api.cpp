@@ -293,4 +293,40 @@ int gdf_plan_read_timing(gdf_plan* p, double* ms_total, long* launches, double* 
   return plan_read_timing(p->p, ms_total, launches, flops_total);
 }
 
+
+// ---- CU-partitioned streams (gdf.h) -------------------------------------------------------------------------------------------
+int gdf_stream_create_cu_mask(const uint32_t* mask, int n_words, void** stream) {
+  if (!mask || n_words < 1 || !stream) { set_error("gdf_stream_create_cu_mask: bad arguments"); return GDF_ERR_ARG; }
+  hipStream_t s = nullptr;
+  const hipError_t e = hipExtStreamCreateWithCUMask(&s, (uint32_t)n_words, mask);
+  if (e != hipSuccess) { set_error(std::string("hipExtStreamCreateWithCUMask: ") + hipGetErrorString(e)); return GDF_ERR_HIP; }
+  *stream = (void*)s;
+  return GDF_OK;
+}
+int gdf_stream_destroy(void* stream) {
+  if (!stream) return GDF_OK;
+  return hipStreamDestroy((hipStream_t)stream) == hipSuccess ? GDF_OK : GDF_ERR_HIP;
+}
+int gdf_device_cu_count(void) {
+  int dev = 0, n = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return -1;
+  return n;
+}
+
 }  // extern "C"
+
+// one record per workgroup: (XCC_ID, HW_ID) of the CU it ran on — which physical CUs a CU-masked stream really uses
+__global__ void gdf_cu_census_kernel(uint32_t* out, int spin) {
+  if (threadIdx.x == 0) {
+    const uint32_t xcc = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11));     // HW_REG_XCC_ID
+    const uint32_t hw = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));       // HW_REG_HW_ID
+    out[2 * blockIdx.x] = xcc; out[2 * blockIdx.x + 1] = hw;
+  }
+  // keep the workgroup resident for a while so that the grid spreads over every CU the stream may use
+  for (int i = 0; i < spin; ++i) __builtin_amdgcn_s_sleep(64);
+}
+extern "C" int gdf_cu_census(uint32_t* dev_out, int n_blocks, int spin, void* stream) {
+  if (!dev_out || n_blocks < 1) { gdf::set_error("gdf_cu_census: bad arguments"); return GDF_ERR_ARG; }
+  hipLaunchKernelGGL(gdf_cu_census_kernel, dim3(n_blocks), dim3(64), 0, (hipStream_t)stream, dev_out, spin);
+  return hipGetLastError() == hipSuccess ? GDF_OK : GDF_ERR_HIP;
+}

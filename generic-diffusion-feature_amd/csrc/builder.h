@@ -121,14 +121,31 @@ struct PlanBuilder {
   // stored as a split pair (hi, lo) = 22 mantissa bits, and the contraction runs over [hi | lo] against the weights read twice
   // (GemmParams::k_w): the fp16-OPERAND rounding of DESIGN.md §4 disappears, at twice the MFMA work.  Attention internals (q, k,
   // v, P) stay fp16.  px = 2 in such a plan: width factor of every 16-bit image.
-  bool precise = false;
-  int px = 1;
+  //
+  // Round 4: the split is PER OPERAND CLASS (gdf.h, gdf_plan_opts.reserved[1] = mask << 8; 1 = every class = the round-3 "precise" plan).
+  // tools/operand_subsets.py measures each class's contribution to the hook error on the CPU oracle: the roundings on the MAIN PATH — the fp16
+  // image of the residual stream as read by the 1x1 shortcuts, the down / upsampler convs, proj_out and the GroupNorms, and the GroupNorm output
+  // in front of proj_in — carry most of it and are cheap to split (few, small GEMMs); the branch-internal operands (LayerNorm outputs, GEGLU
+  // inner, resnet conv operands) are expensive and matter less.
+  enum { SP_STREAM = 1,      // fp16 images of residual-stream tensors (incl. the skip-concat buffers): shortcut / sampler / proj_out operands, GroupNorm inputs
+         SP_GNV = 2,         // Transformer2DModel.norm output  -> proj_in operand
+         SP_LN_ATTN = 4,     // LayerNorm-1 / -2 outputs        -> to_q|k|v, cross to_q operands
+         SP_ATTN_OUT = 8,    // attention outputs               -> to_out.0 operands
+         SP_LN_FF = 16,      // LayerNorm-3 output              -> GEGLU projection operand
+         SP_FF_INNER = 32,   // GEGLU inner tensor              -> ff.net.2 operand
+         SP_RES = 64,        // resnet GroupNorm(+SiLU) outputs and the conv1 output -> conv1 / conv2 operands, norm2 input
+         SP_OUT = 128,       // conv_norm_out output            -> conv_out operand
+         SP_ALL = 255 };
+  int split = 0;              // mask of the classes above
+  bool precise = false;       // split != 0
+  bool spl(int cls) const { return (split & cls) != 0; }
+  int pxc(int cls) const { return spl(cls) ? 2 : 1; }
 
   PlanBuilder(const Model& mm, Plan& pp, bool d, const PlanOpts& o) : m(mm), P(pp), dry(d), opt(o) {
-    precise = o.reserved[1] != 0 && mm.kind == 0;        // the UNet op program only
-    px = precise ? 2 : 1;
+    if (mm.kind == 0) split = o.reserved[1] == 1 ? SP_ALL : ((o.reserved[1] >> 8) & SP_ALL);      // the UNet op program only
+    precise = split != 0;
   }
-  size_t img_bytes(size_t nrows, int C) const { return nrows * (size_t)C * 2 * px; }     // a contiguous 16-bit image (split: [hi | lo])
+  size_t img_bytes(size_t nrows, int C, int cls) const { return nrows * (size_t)C * 2 * pxc(cls); }     // a contiguous 16-bit image (split: [hi | lo])
 
   Ref ws(size_t off) const { return Ref{BUF_WS, off}; }
   Ref wt(size_t off) const { return Ref{BUF_WT, off}; }
@@ -147,8 +164,9 @@ struct PlanBuilder {
 
   size_t rows(const Act& a) const { return (size_t)Bn * a.H * a.W; }
 
-  Act new_act(int C, int H, int W, bool master) {
-    Act a; a.C = C; a.H = H; a.W = W; a.ld = C * px; a.lo = precise ? C : 0; a.hscale = act_scale;
+  Act new_act(int C, int H, int W, bool master, int cls = SP_STREAM) {
+    const int px = pxc(cls);
+    Act a; a.C = C; a.H = H; a.W = W; a.ld = C * px; a.lo = spl(cls) ? C : 0; a.hscale = act_scale;
     a.h_bytes = (size_t)Bn * H * W * C * 2 * px;
     a.h_alloc = dry ? 0 : ar.alloc(a.h_bytes);
     a.h = ws(a.h_alloc);
@@ -279,6 +297,7 @@ struct PlanBuilder {
     const int K = a_lo > 0 ? 2 * Kw : Kw;
     GemmParams gk{}; gk.M = (int)M; gk.N = N; gk.K = K; gk.mode = A_DENSE; gk.geglu = e.geglu; gk.bn = e.bn; gk.dit = e.dit; gk.bf16 = e.bf16;
     gk.k_w = a_lo > 0 ? Kw : 0; gk.o16_lo = e.has_o16 ? e.o16_lo : 0;      // split operands: their own kernel instantiations / tile set
+    const int cus = opt.reserved[2]; gk.cus = cus;                           // CU partition of the launch stream (0 = whole chip)
     gk.res32 = e.has_r32 ? (const float*)1 : nullptr;      // tile selection looks at the epilogue form (never dereferenced)
     // few output tiles, long K (small batches: ff_out at 1024-2048 rows): deterministic split-K (see conv3)
     const int splitk = gemm_splitk_factor(gk);
@@ -288,7 +307,7 @@ struct PlanBuilder {
     op(name, 2.0 * (double)M * N * Kw, [=](const Bind& b, hipStream_t s) {      // algorithmic FLOPs (the split doubles the MFMA work, not these)
       GemmParams g{};
       g.A = (const half_t*)b.p(A); g.lda = lda; g.a_bytes = (uint32_t)(((size_t)M - 1) * lda * 2 + (size_t)(a_lo + Kw) * 2);
-      g.M = (int)M; g.N = N; g.K = K; g.mode = A_DENSE;
+      g.M = (int)M; g.N = N; g.K = K; g.mode = A_DENSE; g.cus = cus;
       if (a_lo > 0) { g.k_w = Kw; g.a_lo_bytes = (uint32_t)a_lo * 2u; }
       g.Wt = (const half_t*)b.p(W); g.w_bytes = (uint32_t)((size_t)N * Kw * 2);
       fill_epi(g, e, b);
@@ -301,14 +320,15 @@ struct PlanBuilder {
 
   // ---- primitive emitters -----------------------------------------------------------------------
   // GroupNorm (+SiLU) of x -> contiguous fp16 tensor (workspace offset returned)
-  size_t groupnorm(const Act& x, const NormW& w, float eps_true, bool silu) {
+  // out_cls: operand class of the OUTPUT (split pair when that class is split)
+  size_t groupnorm(const Act& x, const NormW& w, float eps_true, bool silu, int out_cls = 0) {
     const float eps = eps_true * x.hscale * x.hscale;      // GN(s x, s^2 eps) == GN(x, eps): the scaled fp16 image normalises identically
     const size_t n = rows(x);
-    const size_t y = tmp(img_bytes(n, x.C));
-    // precise plans: the input is the fp32 master where there is one, else the split image; the output is a split image
-    const bool from_f = precise && x.has_f;
+    const size_t y = tmp(img_bytes(n, x.C, out_cls));
+    // a split input image: read the fp32 master where there is one, else the pair; the output is a split image when its class is
+    const bool from_f = x.lo > 0 && x.has_f;
     const Ref xh = x.h, xf = x.f; const int ld = from_f ? x.C : x.ld, C = x.C, HW = x.H * x.W, Bq = Bn;
-    const int x_lo = from_f ? 0 : x.lo, ldy = C * px, y_lo = precise ? C : 0;
+    const int x_lo = from_f ? 0 : x.lo, ldy = C * pxc(out_cls), y_lo = spl(out_cls) ? C : 0;
     const Ref g = wt(w.g), bt = wt(w.b);
     if (gn_fused_slab(Bn, x.H * x.W, x.C, 32)) {            // small feature map: statistics + apply in one launch
       op(silu ? "gn_fused_silu" : "gn_fused", 0, [=](const Bind& b, hipStream_t s) {
@@ -343,6 +363,7 @@ struct PlanBuilder {
     const int N = w.cout, Bq = Bn;
     GemmParams gk{}; gk.M = (int)M; gk.N = N; gk.K = 9 * Cin * kx; gk.mode = A_CONV3; gk.bn = e.bn;
     gk.k_w = a_lo > 0 ? 9 * Cin : 0; gk.o16_lo = e.has_o16 ? e.o16_lo : 0;
+    const int cus = opt.reserved[2]; gk.cus = cus;
     // few output tiles, long K (SD1.5's 8x8 level: 160 tiles of 128x128 walking 180-360 K-tiles each): deterministic split-K
     const int splitk = gemm_splitk_factor(gk);
     const size_t ws_b = splitk > 1 ? (size_t)splitk * M * N * 4 : 0;
@@ -352,7 +373,7 @@ struct PlanBuilder {
       GemmParams g{};
       g.A = (const half_t*)b.p(src); g.lda = ld;
       g.a_bytes = (uint32_t)(((size_t)Bq * H * W - 1) * ld * 2 + (size_t)(a_lo + Cin) * 2);
-      g.M = (int)M; g.N = N; g.K = 9 * Cin * kx; g.mode = A_CONV3; g.H = H; g.W = W; g.OH = OH; g.OW = OW;
+      g.M = (int)M; g.N = N; g.K = 9 * Cin * kx; g.mode = A_CONV3; g.H = H; g.W = W; g.OH = OH; g.OW = OW; g.cus = cus;
       if (a_lo > 0) { g.k_w = 9 * Cin; g.a_lo_bytes = (uint32_t)a_lo * 2u; }
       g.stride = stride; g.ups = ups ? 1 : 0; g.Cin = Cin; g.pad0 = e.pad0;
       g.Wt = (const half_t*)b.p(Wr); g.w_bytes = (uint32_t)((size_t)N * 9 * Cin * 2);
@@ -368,9 +389,9 @@ struct PlanBuilder {
     if (stop) return;
     const size_t n = rows(x);
     const int HW = x.H * x.W;
-    const size_t n1 = groupnorm(x, w.n1, w.eps, true);
-    const int slo = precise ? 1 : 0;                     // GroupNorm outputs of a precise plan: [rows][2C], lo at +C
-    Act h1 = new_act(w.cout, x.H, x.W, false);
+    const size_t n1 = groupnorm(x, w.n1, w.eps, true, SP_RES);
+    const int slo = spl(SP_RES) ? 1 : 0, px = pxc(SP_RES);   // split GroupNorm outputs: [rows][2C], lo at +C
+    Act h1 = new_act(w.cout, x.H, x.W, false, SP_RES);
     {
       Epi e; e.bias = wt(w.c1.b); e.has_bias = true;
       if (w.has_temb) {                                                                    // resnet.py:343-350
@@ -379,8 +400,8 @@ struct PlanBuilder {
       out_to(e, h1);
       conv3("res_conv1", ws(n1), x.C * px, x.C, x.H, x.W, 1, false, w.c1, e, slo * x.C);
     }
-    untmp(n1, img_bytes(n, x.C));
-    const size_t n2 = groupnorm(h1, w.n2, w.eps, true);
+    untmp(n1, img_bytes(n, x.C, SP_RES));
+    const size_t n2 = groupnorm(h1, w.n2, w.eps, true, SP_RES);
     free_act(h1);
     // shortcut: 1x1 conv of x into an fp32 residual buffer
     size_t sc = NPOS; const size_t sc_b = n * w.cout * 4;
@@ -399,7 +420,7 @@ struct PlanBuilder {
       conv3("res_conv2", ws(n2), w.cout * px, w.cout, x.H, x.W, 1, false, w.c2, e, slo * w.cout);
       if (e.aux_slot >= 0) hook_done();
     }
-    untmp(n2, img_bytes(n, w.cout));
+    untmp(n2, img_bytes(n, w.cout, SP_RES));
     if (w.has_sc) untmp(sc, sc_b);
     gather(id + "-res-out", y);                                                           // resnet.py:376-377
   }

@@ -1157,7 +1157,7 @@ static hipError_t launch_t(const GemmParams& p, hipStream_t s) {
   GemmParams q = p;
   q.sb_gm = q.sb_gn = 0;
   if (!p.no_superblock) {
-    const int conc = 32 * ((BM == 256) ? 1 : 2);         // workgroups one XCD keeps resident (32 CUs x 1 or 2)
+    const int conc = (p.cus > 0 ? p.cus / 8 : 32) * ((BM == 256) ? 1 : 2);   // workgroups one XCD keeps resident (32 CUs x 1 or 2; a CU partition: cus / 8)
     static const int gn_max = [] { const char* e = getenv("GDF_SB_GN_MAX"); return e ? atoi(e) : 4; }();   // diagnostics: widest super-block
     for (int gn = gn_max; gn >= 2; gn >>= 1) {
       const int gm = conc / gn;
@@ -1168,7 +1168,8 @@ static hipError_t launch_t(const GemmParams& p, hipStream_t s) {
     }
   }
   int gx = tiles_m * tiles_n;
-  if (STAGES == 8 && gx > persist_wgs() && !(p.batch > 1)) gx = persist_wgs();   // persistent: one workgroup per CU walks the tiles
+  const int pw = (p.cus > 0 && p.cus < persist_wgs()) ? p.cus : persist_wgs();
+  if (STAGES == 8 && gx > pw && !(p.batch > 1)) gx = pw;   // persistent: one workgroup per CU walks the tiles
   const dim3 grid(gx, (STAGES == 2 && p.splitk > 1) ? p.splitk : p.batch > 1 ? p.batch : 1);
   if constexpr (DIT) hipLaunchKernelGGL((gemm_dit_kernel<BM, BN, STAGES, BF, QKN>), grid, dim3(BM * 2), smem, s, q);
   else if constexpr (SPLIT) hipLaunchKernelGGL((gemm_split_kernel<MODE, BM, BN, STAGES, GEGLU>), grid, dim3(BM * 2), smem, s, q);
@@ -1199,6 +1200,7 @@ static int pick_variant(const GemmParams& p) {
   return (v == 932 || v == 160) ? v : 128;
 }
 static int pick_variant_any(const GemmParams& p) {
+  const int S1 = p.cus > 0 ? p.cus : 256, S2 = 2 * S1;   // workgroup slots at 1 / 2 workgroups per CU (whole chip or a CU partition)
   if (p.dit) {   // MMDiT widths are multiples of 256 (3072 = 24 x 128): 256x256 tiles (128 KiB ring, 1 workgroup / CU)
     const long t256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
     if (p.variant == 128 || p.variant == 1256 || p.variant == 2128 || p.variant == 8256) return p.variant;
@@ -1219,16 +1221,16 @@ static int pick_variant_any(const GemmParams& p) {
     const long tm256 = (p.M + 255) / 256, tm128 = (p.M + 127) / 128;
     double best = 0.0; int bv = 128;
     auto cand = [&](int v, double rate, long tiles, int slots) { const double sc = rate * round_fill(tiles, slots); if (sc > best) { best = sc; bv = v; } };
-    if (p.N % 256 == 0) cand(825, 1.00, tm256 * (p.N / 256), 256);
-    if (p.N % 320 == 0) cand(320, 0.95, tm256 * (p.N / 320), 256);
-    cand(256, 0.80, tm256 * ((p.N + 127) / 128), 256);
-    cand(128, 0.70, tm128 * ((p.N + 127) / 128), 512);
+    if (p.N % 256 == 0) cand(825, 1.00, tm256 * (p.N / 256), S1);
+    if (p.N % 320 == 0) cand(320, 0.95, tm256 * (p.N / 320), S1);
+    cand(256, 0.80, tm256 * ((p.N + 127) / 128), S1);
+    cand(128, 0.70, tm128 * ((p.N + 127) / 128), S2);
     return bv;
   }
   if (p.mode != A_DENSE) {                                                 // convs (K = 9 Cin is long)
     if (p.N % 320 == 0) {                                                  // 8-phase 256x320: 1150-1350 TFLOP/s (ring 1090-1310, 128x160 950-1140)
-      const double s932 = 1.00 * round_fill(tiles320, 256), s160 = 0.85 * round_fill((long)((p.M + 127) / 128) * (p.N / 160), 512);
-      const double s128 = 0.70 * round_fill((long)((p.M + 127) / 128) * ((p.N + 127) / 128), 512);
+      const double s932 = 1.00 * round_fill(tiles320, S1), s160 = 0.85 * round_fill((long)((p.M + 127) / 128) * (p.N / 160), S2);
+      const double s128 = 0.70 * round_fill((long)((p.M + 127) / 128) * ((p.N + 127) / 128), S2);
       return (s932 >= s160 && s932 >= s128) ? 932 : (s160 >= s128 ? 160 : 128);
     }
     if (p.N % 160 == 0) return 160;
@@ -1241,15 +1243,15 @@ static int pick_variant_any(const GemmParams& p) {
   // (round 2: with the two-phase main loop the 256x320 tile wins again where its tiles fill whole rounds — 16384 x 1280 x 1280
   // 64.7 vs 77.7 us, 32768 x 640 x 640 47.0 vs 49.8, 65536 x 640 x 640 equal; it still loses at half-filled rounds, 8192 x 1280 x 1280
   // 47.3 vs 37.3, and at N = 320, tools/bench_res32.py)
-  if (p.res32 && p.K <= 1536 && p.N % 160 == 0 && tiles320 <= 512 &&
-      !(p.N % 320 == 0 && p.N >= 640 && p.K >= 640 && tiles320 % 256 == 0)) return 160;
+  if (p.res32 && p.K <= 1536 && p.N % 160 == 0 && tiles320 <= S2 &&
+      !(p.N % 320 == 0 && p.N >= 640 && p.K >= 640 && tiles320 % S1 == 0)) return 160;
   if (p.N % 320 == 0) {                                                    // 8-phase: qkv 1113, ff_out 1088, attn2_q 1045, shortcut 1086 (ring: 1051 / 983 / 980 / 1002)
-    const double s932 = 1.00 * round_fill(tiles320, 256), s160 = 0.87 * round_fill((long)((p.M + 127) / 128) * (p.N / 160), 512);
-    const double s128 = 0.72 * round_fill((long)((p.M + 127) / 128) * ((p.N + 127) / 128), 512);
+    const double s932 = 1.00 * round_fill(tiles320, S1), s160 = 0.87 * round_fill((long)((p.M + 127) / 128) * (p.N / 160), S2);
+    const double s128 = 0.72 * round_fill((long)((p.M + 127) / 128) * ((p.N + 127) / 128), S2);
     return (s932 >= s160 && s932 >= s128) ? 932 : (s160 >= s128 ? 160 : 128);
   }
   if (p.N % 160 == 0 && p.K >= 1024) return 160;
-  if ((long)p.M * p.N >= (1L << 26) && tiles256 >= 512) return 256;        // short-K, large MxN (qkv @ C=640): 712 vs 642
+  if ((long)p.M * p.N >= (1L << 26) && tiles256 >= S2) return 256;        // short-K, large MxN (qkv @ C=640): 712 vs 642
   return 128;
 }
 
@@ -1427,8 +1429,9 @@ int gemm_splitk_factor(const GemmParams& p) {
   if (off || p.dit || p.geglu || p.bn == 16 || p.batch > 1 || p.mode == A_CONV_SMALLC || p.variant || (p.N % 128) || (p.K % BK)) return 1;
   const long tiles = (long)((p.M + 127) / 128) * (p.N / 128);
   const int nk = p.K / BK;
-  if (tiles >= 256 || nk < 64) return 1;
-  int s = (int)(512 / tiles);
+  const int S1 = p.cus > 0 ? p.cus : 256;
+  if (tiles >= S1 || nk < 64) return 1;
+  int s = (int)(2 * S1 / tiles);
   if (s > nk / 16) s = nk / 16;
   if (s > 8) s = 8;
   return s < 2 ? 1 : s;

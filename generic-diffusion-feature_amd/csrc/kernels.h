@@ -122,6 +122,10 @@ struct GemmParams {
   int k_w;
   uint32_t a_lo_bytes;
   int o16_lo;
+  // CU PARTITION (gdf_plan_opts.reserved[2]): > 0 = the launch stream is restricted to this many CUs (a CU-masked stream,
+  // gdf_stream_create_cu_mask): tile selection, persistent grids and the XCD super-block order count workgroup slots on `cus`
+  // CUs instead of the whole chip.  0 = the whole device.
+  int cus;
 };
 hipError_t launch_gemm(const GemmParams& p, hipStream_t s);
 // Deterministic split-K for problems with few output tiles and a long K (the 8x8-level 3x3 convs of SD1.5: 160 tiles of 128x128,

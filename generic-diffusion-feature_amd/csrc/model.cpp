@@ -260,77 +260,79 @@ struct B : PlanBuilder {   // UNet op program
     const bool maps = P.want_maps;
     // GroupNorm(eps 1e-6) -> proj_in  (conv1x1 == linear in NHWC)
     // precise plans: every GEMM A operand below is a split image [hi | lo] (row width 2K, lo at +K): builder.h gemm(..., a_lo)
-    const int sp = precise ? 1 : 0;
-    const size_t gn = groupnorm(x, w.gn, 1e-6f, false);
+    // split operand classes (builder.h SP_*): s_x = 1 when the class is stored as pairs, p_x = its row-width factor
+    const int s_gnv = spl(SP_GNV), s_lna = spl(SP_LN_ATTN), s_ao = spl(SP_ATTN_OUT), s_lnf = spl(SP_LN_FF), s_inn = spl(SP_FF_INNER);
+    const int p_gnv = 1 + s_gnv, p_lna = 1 + s_lna, p_ao = 1 + s_ao, p_lnf = 1 + s_lnf, p_inn = 1 + s_inn;
+    const size_t gn = groupnorm(x, w.gn, 1e-6f, false, SP_GNV);
     Act tok = new_act(C, x.H, x.W, true);
     {
       Epi e; e.bias = wt(w.pin.b); e.has_bias = true; out_to(e, tok, /*need_shadow=*/w.blocks.empty());
-      gemm("proj_in", ws(gn), C * px, n, w.pin, C, C, 0, e, sp * C);
+      gemm("proj_in", ws(gn), C * p_gnv, n, w.pin, C, C, 0, e, s_gnv * C);
     }
-    untmp(gn, img_bytes(n, C));
+    untmp(gn, img_bytes(n, C, SP_GNV));
     for (size_t bi = 0; bi < w.blocks.size() && !stop; ++bi) {
       const BlockW& bw = w.blocks[bi];
       const std::string bid = id + "-block" + std::to_string(bi);
       const size_t nb = n * C * 2;            // a plain fp16 [n][C] tensor (q, hooks)
-      const size_t nbx = img_bytes(n, C);     // an MFMA A operand [n][C] (split in a precise plan)
+      const size_t nb_lna = img_bytes(n, C, SP_LN_ATTN), nb_ao = img_bytes(n, C, SP_ATTN_OUT), nb_lnf = img_bytes(n, C, SP_LN_FF);
       // --- self attention ---
-      size_t ln = layernorm(tok, bw.ln1);
+      size_t ln = layernorm(tok, bw.ln1, SP_LN_ATTN);
       const size_t qkv = tmp(n * 3 * C * 2);
-      { Epi e; e.out16 = ws(qkv); e.has_o16 = true; e.ldo16 = 3 * C; gemm("attn1_qkv", ws(ln), C * px, n, bw.qkv, 3 * C, C, 0, e, sp * C); }
-      untmp(ln, nbx);
+      { Epi e; e.out16 = ws(qkv); e.has_o16 = true; e.ldo16 = 3 * C; gemm("attn1_qkv", ws(ln), C * p_lna, n, bw.qkv, 3 * C, C, 0, e, s_lna * C); }
+      untmp(ln, nb_lna);
       hook_copy(want(bid + "-self-q", C, x.H, x.W), ws(qkv), 3 * C, n, C);                 // attention_processor.py:3291-3294
       hook_copy(want(bid + "-self-k", C, x.H, x.W), ws(qkv + (size_t)C * 2), 3 * C, n, C);
       hook_copy(want(bid + "-self-v", C, x.H, x.W), ws(qkv + (size_t)2 * C * 2), 3 * C, n, C);
-      size_t ao = tmp(nbx);
+      size_t ao = tmp(nb_ao);
       const int ms = maps ? want_map(bid + "-self-map", heads, S, S) : (dry_map(bid + "-self-map"), -1);
-      attention("attn1", ws(qkv), 3 * C, ws(qkv + (size_t)C * 2), 3 * C, ws(qkv + (size_t)2 * C * 2), 3 * C, ws(ao), C * px, heads,
-                S, S, D, ms, -1, sp * C);
+      attention("attn1", ws(qkv), 3 * C, ws(qkv + (size_t)C * 2), 3 * C, ws(qkv + (size_t)2 * C * 2), 3 * C, ws(ao), C * p_ao, heads,
+                S, S, D, ms, -1, s_ao * C);
       untmp(qkv, n * 3 * C * 2);
       { Epi e; e.bias = wt(bw.o1.b); e.has_bias = true; residual_from(e, tok); out_to(e, tok, false);
-        gemm("attn1_out", ws(ao), C * px, n, bw.o1, C, C, 0, e, sp * C); }
-      untmp(ao, nbx);
+        gemm("attn1_out", ws(ao), C * p_ao, n, bw.o1, C, C, 0, e, s_ao * C); }
+      untmp(ao, nb_ao);
       if (stop) break;
       // --- cross attention ---
-      ln = layernorm(tok, bw.ln2);
+      ln = layernorm(tok, bw.ln2, SP_LN_ATTN);
       // a hooked `cross-q` / `ffn-inner` is a whole contiguous tensor with one producer: the GEMM writes it straight into
       // the caller's hook buffer and the consumer reads it from there (no workspace copy, no hook_store pass)
       const int hq = want(bid + "-cross-q", C, x.H, x.W);
       const size_t q2 = hq >= 0 ? 0 : tmp(nb);
       const Ref q2r = hq >= 0 ? Ref{BUF_HOOK0 + hq, 0} : ws(q2);
-      { Epi e; e.out16 = q2r; e.has_o16 = true; e.ldo16 = C; gemm("attn2_q", ws(ln), C * px, n, bw.q2, C, C, 0, e, sp * C); }
-      untmp(ln, nbx);
+      { Epi e; e.out16 = q2r; e.has_o16 = true; e.ldo16 = C; gemm("attn2_q", ws(ln), C * p_lna, n, bw.q2, C, C, 0, e, s_lna * C); }
+      untmp(ln, nb_lna);
       if (hq >= 0) hook_done();
       // text K/V: precomputed for all blocks by the grouped GEMM at the head of the plan; with one prompt repeated over
       // the batch (reference diffusion_feature.py:272, opts.reserved[0]) there is a single K/V set per block
       const bool shared = opt.reserved[0] != 0;
       const size_t kv = dry ? 0 : kv_bufs[bw.kv_group].first + (size_t)bw.kv_index * kv_bufs[bw.kv_group].second;
-      ao = tmp(nbx);
+      ao = tmp(nb_ao);
       const int mc = maps ? want_map(bid + "-cross-map", heads, S, n_ctx) : (dry_map(bid + "-cross-map"), -1);
-      attention("attn2", q2r, C, ws(kv), 2 * C, ws(kv + (size_t)C * 2), 2 * C, ws(ao), C * px, heads, S, n_ctx, D, mc,
-                shared ? 0 : n_ctx, sp * C);
+      attention("attn2", q2r, C, ws(kv), 2 * C, ws(kv + (size_t)C * 2), 2 * C, ws(ao), C * p_ao, heads, S, n_ctx, D, mc,
+                shared ? 0 : n_ctx, s_ao * C);
       if (hq < 0) untmp(q2, nb);
       { Epi e; e.bias = wt(bw.o2.b); e.has_bias = true; residual_from(e, tok); out_to(e, tok, false);
-        gemm("attn2_out", ws(ao), C * px, n, bw.o2, C, C, 0, e, sp * C); }
-      untmp(ao, nbx);
+        gemm("attn2_out", ws(ao), C * p_ao, n, bw.o2, C, C, 0, e, s_ao * C); }
+      untmp(ao, nb_ao);
       if (stop) break;
       // --- feed forward (GEGLU) ---
-      ln = layernorm(tok, bw.ln3);
+      ln = layernorm(tok, bw.ln3, SP_LN_FF);
       const int hi = want(bid + "-ffn-inner", 4 * C, x.H, x.W);                             // attention.py:1255-1257
-      // (precise plans: the inner tensor is a split pair in workspace; a hooked `ffn-inner` is then a copy of its hi half)
-      const bool direct = hi >= 0 && !precise;
-      const size_t inner_b = img_bytes(n, 4 * C);
+      // (split inner tensor: a pair in workspace; a hooked `ffn-inner` is then a copy of its hi half)
+      const bool direct = hi >= 0 && !s_inn;
+      const size_t inner_b = img_bytes(n, 4 * C, SP_FF_INNER);
       const size_t inner = direct ? 0 : tmp(inner_b);
       const Ref innr = direct ? Ref{BUF_HOOK0 + hi, 0} : ws(inner);
-      { Epi e; e.bias = wt(bw.ff1.b); e.has_bias = true; e.geglu = geglu_group(8 * C); e.out16 = innr; e.has_o16 = true; e.ldo16 = 4 * C * px;
-        e.o16_lo = sp * 4 * C;
-        gemm("ff_geglu", ws(ln), C * px, n, bw.ff1, 8 * C, C, 0, e, sp * C); }
-      untmp(ln, nbx);
+      { Epi e; e.bias = wt(bw.ff1.b); e.has_bias = true; e.geglu = geglu_group(8 * C); e.out16 = innr; e.has_o16 = true; e.ldo16 = 4 * C * p_inn;
+        e.o16_lo = s_inn * 4 * C;
+        gemm("ff_geglu", ws(ln), C * p_lnf, n, bw.ff1, 8 * C, C, 0, e, s_lnf * C); }
+      untmp(ln, nb_lnf);
       if (direct) hook_done();
-      else if (hi >= 0) hook_copy(hi, innr, 4 * C * px, n, 4 * C);
+      else if (hi >= 0) hook_copy(hi, innr, 4 * C * p_inn, n, 4 * C);
       { // the fp16 image of the block output is only needed by the `blockN-out` hook and by proj_out (last block)
         const bool shadow = (bi + 1 == w.blocks.size()) || (!dry && P.requested.count(bid + "-out"));
         Epi e; e.bias = wt(bw.ff2.b); e.has_bias = true; residual_from(e, tok); out_to(e, tok, shadow);
-        gemm("ff_out", innr, 4 * C * px, n, bw.ff2, C, 4 * C, 0, e, sp * 4 * C); }
+        gemm("ff_out", innr, 4 * C * p_inn, n, bw.ff2, C, 4 * C, 0, e, s_inn * 4 * C); }
       if (!direct) untmp(inner, inner_b);
       gather(bid + "-out", tok);                                                           // attention.py:589-590
     }
@@ -343,13 +345,13 @@ struct B : PlanBuilder {   // UNet op program
   }
   void dry_map(const std::string& id) { if (dry) P.dry_ids.push_back(id); }
 
-  size_t layernorm(const Act& x, const NormW& w) {
+  size_t layernorm(const Act& x, const NormW& w, int out_cls) {
     const size_t n = rows(x);
-    const size_t y = tmp(img_bytes(n, x.C));
+    const size_t y = tmp(img_bytes(n, x.C, out_cls));
     const Ref xh = x.h, xf = x.f; const bool hf = x.has_f; const int ld = x.ld, C = x.C;
     const Ref g = wt(w.g), bt = wt(w.b);
-    const int ldy = C * px, y_lo = precise ? C : 0;       // precise plans: split output [hi | lo]
-    if (precise && !hf && !dry) { set_error("precise plan: LayerNorm input without an fp32 master"); bad = true; }
+    const int ldy = C * pxc(out_cls), y_lo = spl(out_cls) ? C : 0;       // split output [hi | lo] when its operand class is split
+    if (spl(out_cls) && !hf && !dry) { set_error("split LayerNorm output without an fp32 master of the input"); bad = true; }
     op("layernorm", 0, [=](const Bind& b, hipStream_t s) {
       return launch_layernorm(hf ? nullptr : (const half_t*)b.p(xh), hf ? (const float*)b.p(xf) : nullptr, hf ? C : ld,
                               (int)n, C, 1e-5f, (const float*)b.p(g), (const float*)b.p(bt), (half_t*)b.ws(y), s, ldy, y_lo);
@@ -433,6 +435,7 @@ struct B : PlanBuilder {   // UNet op program
 
     // ---- concat buffers of the up path: cat([h, skip]) laid out in place --------------------------
     // skip producers in order: conv_in, every down resnet(+vit) output, every downsampler output
+    const int px = pxc(SP_STREAM); const bool sps = spl(SP_STREAM);
     struct Cat { size_t off, bytes; int ch, cs, H, W; };
     std::vector<Cat> cats;        // in up-path consumption order
     {
@@ -442,7 +445,7 @@ struct B : PlanBuilder {   // UNet op program
         const int lv = L - 1 - i, co = boc[lv], cin_skip = boc[std::max(lv - 1, 0)];
         for (int r = 0; r < nl + 1; ++r) {
           Cat c; c.ch = (r == 0) ? prev : co; c.cs = (r == nl) ? cin_skip : co; c.H = hh; c.W = ww;
-          c.bytes = (size_t)Bn * hh * ww * (c.ch + c.cs) * 2 * px;          // precise plans: [h_hi | skip_hi | h_lo | skip_lo]
+          c.bytes = (size_t)Bn * hh * ww * (c.ch + c.cs) * 2 * px;          // split stream images: [h_hi | skip_hi | h_lo | skip_lo]
           c.off = tmp(c.bytes);
           cats.push_back(c);
         }
@@ -453,7 +456,7 @@ struct B : PlanBuilder {   // UNet op program
     int skip_idx = 0;                 // k-th produced skip is consumed by cats[n_skips-1-k]
     auto skip_dst = [&](int C, int hh, int ww) -> Act {
       const Cat& c = cats[n_skips - 1 - skip_idx++];
-      return view_act(ws(c.off + (size_t)c.ch * 2), (c.ch + c.cs) * px, C, hh, ww, true, precise ? c.ch + c.cs : 0);
+      return view_act(ws(c.off + (size_t)c.ch * 2), (c.ch + c.cs) * px, C, hh, ww, true, sps ? c.ch + c.cs : 0);
     };
 
     // ---- conv_in ----
@@ -482,7 +485,7 @@ struct B : PlanBuilder {   // UNet op program
         g.Wt = (const half_t*)b.p(Wr); g.w_bytes = (uint32_t)((size_t)N * 128 * 2);
         fill_epi(g, ee, b);
         return launch_gemm(g, s);
-      }, precise ? gemm_kernel_name(gk) : nullptr);
+      }, gk.o16_lo > 0 ? gemm_kernel_name(gk) : nullptr);
     }
     untmp(lat8, lat8_b);
     gather("unet-after-conv-in", cur);                                                      // :1172-1173
@@ -527,7 +530,7 @@ struct B : PlanBuilder {   // UNet op program
       vit("mid-vit", m.mid_vit, a0, a1);
       free_act(a0);
       // mid output feeds cats[0] channel slice [0, ch)
-      Act a2 = view_act(ws(cats[0].off), (cats[0].ch + cats[0].cs) * px, boc[L - 1], hh, ww, false, precise ? cats[0].ch + cats[0].cs : 0);
+      Act a2 = view_act(ws(cats[0].off), (cats[0].ch + cats[0].cs) * px, boc[L - 1], hh, ww, false, sps ? cats[0].ch + cats[0].cs : 0);
       resnet("mid-repeat1", m.mid_res1, a1, a2);
       free_act(a1);
       cur = a2;
@@ -540,14 +543,14 @@ struct B : PlanBuilder {   // UNet op program
       for (int r = 0; r < nl + 1 && !stop; ++r, ++ci) {
         const std::string id = "up-level" + std::to_string(i) + "-repeat" + std::to_string(r);
         const Cat& c = cats[ci];
-        Act cat = view_act(ws(c.off), (c.ch + c.cs) * px, c.ch + c.cs, c.H, c.W, false, precise ? c.ch + c.cs : 0);   // torch.cat([h, skip], 1)
+        Act cat = view_act(ws(c.off), (c.ch + c.cs) * px, c.ch + c.cs, c.H, c.W, false, sps ? c.ch + c.cs : 0);   // torch.cat([h, skip], 1)
         // destination: the h-slice of the next concat buffer, or a fresh tensor at the end of a level
         const bool last_in_level = (r == nl);
         const bool attn = a.has_attn[lv];
         auto make_dst = [&](bool master) -> Act {
           if (!last_in_level) {
             const Cat& nc = cats[ci + 1];
-            return view_act(ws(nc.off), (nc.ch + nc.cs) * px, boc[lv], c.H, c.W, master, precise ? nc.ch + nc.cs : 0);
+            return view_act(ws(nc.off), (nc.ch + nc.cs) * px, boc[lv], c.H, c.W, master, sps ? nc.ch + nc.cs : 0);
           }
           return new_act(boc[lv], c.H, c.W, master);
         };
@@ -567,7 +570,7 @@ struct B : PlanBuilder {   // UNet op program
       }
       if (lw.has_sampler && !stop) {
         const Cat& nc = cats[ci];
-        Act nxt = view_act(ws(nc.off), (nc.ch + nc.cs) * px, boc[lv], cur.H * 2, cur.W * 2, false, precise ? nc.ch + nc.cs : 0);
+        Act nxt = view_act(ws(nc.off), (nc.ch + nc.cs) * px, boc[lv], cur.H * 2, cur.W * 2, false, sps ? nc.ch + nc.cs : 0);
         Epi e; e.bias = wt(lw.sampler.b); e.has_bias = true; out_to(e, nxt);
         conv3("upsample", cur.h, cur.ld, cur.C, cur.H, cur.W, 1, true, lw.sampler, e, cur.lo);   // upsampling.py:176-193
         free_act(cur);
@@ -578,12 +581,12 @@ struct B : PlanBuilder {   // UNet op program
     // ---- out ----
     if (!stop) {
       const size_t n = rows(cur);
-      const size_t no = groupnorm(cur, m.norm_out, 1e-5f, true);                             // :1304-1306
+      const size_t no = groupnorm(cur, m.norm_out, 1e-5f, true, SP_OUT);                     // :1304-1306
       Epi e; e.bias = wt(m.conv_out.b); e.has_bias = true; e.bn = 16;
       e.out16 = Ref{BUF_NOISE, 0}; e.has_o16 = true; e.ldo16 = a.out_channels;
       P.writes_noise = true;
-      conv3("conv_out", ws(no), cur.C * px, cur.C, cur.H, cur.W, 1, false, m.conv_out, e, precise ? cur.C : 0);
-      untmp(no, img_bytes(n, cur.C));
+      conv3("conv_out", ws(no), cur.C * pxc(SP_OUT), cur.C, cur.H, cur.W, 1, false, m.conv_out, e, spl(SP_OUT) ? cur.C : 0);
+      untmp(no, img_bytes(n, cur.C, SP_OUT));
       const int slot = want("unet-out", a.out_channels, cur.H, cur.W);                       // :1309-1310
       hook_copy(slot, Ref{BUF_NOISE, 0}, a.out_channels, n, a.out_channels);
       free_act(cur);

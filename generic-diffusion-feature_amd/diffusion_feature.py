@@ -33,6 +33,9 @@ class FeatureExtractor(nn.Module):
                  attention=None,
                  train_unet=False,
                  external_model=None,
+                 precise=None,     # native extension: operand plan of the UNet versions — None = 'auto' (the cheapest plan level that keeps
+                                   # every REQUESTED layer within 1e-3 of the fp32 reference: plain fp16 operands / the selective split /
+                                   # the full split), False = plain, True = full split, 'selective', or a class list ('stream,attn_out')
                  ):
         super().__init__()
         if control:
@@ -55,6 +58,16 @@ class FeatureExtractor(nn.Module):
             # transformer's 8-channel output (learned sigma) against 4-channel latents (:466-480) — there is no working behaviour to match
             raise NotImplementedError("'vae-out' exists for the UNet versions ('1-5', '2-1', 'xl', 'pgv2') only")
 
+        if self.store_vae_output:
+            # built HERE, on every rank: under a data-parallel launch its weight fill is a collective (components/dist.py), and a rank
+            # whose image shard is empty never reaches extract()
+            from components.models import native_vae_decoder
+            native_vae_decoder(pipe, device)
+        if precise is not None:
+            if hasattr(pipe.unet, "set_precise"):
+                pipe.unet.set_precise(precise)
+            elif precise not in (False, 0, "auto"):
+                raise NotImplementedError("split-operand plans exist for the UNet versions ('1-5', '2-1', 'xl', 'pgv2') only")
         self.pipe = pipe
         self.control_pipe = None
         self.attention_store = None

@@ -93,7 +93,9 @@ typedef struct gdf_plan_opts {
                           contraction and every GroupNorm input is kept as a split fp16 pair hi + lo (22 mantissa bits) and
                           multiplied as [hi | lo] x [W | W] (K doubled, weights read twice) — removes the fp16-operand rounding
                           that bounds the default plans at ~1.0-1.3e-3 on `ffn-inner` / `unet-out`;
-                          about twice the GEMM / conv time.  Attention internals (q, k, v, P) stay fp16. */
+                          about twice the GEMM / conv time.  Attention internals (q, k, v, P) stay fp16.
+                          reserved[2] = cus: the plan will run on a stream restricted to this many CUs (gdf_stream_create_cu_mask):
+                          tile selection, persistent grids and the XCD super-block order are sized for that partition. 0 = whole chip. */
 } gdf_plan_opts;
 
 int gdf_plan_create(gdf_model* m, int batch, int lat_h, int lat_w, int n_ctx,
@@ -160,6 +162,19 @@ int gdf_plan_read_timing(gdf_plan* p, double* ms_total, long* launches, double* 
  * inside a replayed graph (766 of them: -2.4 % on the SDXL step), a stride of 8 keeps the measurement live and inside the timed
  * region at ~0.3 %.  gdf_plan_read_timing then returns the sums over the SAMPLED launches.  Call before gdf_plan_set_timing. */
 int gdf_plan_set_timing_stride(gdf_plan* p, int stride);
+
+/* ---- CU partitions: two or more forwards side by side on disjoint sets of compute units -----------------------------------
+ * A GEMM / conv workgroup of this library owns its CU's whole register file, and all workgroups of a launch reach their HBM-bound
+ * epilogues together, so on ONE stream MFMA-bound and HBM-bound phases alternate and never overlap.  Two
+ * streams restricted to disjoint halves of the chip (hipExtStreamCreateWithCUMask) each run a half-batch plan built with
+ * gdf_plan_opts.reserved[2] = CUs of the partition; their phases drift apart and one chain's epilogues / norm passes meet the other
+ * chain's main loops.  mask: bit i of word i/32 enables CU i of the device's CU numbering; n_words = ceil(CUs / 32). */
+int gdf_stream_create_cu_mask(const uint32_t* mask, int n_words, void** stream);
+int gdf_stream_destroy(void* stream);
+int gdf_device_cu_count(void);
+/* Diagnostics: launches n_blocks single-wave workgroups on `stream`; workgroup b writes {XCC_ID, HW_ID} of the CU it ran on to
+ * dev_out[2b], dev_out[2b+1] and then idles for ~spin * 64 * 64 cycles, so the records show which physical CUs the stream uses. */
+int gdf_cu_census(uint32_t* dev_out, int n_blocks, int spin, void* stream);
 
 #ifdef __cplusplus
 }

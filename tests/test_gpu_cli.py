@@ -58,7 +58,10 @@ def test_cli_precise_flag(tmp_path, monkeypatch):
             "--input_dir", str(tmp_path / "imgs" / "*.png"), "--prompt_file", str(tmp_path / "prompt.txt"), "--use_original_filename"]
     cli.main(base + ["--output_dir", str(tmp_path / "d")])
     cli.main(base + ["--output_dir", str(tmp_path / "p"), "--precise"])
-    monkeypatch.setenv("GDF_PRECISE", "0")
+    assert os.environ.get("GDF_PRECISE") == "0"            # the flag travels as a constructor argument, not through the environment
+    with pytest.raises(SystemExit):                        # the DiT versions have no split-operand plans: rejected, not silently ignored
+        cli.main(["--layer", str(tmp_path / "layers.json"), "--version", "flux", "--input_dir", "x", "--prompt_file", str(tmp_path / "prompt.txt"),
+                  "--output_dir", str(tmp_path / "f"), "--precise"])
     for k in layers:
         a = np.load(tmp_path / "d" / k / "a.npy").astype(np.float32); b = np.load(tmp_path / "p" / k / "a.npy").astype(np.float32)
         e = np.linalg.norm(a - b) / np.linalg.norm(b)

@@ -344,3 +344,42 @@ def test_feature_extractor_precise_env(monkeypatch):
         assert a.shape == b.shape and a.dtype == b.dtype == torch.float16
         e = rel_l2(a, b)
         assert 0.0 < e < 2.5e-3, (k, e)              # different arithmetic (not bit-equal), same function
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("base,lat,batch", [("xl", 16, 2), ("1-5", 16, 1)])
+def test_split_operand_classes_each_and_selective(base, lat, batch):
+    """Round 4: the split is per operand CLASS (include/gdf.h reserved[1] = mask << 8; components/native.py SPLIT_CLASSES).  Every single class
+    builds and runs (a plan mixes plain and split tensors: each producer / consumer pair must agree on the row layout), stays within the
+    default plan's tolerance, the SELECTIVE preset is measurably closer to the oracle than the default plan, and mask 255 == precise=True."""
+    from components.native import SPLIT_CLASSES, SPLIT_SELECTIVE, SPLIT_ALL, split_mask
+    arch = R.tiny_arch(base)
+    P = R.synth_params(arch, seed=0)
+    I = R.synth_inputs(arch, batch, lat, seed=1)
+    ref = oracle_run(arch, P, I)
+    ids = [k for k in ref.keys() if not k.endswith("-map")]
+    _, dflt = run_native(native(arch, P), I, ids)
+    e_d = {k: rel_l2(dflt[k], ref[k]) for k in ids}
+    med = lambda e: sorted(e.values())[len(e) // 2]
+    for name, bit in SPLIT_CLASSES.items():
+        u = native(arch, P, precise=name)
+        assert u.split == bit and not u.precise
+        _, h = run_native(u, I, ids)
+        assert list(h.keys()) == ids
+        e = {k: rel_l2(h[k], ref[k]) for k in ids}
+        bad = {k: v for k, v in e.items() if not v < TOL}
+        assert not bad, (name, sorted(bad.items(), key=lambda kv: -kv[1])[:5])
+        assert med(e) < 1.1 * med(e_d), (name, med(e), med(e_d))
+        print(f"[{base}] split class {name:9s}: median {med(e):.2e} worst {max(e.values()):.2e}   (default {med(e_d):.2e} / {max(e_d.values()):.2e})")
+    us = native(arch, P, precise="selective")
+    assert us.split == SPLIT_SELECTIVE == split_mask("selective")
+    _, hs = run_native(us, I, ids)
+    e_s = {k: rel_l2(hs[k], ref[k]) for k in ids}
+    print(f"[{base}] selective: median {med(e_s):.2e} worst {max(e_s.values()):.2e}")
+    assert med(e_s) < 0.85 * med(e_d) and max(e_s.values()) < max(e_d.values())
+    ua, up = native(arch, P, precise=SPLIT_ALL), native(arch, P, precise=True)
+    assert ua.precise and up.precise
+    _, ha = run_native(ua, I, ids)
+    _, hp = run_native(up, I, ids)
+    for k in ids:
+        assert torch.equal(ha[k], hp[k]), k

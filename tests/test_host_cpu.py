@@ -356,3 +356,44 @@ def test_every_layer_config_of_the_reference_is_served():
         for n in names:
             assert json.load(open(os.path.join(ref_dir, n))) == json.load(open(os.path.join(cdir, n))), n
             assert list(json.load(open(os.path.join(ref_dir, n)))) == list(json.load(open(os.path.join(cdir, n)))), n     # key order too
+
+
+def test_operand_plan_selection_table_and_masks():
+    """Round 4: the operand plan is chosen per hook set (components/native.py choose_split) from the committed CPU-emulation table
+    (components/operand_error_table.json, tools/operand_subsets.py): plain fp16 operands when every requested hook's emulated error is
+    <= 9.5e-4, else the architecture's selective preset, else the full split.  Every shipped layer config lands on a level whose emulated
+    worst hook is within the bound; the BASELINE headline hooks stay on the plain plan."""
+    import glob
+    import json
+    from components import native as N
+    assert N.split_mask(None) == 0 and N.split_mask(False) == 0 and N.split_mask(True) == N.SPLIT_ALL == N.split_mask("precise") == 255
+    assert N.split_mask("selective") == N.SPLIT_SELECTIVE == N.split_mask("stream,gnv,attn_out,out") == N.split_mask(139)
+    with pytest.raises(ValueError):
+        N.split_mask("stream,bogus")
+    tab = json.load(open(os.path.join(os.path.dirname(N.__file__), "operand_error_table.json")))
+    import bench
+    for ver, fam in (("xl", "xl"), ("pgv2", "xl"), ("1-5", "1-5"), ("2-1", "1-5")):
+        assert N.arch_family(N.ARCH_CONFIGS[ver]) == fam
+    assert N.choose_split(N.ARCH_CONFIGS["xl"], bench.PRACTICAL["xl"]) == 0               # the headline runs plain fp16 operands
+    assert N.choose_split(N.ARCH_CONFIGS["1-5"], bench.PRACTICAL["1-5"]) == 0
+    worst_xl = max(tab["xl"]["hooks"], key=lambda h: tab["xl"]["hooks"][h][0])
+    assert worst_xl.endswith("ffn-inner") and tab["xl"]["hooks"][worst_xl][0] > 1e-3 > tab["xl"]["hooks"][worst_xl][1]
+    assert N.choose_split(N.ARCH_CONFIGS["xl"], [worst_xl]) == N.SELECTIVE_BY_ARCH["xl"]
+    assert N.choose_split(N.ARCH_CONFIGS["xl"], bench.PRACTICAL["xl"] + [worst_xl]) == N.SELECTIVE_BY_ARCH["xl"]
+    assert N.choose_split(N.ARCH_CONFIGS["xl"], ["unet-out"]) == N.SELECTIVE_BY_ARCH["xl"]
+    assert N.choose_split(N.ARCH_CONFIGS["1-5"], ["down-level0-repeat0-vit-block0-self-map"]) == N.SELECTIVE_BY_ARCH["1-5"]
+    assert N.choose_split(N.ARCH_CONFIGS["xl"], []) == 0
+    tiny = dict(N.ARCH_CONFIGS["xl"], block_out_channels=(64, 128, 256))                   # unknown architecture: kind rules
+    assert N.arch_family(tiny) is None and N.choose_split(tiny, ["mid-vit-block0-ffn-inner"]) == N.SPLIT_SELECTIVE
+    assert N.choose_split(tiny, ["unet-in", "unet-after-conv-in"]) == 0
+    cfg_dir = os.path.join(os.path.dirname(os.path.dirname(N.__file__)), "configs")
+    for f in sorted(glob.glob(os.path.join(cfg_dir, "*.json"))):
+        ids = [k for k, v in json.load(open(f)).items() if v]
+        ver = "xl" if ("_xl_" in f or "_pg_" in f) else "1-5"
+        m = N.choose_split(N.ARCH_CONFIGS[ver], ids)
+        assert m in (0, N.SELECTIVE_BY_ARCH[ver]), f                                       # no shipped config needs the full split
+        col = 0 if m == 0 else 1
+        worst = max((tab[ver]["hooks"][i][col] for i in ids if i in tab[ver]["hooks"]), default=0.0)
+        assert worst <= N.AUTO_BOUND, (f, worst)
+        if any(i.endswith("-map") or i == "unet-out" for i in ids):
+            assert m != 0, f

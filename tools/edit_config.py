@@ -3,7 +3,7 @@
 Same job as the reference's feature/configs/edit_config.py (which hard-codes its file names and substrings), as a command line:
 
     python tools/edit_config.py generic-diffusion-feature_amd/configs/config_xl_full.json out.json --off down mid
-    python tools/edit_config.py in.json out.json --only up-level1 --off -map          # keep up-level1 ids, without attention maps
+    python tools/edit_config.py in.json out.json --only up-level1 --off self-map cross-map   # keep up-level1 ids, without attention maps
 """
 import argparse
 import json
