@@ -250,8 +250,10 @@ def main():
     ap.add_argument("--flux-dtype", default="bfloat16", choices=("bfloat16", "float16"), help="--version flux only")
     ap.add_argument("--fp16-stream", action="store_true", help="disable the fp32 master of the residual stream")
     ap.add_argument("--early-exit", action="store_true", help="opt-in: stop after the last requested hook")
-    ap.add_argument("--precise", action="store_true",
-                    help="opt-in split-operand plans (fp16 hi + lo activation operands, K doubled): every hook within 1e-3 of the reference")
+    ap.add_argument("--precise", nargs="?", const="precise", default=None,
+                    help="operand plan of the measured step: absent = 'auto' (chosen from the requested hooks: plain fp16 operands for the headline's "
+                         "four); --precise = every operand class split (fp16 hi + lo, K doubled); --precise selective | plain | stream,attn_out ...")
+    ap.add_argument("--no-extras", action="store_true", help="skip the plans / other_configs / e2e legs (N = 1 only run them)")
     ap.add_argument("--profile-ops", action="store_true", help="print a per-op time table (extra synchronising pass)")
     args = ap.parse_args()
 
@@ -296,7 +298,8 @@ def main():
     B = args.batch
 
     # ---- weights: generated on rank 0 in HBM (already in the kernels' layout), the arena broadcast once over RCCL ----
-    unet = NativeUNet(cfg, device=dev, stream_fp32=not args.fp16_stream, early_exit=args.early_exit, precise=args.precise)
+    unet = NativeUNet(cfg, device=dev, stream_fp32=not args.fp16_stream, early_exit=args.early_exit,
+                      precise=None if args.precise is None else (False if args.precise == "plain" else args.precise))
     t0 = time.time()
     from components import dist as D
     if rank == 0:
@@ -361,6 +364,11 @@ def main():
     def barrier():
         if world > 1:
             dist.barrier()
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_extra as BX
+    sampler = BX.PowerSampler(local) if rank == 0 else None
+    if sampler is not None:
+        sampler.start()
     barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -368,6 +376,7 @@ def main():
         out = step()
     torch.cuda.synchronize(); barrier()
     dt = time.perf_counter() - t0
+    power = sampler.finish(t0, t0 + dt) if sampler is not None else None
     st_after = plan.graph_stats()
     cap_in_region = st_after[0] - st_before[0]
     launches_in_region = st_after[1] - st_before[1]
@@ -396,11 +405,14 @@ def main():
         # HBM bytes/launch of the dominant kernel from the rocprofv3 --pmc passes of THIS command (tools/final_profile.sh ->
         # profiles/pmc_traffic_current.json).  The file is stamped with a hash of the kernel sources it was measured on: a
         # stamp that does not match the sources being benchmarked means the number is stale, and `traffic` is null.
-        traffic = None
+        traffic, traffic_stale = None, None
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_current.json")))
-            if tj.get("_meta", {}).get("csrc_sha") == csrc_sha() and args.version == "xl" and B == 16 and dominant in tj:
-                traffic = tj[dominant]["hbm_bytes_per_launch"]
+            if args.version == "xl" and B == 16 and dominant in tj:
+                if tj.get("_meta", {}).get("csrc_sha") == csrc_sha():
+                    traffic, traffic_stale = tj[dominant]["hbm_bytes_per_launch"], False
+                else:                                              # measured on other kernel sources than the ones benchmarked: say so
+                    traffic_stale = True
         except Exception:
             traffic = None
         achieved = (fl_tot.value / 1e12) / (ms_tot.value / 1e3) if ms_tot.value > 0 else 0.0
@@ -426,8 +438,9 @@ def main():
                                    + (" with early exit" if args.early_exit else ""),
                        "global_batch": world * B, "parallelism": f"dp{world} (batch sharded, weights broadcast once)",
                        "residual_stream": "fp16" if args.fp16_stream else "fp32 master + fp16 shadow",
-                       "operands": ("PRECISE plan: fp16 hi + lo split activation operands, contraction over [hi | lo] x [W | W] (2x MFMA work; "
-                                    "TFLOP/s figures count algorithmic FLOPs)" if args.precise else "fp16 activations x fp16 weights (default plan)"),
+                       "operands": (f"split-operand plan, class mask {unet.last_split} (fp16 hi + lo pairs for those operand classes, contraction over "
+                                    "[hi | lo] x [W | W]; TFLOP/s figures count algorithmic FLOPs)" if unet.last_split else
+                                    "fp16 activations x fp16 weights (the plan level 'auto' selects for these hooks: every one within 1e-3)"),
                        "tflop_per_image": round(fl_img / 1e12, 3),
                        # EXECUTED FLOPs: with one prompt repeated over the batch (reference diffusion_feature.py:272) the text K/V
                        # projections run once per batch (shared_ctx), not once per image
@@ -436,7 +449,7 @@ def main():
                        "weights_init_s": round(t_init, 1), "weights_broadcast_s": round(t_bcast, 3),
                        "per_rank_ms_per_step": {"min": round(per_rank_ms[0], 3), "max": round(per_rank_ms[-1], 3)}},
             "roofline": {"bound": "mfma", "kernel": dominant, "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                         "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_stale": traffic_stale,
                          "frac_of_random_operand_mfma_ceiling": round(achieved / MFMA_RANDOM_DATA_CEILING_TFLOPS, 4),
                          "random_operand_mfma_ceiling": MFMA_RANDOM_DATA_CEILING_TFLOPS,
                          "launches": int(launches.value), "avg_launch_ms": round(ms_tot.value / max(1, launches.value), 4),
@@ -531,6 +544,20 @@ def main():
                                "host_cpu_ms_per_step": round(cpu_graph, 2), "eager_host_cpu_ms_per_step": round(cpu_eager, 2),
                                "captures_total": cap1, "captures_in_timed_steps": cap1 - cap0,
                                "graph_launches": lau1, "ops_per_step": lib.gdf_plan_num_ops(plan.handle)}
+        if power:
+            res["power"] = power
+        if world == 1 and not args.no_extras and args.precise is None and not args.early_exit and not args.fp16_stream:
+            try:
+                res["plans"] = BX.plans_block(unet, step, B, res["hipgraph"]["value"])
+            except Exception as e:
+                res["plans"] = {"error": repr(e)[:300]}
+            unet._plans.clear(); torch.cuda.empty_cache()
+            if args.version == "xl" and B == 16 and not args.img:
+                try:
+                    res["e2e"] = BX.e2e_block(dev, args.version, B, img, ids)
+                except Exception as e:
+                    res["e2e"] = {"error": repr(e)[:300]}
+                res["other_configs"] = BX.other_configs_block(dev, unet_flops_per_image, PRACTICAL)
         if args.profile_ops:
             rows = {}
             for name, ms, f_, _k in prof:

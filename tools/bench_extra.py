@@ -1,0 +1,244 @@
+"""Extra legs of bench.py's JSON line (N = 1, after the headline's timed region; each is bounded to a few seconds):
+
+  plans           the headline step under each operand-plan level (plain = what the headline's four hooks select / selective / precise)
+  other_configs   the other BASELINE.json configs under the driver's eyes: SD1.5 512^2 B = 32 (practical hooks and the full 197-id set of
+                  config C2, auto-selected plan), Flux.1-dev C5 bf16 B = 8
+  e2e             the product call FeatureExtractor.extract(image_type='tensors') on synthetic 1024^2 images: VAE encode + noise-add + UNet +
+                  hooks (reference feature/diffusion_feature.py:358-380, :405-465), and the CLI's D2H + .npy stage behind it
+                  (reference extract_feature.py:113-148)
+  power           package power / shader clock over the timed region (hwmon): the step runs at the 1400-W cap
+"""
+import glob
+import os
+import shutil
+import tempfile
+import threading
+import time
+
+import torch
+
+
+# ---- power / clock sampling (sysfs hwmon of the card behind HIP device `dev`) ------------------------------------------------------
+def _bus_id(dev_index):
+    try:
+        p = torch.cuda.get_device_properties(dev_index)
+        return "%04x:%02x:%02x" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
+    except Exception:
+        return None
+
+
+def _hwmon(dev_index):
+    bus = _bus_id(dev_index)
+    for h in glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"):
+        devp = os.path.realpath(os.path.dirname(os.path.dirname(h))).lower()
+        if bus and bus.lower() not in devp:
+            continue
+        if os.path.exists(os.path.join(h, "power1_input")):
+            return h
+    return None
+
+
+def _rd(p):
+    try:
+        with open(p) as f:
+            return int(f.read().strip())
+    except Exception:
+        return None
+
+
+class PowerSampler(threading.Thread):
+    def __init__(self, dev_index=0, dt=0.02):
+        super().__init__(daemon=True)
+        self.h = _hwmon(dev_index)
+        self.dt = dt
+        self.rows = []
+        self.stop_flag = False
+
+    def run(self):
+        if not self.h:
+            return
+        pw, fq = os.path.join(self.h, "power1_input"), os.path.join(self.h, "freq1_input")
+        while not self.stop_flag:
+            self.rows.append((time.perf_counter(), _rd(pw), _rd(fq)))
+            time.sleep(self.dt)
+
+    def finish(self, t0, t1):
+        self.stop_flag = True
+        if self.is_alive():
+            self.join()
+        if not self.h:
+            return None
+        rows = [r for r in self.rows if t0 + 0.25 * (t1 - t0) <= r[0] <= t1 and r[1] is not None]   # the sensor averages over ~0.5 s
+        if not rows:
+            return None
+        cap = _rd(os.path.join(self.h, "power1_cap"))
+        w = [r[1] / 1e6 for r in rows]
+        f = [r[2] / 1e6 for r in rows if r[2]]
+        return {"watts_avg": round(sum(w) / len(w), 1), "watts_max": round(max(w), 1), "cap_watts": round(cap / 1e6, 1) if cap else None,
+                "sclk_mhz_avg": round(sum(f) / len(f)) if f else None, "sclk_mhz_max": 2400, "samples": len(rows),
+                "note": "hwmon power1_input / freq1_input of this card over the last 75 % of the timed region: every MFMA kernel of the step runs at "
+                        "the package power cap with the shader clock throttled (profiles/r04_power_per_kernel.txt), so images/s follow ENERGY per "
+                        "image, not cycles"}
+
+
+def _time_steps(step, steps, warm):
+    for _ in range(warm):
+        o = step(); del o
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        o = step(); del o
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0
+
+
+# ---- plan levels ----------------------------------------------------------------------------------------------------------------
+def plans_block(unet, step, B, headline_ips, steps=4):
+    """the SAME step (same four hooks) under each operand-plan level: what a hook set that selects that level costs"""
+    from components.native import SELECTIVE_BY_ARCH, arch_family, SPLIT_SELECTIVE
+    out = {"auto_for_these_hooks": {"split_mask": unet.last_split, "images_per_s": round(headline_ips, 2)}}
+    sel = SELECTIVE_BY_ARCH.get(arch_family(unet.cfg), SPLIT_SELECTIVE)
+    for name, spec in (("selective", sel), ("precise", True)):
+        unet.set_precise(spec)
+        dt = _time_steps(step, steps, 3)
+        out[name] = {"split_mask": unet.last_split, "images_per_s": round(B * steps / dt, 2), "ms_per_step": round(1e3 * dt / steps, 2)}
+    unet.set_precise("auto")
+    out["note"] = ("operand plan levels (include/gdf.h reserved[1]): auto = the cheapest level that keeps every REQUESTED hook within 1e-3 of the fp32 "
+                   "reference (components/native.py choose_split: plain fp16 operands for the headline's four hooks); selective = split stream "
+                   "images + proj_in operand + attention outputs + conv_out operand (every hook kind <= 8.2e-4 at full size, "
+                   "tests/test_gpu_fullsize.py); precise = every operand class split (<= 4.9e-4)")
+    return out
+
+
+# ---- other BASELINE configs ---------------------------------------------------------------------------------------------------------
+def _unet_inputs(cfg, B, lat, img, dev, seed=7):
+    g = torch.Generator(device=dev).manual_seed(seed)
+    x = torch.randn(B, 4, lat, lat, generator=g, device=dev).half()
+    ctx = torch.randn(1, 77, cfg["cross_attention_dim"], generator=g, device=dev).half().expand(B, -1, -1).contiguous()
+    t = torch.full((B,), 100.0, device=dev)
+    txt = tid = None
+    if cfg["addition_embed_text_time"]:
+        pooled = cfg["add_in_dim"] - 6 * cfg["addition_time_embed_dim"]
+        txt = torch.randn(1, pooled, generator=g, device=dev).half().expand(B, -1).contiguous()
+        tid = torch.tensor([[img, img, 0, 0, img, img]], dtype=torch.float32, device=dev).repeat(B, 1)
+    return x, t, ctx, txt, tid
+
+
+def other_configs_block(dev, flops_fn, practical, budget_s=45.0):
+    from components.native import NativeUNet, ARCH_CONFIGS, FLUX_CONFIGS, NativeFluxTransformer
+    out = {}
+    t_start = time.time()
+    # ---- BASELINE configs[1]: SD1.5 512^2, batch 32, t = 100: practical hooks and the FULL 197-id layer set (incl. 32 attention maps) ----
+    try:
+        cfg = ARCH_CONFIGS["1-5"]
+        net = NativeUNet(cfg, device=dev).init_synthetic(seed=0)
+        B, lat = 32, 64
+        ins = _unet_inputs(cfg, B, lat, 512, dev)
+        fl_img = sum(flops_fn(cfg, lat).values())
+        for tag, ids, steps in (("sd15_512_b32_practical_hooks", practical["1-5"], 5), ("sd15_512_b32_full_layer_set_config_c2", net.hook_names(), 2)):
+            step = lambda: net.forward_raw(*ins, hook_ids=ids, shared_ctx=True)
+            dt = _time_steps(step, steps, 3)
+            o = step(); hb = sum(v.numel() * 2 for v in o[1].values()); del o
+            out[tag] = {"images_per_s": round(B * steps / dt, 1), "ms_per_step": round(1e3 * dt / steps, 2), "hooks": len(ids),
+                        "hook_gb_per_step": round(hb / 1e9, 2), "split_mask_auto": net.last_split,
+                        "model_tflops_per_s": round(B * steps / dt * fl_img / 1e12, 1), "steps": steps}
+            net._plans.clear(); torch.cuda.empty_cache()
+        del net
+        torch.cuda.empty_cache()
+    except Exception as e:                                     # an extra leg must never cost the headline line
+        out["sd15_error"] = repr(e)[:300]
+    # ---- BASELINE configs[4]: Flux.1-dev MMDiT 1024^2, bf16, batch 8 (tools/bench_flux.py is the full per-model bench) ----
+    if time.time() - t_start < budget_s:
+        try:
+            from oracle.flux_ref import flops_per_image, latent_image_ids, ARCH_FLUX_DEV      # FLOP model + id helper only (not measured)
+            cfg = dict(FLUX_CONFIGS["flux"])
+            net = NativeFluxTransformer(cfg, device=dev, compute_dtype="bfloat16")
+            t0 = time.time(); net.init_synthetic(seed=0); torch.cuda.synchronize(); t_w = time.time() - t0
+            B, grid, T = 8, 64, 512
+            S = grid * grid
+            g = torch.Generator(device=dev).manual_seed(1)
+            x = torch.randn(B, S, cfg["in_channels"], generator=g, device=dev).half()
+            enc = torch.randn(1, T, cfg["joint_attention_dim"], generator=g, device=dev).half().expand(B, -1, -1).contiguous()
+            pooled = torch.randn(1, cfg["pooled_projection_dim"], generator=g, device=dev).half().expand(B, -1).contiguous()
+            ts = torch.full((B,), 0.1, device=dev); gd = torch.full((B,), 1.0, device=dev)
+            img_ids = latent_image_ids(grid, grid).to(dev); txt_ids = torch.zeros(T, 3, device=dev)
+            nl = cfg["num_layers"] + cfg["num_single_layers"]
+            picks = sorted({min(nl - 1, max(0, int(nl * f))) for f in (0.2, 0.4, 0.6, 0.8)})
+            ids = [f"vit-block{i}-out" for i in picks] + [f"vit-block{i}-q" for i in picks]
+            step = lambda: net.forward_raw(x, enc, pooled, ts, img_ids, txt_ids, guidance=gd, hook_ids=ids, grid=(grid, grid))
+            steps = 2
+            dt = _time_steps(step, steps, 2)
+            fl_img = flops_per_image(dict(ARCH_FLUX_DEV), S, T)
+            out["flux_dev_1024_bf16_b8_config_c5"] = {"images_per_s": round(B * steps / dt, 2), "ms_per_step": round(1e3 * dt / steps, 1), "hooks": len(ids),
+                                                      "model_tflops_per_s": round(B * steps / dt * fl_img / 1e12, 1), "weights_init_s": round(t_w, 1),
+                                                      "steps": steps, "dtype": "bf16"}
+            del net
+            torch.cuda.empty_cache()
+        except Exception as e:
+            out["flux_error"] = repr(e)[:300]
+    else:
+        out["flux_dev_1024_bf16_b8_config_c5"] = "skipped: budget"
+    out["seconds"] = round(time.time() - t_start, 1)
+    return out
+
+
+# ---- end to end: images -> hooks (-> .npy) ---------------------------------------------------------------------------------------------
+def e2e_block(dev, version, B, img, practical_ids, steps=4):
+    """FeatureExtractor.extract(image_type='tensors') on synthetic images resident in HBM: VAE encode + sample + noise-add, scheduler
+    scaling, UNet forward, hooks — the whole product call; then the same loop with the CLI's D2H + np.save stage one batch behind."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    import diffusion_feature
+    old = os.environ.get("GDF_SYNTHETIC_WEIGHTS")
+    os.environ["GDF_SYNTHETIC_WEIGHTS"] = "1"
+    try:
+        df = diffusion_feature.FeatureExtractor({k: True for k in practical_ids}, version, device=str(dev), img_size=img)
+    finally:
+        if old is None:
+            os.environ.pop("GDF_SYNTHETIC_WEIGHTS", None)
+        else:
+            os.environ["GDF_SYNTHETIC_WEIGHTS"] = old
+    prompts = df.encode_prompt("a photo of a cat")
+    g = torch.Generator(device=dev).manual_seed(3)
+    imgs = (torch.rand(B, 3, img, img, generator=g, device=dev) * 2 - 1).half()
+    step = lambda: df.extract(prompts, B, imgs, image_type="tensors", t=100)
+    with torch.no_grad():
+        dt = _time_steps(step, steps, 3)
+        out = {"extract_images_per_s": round(B * steps / dt, 2), "extract_ms_per_batch": round(1e3 * dt / steps, 2),
+               "stages": "VAE encode (AutoencoderKL, libgdf) + sample + noise-add -> scale_model_input -> UNet forward + hooks; image tensors resident in HBM"}
+        # the VAE stage alone (same call the extractor makes)
+        lt = torch.full((B,), 100, device=dev)
+        enc = lambda: df.pipe.prepare_latents(imgs, lt, 1, B, torch.float16, dev)
+        dtv = _time_steps(enc, steps, 2)
+        out["vae_encode_ms_per_batch"] = round(1e3 * dtv / steps, 2)
+        out["vae_encode_images_per_s"] = round(B * steps / dtv, 2)
+        # + the CLI's output stage: fp16 D2H into pinned memory on a side stream + np.save per (layer, image), one batch behind the GPU
+        import argparse
+        import extract_feature as cli
+        tmp = tempfile.mkdtemp(prefix="gdf_e2e_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+        try:
+            wargs = argparse.Namespace(output_dir=tmp, aggregate_output=False, sample_name_first=False)
+            w = cli.HostWriter(wargs)
+            def step_w(i=[0]):
+                feats = step()
+                w.submit(feats, [f"img{i[0]}_{j}" for j in range(B)])
+                i[0] += 1
+            for _ in range(2):
+                step_w()
+            w.flush(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step_w()
+            w.flush(); torch.cuda.synchronize()
+            dtw = time.perf_counter() - t0
+            nbytes = sum(os.path.getsize(os.path.join(dp, f)) for dp, _, fs in os.walk(tmp) for f in fs)
+            out["with_npy_output_images_per_s"] = round(B * steps / dtw, 2)
+            out["npy_mb_per_image"] = round(nbytes / (B * (steps + 2)) / 1e6, 2)
+            out["npy_note"] = "extract_feature.HostWriter (pinned D2H on a side stream, np.save per layer and image to a tmpfs directory, one batch behind)"
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+    del df
+    torch.cuda.empty_cache()
+    return out
