@@ -95,13 +95,19 @@ class HostWriter:
                 if v.is_cuda:
                     buf = torch.empty(v.shape, dtype=v.dtype, pin_memory=True)
                     buf.copy_(v, non_blocking=True)
-                    v.record_stream(self.stream)
                     host[k] = buf
                 else:
                     host[k] = v
         ev = torch.cuda.Event() if self.stream is not None else None
         if ev is not None:
             ev.record(self.stream)
+            # the D2H copies read the hook buffers on THIS stream: announce it, so that the extractor may recycle the buffers as soon as
+            # `feats` is dropped (components/native.py release_after — the record_stream() of the native hook buffers)
+            try:
+                from components.native import release_after
+                release_after([v for v in feats.values() if torch.is_tensor(v)], self.stream)
+            except ImportError:
+                pass
         self.pending = (host, names, ev)
 
     def flush(self):

@@ -335,43 +335,92 @@ def config_from_diffusers(uc):
                 add_in_dim=(getattr(uc, "projection_class_embeddings_input_dim", None) or 0) if text_time else 0)
 
 
-def _use_count(t):
-    """References to the storage of tensor `t` (views handed to callers included) — the liveness test of a hook-buffer set.
-    Private torch API; when a torch build lacks it, sets are never pooled (fresh buffers per forward, eager launches)."""
-    try:
-        return torch._C._storage_Use_Count(t.untyped_storage()._cdata)
-    except Exception:
-        return None
+class _Lease:
+    """One hand-out of a hook-buffer set.  The tensors a forward returns are views of ONE tensor created from this object through the CUDA
+    array interface, so their shared storage keeps the lease alive; when the caller has dropped every view (and every view of a view), the
+    storage dies, the lease's finalizer runs and the set may be handed out again.  Public API only (round 3 used the private
+    torch._C._storage_Use_Count for this liveness test)."""
+
+    def __init__(self, ptr, n_halves):
+        self.__cuda_array_interface__ = dict(shape=(n_halves,), typestr="<f2", data=(ptr, False), version=2)
+
+
+_SETS_BY_RANGE = []          # (weakref to _HookSet) for release_after(): which set backs a given device pointer
+
+
+def release_after(tensors, stream=None):
+    """Tell the library that hook tensors returned by a forward / FeatureExtractor.extract are still being READ on `stream` (default: the
+    current stream) by work queued so far — the analogue of Tensor.record_stream() for these buffers.  The buffers are recycled (and then
+    overwritten by a later forward) once the caller has dropped every reference; work on the stream that was current at extract() time is
+    ordered automatically, a consumer on ANY OTHER stream calls this after queueing its reads and may then drop the tensors at once.
+    `tensors`: a tensor, a dict of tensors (the extract() result) or an iterable of tensors."""
+    if torch.is_tensor(tensors):
+        tensors = [tensors]
+    elif isinstance(tensors, dict):
+        tensors = list(tensors.values())
+    done = set()
+    for t in tensors:
+        if not (torch.is_tensor(t) and t.is_cuda):
+            continue
+        p = t.untyped_storage().data_ptr()
+        for ref in list(_SETS_BY_RANGE):
+            hs = ref()
+            if hs is None:
+                _SETS_BY_RANGE.remove(ref)
+                continue
+            if hs.lo <= p < hs.hi and id(hs) not in done:
+                done.add(id(hs))
+                s = stream if stream is not None else torch.cuda.current_stream(t.device)
+                ev = torch.cuda.Event()
+                ev.record(s)
+                hs.events.append(ev)
 
 
 class _HookSet:
     """One set of caller-visible output buffers of a plan (every hook + the model output) carved out of ONE allocation.
-    The tensors a forward returns are views into it; the set may be handed out again only when the caller has dropped every
-    such view (storage use count back to its baseline), so returned dicts stay valid for as long as they are referenced
-    (reference contract: FeatureStore.reset() rebinds a fresh dict, feature_extractor.py:28-29)."""
+    The tensors a forward returns are views of a per-hand-out lease tensor over it (`_Lease`); the set may be handed out again only when
+    the caller has dropped every such view, so returned dicts stay valid for as long as they are referenced (reference contract:
+    FeatureStore.reset() rebinds a fresh dict, feature_extractor.py:28-29).
+    Reuse is STREAM-ORDERED: the next forward runs on the plan's stream after `side.wait_stream(current)` AND after every event
+    registered through release_after() — so work the caller queued on its current stream, or announced on another stream, is ordered
+    before the buffers are overwritten, and the host keeps queueing forwards without waiting for the GPU."""
 
     def __init__(self, plan, out_elems, dev):
+        import weakref
         self.offs, tot = [], 0
         for (_, _, _, nbytes) in plan.hooks:
             self.offs.append(tot)
             tot += (nbytes // 2 + 127) // 128 * 128
         self.out_off = tot
         tot += (out_elems + 127) // 128 * 128
-        self.buf = torch.empty(max(tot, 128), dtype=torch.float16, device=dev)
+        self.n = max(tot, 128)
+        self.buf = torch.empty(self.n, dtype=torch.float16, device=dev)      # owned by the set for its whole life; never handed out itself
         base = self.buf.data_ptr()
+        self.lo, self.hi = base, base + 2 * self.n
         self.ptrs = (C.c_void_p * max(1, len(self.offs)))(*[base + 2 * o for o in self.offs])
         self.out_ptr = C.c_void_p(base + 2 * self.out_off)
-        self.base_count = _use_count(self.buf)
+        self.leased = False
+        self.events = []                 # release_after(): reads still in flight on other streams
+        _SETS_BY_RANGE.append(weakref.ref(self))
+
+    def lease(self, dev):
+        """-> fp16 tensor over the whole set whose storage keeps the lease alive; the set is free again when that storage dies"""
+        import weakref
+        le = _Lease(self.lo, self.n)
+        le._owner = self                 # a one-off set (not pooled by its plan) lives exactly as long as its views
+        self.leased = True
+        me = weakref.ref(self)
+
+        def _released(me=me):
+            hs = me()
+            if hs is not None:
+                hs.leased = False
+        weakref.finalize(le, _released)
+        with torch.cuda.device(dev):
+            return torch.as_tensor(le, device=dev)
 
     def free(self):
-        """Reusable once the caller dropped every view.  Reuse is STREAM-ORDERED, not event-guarded: the next forward runs on the
-        plan's stream after `side.wait_stream(current)`, so everything the caller enqueued on its current stream before calling
-        the next forward (a D2H copy of the hooks, a consumer kernel) is ordered before the buffers are overwritten, and the host
-        can keep queueing forwards without waiting for the GPU.
-        CONTRACT (differs from the caching allocator, where record_stream() on a view protects it): a consumer that reads the
-        returned tensors on ANOTHER stream must keep them referenced until that stream's work has been ordered before its next
-        extract() call (e.g. current_stream.wait_stream(other)), exactly as for any buffer it would hand back to a producer."""
-        return self.base_count is not None and _use_count(self.buf) == self.base_count
+        return not self.leased
 
 
 class _Plan:
@@ -387,7 +436,6 @@ class _Plan:
     # the event is polled), unbounded 35 ms — identical throughput (141.6 / 141.9 img/s).  So the queue stays unbounded; the knob
     # remains for hosts that prefer a shallow queue.
     MAX_INFLIGHT = int(os.environ.get("GDF_MAX_INFLIGHT", "0"))
-    _warned_no_use_count = False
 
     def __init__(self, lib, handle):
         self.lib, self.handle = lib, handle
@@ -453,16 +501,12 @@ class _Plan:
             pooled = True
             if hs is None:
                 hs = _HookSet(self, n_out, dev)
-                # more live result sets than MAX_SETS — or a torch build without the storage use count (sets can never be recycled):
-                # one-off buffers, eager launches
-                pooled = len(self.sets) < self.MAX_SETS and hs.base_count is not None
+                pooled = len(self.sets) < self.MAX_SETS        # more live result sets than that: one-off buffers, run eagerly
                 if pooled:
                     self.sets.append(hs)
-                elif hs.base_count is None and not _Plan._warned_no_use_count:
-                    _Plan._warned_no_use_count = True
-                    import warnings
-                    warnings.warn("torch._C._storage_Use_Count is unavailable: hook-buffer sets cannot be recycled, every forward allocates "
-                                  "fresh buffers and launches eagerly (no hipGraph replay)")
+            for ev in hs.events:                               # readers announced through release_after(): ordered before the overwrite
+                side.wait_event(ev)
+            hs.events = []
             no_graph = self.graph and (eager or profile or not pooled)
             if no_graph:
                 self.lib.gdf_plan_set_graph(self.handle, 0)
@@ -471,16 +515,16 @@ class _Plan:
             finally:
                 if no_graph:
                     self.lib.gdf_plan_set_graph(self.handle, 1)
-            hs.buf.record_stream(cur)
             if self.MAX_INFLIGHT > 0:
                 done = torch.cuda.Event()
                 done.record(side)
                 self.inflight.append(done)
         cur.wait_stream(side)
+        base = hs.lease(dev)                                   # every returned tensor is a view of this one hand-out (see _Lease)
         feats = {}
         for off, (hid, shape, stride, _) in zip(hs.offs, self.hooks):
-            feats[hid] = torch.as_strided(hs.buf, shape, stride, storage_offset=off)
-        out = hs.buf[hs.out_off:hs.out_off + n_out].view(out_dtype).view(out_shape)      # fp16 or bf16: same 16-bit container
+            feats[hid] = torch.as_strided(base, shape, stride, storage_offset=off)
+        out = base[hs.out_off:hs.out_off + n_out].view(out_dtype).view(out_shape)      # fp16 or bf16: same 16-bit container
         return out, feats, ret
 
 
@@ -681,7 +725,10 @@ class NativeUNet(_NativeModel):
         return self
 
     def split_for(self, hook_ids):
-        return choose_split(self.cfg, hook_ids) if getattr(self, "auto_split", False) else self.split
+        if getattr(self, "auto_split", False):
+            # (split plans need the fp32 master of the stream: the opt-out fp16-stream mode keeps plain operands)
+            return choose_split(self.cfg, hook_ids) if self.stream_fp32 else 0
+        return self.split
 
     def _is_norm(self, name):
         return ".norm" in name or name.startswith("conv_norm_out")

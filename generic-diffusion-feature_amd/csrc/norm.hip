@@ -19,10 +19,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // pixel rows per stage-1 block: sized so that the stage-1 grid has >= ~2048 workgroups (32x32 levels used to run
 // 64 workgroups at 1 TB/s)
+// (round 4: the cap was 256 rows — the VAE's 1024^2 maps then produced 4096 slabs per sample, and the finalize pass, one wave per
+// (sample, group) walking 16384 partial pairs in a dependent double-precision chain, took longer than the statistics read itself:
+// gn_stats 3.2 ms vs gn_apply 2.6 ms per 4-image sub-batch although it moves a third of the bytes)
 static int gn_slab(int B, int HW) {
   long s = (long)B * HW / 2048;
   int slab = 16;
-  while (slab < s && slab < 256) slab *= 2;
+  while (slab < s && slab < 4096) slab *= 2;
   return slab;
 }
 
@@ -78,7 +81,17 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const half_t* x16, cons
 #pragma unroll
     for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.f;
     if (tr < rgroups) {
-      for (int r = r0 + tr; r < r1; r += rgroups) {
+      int r = r0 + tr;
+      for (; r + 3 * rgroups < r1; r += 4 * rgroups) {          // four rows in flight per thread (long slabs: the VAE's 1024^2 maps)
+        float v[4][8];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) load8(x16, x32, ((size_t)b * HW + r + u * rgroups) * ld + c * 8, v[u], x_lo);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { s[e] += v[u][e]; q[e] += v[u][e] * v[u][e]; }
+      }
+      for (; r < r1; r += rgroups) {
         float v[8];
         load8(x16, x32, ((size_t)b * HW + r) * ld + c * 8, v, x_lo);
 #pragma unroll
@@ -100,18 +113,24 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const half_t* x16, cons
 }
 
 // stage 2: one block per (sample, group): combine slabs (in double), emit the per-channel affine table
-__global__ __launch_bounds__(64) void gn_finalize_kernel(const float* partial, int nslab, int HW, int C, int G, float eps,
-                                                         const float* gamma, const float* beta, float* ab) {
-  const int b = blockIdx.y, g = blockIdx.x, lane = threadIdx.x;
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* partial, int nslab, int HW, int C, int G, float eps,
+                                                          const float* gamma, const float* beta, float* ab) {
+  const int b = blockIdx.y, g = blockIdx.x, lane = threadIdx.x & 63, tid = threadIdx.x;
   const int cpg = C / G;
+  __shared__ double red[8];
   double s = 0.0, q = 0.0;
-  for (int i = lane; i < nslab * cpg; i += 64) {
+  // 256 threads, fixed assignment of partials to threads and a fixed combine order: deterministic
+  for (int i = tid; i < nslab * cpg; i += 256) {
     const int sl = i / cpg, c = g * cpg + (i - sl * cpg);
-    const float* pp = partial + (((size_t)b * nslab + sl) * C + c) * 2;
-    s += (double)pp[0]; q += (double)pp[1];
+    const float2 pp = *(const float2*)(partial + (((size_t)b * nslab + sl) * C + c) * 2);
+    s += (double)pp.x; q += (double)pp.y;
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) { s += __shfl_xor(s, off); q += __shfl_xor(q, off); }
+  if (lane == 0) { red[(tid >> 6) * 2] = s; red[(tid >> 6) * 2 + 1] = q; }
+  __syncthreads();
+  s = red[0] + red[2] + red[4] + red[6]; q = red[1] + red[3] + red[5] + red[7];
+  if (tid >= 64) return;
   const double n = (double)HW * cpg;
   const double mean = s / n;
   double var = q / n - mean * mean;
@@ -132,7 +151,7 @@ hipError_t launch_gn_stats(const half_t* x16, const float* x32, int ld, int B, i
   const int CH = C / 8, cht = CH < 256 ? CH : 256, rgroups = 256 / cht;
   const size_t smem = (size_t)rgroups * C * 2 * sizeof(float);
   hipLaunchKernelGGL(gn_partial_kernel, dim3(nslab, B), dim3(256), smem, s, x16, x32, ld, HW, C, partial, slab, x_lo);
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(G, B), dim3(64), 0, s, partial, nslab, HW, C, G, eps, gamma, beta, ab);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(G, B), dim3(256), 0, s, partial, nslab, HW, C, G, eps, gamma, beta, ab);
   return hipGetLastError();
 }
 

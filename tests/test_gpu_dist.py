@@ -112,3 +112,46 @@ def test_two_threads_two_extractors(monkeypatch):
         for k in want[i]:
             assert torch.equal(got[i][k], want[i][k]), (i, k)
     assert not torch.equal(want[0]["up-level2-repeat2-res-out"], want[1]["up-level2-repeat2-res-out"])
+
+
+def test_four_rank_cli_with_empty_shard_and_vae_out(tmp_path):
+    """Row (e) launch-readiness: FOUR ranks on one GPU through extract_feature.py with only THREE images — one
+    rank's shard is empty — and 'vae-out' in the layer config: the decoder's weight fill is a collective, so it must be built on every rank
+    in the constructor (a rank that never calls extract() used to leave the others blocked in the broadcast).  Output = the single-process
+    files, bit for bit."""
+    from PIL import Image
+    rs = np.random.RandomState(1)
+    (tmp_path / "imgs").mkdir()
+    for n in "abc":
+        Image.fromarray((rs.rand(64, 64, 3) * 255).astype(np.uint8)).save(tmp_path / "imgs" / f"{n}.png")
+    (tmp_path / "prompt.txt").write_text("a photo of a dog")
+    (tmp_path / "layers.json").write_text(json.dumps({"up-level1-repeat2-res-out": True, "vae-out": True}))
+    base = [os.path.join(ROOT, "extract_feature.py"), "--layer", str(tmp_path / "layers.json"), "--version", "1-5", "--img_size", "128",
+            "--t", "100", "-b", "2", "--input_dir", str(tmp_path / "imgs" / "*.png"), "--prompt_file", str(tmp_path / "prompt.txt")]
+    env = dict(os.environ, GDF_SYNTHETIC_WEIGHTS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable] + base + ["--output_dir", str(tmp_path / "one")], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port())] + base + ["--output_dir", str(tmp_path / "four")],
+                       env=dict(env, GDF_SHARE_GPU="1"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    one, four = _tree(tmp_path / "one"), _tree(tmp_path / "four")
+    assert sorted(one) == sorted(four) and len(one) == 6                     # 2 layers x 3 images
+    for k in one:
+        assert np.array_equal(one[k].view(np.uint16), four[k].view(np.uint16)), k
+
+
+def test_four_rank_bench_line():
+    """bench.py --gpus 4 on one GPU (GDF_BENCH_SHARE_GPU=1): the line carries the broadcast time and the per-rank step times, and the whole-job
+    value is 4 ranks x batch x steps / the slowest rank's time."""
+    env = dict(os.environ, GDF_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "2", "--warmup", "1",
+                        "--version", "1-5", "--batch", "2", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    c = line["config"]
+    assert line["n_gpus"] == 4 and line["scaling"] == "weak" and c["global_batch"] == 8 and line["value"] > 0
+    assert c["weights_broadcast_s"] >= 0 and 0 < c["per_rank_ms_per_step"]["min"] <= c["per_rank_ms_per_step"]["max"]
+    assert abs(line["value"] - 8 * 1e3 / c["per_rank_ms_per_step"]["max"]) < 0.02 * line["value"]
+    assert "plans" not in line and "e2e" not in line                         # the extra legs are single-GPU only
