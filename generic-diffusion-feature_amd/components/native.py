@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(os.path.dirname(_HERE), "libgdf.so")
 
-GDF_F16, GDF_F32, GDF_BF16 = 0, 1, 2
+GDF_F16, GDF_F32, GDF_BF16, GDF_BF16X2 = 0, 1, 2, 3
 MAX_LEVELS = 4
 
 
@@ -190,6 +190,8 @@ def choose_split(cfg, hook_ids):
         if h.endswith("-map"):
             level = max(level, 1)
             continue
+        if h == "vae-out":                               # decode(step(latents, noise_pred)): as accurate as the noise prediction
+            h = "unet-out"
         row = tab.get(h) if tab else None
         if row is None:                                  # unknown architecture or id: conservative kind rule
             risky = h.endswith(("ffn-inner", "unet-out", "-q", "-k", "-v")) or (fam != "xl" and h.endswith(("-out", "res-increment")))
@@ -829,7 +831,7 @@ def flux_desc(cfg):
         setattr(d, k, int(cfg[k]))
     d.guidance_embeds = int(bool(cfg["guidance_embeds"]))
     d.mlp_ratio = int(cfg.get("mlp_ratio", 4))
-    d.compute_dtype = {"bfloat16": GDF_BF16, "float16": GDF_F16}[cfg.get("compute_dtype", "bfloat16")]
+    d.compute_dtype = {"bfloat16": GDF_BF16, "float16": GDF_F16, "bfloat16x2": GDF_BF16X2}[cfg.get("compute_dtype", "bfloat16")]
     for i in range(3):
         d.axes_dims_rope[i] = int(cfg["axes_dims_rope"][i])
     return d
@@ -877,7 +879,7 @@ class NativeFluxTransformer(_NativeModel):
         self.single_forward = False      # True: __call__ raises SingleForwardDone after one forward (stock diffusers pipelines)
         self.calls = 0                   # number of __call__ forwards so far (tests count one per pipe(...) call)
         self._plans = {}
-        self.io_dtype = torch.bfloat16 if self.cfg["compute_dtype"] == "bfloat16" else torch.float16   # inputs / `out` of libgdf
+        self.io_dtype = torch.float16 if self.cfg["compute_dtype"] == "float16" else torch.bfloat16    # inputs / `out` of libgdf
         self.dtype = self.io_dtype
         self.config = types.SimpleNamespace(in_channels=cfg["in_channels"], guidance_embeds=bool(cfg["guidance_embeds"]),
                                             joint_attention_dim=cfg["joint_attention_dim"],

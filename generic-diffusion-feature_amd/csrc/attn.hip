@@ -48,6 +48,16 @@ __device__ __forceinline__ _Float16 out16(float v) {
   if constexpr (BF) return __builtin_bit_cast(_Float16, (__bf16)v);
   else return (_Float16)v;
 }
+// split output pair (AttnParams::o_lo): hi / lo halves of v as fp16, or as bf16 when `pbf` (o_pair_bf16: an fp16-internal attention
+// feeding a bf16 split-operand GEMM, the MMDiT 'bfloat16x2' plans)
+__device__ __forceinline__ _Float16 pair_hi(float v, bool pbf) {
+  return pbf ? __builtin_bit_cast(_Float16, (__bf16)v) : (_Float16)v;
+}
+__device__ __forceinline__ _Float16 pair_lo(float v, bool pbf) {
+  if (pbf) { const __bf16 h = (__bf16)v; return __builtin_bit_cast(_Float16, (__bf16)(v - (float)h)); }
+  const _Float16 h = (_Float16)v;
+  return (_Float16)(v - (float)h);
+}
 
 // combine a value with the one held by lane ^ 32 (the other half-wave owns the other keys of the same query):
 // v_permlane32_swap instead of an LDS round trip (ds_bpermute)
@@ -152,6 +162,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(const AttnParams p) {
   // (Measured and rejected: fetching Q with whole rows per group of lanes through the same staging slab that transposes O at
   // the end — the extra LDS round trip and workgroup barrier before the first K / V tile cost more than the scattered 16-byte
   // fragment loads: cross-attention 31 -> 36 us, self-attention at 1024 tokens 122 -> 129 us.)
+  const bool pbf = p.o_lo > 0 && p.o_pair_bf16;                // output pair as bf16 hi + bf16 lo (fp16 internals): 'bfloat16x2' MMDiT plans
   constexpr int RSH = D + 8;                                    // O staging row stride in halves (16-byte aligned rows)
   constexpr bool STG = (NW / 2) * QBW * RSH <= 2 * KT * LDR && (NW / 2) * QBW * RSH <= 2 * KT * LDV;   // not at D = 32 (tiny rings)
   constexpr int LPRO = D / 8;                                   // lanes per staged row
@@ -447,7 +458,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(const AttnParams p) {
           if (d0 < D) {
             f16x4 hv;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) hv[e] = out16<BF>(o[w][db][rq * 4 + e] * inv);
+            for (int e = 0; e < 4; ++e) hv[e] = (!BF && pbf) ? pair_hi(o[w][db][rq * 4 + e] * inv, true) : out16<BF>(o[w][db][rq * 4 + e] * inv);
             *(f16x4*)(stg + (w * 32 + lq) * RSH + d0) = hv;
           }
         }
@@ -474,7 +485,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(const AttnParams p) {
             if (d0 < D) {
               f16x4 lv;
 #pragma unroll
-              for (int e = 0; e < 4; ++e) { const float x = o[w][db][rq * 4 + e] * inv; lv[e] = (_Float16)(x - (float)(_Float16)x); }
+              for (int e = 0; e < 4; ++e) lv[e] = pair_lo(o[w][db][rq * 4 + e] * inv, pbf);
               *(f16x4*)(stg + (w * 32 + lq) * RSH + d0) = lv;
             }
           }
@@ -505,12 +516,12 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(const AttnParams p) {
           if (d0 < D) {
             f16x4 hv;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) hv[e] = out16<BF>(o[w][db][rq * 4 + e] * inv);
+            for (int e = 0; e < 4; ++e) hv[e] = (!BF && pbf) ? pair_hi(o[w][db][rq * 4 + e] * inv, true) : out16<BF>(o[w][db][rq * 4 + e] * inv);
             *(f16x4*)(op + d0) = hv;
             if (!BF && p.o_lo > 0) {
               f16x4 lv;
 #pragma unroll
-              for (int e = 0; e < 4; ++e) lv[e] = (_Float16)(o[w][db][rq * 4 + e] * inv - (float)hv[e]);
+              for (int e = 0; e < 4; ++e) lv[e] = pair_lo(o[w][db][rq * 4 + e] * inv, pbf);
               *(f16x4*)(op + d0 + p.o_lo) = lv;
             }
           }
@@ -908,13 +919,14 @@ __global__ __launch_bounds__(LW ? 320 : 256, OCC) void attn_map_kernel(const Att
         const int d0 = db * 32 + 8 * rq + 4 * lh;
         if (d0 < D) {
           f16x4 hv;
+          const bool pbf = p.o_lo > 0 && p.o_pair_bf16;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) hv[e] = out16<BF>(o[db][rq * 4 + e]);
+          for (int e = 0; e < 4; ++e) hv[e] = (!BF && pbf) ? pair_hi(o[db][rq * 4 + e], true) : out16<BF>(o[db][rq * 4 + e]);
           *(f16x4*)(op + d0) = hv;
           if (!BF && p.o_lo > 0) {
             f16x4 lv;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) lv[e] = (_Float16)(o[db][rq * 4 + e] - (float)hv[e]);
+            for (int e = 0; e < 4; ++e) lv[e] = pair_lo(o[db][rq * 4 + e], pbf);
             *(f16x4*)(op + d0 + p.o_lo) = lv;
           }
         }

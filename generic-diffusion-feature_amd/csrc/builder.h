@@ -224,12 +224,13 @@ struct PlanBuilder {
     if (--remaining == 0 && opt.early_exit) stop = true;
   }
   // coalesced hook store: fp16 copy of `rows x C` from (src, ld)
-  void hook_copy(int slot, Ref src, int ld, size_t nrows, int C) {
+  // s_lo > 0: the source is a split pair (hook = fp16(hi + lo)); src_bf: element type of the source (-1 = the model's)
+  void hook_copy(int slot, Ref src, int ld, size_t nrows, int C, int s_lo = 0, int src_bf = -1) {
     if (slot < 0) return;
     P.hooks[slot].copied = true;
-    const int bf = m.bf16, sat = (m.kind == 1);          // MMDiT hooks: bf16 or range-critical fp16 source -> saturating fp16
+    const int bf = src_bf >= 0 ? src_bf : m.bf16, sat = (m.kind == 1);   // MMDiT hooks: bf16 or range-critical fp16 source -> saturating fp16
     op("hook_store", 0, [=](const Bind& b, hipStream_t s) {
-      return launch_copy2d((const half_t*)b.p(src), nullptr, ld, (half_t*)b.hook(slot), C, (int)nrows, C, s, bf, sat);
+      return launch_copy2d((const half_t*)b.p(src), nullptr, ld, (half_t*)b.hook(slot), C, (int)nrows, C, s, bf, sat, s_lo);
     });
     hook_done();
   }
@@ -247,6 +248,7 @@ struct PlanBuilder {
     int geglu = 0; int bn = 128;
     int dit = 0, act = 0, rv_mul = 0, rv_seg_rows = 0, rv_rps2 = 0;     // MMDiT epilogue (kernels.h)
     int bf16 = 0;                                                         // bf16 operands / activations (set by gemm() from the model)
+    int out_f16 = 0;                                                      // bf16 kernel storing out16 as saturating fp16 (GemmParams::out_f16)
     float acc_scale = 0.f, out16_scale = 0.f;                             // fp16 range control (kernels.h), 0 = 1
     int pad0 = 0;                                                         // conv3: 1 = pad right / bottom only
     int rv_tok = 0;                                                       // row vector indexed by token (row % rps)
@@ -278,6 +280,7 @@ struct PlanBuilder {
     g.out16 = e.has_o16 ? (half_t*)b.p(e.out16) : nullptr; g.ldo16 = e.ldo16;
     g.out32 = e.has_o32 ? (float*)b.p(e.out32) : nullptr; g.ldo32 = e.ldo32;
     g.aux16 = e.aux_slot >= 0 ? (half_t*)b.hook(e.aux_slot) : nullptr; g.ldaux = e.ldaux;
+    g.out_f16 = e.out_f16;
     g.geglu = e.geglu; g.bn = e.bn; g.bf16 = e.bf16; g.acc_scale = e.acc_scale; g.out16_scale = e.out16_scale; g.o16_lo = e.o16_lo;
     g.dit = e.dit; g.act = e.act; g.rv_mul = e.rv_mul; g.rv_seg_rows = e.rv_seg_rows; g.rv_rps2 = e.rv_rps2; g.rv_tok = e.rv_tok;
     g.qkn_nq = e.qkn_nq;

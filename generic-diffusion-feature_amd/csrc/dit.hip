@@ -19,7 +19,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 template <int MAXC>
 __global__ __launch_bounds__(256) void layernorm_mod_kernel(const half_t* x16, const float* x32, int ld, int R, int C,
                                                             float eps, const float* scale, const float* shift, int ldm,
-                                                            int rps, int seg_rows, int rps2, half_t* y, int bf) {
+                                                            int rps, int seg_rows, int rps2, half_t* y, int bf, int ldy, int y_lo) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= R) return;
@@ -68,24 +68,34 @@ __global__ __launch_bounds__(256) void layernorm_mod_kernel(const half_t* x16, c
       const f32x4 g0 = *(const f32x4*)(sc + c * 8), g1 = *(const f32x4*)(sc + c * 8 + 4);
       const f32x4 b0 = *(const f32x4*)(sh + c * 8), b1 = *(const f32x4*)(sh + c * 8 + 4);
       f16x8 o;
+      float t[8];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        o[e] = f32_to_e16((v[i][e] - mean) * rstd * (1.0f + g0[e]) + b0[e], bf);
-        o[4 + e] = f32_to_e16((v[i][4 + e] - mean) * rstd * (1.0f + g1[e]) + b1[e], bf);
+        t[e] = (v[i][e] - mean) * rstd * (1.0f + g0[e]) + b0[e];
+        t[4 + e] = (v[i][4 + e] - mean) * rstd * (1.0f + g1[e]) + b1[e];
       }
-      *(f16x8*)(y + (size_t)row * C + c * 8) = o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = f32_to_e16(t[e], bf);
+      *(f16x8*)(y + (size_t)row * ldy + c * 8) = o;
+      if (y_lo > 0) {                                    // split operand of the consumer GEMM ('bfloat16x2' plans): lo = e16(v - hi)
+        f16x8 l;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) l[e] = f32_to_e16(t[e] - e16_to_f32(o[e], bf), bf);
+        *(f16x8*)(y + (size_t)row * ldy + c * 8 + y_lo) = l;
+      }
     }
   }
 }
 
 hipError_t launch_layernorm_mod(const half_t* x16, const float* x32, int ld, int R, int C, float eps, const float* scale,
                                 const float* shift, int ldm, int rps, int seg_rows, int rps2, half_t* y, hipStream_t s,
-                                int bf16) {
-  if (C % 8 || C > 64 * 8 * 8 || (ldm & 3) || rps <= 0) return hipErrorInvalidValue;
+                                int bf16, int ldy, int y_lo) {
+  if (C % 8 || C > 64 * 8 * 8 || (ldm & 3) || rps <= 0 || (y_lo & 7) || (ldy & 7)) return hipErrorInvalidValue;
+  if (ldy <= 0) ldy = C;
   if (R <= 0) return hipSuccess;
   const int CH = C / 8;
   dim3 grid((R + 3) / 4), blk(256);
-#define GDF_LNM(N) hipLaunchKernelGGL(layernorm_mod_kernel<N>, grid, blk, 0, s, x16, x32, ld, R, C, eps, scale, shift, ldm, rps, seg_rows, rps2, y, bf16)
+#define GDF_LNM(N) hipLaunchKernelGGL(layernorm_mod_kernel<N>, grid, blk, 0, s, x16, x32, ld, R, C, eps, scale, shift, ldm, rps, seg_rows, rps2, y, bf16, ldy, y_lo)
   if (CH <= 64) GDF_LNM(1);
   else if (CH <= 128) GDF_LNM(2);
   else if (CH <= 256) GDF_LNM(4);

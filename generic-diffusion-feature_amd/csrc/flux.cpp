@@ -94,16 +94,20 @@ struct FB : PlanBuilder {   // Flux op program
   Ref stream_rows(size_t row) const { return ws(xf + row * (size_t)f.C * 4); }
 
   // y[rows r0..r0+n) = LN(stream rows) * (1 + scale) + shift  -> fp16 [n][C] at `dst`
+  // 'bfloat16x2' plans (m.x2): every MFMA A operand is a bf16 hi + lo pair [hi C | lo C] in one row (px = 2), multiplied as
+  // [hi | lo] x [W | W]; q / k / v and the attention internals are fp16
+  int px() const { return m.x2 ? 2 : 1; }
   void adaln(const char* name, size_t r0, size_t n, int shift_col, int scale_col, int rps, size_t seg_rows, int rps2, Ref dst) {
     const Ref x = stream_rows(r0), sc = modv(scale_col), sh = modv(shift_col);
-    const int C = f.C, ldm = f.mod_total, bf = m.bf16;
+    const int C = f.C, ldm = f.mod_total, bf = m.bf16, ldy = C * px(), y_lo = m.x2 ? C : 0;
     op(name, 0, [=](const Bind& b, hipStream_t s) {
       return launch_layernorm_mod(nullptr, (const float*)b.p(x), C, (int)n, C, 1e-6f, (const float*)b.p(sc), (const float*)b.p(sh),
-                                  ldm, rps, (int)seg_rows, rps2, (half_t*)b.p(dst), s, bf);
+                                  ldm, rps, (int)seg_rows, rps2, (half_t*)b.p(dst), s, bf, ldy, y_lo);
     });
   }
-  void hook_rows16(const std::string& id, Ref src, int ld, int C) {      // image-token hook from an fp16 matrix
-    hook_copy(want(id, C, gh, gw), src, ld, NS, C);
+  // image-token hook from a 16-bit matrix; s_lo > 0: a split pair; src_bf: element type (-1 = the model's)
+  void hook_rows16(const std::string& id, Ref src, int ld, int C, int s_lo = 0, int src_bf = -1) {
+    hook_copy(want(id, C, gh, gw), src, ld, NS, C, s_lo, src_bf);
   }
   void hook_rows32(const std::string& id, Ref src, int ld, int C) {      // ... from the fp32 stream
     const int slot = want(id, C, gh, gw);
@@ -127,7 +131,7 @@ struct FB : PlanBuilder {   // Flux op program
   }
   // RMSNorm(q), RMSNorm(k) + RoPE in place on rows [r0, r0+n) of the qkv buffer (ld 3C)
   void qk_norm_rope(size_t qkv, size_t r0, size_t n, size_t wq, size_t wk, int pos0, int rps) {
-    const int C = f.C, heads = C / f.D, D = f.D, bf = m.bf16;
+    const int C = f.C, heads = C / f.D, D = f.D, bf = m.x2 ? 0 : m.bf16;          // ('bfloat16x2': the q / k / v buffer is fp16)
     const Ref x = ws(qkv + r0 * (size_t)(3 * C) * 2), q = wt(wq), k = wt(wk), cs = ws(cosb), sn = ws(sinb);
     op("qk_norm_rope", 0, [=](const Bind& b, hipStream_t s) {
       return launch_qk_norm_rope((half_t*)b.p(x), 3 * C, (int)n, heads, D, 0, C, (const float*)b.p(q), (const float*)b.p(k), 1e-6f,
@@ -136,15 +140,15 @@ struct FB : PlanBuilder {   // Flux op program
   }
   // cross_slot / self_slot: hook slots of `cross-map` (B, heads, S, T) / `self-map` (B, heads, S, S) or -1
   // (FluxAttnStoreProcessor, components/attention.py:493-502: image queries only, split by key)
-  void joint_attention(size_t qkv, Ref o, int ldo, int cross_slot = -1, int self_slot = -1) {
-    const int C = f.C, D = f.D, heads = C / D, Bq = Bn, Sj = T + S, Tq = T, bf = m.bf16;
+  void joint_attention(size_t qkv, Ref o, int ldo, int cross_slot = -1, int self_slot = -1, int o_lo = 0) {
+    const int C = f.C, D = f.D, heads = C / D, Bq = Bn, Sj = T + S, Tq = T, bf = m.x2 ? 0 : m.bf16, pbf = m.x2;
     const Ref q = ws(qkv), k = ws(qkv + (size_t)C * 2), v = ws(qkv + (size_t)2 * C * 2);
     op("joint_attn", 4.0 * (double)Bn * heads * Sj * (double)Sj * D, [=](const Bind& b, hipStream_t s) {
       AttnParams a{};
       a.q = (const half_t*)b.p(q); a.ldq = 3 * C; a.k = (const half_t*)b.p(k); a.ldk = 3 * C;
       a.v = (const half_t*)b.p(v); a.ldv = 3 * C; a.o = (half_t*)b.p(o); a.ldo = ldo;
       a.B = Bq; a.heads = heads; a.Sq = Sj; a.Sk = Sj; a.D = D; a.scale = 1.0f / sqrtf((float)D);
-      a.kv_bstride = Sj; a.seg_T = Tq; a.bf16 = bf;
+      a.kv_bstride = Sj; a.seg_T = Tq; a.bf16 = bf; a.o_lo = o_lo; a.o_pair_bf16 = pbf;
       a.map = self_slot >= 0 ? (half_t*)b.hook(self_slot) : nullptr;
       a.map2 = cross_slot >= 0 ? (half_t*)b.hook(cross_slot) : nullptr;
       return launch_attention(a, s);
@@ -246,7 +250,8 @@ struct FB : PlanBuilder {   // Flux op program
     { Epi e = plain(f.ctx_emb); e.out32 = stream_rows(0); e.has_o32 = true; e.ldo32 = C;
       gemm("context_embedder", Ref{BUF_CTX, 0}, d.joint_attention_dim, nt, f.ctx_emb, C, d.joint_attention_dim, 0, e); }
 
-    const size_t ln_b = nr * C * 2, qkv_b = nr * 3 * C * 2;
+    const int X = px(), x2 = m.x2;                                                  // 'bfloat16x2': operand rows hold [hi | lo]
+    const size_t ln_b = nr * C * 2 * X, qkv_b = nr * 3 * C * 2;
     // ================= double (MMDiT) blocks =================
     for (int i = 0; i < d.num_layers && !stop; ++i) {
       const FluxDoubleW& w = f.dbl[i];
@@ -254,22 +259,23 @@ struct FB : PlanBuilder {   // Flux op program
       // norm1 / norm1_context (AdaLayerNormZero): chunks shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
       const size_t ln = tmp(ln_b);
       adaln("adaln_txt", 0, nt, w.cmod + 0, w.cmod + C, T, 0, 0, ws(ln));
-      adaln("adaln", nt, ns, w.mod + 0, w.mod + C, S, 0, 0, ws(ln + nt * C * 2));
+      adaln("adaln", nt, ns, w.mod + 0, w.mod + C, S, 0, 0, ws(ln + nt * C * 2 * X));
       const size_t qkv = tmp(qkv_b);
       // un-hooked blocks: RMSNorm(q), RMSNorm(k) + RoPE ride in the QKV GEMM epilogue (on the fp32 accumulators); the `q/k/v`
       // hooks are the PRE-norm projections, so a block that has one of them requested keeps the separate pass
       const bool fuse = qkn_fusable(bid) && gemm_qkn_ok((int)nt, 3 * C, C) && gemm_qkn_ok((int)ns, 3 * C, C);
-      { Epi e = plain(w.cqkv); e.out16 = ws(qkv); e.has_o16 = true; e.ldo16 = 3 * C;
+      { Epi e = plain(w.cqkv); e.out16 = ws(qkv); e.has_o16 = true; e.ldo16 = 3 * C; e.out_f16 = x2;
         if (fuse) qkn(e, w.cnq, w.cnk, 0, T, 0, 0, 1);
-        gemm("add_qkv_proj", ws(ln), C, nt, w.cqkv, 3 * C, C, 0, e); }
-      { Epi e = plain(w.qkv); e.out16 = ws(qkv + nt * 3 * C * 2); e.has_o16 = true; e.ldo16 = 3 * C;
+        gemm("add_qkv_proj", ws(ln), C * X, nt, w.cqkv, 3 * C, C, 0, e, x2 * C); }
+      { Epi e = plain(w.qkv); e.out16 = ws(qkv + nt * 3 * C * 2); e.has_o16 = true; e.ldo16 = 3 * C; e.out_f16 = x2;
         if (fuse) qkn(e, w.nq, w.nk, T, S, 0, 0, 1);
-        gemm("attn_qkv", ws(ln + nt * C * 2), C, ns, w.qkv, 3 * C, C, 0, e); }
+        gemm("attn_qkv", ws(ln + nt * C * 2 * X), C * X, ns, w.qkv, 3 * C, C, 0, e, x2 * C); }
       untmp(ln, ln_b);
       const size_t qi = qkv + nt * 3 * C * 2;                                        // image rows of the qkv buffer
-      hook_rows16(bid + "-q", ws(qi), 3 * C, C);                                     // attention_processor.py:2283-2286
-      hook_rows16(bid + "-k", ws(qi + (size_t)C * 2), 3 * C, C);
-      hook_rows16(bid + "-v", ws(qi + (size_t)2 * C * 2), 3 * C, C);
+      const int qbf = x2 ? 0 : -1;                                                   // ('bfloat16x2': the q / k / v buffer is fp16)
+      hook_rows16(bid + "-q", ws(qi), 3 * C, C, 0, qbf);                             // attention_processor.py:2283-2286
+      hook_rows16(bid + "-k", ws(qi + (size_t)C * 2), 3 * C, C, 0, qbf);
+      hook_rows16(bid + "-v", ws(qi + (size_t)2 * C * 2), 3 * C, C, 0, qbf);
       if (stop) { untmp(qkv, qkv_b); break; }
       if (!fuse) {
         qk_norm_rope(qkv, 0, nt, w.cnq, w.cnk, 0, T);                                // norm_added_q/k, text positions
@@ -278,38 +284,38 @@ struct FB : PlanBuilder {   // Flux op program
       const size_t ao = tmp(ln_b);
       int mc = -1, ms = -1;
       map_slots(bid, mc, ms);
-      joint_attention(qkv, ws(ao), C, mc, ms);
+      joint_attention(qkv, ws(ao), C * X, mc, ms, x2 * C);
       untmp(qkv, qkv_b);
       { Epi e = gated(w.o, nt, w.mod + 2 * C, S);                                    // hidden += gate_msa * to_out(attn)
         e.aux_slot = want(bid + "-attn-out", C, gh, gw); e.ldaux = C;                // :2355-2356 (pre-gate projection)
-        gemm("attn_out", ws(ao + nt * C * 2), C, ns, w.o, C, C, 0, e);
+        gemm("attn_out", ws(ao + nt * C * 2 * X), C * X, ns, w.o, C, C, 0, e, x2 * C);
         if (e.aux_slot >= 0) hook_done(); }
       { Epi e = gated(w.co, 0, w.cmod + 2 * C, T);                                   // enc += c_gate_msa * to_add_out(attn)
-        gemm("attn_add_out", ws(ao), C, nt, w.co, C, C, 0, e); }
+        gemm("attn_add_out", ws(ao), C * X, nt, w.co, C, C, 0, e, x2 * C); }
       untmp(ao, ln_b);
       if (stop) break;
       // ---- image MLP: norm2 + modulate, hooks norm-out / ffn-inner / out (:194-207; `out` stores norm_hidden_states) ----
-      const size_t nx = tmp(ns * C * 2);
+      const size_t nx = tmp(ns * C * 2 * X);
       adaln("adaln", nt, ns, w.mod + 3 * C, w.mod + 4 * C, S, 0, 0, ws(nx));
-      hook_rows16(bid + "-norm-out", ws(nx), C, C);
-      const size_t inner = tmp(ns * hid * 2);
-      { Epi e = plain(w.ff1); e.act = 1; e.out16 = ws(inner); e.has_o16 = true; e.ldo16 = hid;
-        gemm("ff_in", ws(nx), C, ns, w.ff1, hid, C, 0, e); }
-      hook_rows16(bid + "-ffn-inner", ws(inner), hid, hid);                          // attention.py:1255-1257
-      { Epi e = gated(w.ff2, nt, w.mod + 5 * C, S); gemm("ff_out", ws(inner), hid, ns, w.ff2, C, hid, 0, e); }
-      untmp(inner, ns * hid * 2);
-      hook_rows16(bid + "-out", ws(nx), C, C);
-      untmp(nx, ns * C * 2);
+      hook_rows16(bid + "-norm-out", ws(nx), C * X, C, x2 * C);
+      const size_t inner = tmp(ns * hid * 2 * X);
+      { Epi e = plain(w.ff1); e.act = 1; e.out16 = ws(inner); e.has_o16 = true; e.ldo16 = hid * X; e.o16_lo = x2 * hid;
+        gemm("ff_in", ws(nx), C * X, ns, w.ff1, hid, C, 0, e, x2 * C); }
+      hook_rows16(bid + "-ffn-inner", ws(inner), hid * X, hid, x2 * hid);            // attention.py:1255-1257
+      { Epi e = gated(w.ff2, nt, w.mod + 5 * C, S); gemm("ff_out", ws(inner), hid * X, ns, w.ff2, C, hid, 0, e, x2 * hid); }
+      untmp(inner, ns * hid * 2 * X);
+      hook_rows16(bid + "-out", ws(nx), C * X, C, x2 * C);
+      untmp(nx, ns * C * 2 * X);
       if (stop) break;
       // ---- text MLP (:211-218) ----
-      const size_t ne = tmp(nt * C * 2);
+      const size_t ne = tmp(nt * C * 2 * X);
       adaln("adaln_txt", 0, nt, w.cmod + 3 * C, w.cmod + 4 * C, T, 0, 0, ws(ne));
-      const size_t cin = tmp(nt * hid * 2);
-      { Epi e = plain(w.cff1); e.act = 1; e.out16 = ws(cin); e.has_o16 = true; e.ldo16 = hid;
-        gemm("ff_context_in", ws(ne), C, nt, w.cff1, hid, C, 0, e); }
-      untmp(ne, nt * C * 2);
-      { Epi e = gated(w.cff2, 0, w.cmod + 5 * C, T); gemm("ff_context_out", ws(cin), hid, nt, w.cff2, C, hid, 0, e); }
-      untmp(cin, nt * hid * 2);
+      const size_t cin = tmp(nt * hid * 2 * X);
+      { Epi e = plain(w.cff1); e.act = 1; e.out16 = ws(cin); e.has_o16 = true; e.ldo16 = hid * X; e.o16_lo = x2 * hid;
+        gemm("ff_context_in", ws(ne), C * X, nt, w.cff1, hid, C, 0, e, x2 * C); }
+      untmp(ne, nt * C * 2 * X);
+      { Epi e = gated(w.cff2, 0, w.cmod + 5 * C, T); gemm("ff_context_out", ws(cin), hid * X, nt, w.cff2, C, hid, 0, e, x2 * hid); }
+      untmp(cin, nt * hid * 2 * X);
     }
     // ================= single blocks over the joint stream =================
     const int CK = C + hid;
@@ -318,40 +324,60 @@ struct FB : PlanBuilder {   // Flux op program
       const std::string bid = "vit-block" + std::to_string(d.num_layers + j);
       const size_t ln = tmp(ln_b);
       adaln("adaln", 0, nr, w.mod + 0, w.mod + C, T, nt, S, ws(ln));                 // AdaLayerNormZeroSingle: shift, scale, gate
-      const size_t qkv = tmp(qkv_b), cat = tmp(nr * CK * 2);
+      // 'bfloat16x2': the concatenated operand row is [attn_hi C | mlp_hi hid | attn_lo C | mlp_lo hid]
+      const size_t cat_b = nr * CK * 2 * X;
+      const size_t qkv = tmp(qkv_b), cat = tmp(cat_b);
       const bool fuse = qkn_fusable(bid) && gemm_qkn_ok((int)nr, 3 * C, C);
-      { Epi e = plain(w.qkv); e.out16 = ws(qkv); e.has_o16 = true; e.ldo16 = 3 * C;
+      { Epi e = plain(w.qkv); e.out16 = ws(qkv); e.has_o16 = true; e.ldo16 = 3 * C; e.out_f16 = x2;
         if (fuse) qkn(e, w.nq, w.nk, 0, T, (int)nt, T, S);
-        gemm("attn_qkv", ws(ln), C, nr, w.qkv, 3 * C, C, 0, e); }
-      { Epi e = plain(w.mlp); e.act = 1; e.out16 = ws(cat + (size_t)C * 2); e.has_o16 = true; e.ldo16 = CK;   // :95
-        gemm("proj_mlp", ws(ln), C, nr, w.mlp, hid, C, 0, e); }
+        gemm("attn_qkv", ws(ln), C * X, nr, w.qkv, 3 * C, C, 0, e, x2 * C); }
+      { Epi e = plain(w.mlp); e.act = 1; e.out16 = ws(cat + (size_t)C * 2); e.has_o16 = true; e.ldo16 = CK * X; e.o16_lo = x2 * CK;   // :95
+        gemm("proj_mlp", ws(ln), C * X, nr, w.mlp, hid, C, 0, e, x2 * C); }
       untmp(ln, ln_b);
       const size_t qi = qkv + nt * 3 * C * 2;
-      hook_rows16(bid + "-q", ws(qi), 3 * C, C);                                     // :2287-2291 image tokens only
-      hook_rows16(bid + "-k", ws(qi + (size_t)C * 2), 3 * C, C);
-      hook_rows16(bid + "-v", ws(qi + (size_t)2 * C * 2), 3 * C, C);
-      if (stop) { untmp(qkv, qkv_b); untmp(cat, nr * CK * 2); break; }
+      const int qbf = x2 ? 0 : -1;
+      hook_rows16(bid + "-q", ws(qi), 3 * C, C, 0, qbf);                             // :2287-2291 image tokens only
+      hook_rows16(bid + "-k", ws(qi + (size_t)C * 2), 3 * C, C, 0, qbf);
+      hook_rows16(bid + "-v", ws(qi + (size_t)2 * C * 2), 3 * C, C, 0, qbf);
+      if (stop) { untmp(qkv, qkv_b); untmp(cat, cat_b); break; }
       if (!fuse) {
         qk_norm_rope(qkv, 0, nt, w.nq, w.nk, 0, T);
         qk_norm_rope(qkv, nt, ns, w.nq, w.nk, T, S);
       }
       int mc = -1, ms = -1;
       map_slots(bid, mc, ms);
-      joint_attention(qkv, ws(cat), CK, mc, ms);                                     // cat([attn_output, mlp], 2) in place (:103)
+      joint_attention(qkv, ws(cat), CK * X, mc, ms, x2 * CK);                        // cat([attn_output, mlp], 2) in place (:103)
       untmp(qkv, qkv_b);
-      hook_rows16(bid + "-attn-out", ws(cat + nt * CK * 2), CK, C);                  // :2360-2361
-      { Epi e = gated(w.out, 0, w.mod + 2 * C, T, nt, S); gemm("proj_out", ws(cat), CK, nr, w.out, C, CK, 0, e); }   // :104-106
-      untmp(cat, nr * CK * 2);
+      hook_rows16(bid + "-attn-out", ws(cat + nt * CK * 2 * X), CK * X, C, x2 * CK); // :2360-2361
+      if (cat_b < (1ull << 31)) {
+        Epi e = gated(w.out, 0, w.mod + 2 * C, T, nt, S); gemm("proj_out", ws(cat), CK * X, nr, w.out, C, CK, 0, e, x2 * CK);   // :104-106
+      } else {
+        // the A operand is addressed through 32-bit buffer offsets (< 2 GiB): the pair form of [rows][C + hid] at batch 8 is 2.26 GB, so
+        // the GEMM runs over row ranges cut at sample boundaries — text rows + the first image samples, then the remaining samples
+        const size_t row_b = (size_t)CK * 2 * X;
+        const int per = (int)(((1ull << 31) - 1) / row_b);                           // rows per launch
+        int k0 = (int)std::min<size_t>((size_t)Bn, per > (int)nt ? (size_t)(per - (int)nt) / S : 0);
+        if (per < (int)nt || k0 < 1) { set_error("bfloat16x2: tokens per sample too large for 32-bit buffer offsets"); bad = true; k0 = Bn; }
+        { Epi e = gated(w.out, 0, w.mod + 2 * C, T, nt, S);
+          gemm("proj_out", ws(cat), CK * X, nt + (size_t)k0 * S, w.out, C, CK, 0, e, x2 * CK); }
+        for (int k = k0; k < Bn; ) {
+          const int kn = std::min(Bn - k, std::max(1, per / S));
+          Epi e = gated(w.out, nt + (size_t)k * S, w.mod + 2 * C + k * f.mod_total, S);      // gate rows of samples k.. (row vector table offset by k samples)
+          gemm("proj_out", ws(cat + (nt + (size_t)k * S) * row_b), CK * X, (size_t)kn * S, w.out, C, CK, 0, e, x2 * CK);
+          k += kn;
+        }
+      }
+      untmp(cat, cat_b);
       hook_rows32(bid + "-out", stream_rows(nt), C, C);                              // :107-108
     }
     // ================= norm_out (AdaLayerNormContinuous: scale, shift) + proj_out (:591-594) =================
     if (!stop) {
-      const size_t no = tmp(ns * C * 2);
+      const size_t no = tmp(ns * C * 2 * X);
       adaln("norm_out", nt, ns, f.mod_out + C, f.mod_out + 0, S, 0, 0, ws(no));
       Epi e = plain(f.proj_out); e.out16 = Ref{BUF_NOISE, 0}; e.has_o16 = true; e.ldo16 = d.in_channels;
       P.writes_noise = true;
-      gemm("final_proj_out", ws(no), C, ns, f.proj_out, d.in_channels, C, 0, e);
-      untmp(no, ns * C * 2);
+      gemm("final_proj_out", ws(no), C * X, ns, f.proj_out, d.in_channels, C, 0, e, x2 * C);
+      untmp(no, ns * C * 2 * X);
     }
     untmp(xf, xf_b); untmp(mod, mod_b); untmp(stemb, vb); untmp(cosb, rope_b); untmp(sinb, rope_b);
   }
@@ -367,10 +393,13 @@ Model* flux_model_create(const gdf_flux_desc& d) {
   if (d.in_channels % 64 || d.joint_attention_dim % 64 || d.pooled_projection_dim % 8) {
     set_error("in_channels / joint_attention_dim must be multiples of 64, pooled_projection_dim of 8"); return nullptr;
   }
-  if (d.compute_dtype != GDF_F16 && d.compute_dtype != GDF_BF16) { set_error("compute_dtype must be GDF_F16 or GDF_BF16"); return nullptr; }
+  if (d.compute_dtype != GDF_F16 && d.compute_dtype != GDF_BF16 && d.compute_dtype != GDF_BF16X2) {
+    set_error("compute_dtype must be GDF_F16, GDF_BF16 or GDF_BF16X2"); return nullptr;
+  }
   Model* m = new Model();
   m->kind = 1;
-  m->bf16 = d.compute_dtype == GDF_BF16;
+  m->bf16 = d.compute_dtype == GDF_BF16 || d.compute_dtype == GDF_BF16X2;
+  m->x2 = d.compute_dtype == GDF_BF16X2;
   m->flux.d = d;
   m->flux.D = d.attention_head_dim;
   m->flux.C = d.num_attention_heads * d.attention_head_dim;
@@ -393,7 +422,10 @@ int flux_plan_build(const Model& m, Plan& P, int batch, int img_h, int img_w, in
   for (int i = 0; i < n_ids; ++i)
     if (ids[i] && strstr(ids[i], "-map") && (n_txt % 8)) { set_error("'-map' hooks need n_txt % 8 == 0"); return GDF_ERR_UNSUPPORTED; }
   const size_t rows = (size_t)batch * ((size_t)img_h * img_w + n_txt);
-  if (rows * (size_t)(m.flux.C + m.flux.hid) * 2 >= (1ull << 31)) {      // 32-bit buffer offsets of the GEMM A operand
+  // 32-bit buffer offsets of the GEMM A operands ('bfloat16x2': the widest one, the single blocks' [C + hid] pair rows, is cut into row
+  // ranges by the builder; the next widest is the MLP hidden pair [2 hid])
+  const size_t widest = m.x2 ? (size_t)m.flux.hid * 2 : (size_t)(m.flux.C + m.flux.hid);
+  if (rows * widest * 2 >= (1ull << 31)) {
     set_error("batch * tokens too large for 32-bit buffer offsets; split the batch"); return GDF_ERR_UNSUPPORTED;
   }
   P.batch = batch; P.H = img_h; P.W = img_w; P.n_ctx = n_txt; P.opts = opts;
@@ -407,6 +439,7 @@ int flux_plan_build(const Model& m, Plan& P, int batch, int img_h, int img_w, in
     if (opts.early_exit && b.remaining == 0) b.stop = true;
   }
   b.build();
+  if (b.bad) return GDF_ERR_UNSUPPORTED;
   P.ws_bytes = b.ar.peak + 256;
   return GDF_OK;
 }

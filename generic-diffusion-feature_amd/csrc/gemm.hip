@@ -1056,17 +1056,26 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
         for (int it = 0; it < NIT; ++it)
           if (okr[it]) {
             f16x8 hv;
+            if (DIT && BF && p.out_f16) {                // 'bfloat16x2' plans: the attention operands q / k / v as saturating fp16
 #pragma unroll
-            for (int e = 0; e < 8; ++e) hv[e] = act16<DIT, BF>(v[it][e] * o_sc);
+              for (int e = 0; e < 8; ++e) hv[e] = f32_to_f16_sat(v[it][e] * o_sc);
+            } else {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) hv[e] = act16<DIT, BF>(v[it][e] * o_sc);
+            }
             *(f16x8*)(out16 + (size_t)rowi[it] * p.ldo16 + col) = hv;
           }
-        if (SPLIT && p.o16_lo > 0) {                     // split operand for the consumer GEMM: lo = fp16(v - hi)
+        if (SPLIT && p.o16_lo > 0) {                     // split operand for the consumer GEMM: lo = e16(v - hi)
 #pragma unroll
           for (int it = 0; it < NIT; ++it)
             if (okr[it]) {
               f16x8 lv;
 #pragma unroll
-              for (int e = 0; e < 8; ++e) { const float x = v[it][e] * o_sc; lv[e] = (_Float16)(x - (float)(_Float16)x); }
+              for (int e = 0; e < 8; ++e) {
+                const float x = v[it][e] * o_sc;
+                if constexpr (BF) lv[e] = __builtin_bit_cast(_Float16, (__bf16)(x - (float)(__bf16)x));
+                else lv[e] = (_Float16)(x - (float)(_Float16)x);
+              }
               *(f16x8*)(out16 + (size_t)rowi[it] * p.ldo16 + col + p.o16_lo) = lv;
             }
         }
@@ -1125,6 +1134,12 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_dit_kernel(const GemmParams p)
   gemm_body<A_DENSE, BM, BN, STAGES, false, true, BF, QKN>(p);
 }
 
+// the MMDiT kernels with split bf16 hi + lo A operands / outputs ('bfloat16x2' plans, gdf_flux.h)
+template <int BM, int BN, int STAGES, bool BF, bool QKN>
+__global__ __launch_bounds__(BM * 2, 2) void gemm_dit_split_kernel(const GemmParams p) {
+  gemm_body<A_DENSE, BM, BN, STAGES, false, true, BF, QKN, true>(p);
+}
+
 // workgroups of a persistent launch of a 1-workgroup-per-CU kernel: the CU count of the current device (a multiple of 8 XCDs);
 // GDF_PERSIST=0 (diagnostics) launches one workgroup per tile instead
 static int persist_wgs() {
@@ -1148,7 +1163,8 @@ static hipError_t launch_t(const GemmParams& p, hipStream_t s) {
   static std::atomic<uint64_t> attr_mask{0};             // per template instantiation, one bit per device
   {
     const void* fn;
-    if constexpr (DIT) fn = (const void*)gemm_dit_kernel<BM, BN, STAGES, BF, QKN>;
+    if constexpr (DIT && SPLIT) fn = (const void*)gemm_dit_split_kernel<BM, BN, STAGES, BF, QKN>;
+    else if constexpr (DIT) fn = (const void*)gemm_dit_kernel<BM, BN, STAGES, BF, QKN>;
     else if constexpr (SPLIT) fn = (const void*)gemm_split_kernel<MODE, BM, BN, STAGES, GEGLU>;
     else fn = (const void*)gemm_kernel<MODE, BM, BN, STAGES, GEGLU>;
     const hipError_t e = ensure_dyn_smem(attr_mask, fn, smem);
@@ -1171,7 +1187,8 @@ static hipError_t launch_t(const GemmParams& p, hipStream_t s) {
   const int pw = (p.cus > 0 && p.cus < persist_wgs()) ? p.cus : persist_wgs();
   if (STAGES == 8 && gx > pw && !(p.batch > 1)) gx = pw;   // persistent: one workgroup per CU walks the tiles
   const dim3 grid(gx, (STAGES == 2 && p.splitk > 1) ? p.splitk : p.batch > 1 ? p.batch : 1);
-  if constexpr (DIT) hipLaunchKernelGGL((gemm_dit_kernel<BM, BN, STAGES, BF, QKN>), grid, dim3(BM * 2), smem, s, q);
+  if constexpr (DIT && SPLIT) hipLaunchKernelGGL((gemm_dit_split_kernel<BM, BN, STAGES, BF, QKN>), grid, dim3(BM * 2), smem, s, q);
+  else if constexpr (DIT) hipLaunchKernelGGL((gemm_dit_kernel<BM, BN, STAGES, BF, QKN>), grid, dim3(BM * 2), smem, s, q);
   else if constexpr (SPLIT) hipLaunchKernelGGL((gemm_split_kernel<MODE, BM, BN, STAGES, GEGLU>), grid, dim3(BM * 2), smem, s, q);
   else hipLaunchKernelGGL((gemm_kernel<MODE, BM, BN, STAGES, GEGLU>), grid, dim3(BM * 2), smem, s, q);
   return hipGetLastError();
@@ -1192,8 +1209,10 @@ static int pick_variant_any(const GemmParams& p);
 // split-operand launches ("precise" plans) are instantiated for a reduced set of tiles: dense / conv 256x320 two-group, 128x160,
 // 128x128; GEGLU 256x256 two-group and 128x128; the narrow-N tile
 static bool is_split(const GemmParams& p) { return !p.dit && (p.k_w > 0 || p.o16_lo > 0); }
+static bool is_dit_split(const GemmParams& p) { return p.dit && (p.k_w > 0 || p.o16_lo > 0); }
 static int pick_variant(const GemmParams& p) {
   const int v = pick_variant_any(p);
+  if (is_dit_split(p)) return (v == 8256 || v == 1256) ? 8256 : 128;      // 'bfloat16x2' MMDiT plans: 256x256 two-group or 128x128
   if (!is_split(p) || v == 16) return v;
   if (p.geglu) return v == 825 ? 825 : 128;
   if (p.mode == A_CONV_SMALLC) return v == 160 ? 160 : 128;
@@ -1270,7 +1289,7 @@ const char* gemm_kernel_name(const GemmParams& p) {
   else if (v == 825) { bm = 256; bn = 256; st = 8; } else if (v == 932) { bm = 256; bn = 320; st = 9; } else if (v == 826) { bm = 256; bn = 256; st = 8; }
   if (p.mode == A_CONV_SMALLC && v != 160) { bm = 128; bn = 128; st = 2; }
   char tmp[64];
-  if (p.dit) snprintf(tmp, sizeof tmp, "gemm_dit_kernel<%d, %d, %d, %s, %s>", v == 128 ? 128 : 256, (v == 1256 || v == 8256) ? 256 : 128, v == 8256 ? 8 : v == 2128 ? 3 : 2, p.bf16 ? "true" : "false", p.qkn_nq ? "true" : "false");
+  if (p.dit) snprintf(tmp, sizeof tmp, "%s<%d, %d, %d, %s, %s>", is_dit_split(p) ? "gemm_dit_split_kernel" : "gemm_dit_kernel", v == 128 ? 128 : 256, (v == 1256 || v == 8256) ? 256 : 128, v == 8256 ? 8 : v == 2128 ? 3 : 2, p.bf16 ? "true" : "false", p.qkn_nq ? "true" : "false");
   else snprintf(tmp, sizeof tmp, "%s<%d, %d, %d, %d, %s>", is_split(p) ? "gemm_split_kernel" : "gemm_kernel", p.mode, bm, bn, st, p.geglu ? "true" : "false");
   // interned: the returned pointer stays valid for the life of the library (plan build time only, mutex-protected)
   static std::mutex mu;
@@ -1285,9 +1304,10 @@ hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {
   if (p.M <= 0 || p.N <= 0) return hipSuccess;
   if (p.mode != A_CONV_SMALLC && (p.K % BK) != 0) return hipErrorInvalidValue;
   if (p.mode == A_CONV3 && (p.Cin % BK) != 0) return hipErrorInvalidValue;
-  if (p.k_w > 0 && (p.K != 2 * p.k_w || (p.k_w % BK) != 0 || p.mode == A_CONV_SMALLC || p.dit || (p.mode == A_CONV3 && (p.k_w % (9 * BK)) != 0)))
+  if (p.k_w > 0 && (p.K != 2 * p.k_w || (p.k_w % BK) != 0 || p.mode == A_CONV_SMALLC || (p.dit && !p.bf16) || (p.mode == A_CONV3 && (p.k_w % (9 * BK)) != 0)))
     return hipErrorInvalidValue;                                                         // split operands: K = [hi | lo] over one weight matrix
-  if (p.o16_lo > 0 && (p.dit || p.bn == 16 || (p.o16_lo % 8) != 0)) return hipErrorInvalidValue;
+  if (p.o16_lo > 0 && ((p.dit && !p.bf16) || p.bn == 16 || (p.o16_lo % 8) != 0)) return hipErrorInvalidValue;   // (MMDiT: the bf16 pair form only)
+  if (p.out_f16 && !(p.dit && p.bf16)) return hipErrorInvalidValue;
   const int v = pick_variant(p);
   if (v != 16 && ((p.geglu ? p.N / 2 : p.N) % 8) != 0) return hipErrorInvalidValue;   // ragged N only in the BN = 16 variant
   if (p.bf16 && !p.dit) return hipErrorInvalidValue;                                      // bf16 exists on the MMDiT path only
@@ -1295,6 +1315,10 @@ hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {
     if (p.mode != A_DENSE || p.geglu || p.batch > 1) return hipErrorInvalidValue;
     if (p.qkn_nq && ((v != 8256 && v != 1256) || (p.qkn_nq % 128) != 0)) return hipErrorInvalidValue;   // one head per 128-column wave tile
     if (p.qkn_nq && (p.res32 || p.res16 || p.rowvec || p.aux16 || p.out32)) return hipErrorInvalidValue;  // the QKN instantiation: bias -> norm + RoPE -> out16 only
+    if (is_dit_split(p)) {                                                                // bf16 hi + lo operands ('bfloat16x2' plans)
+      if (v == 8256) return p.qkn_nq ? launch_t<A_DENSE, 256, 256, 8, false, true, true, true, true>(p, s) : launch_t<A_DENSE, 256, 256, 8, false, true, true, false, true>(p, s);
+      return p.qkn_nq ? hipErrorInvalidValue : launch_t<A_DENSE, 128, 128, 2, false, true, true, false, true>(p, s);
+    }
     if (p.bf16) {
       if (v == 8256) return p.qkn_nq ? launch_t<A_DENSE, 256, 256, 8, false, true, true, true>(p, s) : launch_t<A_DENSE, 256, 256, 8, false, true, true>(p, s);
       if (v == 1256) return p.qkn_nq ? launch_t<A_DENSE, 256, 256, 2, false, true, true, true>(p, s) : launch_t<A_DENSE, 256, 256, 2, false, true, true>(p, s);

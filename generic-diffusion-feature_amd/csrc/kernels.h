@@ -126,6 +126,10 @@ struct GemmParams {
   // gdf_stream_create_cu_mask): tile selection, persistent grids and the XCD super-block order count workgroup slots on `cus`
   // CUs instead of the whole chip.  0 = the whole device.
   int cus;
+  // MMDiT 'bfloat16x2' plans (gdf_flux_desc.compute_dtype = GDF_BF16X2): a bf16 kernel (dit, bf16) that stores out16 as SATURATING fp16 — the
+  // q / k / v buffer of the attention kernel, whose internals run in fp16 in that mode (q, k are RMS-normalised, v is a linear of a
+  // normalised tensor: inside the fp16 range by construction; 11 mantissa bits instead of 8)
+  int out_f16;
 };
 hipError_t launch_gemm(const GemmParams& p, hipStream_t s);
 // Deterministic split-K for problems with few output tiles and a long K (the 8x8-level 3x3 convs of SD1.5: 160 tiles of 128x128,
@@ -154,6 +158,7 @@ struct AttnParams {
   int seg_T;             // > 0: MMDiT joint sequence, region-major rows [B x seg_T text][B x (Sq - seg_T) image] (Sq == Sk)
   int bf16;              // D = 128 only: q, k, v, o are bf16 (mfma_f32_32x32x16_bf16, P rounded to bf16); maps stay fp16
   int o_lo;              // > 0 ("precise" plans): o is written as a split (hi, lo) pair, lo at o + o_lo elements in the same row
+  int o_pair_bf16;       // with o_lo > 0 and fp16 q / k / v (bf16 == 0): the pair is written as bf16 hi + bf16 lo (MMDiT 'bfloat16x2' plans)
 };
 hipError_t launch_attention(const AttnParams& p, hipStream_t s);
 
@@ -181,9 +186,10 @@ hipError_t launch_layernorm(const half_t* x16, const float* x32, int ld, int R, 
 // LayerNorm without affine + adaLN modulation (AdaLayerNormZero / ZeroSingle / Continuous and the norm2 modulate of
 // the MMDiT blocks): y = LN(x, eps) * (1 + scale[s][c]) + shift[s][c]; s = row / rps for row < seg_rows (or
 // seg_rows == 0), else (row - seg_rows) / rps2.  x fp32 (or fp16) [R][ld], y fp16 [R][C], scale/shift fp32 rows of ldm.
+// y_lo > 0: y is written as a split pair (rows of ldy elements, hi at column 0, lo = e16(v - hi) at column y_lo)
 hipError_t launch_layernorm_mod(const half_t* x16, const float* x32, int ld, int R, int C, float eps, const float* scale,
                                 const float* shift, int ldm, int rps, int seg_rows, int rps2, half_t* y, hipStream_t s,
-                                int bf16 = 0);
+                                int bf16 = 0, int ldy = 0, int y_lo = 0);
 // RMSNorm(q), RMSNorm(k) per head + rotary embedding, in place on rows [R][ld] fp16: q heads at columns
 // q_col + h*D, k heads at k_col + h*D (D = 128); position of row r = pos0 + r % rps; cos/sin fp32 [pos][D].
 hipError_t launch_qk_norm_rope(half_t* x, int ld, int R, int heads, int D, int q_col, int k_col, const float* wq,
@@ -219,8 +225,9 @@ hipError_t launch_relayout_rows_padk(const void* src, int src_f32, half_t* dst, 
 hipError_t launch_silu_vec(const float* x, float* out, long n, hipStream_t s);
 // strided 2-D copy with cast to fp16: dst[r][c] = src[r][c]   (hook stores)
 // src_bf16: s16 holds bf16; sat: clamp to the fp16 range instead of producing +-inf (hook stores of the bf16 / MMDiT path)
+// s_lo > 0: the 16-bit source is a split pair (lo s_lo elements after hi in the row): dst = fp16(hi + lo)
 hipError_t launch_copy2d(const half_t* s16, const float* s32, int lds_, half_t* dst, int ldd, int R, int C,
-                         hipStream_t s, int src_bf16 = 0, int sat = 0);
+                         hipStream_t s, int src_bf16 = 0, int sat = 0, int s_lo = 0);
 // latents NCHW fp16 (B,Cin,H,W) -> NHWC padded to 8 channels (conv_in operand) and optional NHWC hook copy
 hipError_t launch_pack_latents(const half_t* x, int B, int Cin, int H, int W, half_t* nhwc8, half_t* hook_nhwc,
                                hipStream_t s);

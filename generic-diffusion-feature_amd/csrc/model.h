@@ -89,6 +89,7 @@ struct VaeW {
 
 struct Model {
   int bf16 = 0;                                // 16-bit element type of weights / activations: 0 fp16, 1 bf16 (Flux only)
+  int x2 = 0;                                  // Flux 'bfloat16x2' (GDF_BF16X2): bf16 weights, activation operands as bf16 hi + lo pairs, fp16 attention internals
   int kind = 0;                                // 0: UNet2DConditionModel, 1: FluxTransformer2DModel, 2: AutoencoderKL encoder, 3: PixArt DiT, 4: AutoencoderKL decoder
   FluxW flux;
   VaeW vae;

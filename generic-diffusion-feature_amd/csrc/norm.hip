@@ -359,7 +359,7 @@ hipError_t launch_layernorm(const half_t* x16, const float* x32, int ld, int R, 
 // (`bf`) and the fp16 result saturates at +-65504 instead of overflowing to inf (`sat`).
 template <bool CVT>
 __global__ __launch_bounds__(256) void copy2d_kernel(const half_t* s16, const float* s32, int lds_, half_t* dst, int ldd,
-                                                     long R, int C, int bf, int sat) {
+                                                     long R, int C, int bf, int sat, int s_lo) {
   if ((C & 7) == 0 && (lds_ & 7) == 0 && (ldd & 7) == 0) {
     const int CH = C / 8;
     const long total = R * CH;
@@ -367,10 +367,15 @@ __global__ __launch_bounds__(256) void copy2d_kernel(const half_t* s16, const fl
       const long r = i / CH;
       const int c = (int)(i - r * CH) * 8;
       float v[8];
-      if (CVT && bf && !s32) {
+      if (CVT && !s32 && (bf || s_lo > 0)) {
         const f16x8 raw = *(const f16x8*)(s16 + (size_t)r * lds_ + c);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = e16_to_f32(raw[e], 1);
+        for (int e = 0; e < 8; ++e) v[e] = e16_to_f32(raw[e], bf);
+        if (s_lo > 0) {                                  // split pair source: hi + lo
+          const f16x8 rl = *(const f16x8*)(s16 + (size_t)r * lds_ + c + s_lo);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += e16_to_f32(rl[e], bf);
+        }
       } else {
         load8(s16, s32, (size_t)r * lds_ + c, v);
       }
@@ -384,22 +389,23 @@ __global__ __launch_bounds__(256) void copy2d_kernel(const half_t* s16, const fl
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
       const long r = i / C;
       const int c = (int)(i - r * C);
-      const float v = s32 ? s32[(size_t)r * lds_ + c] : e16_to_f32(s16[(size_t)r * lds_ + c], CVT && bf);
+      float v = s32 ? s32[(size_t)r * lds_ + c] : e16_to_f32(s16[(size_t)r * lds_ + c], CVT && bf);
+      if (CVT && s_lo > 0 && !s32) v += e16_to_f32(s16[(size_t)r * lds_ + c + s_lo], bf);
       dst[(size_t)r * ldd + c] = (CVT && sat) ? f32_to_f16_sat(v) : (_Float16)v;
     }
   }
 }
 
 hipError_t launch_copy2d(const half_t* s16, const float* s32, int lds_, half_t* dst, int ldd, int R, int C,
-                         hipStream_t s, int src_bf16, int sat) {
+                         hipStream_t s, int src_bf16, int sat, int s_lo) {
   const long work = (long)R * ((C + 7) / 8);
   long blocks = (work + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   if (blocks < 1) blocks = 1;
-  if (src_bf16 || sat)
-    hipLaunchKernelGGL(copy2d_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, s16, s32, lds_, dst, ldd, (long)R, C, src_bf16, sat);
+  if (src_bf16 || sat || s_lo > 0)
+    hipLaunchKernelGGL(copy2d_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, s16, s32, lds_, dst, ldd, (long)R, C, src_bf16, sat, s_lo);
   else
-    hipLaunchKernelGGL(copy2d_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, s16, s32, lds_, dst, ldd, (long)R, C, 0, 0);
+    hipLaunchKernelGGL(copy2d_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, s16, s32, lds_, dst, ldd, (long)R, C, 0, 0, 0);
   return hipGetLastError();
 }
 

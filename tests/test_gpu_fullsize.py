@@ -237,7 +237,7 @@ def test_sd15_512_full_layer_set_with_maps_batch2_and_batch32():
     _check(errs_a32, None, lambda kd: 1.0e-3)
 
 
-@pytest.mark.parametrize("dt", ["bfloat16", "float16"])
+@pytest.mark.parametrize("dt", ["bfloat16", "float16", "bfloat16x2"])
 def test_flux_full_width_batch8(dt):
     """BASELINE config C5 widths (24 heads x 128, 4096 + 512 tokens, T5 width 4096) with a reduced stack (2 double + 3 single
     blocks so the CPU oracle finishes within a minute), batch 8 on one sample repeated: every non-map hook, both QKV paths
@@ -248,10 +248,10 @@ def test_flux_full_width_batch8(dt):
     arch = dict(FR.ARCH_FLUX_DEV); arch.update(num_layers=2, num_single_layers=3)
     P = FR.synth_params(arch, seed=0)
     I = FR.synth_inputs(arch, 1, 64, 512, seed=1)
-    tdt = torch.bfloat16 if dt == "bfloat16" else torch.float16
+    tdt = torch.float16 if dt == "float16" else torch.bfloat16
     P = {k: v.to(tdt).float() for k, v in P.items()}            # the oracle runs on the values the model's element type holds
     I = {k: (v.to(tdt).float() if k in ("hidden_states", "encoder_hidden_states", "pooled_projections") else v) for k, v in I.items()}
-    tol = 4e-3 if dt == "bfloat16" else 6e-4
+    tol = {"bfloat16": 4e-3, "float16": 6e-4, "bfloat16x2": 1e-3}[dt]
     st = FR.Store(None)
     with torch.no_grad():
         y = FR.flux_forward(P, arch, I["hidden_states"], I["encoder_hidden_states"], I["pooled_projections"], I["timestep"],
@@ -268,9 +268,13 @@ def test_flux_full_width_batch8(dt):
         torch.cuda.synchronize()
         assert list(hooks.keys()) == ids
         errs = {k: max(_rel_each(hooks[k], st.feats[k])) for k in ids}
-        errs["output"] = max(_rel_each(out, y))
+        e_out = max(_rel_each(out, y))
+        if dt == "bfloat16x2":                                  # the model OUTPUT is a bf16 tensor (8 mantissa bits of storage): its own bound
+            assert e_out <= 3e-3, e_out
+        else:
+            errs["output"] = e_out
         worst = max(errs, key=errs.get)
-        print(f"\n[flux widths B=8 {dt}, {len(ids)} hooks] worst {worst} = {errs[worst]:.2e}")
+        print(f"\n[flux widths B=8 {dt}, {len(ids)} hooks] worst {worst} = {errs[worst]:.2e}; output {e_out:.2e}")
         assert errs[worst] <= tol, (worst, errs[worst])
         del hooks, out
 
@@ -310,8 +314,10 @@ def test_flux_dev_full_depth_config_c5_error_vs_depth():
              f"(oracle {t_oracle:.0f} s on {torch.get_num_threads()} threads); relative L2 error, worst sample"]
     # measured (profiles/r03_flux_depth_parity.txt): the error saturates with depth — block `out` 1.7e-3 (block 0) -> 2.65e-3 (block 56) in
     # bf16, 1.3e-4 -> 4.3e-4 in fp16; worst hook (q of the last block) 3.4e-3 / 4.6e-4
-    bounds = {"bfloat16": 4.0e-3, "float16": 6.0e-4}
-    for dt, tdt in (("bfloat16", torch.bfloat16), ("float16", torch.float16)):
+    # round 4: 'bfloat16x2' (bf16 hi + lo operand pairs, fp16 attention internals): every HOOK within the north-star 1e-3 at full depth
+    # without leaving bf16's range on the residual / MLP path (the model output is a bf16 tensor: storage-limited, its own bound)
+    bounds = {"bfloat16": 4.0e-3, "float16": 6.0e-4, "bfloat16x2": 1.0e-3}
+    for dt, tdt in (("bfloat16", torch.bfloat16), ("float16", torch.float16), ("bfloat16x2", torch.bfloat16)):
         net = NativeFluxTransformer(arch, device="cuda:0", compute_dtype=dt)
         net.load_state_dict(_DeviceView(P, tdt))
         args = (rep(I["hidden_states"]), rep(I["encoder_hidden_states"]), rep(I["pooled_projections"]), I["timestep"].cuda(),
@@ -321,13 +327,17 @@ def test_flux_dev_full_depth_config_c5_error_vs_depth():
         assert list(hooks.keys()) == ids
         errs = {k: max(_rel_each(hooks[k], st.feats[k])) for k in ids}
         errs["output"] = max(_rel_each(out, y))
+        e_out = errs["output"]
+        if dt == "bfloat16x2":
+            assert errs.pop("output") <= 3e-3
+            errs["output"] = 0.0
         for k in ids:
             assert torch.isfinite(hooks[k].float()).all(), k
         outs = [errs[f"vit-block{b}-out"] for b in range(nd + ns)]
         lines.append(f"[{dt}] block `out` error by depth: " + " ".join(f"{b}:{e:.2e}" for b, e in enumerate(outs)))
         lines.append(f"[{dt}] other hooks: " + " ".join(f"{k}:{e:.2e}" for k, e in errs.items() if not k.endswith("-out") or k == "output" or "attn" in k))
         worst = max(errs, key=errs.get)
-        lines.append(f"[{dt}] worst {worst} = {errs[worst]:.2e} (bound {bounds[dt]:.1e}); model output {errs['output']:.2e}")
+        lines.append(f"[{dt}] worst {worst} = {errs[worst]:.2e} (bound {bounds[dt]:.1e}); model output {e_out:.2e}")
         print("\n" + "\n".join(lines[-3:]))
         assert errs[worst] <= bounds[dt], (dt, worst, errs[worst])
         del hooks, out, net

@@ -422,7 +422,7 @@ def test_hook_buffers_recycled_after_views_die_and_cross_stream_reader_is_ordere
             host[k].copy_(ha[k], non_blocking=True)
     release_after(ha, s2)
     p0 = ha[ids[0]].data_ptr()
-    del ha
+    del ha, _                                           # (`_` held the model output of that forward: a view of the same lease)
     g = lambda k: Ib[k].cuda() if k in Ib else None
     _, hb2 = u.forward_raw(g("sample"), g("timestep"), g("ctx"), g("text_embeds"), g("time_ids"), hook_ids=ids)   # no synchronize
     assert hb2[ids[0]].data_ptr() == p0                 # the SAME buffers: recycled at once

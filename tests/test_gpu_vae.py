@@ -167,7 +167,8 @@ def test_feature_extractor_vae_out(version, img, monkeypatch):
     if version == "xl":
         kw = dict(text_embeds=pooled.repeat(2, 1, 1).squeeze(1).cuda(),
                   time_ids=torch.tensor([[img, img, 0, 0, img, img]], dtype=torch.float32).repeat(2, 1).cuda())
-    noise, _ = unet.forward_raw(lin, ts[:1], emb.repeat(2, 1, 1).cuda(), kw.get("text_embeds"), kw.get("time_ids"), hook_ids=[hook],
+    # (the same id list as the extractor's: 'vae-out' is no UNet hook, but the automatic operand-plan selection counts it like `unet-out`)
+    noise, _ = unet.forward_raw(lin, ts[:1], emb.repeat(2, 1, 1).cuda(), kw.get("text_embeds"), kw.get("time_ids"), hook_ids=[hook, "vae-out"],
                                 shared_ctx=True)
     img2 = native_vae_decoder(df.pipe, 'cuda').decode(lat.cuda(), noise, c_sample=a, c_eps=b,
                                                        scaling_factor=float(df.pipe.vae.config.scaling_factor))

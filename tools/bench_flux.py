@@ -63,7 +63,7 @@ def main():
     ap.add_argument("--hooks", default="practical", choices=("practical", "all", "none"))
     ap.add_argument("--profile-ops", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--dtype", default="bfloat16", choices=("bfloat16", "float16"),
+    ap.add_argument("--dtype", default="bfloat16", choices=("bfloat16", "float16", "bfloat16x2"),
                     help="element type of weights / activations / MFMA operands (the reference loads Flux in bfloat16)")
     args = ap.parse_args()
     if not torch.cuda.is_available():
@@ -126,7 +126,7 @@ def main():
     res = {"metric": "images/sec feature-extract, Flux.1-dev MMDiT 1024^2 single forward", "value": round(ips, 3),
            "unit": "images/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(1e3 * dt / args.steps, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-           "dtype": "bf16" if args.dtype == "bfloat16" else "f16", "data": "synthetic",
+           "dtype": {"bfloat16": "bf16", "float16": "f16", "bfloat16x2": "bf16 hi+lo operand pairs (fp16 attention internals)"}[args.dtype], "data": "synthetic",
            "config": {"workload": f"Flux MMDiT ({args.layers} double + {args.single_layers} single blocks, 24 heads x 128), "
                                   f"{S}+{T} tokens, batch {B}, hooks={args.hooks} ({len(out[1])} ids, "
                                   f"{hook_bytes / B / 1e6:.1f} MB/img)",
@@ -134,7 +134,10 @@ def main():
                       "weights_gb": round(lib.gdf_model_weight_bytes(net.handle) / 1e9, 2), "weights_init_s": round(t_w, 1),
                       "workspace_gb": round(plan.ws_bytes / 1e9, 2),
                       "arithmetic": ("bf16 MFMA operands / weights / activations (the reference's dtype, components/models.py:158-169)"
-                                     if args.dtype == "bfloat16" else "fp16 MFMA operands / weights / activations (reference: bf16)")
+                                     if args.dtype == "bfloat16" else
+                                     "bf16 weights; every activation operand a bf16 hi + lo pair contracted as [hi | lo] x [W | W] (2x MFMA work; TFLOP/s "
+                                     "count algorithmic FLOPs); q / k / v / P fp16" if args.dtype == "bfloat16x2" else
+                                     "fp16 MFMA operands / weights / activations (reference: bf16)")
                                     + ", fp32 accumulate, fp32 residual stream, fp16 hooks (saturating)"},
            "roofline": {"bound": "mfma", "kernel": dominant, "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS,
                         "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
