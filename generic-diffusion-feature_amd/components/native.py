@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(os.path.dirname(_HERE), "libgdf.so")
 
-GDF_F16, GDF_F32, GDF_BF16, GDF_BF16X2 = 0, 1, 2, 3
+GDF_F16, GDF_F32, GDF_BF16, GDF_BF16X2, GDF_FP8MX = 0, 1, 2, 3, 4
 MAX_LEVELS = 4
 
 
@@ -831,7 +831,7 @@ def flux_desc(cfg):
         setattr(d, k, int(cfg[k]))
     d.guidance_embeds = int(bool(cfg["guidance_embeds"]))
     d.mlp_ratio = int(cfg.get("mlp_ratio", 4))
-    d.compute_dtype = {"bfloat16": GDF_BF16, "float16": GDF_F16, "bfloat16x2": GDF_BF16X2}[cfg.get("compute_dtype", "bfloat16")]
+    d.compute_dtype = {"bfloat16": GDF_BF16, "float16": GDF_F16, "bfloat16x2": GDF_BF16X2, "fp8-mx": GDF_FP8MX}[cfg.get("compute_dtype", "bfloat16")]
     for i in range(3):
         d.axes_dims_rope[i] = int(cfg["axes_dims_rope"][i])
     return d

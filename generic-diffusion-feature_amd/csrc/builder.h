@@ -293,12 +293,21 @@ struct PlanBuilder {
 
   // dense GEMM: A (fp16 [M][K], lda) x W[N][K].  a_lo > 0: A is a split pair (lo columns a_lo elements after the hi columns):
   // the contraction runs over [hi | lo] (2K) against W read twice (GemmParams::k_w)
-  void gemm(const char* name, Ref A, int lda, size_t M, const LinW& w, int N, int Kw, size_t w_off_bytes, const Epi& e0, int a_lo = 0) {
+  // mx != null ('fp8-mx' MMDiT plans): the A operand is the fp8 (e4m3) matrix mx->a8 [M][lda8 bytes] with per-row scales mx->ascale, the
+  // weights their fp8 copy + per-output-channel scales inside the model arena (Model::f8_off / sc_off); A / lda are then unused
+  struct MxA { Ref a8; int lda8 = 0; Ref ascale; };
+  static bool mx_ok(size_t M, int N, int K) { return M >= 2048 && (N % 256) == 0 && (K % 128) == 0; }
+  void gemm(const char* name, Ref A, int lda, size_t M, const LinW& w, int N, int Kw, size_t w_off_bytes, const Epi& e0, int a_lo = 0,
+            const MxA* mxp = nullptr) {
     Epi e = e0;
     e.bf16 = (e.dit && m.bf16) ? 1 : 0;
     const Ref W = wt(w.w + w_off_bytes);
     const int K = a_lo > 0 ? 2 * Kw : Kw;
+    const bool use_mx = mxp && m.fp8 && e.dit && a_lo == 0 && mx_ok(M, N, Kw);
+    const MxA mxa = use_mx ? *mxp : MxA{};
+    const Ref W8 = wt(m.f8_off + (w.w + w_off_bytes) / 2), WS = wt(m.sc_off + w.w / 16 + (w_off_bytes / ((size_t)Kw * 2)) * 4);
     GemmParams gk{}; gk.M = (int)M; gk.N = N; gk.K = K; gk.mode = A_DENSE; gk.geglu = e.geglu; gk.bn = e.bn; gk.dit = e.dit; gk.bf16 = e.bf16;
+    gk.mx = use_mx ? 1 : 0;
     gk.k_w = a_lo > 0 ? Kw : 0; gk.o16_lo = e.has_o16 ? e.o16_lo : 0;      // split operands: their own kernel instantiations / tile set
     const int cus = opt.reserved[2]; gk.cus = cus;                           // CU partition of the launch stream (0 = whole chip)
     gk.res32 = e.has_r32 ? (const float*)1 : nullptr;      // tile selection looks at the epilogue form (never dereferenced)
@@ -314,6 +323,11 @@ struct PlanBuilder {
       if (a_lo > 0) { g.k_w = Kw; g.a_lo_bytes = (uint32_t)a_lo * 2u; }
       g.Wt = (const half_t*)b.p(W); g.w_bytes = (uint32_t)((size_t)N * Kw * 2);
       fill_epi(g, e, b);
+      if (use_mx) {                                        // fp8 rows in 2-byte units (kernels.h GemmParams::mx)
+        g.A = (const half_t*)b.p(mxa.a8); g.lda = mxa.lda8 / 2; g.a_bytes = (uint32_t)(((size_t)M - 1) * mxa.lda8 + (size_t)Kw);
+        g.K = Kw / 2; g.Wt = (const half_t*)b.p(W8); g.w_bytes = (uint32_t)((size_t)N * Kw);
+        g.mx = 1; g.mx_rowscale = (const float*)b.p(mxa.ascale); g.mx_colscale = (const float*)b.p(WS);
+      }
       return splitk > 1 ? launch_gemm_splitk(g, splitk, (float*)b.ws(wsk), s) : launch_gemm(g, s);
     }, gemm_kernel_name(gk));
     if (splitk > 1) untmp(wsk, ws_b);

@@ -16,10 +16,58 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // one wave per row, the row lives in registers (C <= 64 * 8 * MAXC), exact two-pass statistics
+// ---- fp8 (OCP e4m3) row quantisation: q = fp8(v / s), s = the smallest power of two with |v| / s <= 448 (the e4m3 maximum) ----
+__device__ __forceinline__ float fp8_row_scale(float amax) {
+  if (!(amax > 0.f) || !(amax < 3.0e38f)) return 1.0f;
+  int e; (void)frexpf(amax * (1.0f / 448.0f), &e);        // amax / 448 = m 2^e, m in [0.5, 1)  ->  2^e >= amax / 448
+  return ldexpf(1.0f, e);
+}
+__device__ __forceinline__ uint2 pack_fp8x8(const float v[8], float inv) {
+  int lo = 0, hi = 0;
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[0] * inv, v[1] * inv, lo, false);
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[2] * inv, v[3] * inv, lo, true);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[4] * inv, v[5] * inv, hi, false);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[6] * inv, v[7] * inv, hi, true);
+  return uint2{(unsigned)lo, (unsigned)hi};
+}
+// 16-bit rows [R][ld] (K columns used) -> fp8 [R][ldq] + scale[R]; one workgroup per row, two passes (the second read hits L2)
+__global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const half_t* x, int ld, int K, int bf, unsigned char* q, int ldq, float* scale) {
+  const size_t row = blockIdx.x;
+  const half_t* xr = x + row * (size_t)ld;
+  __shared__ float red[4];
+  float amax = 0.f;
+  for (int c = threadIdx.x * 8; c < K; c += 256 * 8) {
+    const f16x8 a = *(const f16x8*)(xr + c);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(e16_to_f32(a[e], bf)));
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = amax;
+  __syncthreads();
+  amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  const float sc = fp8_row_scale(amax), inv = 1.0f / sc;
+  if (threadIdx.x == 0) scale[row] = sc;
+  for (int c = threadIdx.x * 8; c < K; c += 256 * 8) {
+    const f16x8 a = *(const f16x8*)(xr + c);
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = e16_to_f32(a[e], bf);
+    *(uint2*)(q + row * (size_t)ldq + c) = pack_fp8x8(v, inv);
+  }
+}
+hipError_t launch_quant_rows_fp8(const half_t* x, int ld, int R, int K, int bf16, unsigned char* q, int ldq, float* scale, hipStream_t s) {
+  if (R <= 0) return hipSuccess;
+  if ((K & 7) || (ld & 7) || (ldq & 7)) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(quant_rows_fp8_kernel, dim3((unsigned)R), dim3(256), 0, s, x, ld, K, bf16, q, ldq, scale);
+  return hipGetLastError();
+}
+
 template <int MAXC>
 __global__ __launch_bounds__(256) void layernorm_mod_kernel(const half_t* x16, const float* x32, int ld, int R, int C,
                                                             float eps, const float* scale, const float* shift, int ldm,
-                                                            int rps, int seg_rows, int rps2, half_t* y, int bf, int ldy, int y_lo) {
+                                                            int rps, int seg_rows, int rps2, half_t* y, int bf, int ldy, int y_lo,
+                                                            unsigned char* q8, int ldq8, float* q8_scale) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= R) return;
@@ -61,6 +109,7 @@ __global__ __launch_bounds__(256) void layernorm_mod_kernel(const half_t* x16, c
   const int smp = (seg_rows > 0 && row >= seg_rows) ? (row - seg_rows) / rps2 : row / rps;
   const float* sc = scale + (size_t)smp * ldm;
   const float* sh = shift + (size_t)smp * ldm;
+  float amax = 0.f;                                     // fp8 output ('fp8-mx' plans): |max| of the modulated row
 #pragma unroll
   for (int i = 0; i < MAXC; ++i) {
     const int c = lane + 64 * i;
@@ -74,6 +123,10 @@ __global__ __launch_bounds__(256) void layernorm_mod_kernel(const half_t* x16, c
         t[e] = (v[i][e] - mean) * rstd * (1.0f + g0[e]) + b0[e];
         t[4 + e] = (v[i][4 + e] - mean) * rstd * (1.0f + g1[e]) + b1[e];
       }
+      if (q8) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { v[i][e] = t[e]; amax = fmaxf(amax, fabsf(t[e])); }   // keep the modulated values for the fp8 pass
+      }
 #pragma unroll
       for (int e = 0; e < 8; ++e) o[e] = f32_to_e16(t[e], bf);
       *(f16x8*)(y + (size_t)row * ldy + c * 8) = o;
@@ -85,17 +138,28 @@ __global__ __launch_bounds__(256) void layernorm_mod_kernel(const half_t* x16, c
       }
     }
   }
+  if (q8) {                                              // the same row as fp8 (e4m3) with one power-of-two scale (operand of an 'fp8-mx' GEMM)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
+    const float sc8 = fp8_row_scale(amax), inv = 1.0f / sc8;
+    if (lane == 0) q8_scale[row] = sc8;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const int c = lane + 64 * i;
+      if (c < CH) *(uint2*)(q8 + (size_t)row * ldq8 + c * 8) = pack_fp8x8(v[i], inv);
+    }
+  }
 }
 
 hipError_t launch_layernorm_mod(const half_t* x16, const float* x32, int ld, int R, int C, float eps, const float* scale,
                                 const float* shift, int ldm, int rps, int seg_rows, int rps2, half_t* y, hipStream_t s,
-                                int bf16, int ldy, int y_lo) {
-  if (C % 8 || C > 64 * 8 * 8 || (ldm & 3) || rps <= 0 || (y_lo & 7) || (ldy & 7)) return hipErrorInvalidValue;
+                                int bf16, int ldy, int y_lo, unsigned char* q8, int ldq8, float* q8_scale) {
+  if (C % 8 || C > 64 * 8 * 8 || (ldm & 3) || rps <= 0 || (y_lo & 7) || (ldy & 7) || (q8 && ((ldq8 & 7) || !q8_scale))) return hipErrorInvalidValue;
   if (ldy <= 0) ldy = C;
   if (R <= 0) return hipSuccess;
   const int CH = C / 8;
   dim3 grid((R + 3) / 4), blk(256);
-#define GDF_LNM(N) hipLaunchKernelGGL(layernorm_mod_kernel<N>, grid, blk, 0, s, x16, x32, ld, R, C, eps, scale, shift, ldm, rps, seg_rows, rps2, y, bf16, ldy, y_lo)
+#define GDF_LNM(N) hipLaunchKernelGGL(layernorm_mod_kernel<N>, grid, blk, 0, s, x16, x32, ld, R, C, eps, scale, shift, ldm, rps, seg_rows, rps2, y, bf16, ldy, y_lo, q8, ldq8, q8_scale)
   if (CH <= 64) GDF_LNM(1);
   else if (CH <= 128) GDF_LNM(2);
   else if (CH <= 256) GDF_LNM(4);

@@ -97,14 +97,34 @@ struct FB : PlanBuilder {   // Flux op program
   // 'bfloat16x2' plans (m.x2): every MFMA A operand is a bf16 hi + lo pair [hi C | lo C] in one row (px = 2), multiplied as
   // [hi | lo] x [W | W]; q / k / v and the attention internals are fp16
   int px() const { return m.x2 ? 2 : 1; }
-  void adaln(const char* name, size_t r0, size_t n, int shift_col, int scale_col, int rps, size_t seg_rows, int rps2, Ref dst) {
+  // q8 != null ('fp8-mx' plans): the same rows also as fp8 (e4m3) [n][C] + one scale per row, written in the same pass
+  void adaln(const char* name, size_t r0, size_t n, int shift_col, int scale_col, int rps, size_t seg_rows, int rps2, Ref dst,
+             const MxA* q8 = nullptr) {
     const Ref x = stream_rows(r0), sc = modv(scale_col), sh = modv(shift_col);
     const int C = f.C, ldm = f.mod_total, bf = m.bf16, ldy = C * px(), y_lo = m.x2 ? C : 0;
+    const bool hq = q8 != nullptr;
+    const MxA q = hq ? *q8 : MxA{};
     op(name, 0, [=](const Bind& b, hipStream_t s) {
       return launch_layernorm_mod(nullptr, (const float*)b.p(x), C, (int)n, C, 1e-6f, (const float*)b.p(sc), (const float*)b.p(sh),
-                                  ldm, rps, (int)seg_rows, rps2, (half_t*)b.p(dst), s, bf, ldy, y_lo);
+                                  ldm, rps, (int)seg_rows, rps2, (half_t*)b.p(dst), s, bf, ldy, y_lo,
+                                  hq ? (unsigned char*)b.p(q.a8) : nullptr, q.lda8, hq ? (float*)b.p(q.ascale) : nullptr);
     });
   }
+  // fp8 copy of 16-bit rows [n][ld] (K columns) for an 'fp8-mx' GEMM: workspace for the bytes + the row scales
+  MxA quant8(Ref src, int ld, size_t n, int K) {
+    MxA q; q.lda8 = K;
+    const size_t qb = tmp(n * (size_t)K), qs = tmp(n * 4);
+    q.a8 = ws(qb); q.ascale = ws(qs);
+    const int bf = m.bf16;
+    const Ref d8 = q.a8, ds = q.ascale;
+    op("quant_fp8", 0, [=](const Bind& b, hipStream_t s) {
+      return launch_quant_rows_fp8((const half_t*)b.p(src), ld, (int)n, K, bf, (unsigned char*)b.p(d8), K, (float*)b.p(ds), s);
+    });
+    return q;
+  }
+  void free8(const MxA& q, size_t n) { untmp(q.a8.off, n * (size_t)q.lda8); untmp(q.ascale.off, n * 4); }
+  MxA alloc8(size_t n, int K) { MxA q; q.lda8 = K; q.a8 = ws(tmp(n * (size_t)K)); q.ascale = ws(tmp(n * 4)); return q; }
+  static MxA rows8(const MxA& q, size_t r0) { MxA o = q; o.a8.off += r0 * (size_t)q.lda8; o.ascale.off += r0 * 4; return o; }
   // image-token hook from a 16-bit matrix; s_lo > 0: a split pair; src_bf: element type (-1 = the model's)
   void hook_rows16(const std::string& id, Ref src, int ld, int C, int s_lo = 0, int src_bf = -1) {
     hook_copy(want(id, C, gh, gw), src, ld, NS, C, s_lo, src_bf);
@@ -251,6 +271,7 @@ struct FB : PlanBuilder {   // Flux op program
       gemm("context_embedder", Ref{BUF_CTX, 0}, d.joint_attention_dim, nt, f.ctx_emb, C, d.joint_attention_dim, 0, e); }
 
     const int X = px(), x2 = m.x2;                                                  // 'bfloat16x2': operand rows hold [hi | lo]
+    const bool f8 = m.fp8 != 0;                                                     // 'fp8-mx': the large linears multiply e4m3 operands
     const size_t ln_b = nr * C * 2 * X, qkv_b = nr * 3 * C * 2;
     // ================= double (MMDiT) blocks =================
     for (int i = 0; i < d.num_layers && !stop; ++i) {
@@ -258,19 +279,22 @@ struct FB : PlanBuilder {   // Flux op program
       const std::string bid = "vit-block" + std::to_string(i);
       // norm1 / norm1_context (AdaLayerNormZero): chunks shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
       const size_t ln = tmp(ln_b);
-      adaln("adaln_txt", 0, nt, w.cmod + 0, w.cmod + C, T, 0, 0, ws(ln));
-      adaln("adaln", nt, ns, w.mod + 0, w.mod + C, S, 0, 0, ws(ln + nt * C * 2 * X));
+      const MxA ln8 = f8 ? alloc8(nr, C) : MxA{};
+      const MxA ln8t = rows8(ln8, 0), ln8i = rows8(ln8, nt);
+      adaln("adaln_txt", 0, nt, w.cmod + 0, w.cmod + C, T, 0, 0, ws(ln), f8 ? &ln8t : nullptr);
+      adaln("adaln", nt, ns, w.mod + 0, w.mod + C, S, 0, 0, ws(ln + nt * C * 2 * X), f8 ? &ln8i : nullptr);
       const size_t qkv = tmp(qkv_b);
       // un-hooked blocks: RMSNorm(q), RMSNorm(k) + RoPE ride in the QKV GEMM epilogue (on the fp32 accumulators); the `q/k/v`
       // hooks are the PRE-norm projections, so a block that has one of them requested keeps the separate pass
-      const bool fuse = qkn_fusable(bid) && gemm_qkn_ok((int)nt, 3 * C, C) && gemm_qkn_ok((int)ns, 3 * C, C);
+      const bool fuse = !f8 && qkn_fusable(bid) && gemm_qkn_ok((int)nt, 3 * C, C) && gemm_qkn_ok((int)ns, 3 * C, C);   // (the fp8 kernel has no fused RMSNorm + RoPE epilogue)
       { Epi e = plain(w.cqkv); e.out16 = ws(qkv); e.has_o16 = true; e.ldo16 = 3 * C; e.out_f16 = x2;
         if (fuse) qkn(e, w.cnq, w.cnk, 0, T, 0, 0, 1);
-        gemm("add_qkv_proj", ws(ln), C * X, nt, w.cqkv, 3 * C, C, 0, e, x2 * C); }
+        gemm("add_qkv_proj", ws(ln), C * X, nt, w.cqkv, 3 * C, C, 0, e, x2 * C, f8 ? &ln8t : nullptr); }
       { Epi e = plain(w.qkv); e.out16 = ws(qkv + nt * 3 * C * 2); e.has_o16 = true; e.ldo16 = 3 * C; e.out_f16 = x2;
         if (fuse) qkn(e, w.nq, w.nk, T, S, 0, 0, 1);
-        gemm("attn_qkv", ws(ln + nt * C * 2 * X), C * X, ns, w.qkv, 3 * C, C, 0, e, x2 * C); }
+        gemm("attn_qkv", ws(ln + nt * C * 2 * X), C * X, ns, w.qkv, 3 * C, C, 0, e, x2 * C, f8 ? &ln8i : nullptr); }
       untmp(ln, ln_b);
+      if (f8) free8(ln8, nr);
       const size_t qi = qkv + nt * 3 * C * 2;                                        // image rows of the qkv buffer
       const int qbf = x2 ? 0 : -1;                                                   // ('bfloat16x2': the q / k / v buffer is fp16)
       hook_rows16(bid + "-q", ws(qi), 3 * C, C, 0, qbf);                             // attention_processor.py:2283-2286
@@ -286,35 +310,46 @@ struct FB : PlanBuilder {   // Flux op program
       map_slots(bid, mc, ms);
       joint_attention(qkv, ws(ao), C * X, mc, ms, x2 * C);
       untmp(qkv, qkv_b);
+      const MxA ao8 = f8 ? quant8(ws(ao), C, nr, C) : MxA{};
+      const MxA ao8t = rows8(ao8, 0), ao8i = rows8(ao8, nt);
       { Epi e = gated(w.o, nt, w.mod + 2 * C, S);                                    // hidden += gate_msa * to_out(attn)
         e.aux_slot = want(bid + "-attn-out", C, gh, gw); e.ldaux = C;                // :2355-2356 (pre-gate projection)
-        gemm("attn_out", ws(ao + nt * C * 2 * X), C * X, ns, w.o, C, C, 0, e, x2 * C);
+        gemm("attn_out", ws(ao + nt * C * 2 * X), C * X, ns, w.o, C, C, 0, e, x2 * C, f8 ? &ao8i : nullptr);
         if (e.aux_slot >= 0) hook_done(); }
       { Epi e = gated(w.co, 0, w.cmod + 2 * C, T);                                   // enc += c_gate_msa * to_add_out(attn)
-        gemm("attn_add_out", ws(ao), C * X, nt, w.co, C, C, 0, e, x2 * C); }
+        gemm("attn_add_out", ws(ao), C * X, nt, w.co, C, C, 0, e, x2 * C, f8 ? &ao8t : nullptr); }
+      if (f8) free8(ao8, nr);
       untmp(ao, ln_b);
       if (stop) break;
       // ---- image MLP: norm2 + modulate, hooks norm-out / ffn-inner / out (:194-207; `out` stores norm_hidden_states) ----
       const size_t nx = tmp(ns * C * 2 * X);
-      adaln("adaln", nt, ns, w.mod + 3 * C, w.mod + 4 * C, S, 0, 0, ws(nx));
+      const MxA nx8 = f8 ? alloc8(ns, C) : MxA{};
+      adaln("adaln", nt, ns, w.mod + 3 * C, w.mod + 4 * C, S, 0, 0, ws(nx), f8 ? &nx8 : nullptr);
       hook_rows16(bid + "-norm-out", ws(nx), C * X, C, x2 * C);
       const size_t inner = tmp(ns * hid * 2 * X);
       { Epi e = plain(w.ff1); e.act = 1; e.out16 = ws(inner); e.has_o16 = true; e.ldo16 = hid * X; e.o16_lo = x2 * hid;
-        gemm("ff_in", ws(nx), C * X, ns, w.ff1, hid, C, 0, e, x2 * C); }
+        gemm("ff_in", ws(nx), C * X, ns, w.ff1, hid, C, 0, e, x2 * C, f8 ? &nx8 : nullptr); }
+      if (f8) free8(nx8, ns);
       hook_rows16(bid + "-ffn-inner", ws(inner), hid * X, hid, x2 * hid);            // attention.py:1255-1257
-      { Epi e = gated(w.ff2, nt, w.mod + 5 * C, S); gemm("ff_out", ws(inner), hid * X, ns, w.ff2, C, hid, 0, e, x2 * hid); }
+      { const MxA in8 = f8 ? quant8(ws(inner), hid, ns, hid) : MxA{};
+        Epi e = gated(w.ff2, nt, w.mod + 5 * C, S); gemm("ff_out", ws(inner), hid * X, ns, w.ff2, C, hid, 0, e, x2 * hid, f8 ? &in8 : nullptr);
+        if (f8) free8(in8, ns); }
       untmp(inner, ns * hid * 2 * X);
       hook_rows16(bid + "-out", ws(nx), C * X, C, x2 * C);
       untmp(nx, ns * C * 2 * X);
       if (stop) break;
       // ---- text MLP (:211-218) ----
       const size_t ne = tmp(nt * C * 2 * X);
-      adaln("adaln_txt", 0, nt, w.cmod + 3 * C, w.cmod + 4 * C, T, 0, 0, ws(ne));
+      const MxA ne8 = f8 ? alloc8(nt, C) : MxA{};
+      adaln("adaln_txt", 0, nt, w.cmod + 3 * C, w.cmod + 4 * C, T, 0, 0, ws(ne), f8 ? &ne8 : nullptr);
       const size_t cin = tmp(nt * hid * 2 * X);
       { Epi e = plain(w.cff1); e.act = 1; e.out16 = ws(cin); e.has_o16 = true; e.ldo16 = hid * X; e.o16_lo = x2 * hid;
-        gemm("ff_context_in", ws(ne), C * X, nt, w.cff1, hid, C, 0, e, x2 * C); }
+        gemm("ff_context_in", ws(ne), C * X, nt, w.cff1, hid, C, 0, e, x2 * C, f8 ? &ne8 : nullptr); }
+      if (f8) free8(ne8, nt);
       untmp(ne, nt * C * 2 * X);
-      { Epi e = gated(w.cff2, 0, w.cmod + 5 * C, T); gemm("ff_context_out", ws(cin), hid * X, nt, w.cff2, C, hid, 0, e, x2 * hid); }
+      { const MxA ci8 = f8 ? quant8(ws(cin), hid, nt, hid) : MxA{};
+        Epi e = gated(w.cff2, 0, w.cmod + 5 * C, T); gemm("ff_context_out", ws(cin), hid * X, nt, w.cff2, C, hid, 0, e, x2 * hid, f8 ? &ci8 : nullptr);
+        if (f8) free8(ci8, nt); }
       untmp(cin, nt * hid * 2 * X);
     }
     // ================= single blocks over the joint stream =================
@@ -323,17 +358,19 @@ struct FB : PlanBuilder {   // Flux op program
       const FluxSingleW& w = f.sgl[j];
       const std::string bid = "vit-block" + std::to_string(d.num_layers + j);
       const size_t ln = tmp(ln_b);
-      adaln("adaln", 0, nr, w.mod + 0, w.mod + C, T, nt, S, ws(ln));                 // AdaLayerNormZeroSingle: shift, scale, gate
+      const MxA ln8 = f8 ? alloc8(nr, C) : MxA{};
+      adaln("adaln", 0, nr, w.mod + 0, w.mod + C, T, nt, S, ws(ln), f8 ? &ln8 : nullptr);   // AdaLayerNormZeroSingle: shift, scale, gate
       // 'bfloat16x2': the concatenated operand row is [attn_hi C | mlp_hi hid | attn_lo C | mlp_lo hid]
       const size_t cat_b = nr * CK * 2 * X;
       const size_t qkv = tmp(qkv_b), cat = tmp(cat_b);
-      const bool fuse = qkn_fusable(bid) && gemm_qkn_ok((int)nr, 3 * C, C);
+      const bool fuse = !f8 && qkn_fusable(bid) && gemm_qkn_ok((int)nr, 3 * C, C);
       { Epi e = plain(w.qkv); e.out16 = ws(qkv); e.has_o16 = true; e.ldo16 = 3 * C; e.out_f16 = x2;
         if (fuse) qkn(e, w.nq, w.nk, 0, T, (int)nt, T, S);
-        gemm("attn_qkv", ws(ln), C * X, nr, w.qkv, 3 * C, C, 0, e, x2 * C); }
+        gemm("attn_qkv", ws(ln), C * X, nr, w.qkv, 3 * C, C, 0, e, x2 * C, f8 ? &ln8 : nullptr); }
       { Epi e = plain(w.mlp); e.act = 1; e.out16 = ws(cat + (size_t)C * 2); e.has_o16 = true; e.ldo16 = CK * X; e.o16_lo = x2 * CK;   // :95
-        gemm("proj_mlp", ws(ln), C * X, nr, w.mlp, hid, C, 0, e, x2 * C); }
+        gemm("proj_mlp", ws(ln), C * X, nr, w.mlp, hid, C, 0, e, x2 * C, f8 ? &ln8 : nullptr); }
       untmp(ln, ln_b);
+      if (f8) free8(ln8, nr);
       const size_t qi = qkv + nt * 3 * C * 2;
       const int qbf = x2 ? 0 : -1;
       hook_rows16(bid + "-q", ws(qi), 3 * C, C, 0, qbf);                             // :2287-2291 image tokens only
@@ -350,7 +387,9 @@ struct FB : PlanBuilder {   // Flux op program
       untmp(qkv, qkv_b);
       hook_rows16(bid + "-attn-out", ws(cat + nt * CK * 2 * X), CK * X, C, x2 * CK); // :2360-2361
       if (cat_b < (1ull << 31)) {
-        Epi e = gated(w.out, 0, w.mod + 2 * C, T, nt, S); gemm("proj_out", ws(cat), CK * X, nr, w.out, C, CK, 0, e, x2 * CK);   // :104-106
+        const MxA c8 = f8 ? quant8(ws(cat), CK, nr, CK) : MxA{};                     // [attn | mlp] rows as e4m3, one scale per row
+        Epi e = gated(w.out, 0, w.mod + 2 * C, T, nt, S); gemm("proj_out", ws(cat), CK * X, nr, w.out, C, CK, 0, e, x2 * CK, f8 ? &c8 : nullptr);   // :104-106
+        if (f8) free8(c8, nr);
       } else {
         // the A operand is addressed through 32-bit buffer offsets (< 2 GiB): the pair form of [rows][C + hid] at batch 8 is 2.26 GB, so
         // the GEMM runs over row ranges cut at sample boundaries — text rows + the first image samples, then the remaining samples
@@ -393,19 +432,25 @@ Model* flux_model_create(const gdf_flux_desc& d) {
   if (d.in_channels % 64 || d.joint_attention_dim % 64 || d.pooled_projection_dim % 8) {
     set_error("in_channels / joint_attention_dim must be multiples of 64, pooled_projection_dim of 8"); return nullptr;
   }
-  if (d.compute_dtype != GDF_F16 && d.compute_dtype != GDF_BF16 && d.compute_dtype != GDF_BF16X2) {
-    set_error("compute_dtype must be GDF_F16, GDF_BF16 or GDF_BF16X2"); return nullptr;
+  if (d.compute_dtype != GDF_F16 && d.compute_dtype != GDF_BF16 && d.compute_dtype != GDF_BF16X2 && d.compute_dtype != GDF_FP8MX) {
+    set_error("compute_dtype must be GDF_F16, GDF_BF16, GDF_BF16X2 or GDF_FP8MX"); return nullptr;
   }
   Model* m = new Model();
   m->kind = 1;
-  m->bf16 = d.compute_dtype == GDF_BF16 || d.compute_dtype == GDF_BF16X2;
+  m->bf16 = d.compute_dtype != GDF_F16;
   m->x2 = d.compute_dtype == GDF_BF16X2;
+  m->fp8 = d.compute_dtype == GDF_FP8MX;
   m->flux.d = d;
   m->flux.D = d.attention_head_dim;
   m->flux.C = d.num_attention_heads * d.attention_head_dim;
   m->flux.hid = m->flux.C * d.mlp_ratio;
   FluxModelBuilder b(*m);
   b.build();
+  if (m->fp8) {                                  // fp8 copies + per-channel scales live in the same arena (one blob for the data-parallel broadcast)
+    const size_t a = align_up(m->weight_bytes, 4096);
+    m->f8_off = a; m->sc_off = a + a / 2;
+    m->weight_bytes = a + a / 2 + a / 16 + 4096;
+  }
   if (hipMalloc(&m->weights, m->weight_bytes) != hipSuccess) { set_error("hipMalloc(weights) failed"); delete m; return nullptr; }
   (void)hipMemset(m->weights, 0, m->weight_bytes);
   PlanOpts o{}; o.stream_fp32 = 1;

@@ -49,6 +49,16 @@ __device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rsrc, char* lds_wa
 }
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // BF: the 16-byte fragments hold bf16 (MMDiT path of a bf16 model); same MFMA rate, same register layout
+// one K = 128 step on fp8 (e4m3) operands: a = [a0 | a1], b = [b0 | b1] (16 bytes each), unit e8m0 block scales (127 = 2^0)
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 mfma_mx8(const f16x8 a0, const f16x8 a1, const f16x8 b0, const f16x8 b1, const f32x4 c) {
+  const i32x4 x0 = __builtin_bit_cast(i32x4, a0), x1 = __builtin_bit_cast(i32x4, a1);
+  const i32x4 y0 = __builtin_bit_cast(i32x4, b0), y1 = __builtin_bit_cast(i32x4, b1);
+  const i32x8 a = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+  const i32x8 b = {y0[0], y0[1], y0[2], y0[3], y1[0], y1[1], y1[2], y1[3]};
+  return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, /*A fp8 e4m3*/ 0, /*B fp8 e4m3*/ 0, 0, 127, 0, 127);
+}
 template <bool BF>
 __device__ __forceinline__ f32x4 mfma16(const f16x8 a, const f16x8 b, const f32x4 c) {
   if constexpr (BF) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
@@ -131,9 +141,14 @@ __device__ unsigned long long gdf_trace[16384 * 8];
 // SPLIT: split fp16 hi + lo operands of the opt-in "precise" plans (GemmParams::k_w / a_lo_bytes / o16_lo, kernels.h).  A compile-time
 // switch with its own instantiations (gemm_split_kernel): compiled into the default kernels, its few extra live values pushed
 // the 256x320 dense kernel from 253 VGPRs to 139 spilled (140 -> 100 img/s on the SDXL step).
-template <int MODE, int BM, int BN, int STAGES, bool GEGLU, bool DIT, bool BF = false, bool QKN = false, bool SPLIT = false>
+// MX: fp8 (OCP e4m3) operands multiplied with v_mfma_scale_f32_16x16x128_f8f6f4 (unit block scales: the per-row / per-column power-of-two
+// scales of the operands are applied to the fp32 accumulators in the epilogue, GemmParams::mx_rowscale / mx_colscale).  A K-tile is 128
+// fp8 values = the same 128 bytes per row as 64 halves, so staging, swizzle and the 8-phase schedule are unchanged: the host passes lda /
+// K in 2-byte units; a lane's 32-byte fragment of the K = 128 MFMA is the two adjacent 16-byte chunks 2 fk, 2 fk + 1 of its row.
+template <int MODE, int BM, int BN, int STAGES, bool GEGLU, bool DIT, bool BF = false, bool QKN = false, bool SPLIT = false, bool MX = false>
 __device__ __forceinline__ void gemm_body(const GemmParams& p) {
   static_assert(!BF || DIT, "bf16 operands exist on the MMDiT path only");
+  static_assert(!MX || (DIT && STAGES == 8 && !SPLIT && !QKN && !GEGLU), "fp8 operands: the 256x256 two-group MMDiT kernel only");
   constexpr int NW = BM / 32;                    // waves per workgroup (4 or 8)
   // waves along N (the GEGLU form of the 256x320 tile uses 4x2 waves of 64x160: an EVEN number of 16-column fragments,
   // so that every h fragment has its gate fragment in the same lane and register index)
@@ -479,8 +494,9 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
     uint32_t fa[2], fb[2];
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      fa[kk] = (uint32_t)((wm * WTM + frow) * 128 + (((kk * 4 + fk) ^ (frow & 7)) << 4));
-      fb[kk] = (uint32_t)(2 * A_TILE + (wn * WTN + frow) * 128 + (((kk * 4 + fk) ^ (frow & 7)) << 4));
+      const int ch = MX ? 2 * fk + kk : kk * 4 + fk;        // fp8: the two halves of the lane's 32-byte K = 128 fragment
+      fa[kk] = (uint32_t)((wm * WTM + frow) * 128 + ((ch ^ (frow & 7)) << 4));
+      fb[kk] = (uint32_t)(2 * A_TILE + (wn * WTN + frow) * 128 + ((ch ^ (frow & 7)) << 4));
       asm volatile("" : "+v"(fa[kk]), "+v"(fb[kk]));
     }
     auto rd_a = [&](const int cur) {
@@ -497,13 +513,21 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
     };
     auto mma_q = [&](auto ah, auto bh) {
       constexpr int AH = decltype(ah)::value, BH = decltype(bh)::value;
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk)
+      if constexpr (MX) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
           for (int j = 0; j < FNH; ++j)
-            acc[AH * 2 + i][BH * FNH + j] = mfma16<BF>(a8[AH * 2 + i][kk], b8[j][kk], acc[AH * 2 + i][BH * FNH + j]);
+            acc[AH * 2 + i][BH * FNH + j] = mfma_mx8(a8[AH * 2 + i][0], a8[AH * 2 + i][1], b8[j][0], b8[j][1], acc[AH * 2 + i][BH * FNH + j]);
+      } else {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < FNH; ++j)
+              acc[AH * 2 + i][BH * FNH + j] = mfma16<BF>(a8[AH * 2 + i][kk], b8[j][kk], acc[AH * 2 + i][BH * FNH + j]);
+      }
     };
     auto bar = [&]() {
       __builtin_amdgcn_sched_barrier(0);
@@ -854,6 +878,16 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
 
   const float a_sc = p.acc_scale != 0.f ? p.acc_scale : 1.0f;     // range control of the fp16 images (kernels.h)
   const float o_sc = p.out16_scale != 0.f ? p.out16_scale : 1.0f;
+  float mxc[8];                                        // fp8 operands: power-of-two scale of this lane's 8 output columns (weight rows)
+#pragma unroll
+  for (int e = 0; e < 8; ++e) mxc[e] = 1.f;
+  if constexpr (MX) {
+    if (full && p.mx_colscale) {
+      const f32x4 c0 = *(const f32x4*)(p.mx_colscale + col), c1 = *(const f32x4*)(p.mx_colscale + col + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { mxc[e] = c0[e]; mxc[4 + e] = c1[e]; }
+    }
+  }
   float bv[8];                                         // bias of this lane's 8 output columns (plain epilogue)
   float bh[FNV], bgt[FNV];                             // GEGLU: bias of this lane's h / gate accumulator column per fragment pair
 #pragma unroll
@@ -946,8 +980,14 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
       int lr = it * RPI + lane / LPR;
       if (!(lane_ok && lr < PR)) lr = 0;
       const f32x4 x0 = *(const f32x4*)(st + lr * SLD + lc), x1 = *(const f32x4*)(st + lr * SLD + lc + 4);
+      if constexpr (MX) {                                // undo the operand scales: row (activation) x column (weight row)
+        const float rs = (okr[it] && p.mx_rowscale) ? p.mx_rowscale[rowi[it]] : 1.f;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { v[it][e] = x0[e] + bv[e]; v[it][4 + e] = x1[e] + bv[4 + e]; }
+        for (int e = 0; e < 4; ++e) { v[it][e] = x0[e] * (rs * mxc[e]) + bv[e]; v[it][4 + e] = x1[e] * (rs * mxc[4 + e]) + bv[4 + e]; }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[it][e] = x0[e] + bv[e]; v[it][4 + e] = x1[e] + bv[4 + e]; }
+      }
     }
     if (DIT && p.act == 1) {
 #pragma unroll
@@ -1140,6 +1180,12 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_dit_split_kernel(const GemmPar
   gemm_body<A_DENSE, BM, BN, STAGES, false, true, BF, QKN, true>(p);
 }
 
+// MMDiT GEMM on fp8 (e4m3) operands, bf16 output ('fp8-mx' plans, gdf_flux.h): MX-scaled MFMA, K = 128 per instruction
+template <int BM, int BN, int STAGES>
+__global__ __launch_bounds__(BM * 2, 2) void gemm_mx_kernel(const GemmParams p) {
+  gemm_body<A_DENSE, BM, BN, STAGES, false, true, true, false, false, true>(p);
+}
+
 // workgroups of a persistent launch of a 1-workgroup-per-CU kernel: the CU count of the current device (a multiple of 8 XCDs);
 // GDF_PERSIST=0 (diagnostics) launches one workgroup per tile instead
 static int persist_wgs() {
@@ -1156,14 +1202,15 @@ static int persist_wgs() {
   return n;
 }
 
-template <int MODE, int BM, int BN, int STAGES, bool GEGLU, bool DIT = false, bool BF = false, bool QKN = false, bool SPLIT = false>
+template <int MODE, int BM, int BN, int STAGES, bool GEGLU, bool DIT = false, bool BF = false, bool QKN = false, bool SPLIT = false, bool MX = false>
 static hipError_t launch_t(const GemmParams& p, hipStream_t s) {
   const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
   const int smem = (STAGES >= 8 ? 2 : STAGES) * (BM * 128 + BN * 128);
   static std::atomic<uint64_t> attr_mask{0};             // per template instantiation, one bit per device
   {
     const void* fn;
-    if constexpr (DIT && SPLIT) fn = (const void*)gemm_dit_split_kernel<BM, BN, STAGES, BF, QKN>;
+    if constexpr (MX) fn = (const void*)gemm_mx_kernel<BM, BN, STAGES>;
+    else if constexpr (DIT && SPLIT) fn = (const void*)gemm_dit_split_kernel<BM, BN, STAGES, BF, QKN>;
     else if constexpr (DIT) fn = (const void*)gemm_dit_kernel<BM, BN, STAGES, BF, QKN>;
     else if constexpr (SPLIT) fn = (const void*)gemm_split_kernel<MODE, BM, BN, STAGES, GEGLU>;
     else fn = (const void*)gemm_kernel<MODE, BM, BN, STAGES, GEGLU>;
@@ -1187,7 +1234,8 @@ static hipError_t launch_t(const GemmParams& p, hipStream_t s) {
   const int pw = (p.cus > 0 && p.cus < persist_wgs()) ? p.cus : persist_wgs();
   if (STAGES == 8 && gx > pw && !(p.batch > 1)) gx = pw;   // persistent: one workgroup per CU walks the tiles
   const dim3 grid(gx, (STAGES == 2 && p.splitk > 1) ? p.splitk : p.batch > 1 ? p.batch : 1);
-  if constexpr (DIT && SPLIT) hipLaunchKernelGGL((gemm_dit_split_kernel<BM, BN, STAGES, BF, QKN>), grid, dim3(BM * 2), smem, s, q);
+  if constexpr (MX) hipLaunchKernelGGL((gemm_mx_kernel<BM, BN, STAGES>), grid, dim3(BM * 2), smem, s, q);
+  else if constexpr (DIT && SPLIT) hipLaunchKernelGGL((gemm_dit_split_kernel<BM, BN, STAGES, BF, QKN>), grid, dim3(BM * 2), smem, s, q);
   else if constexpr (DIT) hipLaunchKernelGGL((gemm_dit_kernel<BM, BN, STAGES, BF, QKN>), grid, dim3(BM * 2), smem, s, q);
   else if constexpr (SPLIT) hipLaunchKernelGGL((gemm_split_kernel<MODE, BM, BN, STAGES, GEGLU>), grid, dim3(BM * 2), smem, s, q);
   else hipLaunchKernelGGL((gemm_kernel<MODE, BM, BN, STAGES, GEGLU>), grid, dim3(BM * 2), smem, s, q);
@@ -1289,7 +1337,8 @@ const char* gemm_kernel_name(const GemmParams& p) {
   else if (v == 825) { bm = 256; bn = 256; st = 8; } else if (v == 932) { bm = 256; bn = 320; st = 9; } else if (v == 826) { bm = 256; bn = 256; st = 8; }
   if (p.mode == A_CONV_SMALLC && v != 160) { bm = 128; bn = 128; st = 2; }
   char tmp[64];
-  if (p.dit) snprintf(tmp, sizeof tmp, "%s<%d, %d, %d, %s, %s>", is_dit_split(p) ? "gemm_dit_split_kernel" : "gemm_dit_kernel", v == 128 ? 128 : 256, (v == 1256 || v == 8256) ? 256 : 128, v == 8256 ? 8 : v == 2128 ? 3 : 2, p.bf16 ? "true" : "false", p.qkn_nq ? "true" : "false");
+  if (p.dit && p.mx) snprintf(tmp, sizeof tmp, "gemm_mx_kernel<256, 256, 8>");
+  else if (p.dit) snprintf(tmp, sizeof tmp, "%s<%d, %d, %d, %s, %s>", is_dit_split(p) ? "gemm_dit_split_kernel" : "gemm_dit_kernel", v == 128 ? 128 : 256, (v == 1256 || v == 8256) ? 256 : 128, v == 8256 ? 8 : v == 2128 ? 3 : 2, p.bf16 ? "true" : "false", p.qkn_nq ? "true" : "false");
   else snprintf(tmp, sizeof tmp, "%s<%d, %d, %d, %d, %s>", is_split(p) ? "gemm_split_kernel" : "gemm_kernel", p.mode, bm, bn, st, p.geglu ? "true" : "false");
   // interned: the returned pointer stays valid for the life of the library (plan build time only, mutex-protected)
   static std::mutex mu;
@@ -1315,6 +1364,10 @@ hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {
     if (p.mode != A_DENSE || p.geglu || p.batch > 1) return hipErrorInvalidValue;
     if (p.qkn_nq && ((v != 8256 && v != 1256) || (p.qkn_nq % 128) != 0)) return hipErrorInvalidValue;   // one head per 128-column wave tile
     if (p.qkn_nq && (p.res32 || p.res16 || p.rowvec || p.aux16 || p.out32)) return hipErrorInvalidValue;  // the QKN instantiation: bias -> norm + RoPE -> out16 only
+    if (p.mx) {                                                                           // fp8 (e4m3) operands ('fp8-mx' plans): 256x256 two-group tile only
+      if (!p.bf16 || p.qkn_nq || is_dit_split(p) || (p.N % 8)) return hipErrorInvalidValue;
+      return launch_t<A_DENSE, 256, 256, 8, false, true, true, false, false, true>(p, s);
+    }
     if (is_dit_split(p)) {                                                                // bf16 hi + lo operands ('bfloat16x2' plans)
       if (v == 8256) return p.qkn_nq ? launch_t<A_DENSE, 256, 256, 8, false, true, true, true, true>(p, s) : launch_t<A_DENSE, 256, 256, 8, false, true, true, false, true>(p, s);
       return p.qkn_nq ? hipErrorInvalidValue : launch_t<A_DENSE, 128, 128, 2, false, true, true, false, true>(p, s);

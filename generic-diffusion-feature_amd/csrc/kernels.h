@@ -130,6 +130,12 @@ struct GemmParams {
   // q / k / v buffer of the attention kernel, whose internals run in fp16 in that mode (q, k are RMS-normalised, v is a linear of a
   // normalised tensor: inside the fp16 range by construction; 11 mantissa bits instead of 8)
   int out_f16;
+  // MMDiT 'fp8-mx' plans: A and Wt hold fp8 (OCP e4m3) bytes — lda, K, a_bytes, w_bytes are given in 2-BYTE units exactly as for a 16-bit matrix
+  // of half the width (a K-tile is 128 bytes either way) — multiplied with v_mfma_scale_f32_16x16x128_f8f6f4; the operands' power-of-two
+  // scales are undone on the fp32 accumulators: acc * mx_rowscale[row] * mx_colscale[col] (either may be null = 1)
+  int mx;
+  const float* mx_rowscale;
+  const float* mx_colscale;
 };
 hipError_t launch_gemm(const GemmParams& p, hipStream_t s);
 // Deterministic split-K for problems with few output tiles and a long K (the 8x8-level 3x3 convs of SD1.5: 160 tiles of 128x128,
@@ -189,7 +195,10 @@ hipError_t launch_layernorm(const half_t* x16, const float* x32, int ld, int R, 
 // y_lo > 0: y is written as a split pair (rows of ldy elements, hi at column 0, lo = e16(v - hi) at column y_lo)
 hipError_t launch_layernorm_mod(const half_t* x16, const float* x32, int ld, int R, int C, float eps, const float* scale,
                                 const float* shift, int ldm, int rps, int seg_rows, int rps2, half_t* y, hipStream_t s,
-                                int bf16 = 0, int ldy = 0, int y_lo = 0);
+                                int bf16 = 0, int ldy = 0, int y_lo = 0, unsigned char* q8 = nullptr, int ldq8 = 0, float* q8_scale = nullptr);
+// 'fp8-mx' plans: 16-bit rows [R][ld] (K columns) -> fp8 e4m3 [R][ldq] with one power-of-two scale per row (q = fp8(v / scale[r])).
+// launch_layernorm_mod's q8 / q8_scale write the same form of its own output in the same pass.
+hipError_t launch_quant_rows_fp8(const half_t* x, int ld, int R, int K, int bf16, unsigned char* q, int ldq, float* scale, hipStream_t s);
 // RMSNorm(q), RMSNorm(k) per head + rotary embedding, in place on rows [R][ld] fp16: q heads at columns
 // q_col + h*D, k heads at k_col + h*D (D = 128); position of row r = pos0 + r % rps; cos/sin fp32 [pos][D].
 hipError_t launch_qk_norm_rope(half_t* x, int ld, int R, int heads, int D, int q_col, int k_col, const float* wq,

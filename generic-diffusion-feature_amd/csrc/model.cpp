@@ -214,7 +214,13 @@ int model_set_param(Model* m, const char* name, const void* src, int dtype, hipS
     case PK_VEC_GEGLU: e = launch_relayout_vec(src, f32, (float*)(base + p.dst), p.a0, 0, geglu_group(p.a0), s); break;
     case PK_CONV3: e = launch_relayout_conv(src, f32, (half_t*)(base + p.dst), p.a0, p.a1, 9, p.a1, 9, s, 64); break;
     case PK_CONV_IN: e = launch_relayout_conv(src, f32, (half_t*)(base + p.dst), p.a0, p.a1, 9, 8, 16, s); break;
-    case PK_ROWS: e = launch_relayout_rows(src, f32, (half_t*)(base + p.dst), p.a0, p.a1, p.a2, 0, s, m->bf16); break;
+    case PK_ROWS:
+      e = launch_relayout_rows(src, f32, (half_t*)(base + p.dst), p.a0, p.a1, p.a2, 0, s, m->bf16);
+      if (e == hipSuccess && m->fp8 && (p.a1 % 128) == 0)       // 'fp8-mx' plans: the e4m3 copy + per-output-channel scales of these rows
+        e = launch_quant_rows_fp8((const half_t*)(base + p.dst) + (size_t)p.a2 * p.a1, p.a1, p.a0, p.a1, m->bf16,
+                                  (unsigned char*)(base + m->f8_off + p.dst / 2) + (size_t)p.a2 * p.a1, p.a1,
+                                  (float*)(base + m->sc_off + p.dst / 16) + p.a2, s);
+      break;
     case PK_ROWS_PADK: e = launch_relayout_rows_padk(src, f32, (half_t*)(base + p.dst), p.a0, p.a1, p.a2, s); break;
     case PK_ROWS_GEGLU: e = launch_relayout_rows(src, f32, (half_t*)(base + p.dst), p.a0, p.a1, 0, geglu_group(p.a0), s); break;
     default: set_error("bad param kind"); return GDF_ERR_STATE;

@@ -89,6 +89,9 @@ struct VaeW {
 
 struct Model {
   int bf16 = 0;                                // 16-bit element type of weights / activations: 0 fp16, 1 bf16 (Flux only)
+  // Flux 'fp8-mx' (GDF_FP8MX): the arena additionally holds, for every [n][k] linear at byte offset w, its fp8 (e4m3) copy at f8_off + w / 2 and
+  // the per-output-channel power-of-two scales (float[n]) at sc_off + w / 16 (both written when the parameter is set)
+  int fp8 = 0; size_t f8_off = 0, sc_off = 0;
   int x2 = 0;                                  // Flux 'bfloat16x2' (GDF_BF16X2): bf16 weights, activation operands as bf16 hi + lo pairs, fp16 attention internals
   int kind = 0;                                // 0: UNet2DConditionModel, 1: FluxTransformer2DModel, 2: AutoencoderKL encoder, 3: PixArt DiT, 4: AutoencoderKL decoder
   FluxW flux;

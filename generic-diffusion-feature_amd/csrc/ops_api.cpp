@@ -243,6 +243,25 @@ int gdf_op_gemm_dit(const void* A, int lda, const void* W, const float* bias, in
   return fin(launch_gemm(g, (hipStream_t)stream), "gemm_dit");
 }
 
+int gdf_op_quant_rows_fp8(const void* x16, int ld, int R, int K, int src_bf16, void* q8, int ldq, float* scale, void* stream) {
+  return fin(launch_quant_rows_fp8((const half_t*)x16, ld, R, K, src_bf16, (unsigned char*)q8, ldq, scale, (hipStream_t)stream), "quant_rows_fp8");
+}
+
+int gdf_op_gemm_mx(const void* A8, int lda, const float* a_scale, const void* W8, const float* w_scale, const float* bias, int act,
+                   const float* res32, int ldres, void* out16, int ldo16, float* out32, int ldo32, int M, int N, int K, void* stream) {
+  if ((K % 128) || (lda % 2)) { gdf::set_error("gemm_mx: K must be a multiple of 128, lda even"); return GDF_ERR_ARG; }
+  GemmParams g{};
+  if (!span_ok(((size_t)M - 1) * lda + (size_t)K, (size_t)N * K, "gemm_mx")) return GDF_ERR_UNSUPPORTED;
+  // fp8 rows in 2-byte units (kernels.h GemmParams::mx)
+  g.A = (const half_t*)A8; g.lda = lda / 2; g.a_bytes = (uint32_t)(((size_t)M - 1) * lda + (size_t)K);
+  g.M = M; g.N = N; g.K = K / 2; g.mode = A_DENSE;
+  g.Wt = (const half_t*)W8; g.w_bytes = (uint32_t)((size_t)N * K);
+  g.bias = bias; g.dit = 1; g.act = act; g.rows_per_sample = 1; g.rv_rps2 = 1;
+  g.res32 = res32; g.ldres = ldres; g.out16 = (half_t*)out16; g.ldo16 = ldo16; g.out32 = out32; g.ldo32 = ldo32; g.bn = 128; g.bf16 = 1;
+  g.mx = 1; g.mx_rowscale = a_scale; g.mx_colscale = w_scale;
+  return fin(launch_gemm(g, (hipStream_t)stream), "gemm_mx");
+}
+
 int gdf_op_layernorm_mod(const float* x32, int ld, int R, int C, float eps, const float* scale, const float* shift, int ldm,
                          int rps, int seg_rows, int rps2, void* y, void* stream) {
   return fin(launch_layernorm_mod(nullptr, x32, ld, R, C, eps, scale, shift, ldm, rps, seg_rows, rps2, (half_t*)y, (hipStream_t)stream,

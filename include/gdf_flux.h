@@ -50,7 +50,12 @@ typedef struct gdf_flux_desc {
                                    MFMA contraction is kept as a bf16 PAIR hi + lo (16 mantissa bits, bf16's range) and multiplied as
                                    [hi | lo] x [W | W] (K doubled, weights read twice), and the attention internals (q, k after
                                    RMSNorm + RoPE, v, P) are fp16: every hook within 1e-3 of the fp32 reference at full depth
-                                   (bf16: 3.4e-3) without leaving bf16's range on the residual / MLP path; about 1.7x the time. */
+                                   (bf16: 3.4e-3) without leaving bf16's range on the residual / MLP path; about 1.7x the time.
+                                   GDF_FP8MX (4), OPT-IN and LOWER precision than the reference's bf16 (BASELINE.json configs[4]: "optional fp8
+                                   MFMA"): as GDF_BF16, but the large linears (QKV, MLP, attention / block output projections) multiply
+                                   OCP e4m3 operands with v_mfma_scale_f32_16x16x128_f8f6f4 — activations quantised per token, weights per
+                                   output channel, power-of-two (e8m0) scales applied to the fp32 accumulators; the residual stream, norms,
+                                   attention internals and hooks are unchanged.  Never a default; error ~3-4e-2 per hook (stated in the tests). */
 } gdf_flux_desc;
 
 int gdf_flux_model_create(const gdf_flux_desc* desc, gdf_model** out);

@@ -121,6 +121,15 @@ int gdf_op_set_e16(int dtype);
  * (s = row / rps for row < seg_rows or seg_rows == 0, else (row - seg_rows) / rps2; vec fp32 rows of ldvec);
  * aux16 (optional) receives fp16(v) BEFORE the gate; then + res32, stores out16 / out32.
  * Replaces nn.Linear + gate/residual arithmetic of transformer_flux.py:95-106, 191-218. */
+/* 'fp8-mx' MMDiT plans (gdf_flux.h, GDF_FP8MX; opt-in, LOWER precision than the reference's bf16): 16-bit rows -> OCP e4m3 bytes with one
+ * power-of-two scale per row, q = fp8(v / scale[r]) (activations per token, weights per output channel), and the GEMM on such operands:
+ * out = act((A8 W8^T) * a_scale[row] * w_scale[col] + bias) (+ res32), v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales (the
+ * per-row / per-channel scales are applied to the fp32 accumulators), bf16 out16.  K % 128 == 0; 256x256 tiles.
+ * Replaces the same nn.Linear call sites as gdf_op_gemm_dit (transformer_flux.py:86-112, 167-226). */
+int gdf_op_quant_rows_fp8(const void* x16, int ld, int R, int K, int src_bf16, void* q8, int ldq, float* scale, void* stream);
+int gdf_op_gemm_mx(const void* A8, int lda, const float* a_scale, const void* W8, const float* w_scale, const float* bias, int act,
+                   const float* res32, int ldres, void* out16, int ldo16, float* out32, int ldo32, int M, int N, int K, void* stream);
+
 int gdf_op_gemm_dit(const void* A, int lda, const void* W, const float* bias, int act, const float* vec, int ldvec, int vec_mul,
                     int rps, int seg_rows, int rps2, const float* res32, int ldres, void* aux16, int ldaux, void* out16,
                     int ldo16, float* out32, int ldo32, int M, int N, int K, int variant, void* stream);

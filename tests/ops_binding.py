@@ -31,6 +31,8 @@ OPS = {
     "gdf_op_small_linear": (ci, [vp, ci, ci, ci, vp, vp, ci, ci, ci, vp, ci, vp]),
     "gdf_op_set_e16": (ci, [ci]),
     "gdf_op_gemm_dit": (ci, [vp, ci, vp, vp, ci, vp, ci, ci, ci, ci, ci, vp, ci, vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, vp]),
+    "gdf_op_quant_rows_fp8": (ci, [vp, ci, ci, ci, ci, vp, ci, vp, vp]),
+    "gdf_op_gemm_mx": (ci, [vp, ci, vp, vp, vp, vp, ci, vp, ci, vp, ci, vp, ci, ci, ci, ci, vp]),
     "gdf_op_layernorm_mod": (ci, [vp, ci, ci, ci, fp, vp, vp, ci, ci, ci, ci, vp, vp]),
     "gdf_op_qk_norm_rope": (ci, [vp, ci, ci, ci, ci, ci, vp, vp, fp, vp, vp, ci, ci, vp]),
     "gdf_op_rope_table": (ci, [vp, ci, ci, ci, ci, vp, vp, ci, vp]),

@@ -20,8 +20,9 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 TOL = 2e-3
 # "bfloat16x2" (round 4): bf16 weights / inputs / output, activation operands as bf16 hi + lo pairs, fp16 attention internals
-TOLS = {"float16": 2e-3, "bfloat16": 1.5e-2, "bfloat16x2": 1.5e-3}
-TDT = {"float16": torch.float16, "bfloat16": torch.bfloat16, "bfloat16x2": torch.bfloat16}
+# "fp8-mx" (round 4, OPT-IN, lower precision than the reference's bf16): the large linears on OCP e4m3 operands (3 mantissa bits: ~3.7e-2 per GEMM)
+TOLS = {"float16": 2e-3, "bfloat16": 1.5e-2, "bfloat16x2": 1.5e-3, "fp8-mx": 1.0e-1}
+TDT = {"float16": torch.float16, "bfloat16": torch.bfloat16, "bfloat16x2": torch.bfloat16, "fp8-mx": torch.bfloat16}
 
 
 def _ops():
@@ -209,7 +210,7 @@ def test_flux_tiny_all_hooks_vs_oracle(dt):
     print(f"flux tiny [{dt}]: worst rel L2", worst)
 
 
-@pytest.mark.parametrize("dt", ["float16", "bfloat16", "bfloat16x2"])
+@pytest.mark.parametrize("dt", ["float16", "bfloat16", "bfloat16x2", "fp8-mx"])
 def test_flux_fused_qk_norm_rope_epilogue(dt):
     """Blocks without a requested pre-norm q / k / v hook take RMSNorm + RoPE inside the QKV GEMM epilogue; that needs the
     256x256 tile, i.e. a mid-size model: 8 heads x 128, 3 x (1024 + 1024) tokens, 1 double + 1 single block."""
@@ -226,6 +227,17 @@ def test_flux_fused_qk_norm_rope_epilogue(dt):
     net, out, hooks = _run_native(arch, P, I, ids, 32, dt)
     assert list(hooks.keys()) == ids
     assert rel_l2(out, y) < (4e-3 if dt == "bfloat16x2" else TOL), rel_l2(out, y)
+    if dt == "fp8-mx":                                   # the large linears really ran on the MX-scaled fp8 MFMA kernel; no fused RMSNorm + RoPE there
+        _, _, prof8 = net.forward_raw(I["hidden_states"].cuda(), I["encoder_hidden_states"].cuda(), I["pooled_projections"].cuda(),
+                                      I["timestep"].cuda(), I["img_ids"].cuda(), I["txt_ids"].cuda(), guidance=I["guidance"].cuda(),
+                                      hook_ids=ids, grid=(32, 32), profile=True)
+        kern = {r[0]: r[3] for r in prof8}
+        assert kern["attn_qkv"].startswith("gemm_mx_kernel") and kern["ff_out"].startswith("gemm_mx_kernel") and kern["proj_out"].startswith("gemm_mx_kernel")
+        assert "quant_fp8" in kern and "qk_norm_rope" in kern
+        errs8 = {k: rel_l2(hooks[k], st.feats[k]) for k in ids}
+        print("flux fp8-mx: worst hook", max(errs8, key=errs8.get), max(errs8.values()), "median", sorted(errs8.values())[len(errs8) // 2], "output", rel_l2(out, y))
+        assert max(errs8.values()) < TOL and max(errs8.values()) > 5e-3       # fp8's own error level: visibly NOT the bf16 path
+        return
     for k in ids:
         assert rel_l2(hooks[k], st.feats[k]) < TOL, (k, rel_l2(hooks[k], st.feats[k]))
     print(f"flux fused qkn [{dt}]: worst hook", max(rel_l2(hooks[k], st.feats[k]) for k in ids), "output", rel_l2(out, y))
@@ -433,3 +445,53 @@ def test_flux_attention_argument_is_accepted_and_ignored():
     img = Image.fromarray((np.random.RandomState(0).rand(90, 70, 3) * 255).astype(np.uint8))
     feats = df.extract("a photo of a cat", batch_size=1, image=[img], t=10)
     assert list(feats.keys()) == ["vit-block0-out"]
+
+
+@pytest.mark.parametrize("M,N,K,mode", [(512, 256, 256, "plain"), (1000, 768, 3072, "gelu"), (4096, 3072, 1024, "res"), (300, 512, 128, "plain")])
+def test_fp8_mx_quant_and_gemm(M, N, K, mode):
+    """'fp8-mx' building blocks (include/gdf_ops.h): row quantisation to OCP e4m3 with a power-of-two scale per row, and the MX-scaled MFMA
+    GEMM on such operands — checked against fp32 arithmetic on the DEQUANTISED operands (what remains is fp32 summation order and the bf16
+    rounding of the output), and against the unquantised product at fp8's own tolerance."""
+    L, P, ok, stream = _ops()
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    A = (torch.randn(M, K, device="cuda", generator=g) * torch.rand(M, 1, device="cuda", generator=g) * 8).bfloat16()
+    A[::7, 5] *= 30.0                                                  # rows with an outlier
+    W = (torch.randn(N, K, device="cuda", generator=g) * K ** -0.5).bfloat16()
+    bias = torch.randn(N, device="cuda", generator=g)
+
+    def quant(X):
+        q = torch.empty(X.shape, dtype=torch.uint8, device="cuda"); sc = torch.empty(X.shape[0], device="cuda")
+        ok(L.gdf_op_quant_rows_fp8(P(X), X.shape[1], X.shape[0], X.shape[1], 1, P(q), X.shape[1], P(sc), stream()), L)
+        return q, sc
+    A8, sa = quant(A)
+    W8, sw = quant(W)
+    torch.cuda.synchronize()
+    # the quantiser: power-of-two scales, |q| <= 448, dequantised values within e4m3's half-ulp (2^-4 relative) of the source
+    assert torch.all(torch.frexp(sa)[0] == 0.5) and torch.all(torch.frexp(sw)[0] == 0.5)
+    dA = A8.view(torch.float8_e4m3fn).float() * sa[:, None]
+    dW = W8.view(torch.float8_e4m3fn).float() * sw[:, None]
+    assert float(A8.view(torch.float8_e4m3fn).float().abs().max()) <= 448.0
+    amax = A.float().abs().amax(1, keepdim=True)
+    # |err| <= half an ulp of the top binade (e4m3: 3 mantissa bits; the scaled row maximum lies in (224, 448], ulp there = 32)
+    assert float(((dA - A.float()).abs() / amax).max()) <= 16.0 / 224.0 + 1e-6
+    assert rel_l2(dA, A.float()) < 4e-2 and rel_l2(dW, W.float()) < 4e-2
+    o16 = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    o32 = torch.empty(M, N, device="cuda") if mode == "res" else None
+    res = torch.randn(M, N, device="cuda", generator=g) if mode == "res" else None
+    ok(L.gdf_op_gemm_mx(P(A8), K, P(sa), P(W8), P(sw), P(bias), 1 if mode == "gelu" else 0, P(res), N, P(o16), N, P(o32), N, M, N, K, stream()), L)
+    torch.cuda.synchronize()
+    ref = dA @ dW.t() + bias
+    if mode == "gelu":
+        ref = torch.nn.functional.gelu(ref, approximate="tanh")
+    if mode == "res":
+        ref = ref + res
+        assert rel_l2(o32, ref) < 2e-6 * K ** 0.5 + 1e-5, rel_l2(o32, ref)          # fp32 accumulation of exact fp8 products
+    assert rel_l2(o16, ref) < 3e-3, rel_l2(o16, ref)                                 # + the bf16 rounding of the output
+    full = A.float() @ W.float().t() + bias
+    if mode == "gelu":
+        full = torch.nn.functional.gelu(full, approximate="tanh")
+    if mode == "res":
+        full = full + res
+    e = rel_l2(o16, full)
+    print(f"fp8-mx gemm {M}x{N}x{K} {mode}: vs dequantised {rel_l2(o16, ref):.2e}, vs unquantised {e:.2e}")
+    assert e < 6e-2

@@ -63,7 +63,7 @@ def main():
     ap.add_argument("--hooks", default="practical", choices=("practical", "all", "none"))
     ap.add_argument("--profile-ops", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--dtype", default="bfloat16", choices=("bfloat16", "float16", "bfloat16x2"),
+    ap.add_argument("--dtype", default="bfloat16", choices=("bfloat16", "float16", "bfloat16x2", "fp8-mx"),
                     help="element type of weights / activations / MFMA operands (the reference loads Flux in bfloat16)")
     args = ap.parse_args()
     if not torch.cuda.is_available():
@@ -126,7 +126,8 @@ def main():
     res = {"metric": "images/sec feature-extract, Flux.1-dev MMDiT 1024^2 single forward", "value": round(ips, 3),
            "unit": "images/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(1e3 * dt / args.steps, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-           "dtype": {"bfloat16": "bf16", "float16": "f16", "bfloat16x2": "bf16 hi+lo operand pairs (fp16 attention internals)"}[args.dtype], "data": "synthetic",
+           "dtype": {"bfloat16": "bf16", "float16": "f16", "bfloat16x2": "bf16 hi+lo operand pairs (fp16 attention internals)",
+                     "fp8-mx": "fp8-mx (e4m3 operands in the large linears: LOWER than the reference's bf16; opt-in)"}[args.dtype], "data": "synthetic",
            "config": {"workload": f"Flux MMDiT ({args.layers} double + {args.single_layers} single blocks, 24 heads x 128), "
                                   f"{S}+{T} tokens, batch {B}, hooks={args.hooks} ({len(out[1])} ids, "
                                   f"{hook_bytes / B / 1e6:.1f} MB/img)",
@@ -137,6 +138,8 @@ def main():
                                      if args.dtype == "bfloat16" else
                                      "bf16 weights; every activation operand a bf16 hi + lo pair contracted as [hi | lo] x [W | W] (2x MFMA work; TFLOP/s "
                                      "count algorithmic FLOPs); q / k / v / P fp16" if args.dtype == "bfloat16x2" else
+                                     "QKV / MLP / output-projection GEMMs on OCP e4m3 operands (v_mfma_scale_f32_16x16x128_f8f6f4; activations quantised "
+                                     "per token, weights per output channel, power-of-two scales), everything else bf16" if args.dtype == "fp8-mx" else
                                      "fp16 MFMA operands / weights / activations (reference: bf16)")
                                     + ", fp32 accumulate, fp32 residual stream, fp16 hooks (saturating)"},
            "roofline": {"bound": "mfma", "kernel": dominant, "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS,
