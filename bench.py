@@ -88,7 +88,7 @@ def unet_flops_per_image(cfg, lat):
     return f
 
 
-def cpu_baseline(version, lat_full, budget_s=60.0):
+def cpu_baseline(version, lat_full, budget_s=100.0):
     """Time the CPU oracle (oracle/unet_ref.py, fp32) on a BOUNDED sample of the same workload: thread count
     calibrated on one ResnetBlock2D + one BasicTransformerBlock (best of 16/32/64/128), then the largest resolution whose
     predicted time fits `budget_s` (scaled by the algorithmic FLOP ratio when that is not the full resolution)."""
