@@ -144,14 +144,16 @@ SIGNATURES.update({
 _lib = None
 
 # Operand classes of a UNet plan that can be kept as split fp16 pairs hi + lo (csrc/builder.h SP_*, include/gdf.h gdf_plan_opts.reserved[1]).
-SPLIT_CLASSES = {"stream": 1, "gnv": 2, "ln_attn": 4, "attn_out": 8, "ln_ff": 16, "ff_inner": 32, "res": 64, "out": 128}
-SPLIT_ALL = 255
-# The SELECTIVE preset: the main-path roundings (fp16 images of the residual stream, the GroupNorm output in front of proj_in, conv_out's operand)
-# plus the attention outputs — the cheapest subset whose CPU-emulated worst hook stays below 8.5e-4 on SDXL and SD1.5 (tools/operand_subsets.py,
-# profiles/r04_operand_subsets_*.txt)
-SPLIT_SELECTIVE = SPLIT_CLASSES["stream"] | SPLIT_CLASSES["gnv"] | SPLIT_CLASSES["attn_out"] | SPLIT_CLASSES["out"]
+SPLIT_CLASSES = {"stream": 1, "gnv": 2, "ln_attn": 4, "attn_out": 8, "ln_ff": 16, "ff_inner": 32, "res": 64, "out": 128, "sampler": 256,
+                 "attn2_out": 512, "upsampler": 1024}
+SPLIT_ALL = 2047
+# The SELECTIVE preset: the main-path roundings (fp16 images of the residual stream as read by the shortcuts, proj_out, the GroupNorms and the
+# DOWNsampler convs; the GroupNorm output in front of proj_in; conv_out's operand) plus the SELF-attention outputs — the cheapest subset whose
+# CPU-emulated worst hook stays below 8.5e-4 on SDXL and SD1.5 (tools/operand_subsets.py, profiles/r04_operand_subsets_*).  Not in it although
+# on the list of candidates: the cross-attention outputs (1e-8 of variance) and the two upsampler convs (4.5e-8 for 3 ms of the step).
+SPLIT_SELECTIVE = (SPLIT_CLASSES["stream"] | SPLIT_CLASSES["gnv"] | SPLIT_CLASSES["attn_out"] | SPLIT_CLASSES["out"] | SPLIT_CLASSES["sampler"])
 # per architecture family: SD1.5 / SD2.1 (one transformer block per level) do not need the attention outputs
-SELECTIVE_BY_ARCH = {"xl": SPLIT_SELECTIVE, "1-5": SPLIT_CLASSES["stream"] | SPLIT_CLASSES["gnv"] | SPLIT_CLASSES["out"]}
+SELECTIVE_BY_ARCH = {"xl": SPLIT_SELECTIVE, "1-5": SPLIT_CLASSES["stream"] | SPLIT_CLASSES["gnv"] | SPLIT_CLASSES["out"] | SPLIT_CLASSES["sampler"]}
 AUTO_BOUND = 9.5e-4      # emulated error above which the next plan level is chosen (the HIP path sits 0-7 % above the emulation)
 _ERR_TABLE = None
 
@@ -348,6 +350,8 @@ class _Lease:
 
 
 _SETS_BY_RANGE = []          # (weakref to _HookSet) for release_after(): which set backs a given device pointer
+import threading as _threading
+_SETS_LOCK = _threading.Lock()   # one extractor per host thread is a supported mode (reference aggregation_network.py:67-95)
 
 
 def release_after(tensors, stream=None):
@@ -365,10 +369,11 @@ def release_after(tensors, stream=None):
         if not (torch.is_tensor(t) and t.is_cuda):
             continue
         p = t.untyped_storage().data_ptr()
-        for ref in list(_SETS_BY_RANGE):
-            hs = ref()
+        with _SETS_LOCK:
+            live = [(r, r()) for r in _SETS_BY_RANGE]
+            _SETS_BY_RANGE[:] = [r for r, h in live if h is not None]
+        for ref, hs in live:
             if hs is None:
-                _SETS_BY_RANGE.remove(ref)
                 continue
             if hs.lo <= p < hs.hi and id(hs) not in done:
                 done.add(id(hs))
@@ -403,7 +408,8 @@ class _HookSet:
         self.out_ptr = C.c_void_p(base + 2 * self.out_off)
         self.leased = False
         self.events = []                 # release_after(): reads still in flight on other streams
-        _SETS_BY_RANGE.append(weakref.ref(self))
+        with _SETS_LOCK:
+            _SETS_BY_RANGE.append(weakref.ref(self))
 
     def lease(self, dev):
         """-> fp16 tensor over the whole set whose storage keeps the lease alive; the set is free again when that storage dies"""

@@ -127,15 +127,18 @@ struct PlanBuilder {
   // image of the residual stream as read by the 1x1 shortcuts, the down / upsampler convs, proj_out and the GroupNorms, and the GroupNorm output
   // in front of proj_in — carry most of it and are cheap to split (few, small GEMMs); the branch-internal operands (LayerNorm outputs, GEGLU
   // inner, resnet conv operands) are expensive and matter less.
-  enum { SP_STREAM = 1,      // fp16 images of residual-stream tensors (incl. the skip-concat buffers): shortcut / sampler / proj_out operands, GroupNorm inputs
+  enum { SP_STREAM = 1,      // fp16 images of residual-stream tensors (incl. the skip-concat buffers): shortcut / proj_out operands, GroupNorm inputs
          SP_GNV = 2,         // Transformer2DModel.norm output  -> proj_in operand
          SP_LN_ATTN = 4,     // LayerNorm-1 / -2 outputs        -> to_q|k|v, cross to_q operands
-         SP_ATTN_OUT = 8,    // attention outputs               -> to_out.0 operands
+         SP_ATTN_OUT = 8,    // self-attention outputs          -> attn1.to_out.0 operands
          SP_LN_FF = 16,      // LayerNorm-3 output              -> GEGLU projection operand
          SP_FF_INNER = 32,   // GEGLU inner tensor              -> ff.net.2 operand
          SP_RES = 64,        // resnet GroupNorm(+SiLU) outputs and the conv1 output -> conv1 / conv2 operands, norm2 input
          SP_OUT = 128,       // conv_norm_out output            -> conv_out operand
-         SP_ALL = 255 };
+         SP_SAMPLER = 256,   // (with SP_STREAM) the DOWNsampler convs contract over hi + lo of the stream image (else over hi only)
+         SP_ATTN2_OUT = 512, // cross-attention outputs         -> attn2.to_out.0 operands (SP_ATTN_OUT: the self-attention outputs)
+         SP_UPSAMPLER = 1024,// (with SP_STREAM) the UPsampler convs contract over hi + lo (two of the largest convs of the step)
+         SP_ALL = 2047 };
   int split = 0;              // mask of the classes above
   bool precise = false;       // split != 0
   bool spl(int cls) const { return (split & cls) != 0; }

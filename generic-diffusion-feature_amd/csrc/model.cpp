@@ -267,8 +267,8 @@ struct B : PlanBuilder {   // UNet op program
     // GroupNorm(eps 1e-6) -> proj_in  (conv1x1 == linear in NHWC)
     // precise plans: every GEMM A operand below is a split image [hi | lo] (row width 2K, lo at +K): builder.h gemm(..., a_lo)
     // split operand classes (builder.h SP_*): s_x = 1 when the class is stored as pairs, p_x = its row-width factor
-    const int s_gnv = spl(SP_GNV), s_lna = spl(SP_LN_ATTN), s_ao = spl(SP_ATTN_OUT), s_lnf = spl(SP_LN_FF), s_inn = spl(SP_FF_INNER);
-    const int p_gnv = 1 + s_gnv, p_lna = 1 + s_lna, p_ao = 1 + s_ao, p_lnf = 1 + s_lnf, p_inn = 1 + s_inn;
+    const int s_gnv = spl(SP_GNV), s_lna = spl(SP_LN_ATTN), s_ao = spl(SP_ATTN_OUT), s_ao2 = spl(SP_ATTN2_OUT), s_lnf = spl(SP_LN_FF), s_inn = spl(SP_FF_INNER);
+    const int p_gnv = 1 + s_gnv, p_lna = 1 + s_lna, p_ao = 1 + s_ao, p_ao2 = 1 + s_ao2, p_lnf = 1 + s_lnf, p_inn = 1 + s_inn;
     const size_t gn = groupnorm(x, w.gn, 1e-6f, false, SP_GNV);
     Act tok = new_act(C, x.H, x.W, true);
     {
@@ -280,7 +280,7 @@ struct B : PlanBuilder {   // UNet op program
       const BlockW& bw = w.blocks[bi];
       const std::string bid = id + "-block" + std::to_string(bi);
       const size_t nb = n * C * 2;            // a plain fp16 [n][C] tensor (q, hooks)
-      const size_t nb_lna = img_bytes(n, C, SP_LN_ATTN), nb_ao = img_bytes(n, C, SP_ATTN_OUT), nb_lnf = img_bytes(n, C, SP_LN_FF);
+      const size_t nb_lna = img_bytes(n, C, SP_LN_ATTN), nb_ao = img_bytes(n, C, SP_ATTN_OUT), nb_ao2 = img_bytes(n, C, SP_ATTN2_OUT), nb_lnf = img_bytes(n, C, SP_LN_FF);
       // --- self attention ---
       size_t ln = layernorm(tok, bw.ln1, SP_LN_ATTN);
       const size_t qkv = tmp(n * 3 * C * 2);
@@ -312,14 +312,14 @@ struct B : PlanBuilder {   // UNet op program
       // the batch (reference diffusion_feature.py:272, opts.reserved[0]) there is a single K/V set per block
       const bool shared = opt.reserved[0] != 0;
       const size_t kv = dry ? 0 : kv_bufs[bw.kv_group].first + (size_t)bw.kv_index * kv_bufs[bw.kv_group].second;
-      ao = tmp(nb_ao);
+      ao = tmp(nb_ao2);
       const int mc = maps ? want_map(bid + "-cross-map", heads, S, n_ctx) : (dry_map(bid + "-cross-map"), -1);
-      attention("attn2", q2r, C, ws(kv), 2 * C, ws(kv + (size_t)C * 2), 2 * C, ws(ao), C * p_ao, heads, S, n_ctx, D, mc,
-                shared ? 0 : n_ctx, s_ao * C);
+      attention("attn2", q2r, C, ws(kv), 2 * C, ws(kv + (size_t)C * 2), 2 * C, ws(ao), C * p_ao2, heads, S, n_ctx, D, mc,
+                shared ? 0 : n_ctx, s_ao2 * C);
       if (hq < 0) untmp(q2, nb);
       { Epi e; e.bias = wt(bw.o2.b); e.has_bias = true; residual_from(e, tok); out_to(e, tok, false);
-        gemm("attn2_out", ws(ao), C * p_ao, n, bw.o2, C, C, 0, e, s_ao * C); }
-      untmp(ao, nb_ao);
+        gemm("attn2_out", ws(ao), C * p_ao2, n, bw.o2, C, C, 0, e, s_ao2 * C); }
+      untmp(ao, nb_ao2);
       if (stop) break;
       // --- feed forward (GEGLU) ---
       ln = layernorm(tok, bw.ln3, SP_LN_FF);
@@ -521,7 +521,7 @@ struct B : PlanBuilder {   // UNet op program
       if (lw.has_sampler && !stop) {
         Act nxt = skip_dst(boc[lv], hh / 2, ww / 2);
         Epi e; e.bias = wt(lw.sampler.b); e.has_bias = true; out_to(e, nxt);
-        conv3("downsample", cur.h, cur.ld, cur.C, hh, ww, 2, false, lw.sampler, e, cur.lo);  // downsampling.py:132-152
+        conv3("downsample", cur.h, cur.ld, cur.C, hh, ww, 2, false, lw.sampler, e, spl(SP_SAMPLER) ? cur.lo : 0);  // downsampling.py:132-152
         free_master(cur);
         cur = nxt; hh /= 2; ww /= 2;
         gather("down-level" + std::to_string(lv) + "-downsampler-out", cur);
@@ -578,7 +578,7 @@ struct B : PlanBuilder {   // UNet op program
         const Cat& nc = cats[ci];
         Act nxt = view_act(ws(nc.off), (nc.ch + nc.cs) * px, boc[lv], cur.H * 2, cur.W * 2, false, sps ? nc.ch + nc.cs : 0);
         Epi e; e.bias = wt(lw.sampler.b); e.has_bias = true; out_to(e, nxt);
-        conv3("upsample", cur.h, cur.ld, cur.C, cur.H, cur.W, 1, true, lw.sampler, e, cur.lo);   // upsampling.py:176-193
+        conv3("upsample", cur.h, cur.ld, cur.C, cur.H, cur.W, 1, true, lw.sampler, e, spl(SP_UPSAMPLER) ? cur.lo : 0);   // upsampling.py:176-193
         free_act(cur);
         cur = nxt;
         gather("up-level" + std::to_string(i) + "-upsampler-out", cur);

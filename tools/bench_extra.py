@@ -105,7 +105,7 @@ def plans_block(unet, step, B, headline_ips, steps=4):
     unet.set_precise("auto")
     out["note"] = ("operand plan levels (include/gdf.h reserved[1]): auto = the cheapest level that keeps every REQUESTED hook within 1e-3 of the fp32 "
                    "reference (components/native.py choose_split: plain fp16 operands for the headline's four hooks); selective = split stream "
-                   "images + proj_in operand + attention outputs + conv_out operand (every hook kind <= 8.2e-4 at full size, "
+                   "images (shortcut / proj_out / downsampler operands, GroupNorm inputs) + proj_in / conv_out operands + self-attention outputs (every hook kind <= 8.2e-4 at full size, "
                    "tests/test_gpu_fullsize.py); precise = every operand class split (<= 4.9e-4)")
     return out
 

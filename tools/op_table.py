@@ -5,7 +5,8 @@ from components.native import NativeUNet, ARCH_CONFIGS
 import bench as BB
 ver=sys.argv[1] if len(sys.argv)>1 else '1-5'; B=int(sys.argv[2]) if len(sys.argv)>2 else 32
 cfg=ARCH_CONFIGS[ver]; dev=torch.device('cuda:0'); lat=64 if ver=='1-5' else 128
-net=NativeUNet(cfg,device=dev,precise=False).init_synthetic(0)
+import os
+net=NativeUNet(cfg,device=dev,precise=(sys.argv[3] if len(sys.argv)>3 else False)).init_synthetic(0)
 g=torch.Generator(device=dev).manual_seed(1)
 x=torch.randn(B,4,lat,lat,generator=g,device=dev).half()
 ctx=torch.randn(1,77,cfg['cross_attention_dim'],generator=g,device=dev).half().expand(B,-1,-1).contiguous()
@@ -27,6 +28,6 @@ print('total ms',tot)
 # group consecutive identical (name, flops, kernel)
 grp={}
 for i,(name,ms,fl,lab) in acc.items():
-    k=(name,round(fl/1e9,1),lab); g_=grp.setdefault(k,[0,0.0]); g_[0]+=1; g_[1]+=ms
+    k=(name,round(fl/1e9,1),lab) if len(sys.argv)<=4 else (name,0,''); g_=grp.setdefault(k,[0,0.0]); g_[0]+=1; g_[1]+=ms
 for (name,gf,lab),(n,ms) in sorted(grp.items(), key=lambda kv:-kv[1][1])[:45]:
     print(f"{name:14s} n={n:3d} {ms:7.3f} ms  {gf:8.1f} GF/op  {gf*n/ms if ms>0 else 0:7.1f} TF  {lab}")

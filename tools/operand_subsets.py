@@ -30,6 +30,10 @@ LIN_CLASSES = [
     ("proj_out", r"proj_out\.weight$"), ("conv1", r"resnets\.\d+\.conv1\.weight$"), ("conv2", r"resnets\.\d+\.conv2\.weight$"),
     ("shortcut", r"conv_shortcut\.weight$"), ("sampler", r"samplers\.0\.conv\.weight$"), ("conv_out", r"^conv_out\.weight$"),
 ]
+# finer classes for follow-up studies (python tools/operand_subsets.py xl 128 --classes attn1_out,attn2_out,upsampler,downsampler); a weight may
+# belong to one coarse and one fine class
+FINE_CLASSES = [("attn1_out", r"attn1\.to_out\.0\.weight$"), ("attn2_out", r"attn2\.to_out\.0\.weight$"),
+                ("upsampler", r"upsamplers\.0\.conv\.weight$"), ("downsampler", r"downsamplers\.0\.conv\.weight$")]
 GN_CLASSES = [("gn_res1", r"resnets\.\d+\.norm1\.weight$"), ("gn_res2", r"resnets\.\d+\.norm2\.weight$"),
               ("gn_vit", r"attentions\.\d+\.norm\.weight$"), ("gn_out", r"^conv_norm_out\.weight$")]
 ALL = [c for c, _ in LIN_CLASSES] + [c for c, _ in GN_CLASSES] + ["qkv_store", "P"]
@@ -39,10 +43,10 @@ def _r(x):
     return x.to(torch.float16).to(torch.float32) if x.dtype == torch.float32 and x.dim() >= 2 else x
 
 
-def classify(P):
+def classify(P, fine=False):
     m = {}
     for name, t in P.items():
-        for cls, rx in LIN_CLASSES + GN_CLASSES:
+        for cls, rx in (FINE_CLASSES if fine else LIN_CLASSES + GN_CLASSES):
             if re.search(rx, name):
                 m[id(t)] = cls
     return m
@@ -87,8 +91,18 @@ def table(errs, title):
 
 
 # plan operand classes (csrc/builder.h SP_*, components/native.py SPLIT_CLASSES) -> the emulation classes they remove
-PLAN_CLASSES = {"stream": ["shortcut", "sampler", "proj_out", "gn_vit", "gn_res1", "gn_out"], "gnv": ["proj_in"], "ln_attn": ["qkv", "xq"],
-                "attn_out": ["attn_out"], "ln_ff": ["geglu"], "ff_inner": ["ff_out"], "res": ["conv1", "conv2", "gn_res2"], "out": ["conv_out"]}
+# (the emulation classes `attn_out` and `sampler` are superseded by their halves attn1_out / attn2_out and downsampler / upsampler, measured in a
+# second run with --classes attn1_out,attn2_out,upsampler,downsampler and merged by merge_fine())
+PLAN_CLASSES = {"stream": ["shortcut", "proj_out", "gn_vit", "gn_res1", "gn_out"], "gnv": ["proj_in"], "ln_attn": ["qkv", "xq"],
+                "attn_out": ["attn1_out"], "attn2_out": ["attn2_out"], "sampler": ["downsampler"], "upsampler": ["upsampler"],
+                "ln_ff": ["geglu"], "ff_inner": ["ff_out"], "res": ["conv1", "conv2", "gn_res2"], "out": ["conv_out"]}
+
+
+def merge_fine(res, fine):
+    """replace the coarse classes attn_out / sampler of `res` by the four finer ones of `fine` (same model, same inputs)"""
+    out = dict(res); out["classes"] = {c: e for c, e in res["classes"].items() if c not in ("attn_out", "sampler")}
+    out["classes"].update(fine["classes"])
+    return out
 
 
 def predict(res, plan_classes):
@@ -107,6 +121,13 @@ def make_table(paths, out):
                      "columns": ["plain", "selective"]}}
     for pth in paths:
         res = json.load(open(pth))
+        fpth = pth.replace("operand_subsets_", "operand_subsets_fine_").replace("subsets_", "fine_") if "fine" not in pth else None
+        for cand in (pth.replace("operand_subsets_", "operand_subsets_fine_"), os.path.join(os.path.dirname(pth), os.path.basename(pth).replace("subsets_", "fine_"))):
+            if cand != pth and os.path.exists(cand):
+                res = merge_fine(res, json.load(open(cand)))
+                break
+        else:
+            raise SystemExit("no fine-class file next to " + pth)
         ver = res["ver"]
         names = [k for k, b in SPLIT_CLASSES.items() if SELECTIVE_BY_ARCH[ver] & b]
         pl, se = predict(res, []), predict(res, names)
@@ -128,7 +149,8 @@ def main():
     arch = R.ARCHS[a.ver]
     P = R.synth_params(arch, seed=0); I = R.synth_inputs(arch, 1, a.lat, seed=1)
     ids = [i for i in R.stored_hook_ids(arch) if not i.endswith("-map")]
-    cls_of = classify(P)
+    fine = any(c in dict(FINE_CLASSES) for c in a.classes.split(","))
+    cls_of = classify(P, fine)
 
     def run(rounded):
         st = R.Store({k: True for k in ids}, out_dtype=None)
@@ -154,8 +176,9 @@ def main():
         table(res["classes"][c], "%s only (no storage rounding)  [%.0f s]" % (c, time.time() - t0))
         if a.out:
             json.dump(res, open(a.out, "w"))
-    res["all"] = err(run(ALL), ref)
-    table(res["all"], "all classes + storage")
+    if not fine:
+        res["all"] = err(run(ALL), ref)
+        table(res["all"], "all classes + storage")
     if a.out:
         json.dump(res, open(a.out, "w"))
 
