@@ -64,6 +64,8 @@ def parse_args(argv=None):
                         "plan that keeps every requested layer within 1e-3 of the fp32 reference (plain fp16 operands, the selective split or the "
                         "full split).  --precise = the full split (every feature <= 5e-4, ~1.6x the time); --precise selective | plain | "
                         "a class list such as stream,attn_out")
+    p.add_argument('--early_exit', action='store_true',
+                   help='native extension (not in the reference CLI): stop the denoiser forward after the last requested layer (same files, less work)')
     return p.parse_args(argv)
 
 
@@ -173,7 +175,7 @@ def main(argv=None):
         args.layer, args.version, device=device, dtype=args.dtype, offline_lora=args.offline_lora,
         offline_lora_filename=args.offline_lora_filename, feature_resize=args.feature_resize, control=args.control,
         attention=args.attention, img_size=args.img_size,
-        precise=None if args.precise is None else (False if args.precise == 'plain' else args.precise))
+        precise=None if args.precise is None else (False if args.precise == 'plain' else args.precise), early_exit=args.early_exit)
 
     paths = sorted(glob.glob(args.input_dir, recursive=True))
     lo, hi = 0, len(paths)

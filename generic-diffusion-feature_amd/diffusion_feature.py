@@ -36,6 +36,9 @@ class FeatureExtractor(nn.Module):
                  precise=None,     # native extension: operand plan of the UNet versions — None = 'auto' (the cheapest plan level that keeps
                                    # every REQUESTED layer within 1e-3 of the fp32 reference: plain fp16 operands / the selective split /
                                    # the full split), False = plain, True = full split, 'selective', or a class list ('stream,attn_out')
+                 early_exit=False, # native extension, OPT-IN: stop the denoiser forward after the last requested layer (the reference always runs the
+                                   # whole forward and discards `noise_pred`; the returned features are bit-identical either way).  Ignored when
+                                   # 'vae-out' (which needs the model output) is requested
                  ):
         super().__init__()
         if control:
@@ -63,6 +66,8 @@ class FeatureExtractor(nn.Module):
             # whose image shard is empty never reaches extract()
             from components.models import native_vae_decoder
             native_vae_decoder(pipe, device)
+        if early_exit and not self.store_vae_output and hasattr(pipe.unet, "early_exit"):
+            pipe.unet.early_exit = True
         if precise is not None:
             if hasattr(pipe.unet, "set_precise"):
                 pipe.unet.set_precise(precise)

@@ -68,6 +68,21 @@ def test_cli_precise_flag(tmp_path, monkeypatch):
         assert a.shape == b.shape and 0.0 < e < 2.5e-3, (k, e)
 
 
+def test_cli_early_exit_flag_same_files(tmp_path, monkeypatch):
+    """--early_exit (native extension): the forward stops after the last requested layer; the files are bit-identical."""
+    monkeypatch.setenv("GDF_SYNTHETIC_WEIGHTS", "1")
+    sys.path.insert(0, ROOT)
+    import extract_feature as cli
+    layers = _setup(tmp_path)
+    base = ["--layer", str(tmp_path / "layers.json"), "--version", "1-5", "--img_size", "256", "--t", "100", "-b", "2",
+            "--input_dir", str(tmp_path / "imgs" / "*.png"), "--prompt_file", str(tmp_path / "prompt.txt"), "--use_original_filename"]
+    cli.main(base + ["--output_dir", str(tmp_path / "full")])
+    cli.main(base + ["--output_dir", str(tmp_path / "ee"), "--early_exit"])
+    for k in layers:
+        for n in "abc":
+            assert np.array_equal(np.load(tmp_path / "full" / k / f"{n}.npy").view(np.uint16), np.load(tmp_path / "ee" / k / f"{n}.npy").view(np.uint16)), (k, n)
+
+
 def test_output_stage_matches_reference_files_on_gpu(tmp_path):
     """(f)2 on device tensors: nearest resize + concat on the GPU, pinned async D2H, byte-identical to the reference's files."""
     from test_host_cpu import _run_output_stage, check_output_stage

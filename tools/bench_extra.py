@@ -208,6 +208,12 @@ def e2e_block(dev, version, B, img, practical_ids, steps=4):
         dt = _time_steps(step, steps, 3)
         out = {"extract_images_per_s": round(B * steps / dt, 2), "extract_ms_per_batch": round(1e3 * dt / steps, 2),
                "stages": "VAE encode (AutoencoderKL, libgdf) + sample + noise-add -> scale_model_input -> UNet forward + hooks; image tensors resident in HBM"}
+        # opt-in early exit (FeatureExtractor(early_exit=True)): the forward stops after the last requested layer — same features, the reference
+        # itself always runs (and discards) the rest of the forward; NOT the headline and not the default
+        df.pipe.unet.early_exit = True
+        dte = _time_steps(step, steps, 3)
+        df.pipe.unet.early_exit = False
+        out["extract_early_exit_opt_in_images_per_s"] = round(B * steps / dte, 2)
         # the VAE stage alone (same call the extractor makes)
         lt = torch.full((B,), 100, device=dev)
         enc = lambda: df.pipe.prepare_latents(imgs, lt, 1, B, torch.float16, dev)
