@@ -242,18 +242,25 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(const AttnParams p) {
     }
   };
 
-  // Fast tile load (head dims without pad chunks, tiles that lie inside one region and hold KT valid keys): buffer loads with a
+  // Fast tile load (tiles that lie inside one region and hold KT valid keys): buffer loads with a
   // per-lane byte offset computed ONCE and the tile's row offset in the scalar operand — no per-tile address arithmetic (the
   // generic form above spends ~25 VALU instructions per tile on clamping, region select and 64-bit address math, 10 % of the
   // loop's VALU work; tools/ablate_attn.py: the K / V global loads cost 12-15 % of the kernel, their LDS stores nothing).
-  constexpr bool FASTLD = !PADDED && (KT * CPR) % NT == 0;
+  // Padded head dims (40 / 80) take the same path: a pad chunk's lane re-reads one of the row's own VALID chunks instead of being
+  // zero-filled — K's pad columns meet the zero pad columns of the Q fragments, V's pad columns only reach O^T rows d >= D that
+  // are never stored — so the loads stay unconditional, in bounds, and finite whenever the row itself is.
+  // (same-box A/B, round 4: D = 72 635 -> 653 TFLOP/s, D = 80 598-612 -> 623, D = 40 unchanged; SD1.5 B = 32 856 -> 860 img/s)
+  constexpr bool FASTLD = (KT * CPR) % NT == 0;
+  constexpr int CPV = D / 8;                     // chunks per row that hold data
+  static_assert(CPR - CPV <= CPV, "pad chunks alias valid ones");
   uint32_t kvo[NCH], vvo[NCH];
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
     const int idx = tid + c * NT;
     const int row = idx / CPR, ch = idx - row * CPR;
-    kvo[c] = ((uint32_t)row * ldk + (uint32_t)(ch * 8)) * 2u;
-    vvo[c] = ((uint32_t)row * ldv + (uint32_t)(ch * 8)) * 2u;
+    const int chv = (PADDED && ch >= CPV) ? ch - CPV : ch;
+    kvo[c] = ((uint32_t)row * ldk + (uint32_t)(chv * 8)) * 2u;
+    vvo[c] = ((uint32_t)row * ldv + (uint32_t)(chv * 8)) * 2u;
   }
   const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, 0xffffffffu, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, 0xffffffffu, 0x00020000);

@@ -10,7 +10,7 @@ def t(fn, it=10):
     torch.cuda.synchronize(); e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True); e0.record()
     for _ in range(it): fn()
     e1.record(); torch.cuda.synchronize(); return e0.elapsed_time(e1) / it
-for name, B, h, S, D in (("sdxl_1024", 16, 20, 1024, 64), ("sdxl_4096", 16, 10, 4096, 64), ("pixart_4096_d72", 16, 16, 4096, 72), ("sd15_4096_d40", 8, 8, 4096, 40)):
+for name, B, h, S, D in (("sdxl_1024", 16, 20, 1024, 64), ("sdxl_4096", 16, 10, 4096, 64), ("pixart_4096_d72", 16, 16, 4096, 72), ("sd15_4096_d40", 8, 8, 4096, 40), ("sd15_1024_d80", 32, 8, 1024, 80), ("sd15_256_d160", 32, 8, 256, 160)):
     C = h * D
     qkv = torch.randn(B * S, 3 * C, device="cuda").half(); o = torch.empty(B * S, C, device="cuda", dtype=torch.half)
     pk = ctypes.c_void_p(qkv.data_ptr() + C * 2); pv = ctypes.c_void_p(qkv.data_ptr() + 2 * C * 2)
