@@ -118,8 +118,9 @@ __device__ unsigned long long gdf_attn_trace[8192 * 8];
 // 128 v_fma take 533 + 321 cycles whether they come from one wave, interleaved, or from two waves — only transcendentals do
 // (16 MFMAs + 64 v_exp: 727 cycles against 533 and 644 alone).  The loop's bound is therefore MFMA + plain-VALU + LDS-read issue
 // time, and the lever is the instruction count, not the placement.)
-template <int D, int QW, int NW = 4, bool BF = false>
-__global__ __launch_bounds__(NW * 64, 2) void attn_kernel(const AttnParams p) {
+// OCC = workgroups per CU the register budget is sized for (2; 1 only in the GDF_ATTN_QW4 experiment below)
+template <int D, int QW, int NW = 4, bool BF = false, int OCC = 2>
+__global__ __launch_bounds__(NW * 64, OCC) void attn_kernel(const AttnParams p) {
   GDF_AT_ENTRY
   constexpr int NT = NW * 64;                    // threads per workgroup
   constexpr int DQK = (D + 15) / 16 * 16;        // contraction length of QK^T, padded
@@ -963,6 +964,16 @@ static hipError_t launch_d(const AttnParams& p, hipStream_t s) {
     // workgroups: pick by rate x fill of the 512 workgroup slots
     const long nb2 = (long)p.B * p.heads * ((p.Sq + 255) / 256), nb1 = (long)p.B * p.heads * ((p.Sq + 127) / 128);
     auto fill = [](long n, long slots) { const long r = (n + slots - 1) / slots; return (double)n / (double)(r * slots); };
+#if defined(GDF_ATTN_QW4)
+    // experiment (tools/build_variant.sh qw4 -DGDF_ATTN_QW4=4 | =3): ONE wave per SIMD holding 4 (3) query blocks of 32 rows — every K / V fragment
+    // read from LDS feeds 4 (3) MFMAs, all 512 registers to one wave (result in DESIGN.md §3.11)
+    if (!BF && D == 64 && p.Sq >= 1024) {
+      constexpr int Q4 = (D == 64) ? GDF_ATTN_QW4 : 1;
+      const int nqb = (p.Sq + 128 * Q4 - 1) / (128 * Q4);
+      hipLaunchKernelGGL((attn_kernel<D, Q4, 4, false, 1>), dim3(p.B * p.heads * nqb), dim3(256), 0, s, p);
+      return hipGetLastError();
+    }
+#endif
     if (!BF && can2 && p.Sq >= 512 && 1.00 * fill(nb2, 512) >= 0.80 * fill(nb1, 512)) {
       const int nqb = (p.Sq + 255) / 256;
       hipLaunchKernelGGL((attn_kernel<D, can2 ? 2 : 1>), dim3(p.B * p.heads * nqb), dim3(256), 0, s, p);
