@@ -967,8 +967,15 @@ static hipError_t launch_d(const AttnParams& p, hipStream_t s) {
 #if defined(GDF_ATTN_QW4)
     // experiment (tools/build_variant.sh qw4 -DGDF_ATTN_QW4=4 | =3): ONE wave per SIMD holding 4 (3) query blocks of 32 rows — every K / V fragment
     // read from LDS feeds 4 (3) MFMAs, all 512 registers to one wave (result in DESIGN.md §3.11)
+#if GDF_ATTN_QW4 == 28       // 8 waves x 2 query blocks, one workgroup per CU: every staged K / V tile serves 512 query rows (half the L2 -> LDS traffic)
     if (!BF && D == 64 && p.Sq >= 1024) {
-      constexpr int Q4 = (D == 64) ? GDF_ATTN_QW4 : 1;
+      const int nqb = (p.Sq + 511) / 512;
+      hipLaunchKernelGGL((attn_kernel<D, (D == 64) ? 2 : 1, 8, false, 1>), dim3(p.B * p.heads * nqb), dim3(512), 0, s, p);
+      return hipGetLastError();
+    }
+#endif
+    if (!BF && D == 64 && p.Sq >= 1024) {
+      constexpr int Q4 = (D == 64 && GDF_ATTN_QW4 <= 4) ? GDF_ATTN_QW4 : 1;
       const int nqb = (p.Sq + 128 * Q4 - 1) / (128 * Q4);
       hipLaunchKernelGGL((attn_kernel<D, Q4, 4, false, 1>), dim3(p.B * p.heads * nqb), dim3(256), 0, s, p);
       return hipGetLastError();
