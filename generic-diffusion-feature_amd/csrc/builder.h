@@ -102,6 +102,9 @@ struct Act {
   int C = 0, H = 0, W = 0;
   size_t h_alloc = NPOS, h_bytes = 0;   // workspace block owned by h (NPOS: lives in a concat buffer / elsewhere)
   size_t f_alloc = NPOS, f_bytes = 0;
+  // GroupNorm partial sums of the fp16 image, written by the epilogue of the conv that produced it (GemmParams::gn_partial; PlanBuilder::gn_epi):
+  // [rows / gp_rows][C][2] floats.  groupnorm() then skips its statistics pass.
+  size_t gp_alloc = NPOS, gp_bytes = 0; int gp_rows = 0;
 };
 
 struct PlanBuilder {
@@ -139,6 +142,7 @@ struct PlanBuilder {
          SP_ATTN2_OUT = 512, // cross-attention outputs         -> attn2.to_out.0 operands (SP_ATTN_OUT: the self-attention outputs)
          SP_UPSAMPLER = 1024,// (with SP_STREAM) the UPsampler convs contract over hi + lo (two of the largest convs of the step)
          SP_ALL = 2047 };
+  bool gn_epi = false;        // VAE op programs: 3x3 convs emit the GroupNorm partial sums of their output (Act::gp_*)
   int split = 0;              // mask of the classes above
   bool precise = false;       // split != 0
   bool spl(int cls) const { return (split & cls) != 0; }
@@ -191,6 +195,7 @@ struct PlanBuilder {
     if (dry) return;
     if (a.h_alloc != NPOS) { ar.release(a.h_alloc, a.h_bytes); a.h_alloc = NPOS; }
     if (a.f_alloc != NPOS) { ar.release(a.f_alloc, a.f_bytes); a.f_alloc = NPOS; a.has_f = false; }
+    if (a.gp_alloc != NPOS) { ar.release(a.gp_alloc, a.gp_bytes); a.gp_alloc = NPOS; a.gp_rows = 0; }
   }
   void free_master(Act& a) {
     if (dry) return;
@@ -357,6 +362,21 @@ struct PlanBuilder {
       });
       return y;
     }
+    if (x.gp_alloc != NPOS && x.gp_rows > 0 && !from_f && x_lo == 0) {     // the producing conv left the per-slab channel sums: finalize only
+      const size_t ab_b = (size_t)Bn * x.C * 8, ab = tmp(ab_b);
+      const size_t gp = x.gp_alloc; const int nslab = HW / x.gp_rows;
+      const size_t fold_b = gn_fold_floats(Bn, nslab, C) * 4, fold = fold_b ? tmp(fold_b) : 0;
+      op("gn_finalize", 0, [=](const Bind& b, hipStream_t s) {
+        return launch_gn_finalize((const float*)b.ws(gp), nslab, Bq, HW, C, 32, eps, (const float*)b.p(g), (const float*)b.p(bt), (float*)b.ws(ab),
+                                  fold_b ? (float*)b.ws(fold) : nullptr, s);
+      });
+      op(silu ? "gn_apply_silu" : "gn_apply", 0, [=](const Bind& b, hipStream_t s) {
+        return launch_gn_apply((const half_t*)b.p(xh), nullptr, ld, Bq, HW, C, (const float*)b.ws(ab), silu ? 1 : 0, (half_t*)b.ws(y), s, 0, ldy, y_lo);
+      });
+      untmp(ab, ab_b);
+      if (fold_b) untmp(fold, fold_b);
+      return y;
+    }
     const size_t part_b = gn_partial_floats(Bn, x.H * x.W, x.C) * 4, ab_b = (size_t)Bn * x.C * 8;
     const size_t part = tmp(part_b), ab = tmp(ab_b);
     op("gn_stats", 0, [=](const Bind& b, hipStream_t s) {
@@ -373,7 +393,10 @@ struct PlanBuilder {
 
   // 3x3 conv as implicit GEMM over NHWC `src` (Bn, H, W, ld>=Cin)
   // a_lo > 0: the source pixels are split pairs (lo channels a_lo elements after the hi channels), see gemm()
-  void conv3(const char* name, Ref src, int ld, int Cin, int H, int W, int stride, bool ups, const ConvW& w, const Epi& e0, int a_lo = 0) {
+  // stats != null (and gn_epi): the epilogue also writes the GroupNorm partial sums of the fp16 image it stores into a buffer attached to *stats
+  // (the activation being produced), when the tile the launcher picks supports it (gemm_gn_slab_rows)
+  void conv3(const char* name, Ref src, int ld, int Cin, int H, int W, int stride, bool ups, const ConvW& w, const Epi& e0, int a_lo = 0,
+             Act* stats = nullptr) {
     Epi e = e0;
     const int kx = a_lo > 0 ? 2 : 1;
     const int IH = ups ? 2 * H : H, IW = ups ? 2 * W : W;
@@ -389,8 +412,18 @@ struct PlanBuilder {
     const size_t ws_b = splitk > 1 ? (size_t)splitk * M * N * 4 : 0;
     const size_t wsk = splitk > 1 ? tmp(ws_b) : 0;
     gk.splitk = splitk;
+    size_t gp = NPOS;
+    if (stats && gn_epi && !stop && e.has_o16 && a_lo == 0 && e.o16_lo == 0) {
+      const int sr = gemm_gn_slab_rows(gk);
+      if (sr > 0 && (OH * OW) % sr == 0) {
+        stats->gp_rows = sr; stats->gp_bytes = M / sr * (size_t)N * 8;
+        stats->gp_alloc = gp = dry ? 0 : ar.alloc(stats->gp_bytes);
+        gk.gn_partial = (float*)1;                          // kernel label only (never dereferenced)
+      }
+    }
     op(name, 2.0 * (double)M * N * 9 * Cin, [=](const Bind& b, hipStream_t s) {
       GemmParams g{};
+      if (gp != NPOS) g.gn_partial = (float*)b.ws(gp);
       g.A = (const half_t*)b.p(src); g.lda = ld;
       g.a_bytes = (uint32_t)(((size_t)Bq * H * W - 1) * ld * 2 + (size_t)(a_lo + Cin) * 2);
       g.M = (int)M; g.N = N; g.K = 9 * Cin * kx; g.mode = A_CONV3; g.H = H; g.W = W; g.OH = OH; g.OW = OW; g.cus = cus;
@@ -418,7 +451,7 @@ struct PlanBuilder {
         e.rowvec = Ref{temb_all.buf, temb_all.off + (size_t)w.temb_off * 4}; e.has_rv = true; e.rps = HW; e.ldrv = m.temb_total;
       }
       out_to(e, h1);
-      conv3("res_conv1", ws(n1), x.C * px, x.C, x.H, x.W, 1, false, w.c1, e, slo * x.C);
+      conv3("res_conv1", ws(n1), x.C * px, x.C, x.H, x.W, 1, false, w.c1, e, slo * x.C, &h1);
     }
     untmp(n1, img_bytes(n, x.C, SP_RES));
     const size_t n2 = groupnorm(h1, w.n2, w.eps, true, SP_RES);
@@ -437,7 +470,7 @@ struct PlanBuilder {
       if (w.has_sc) { e.res32 = ws(sc); e.has_r32 = true; e.ldres = w.cout; }
       else residual_from(e, x);
       out_to(e, y);
-      conv3("res_conv2", ws(n2), w.cout * px, w.cout, x.H, x.W, 1, false, w.c2, e, slo * w.cout);
+      conv3("res_conv2", ws(n2), w.cout * px, w.cout, x.H, x.W, 1, false, w.c2, e, slo * w.cout, &y);
       if (e.aux_slot >= 0) hook_done();
     }
     untmp(n2, img_bytes(n, w.cout, SP_RES));

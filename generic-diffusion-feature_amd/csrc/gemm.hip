@@ -145,9 +145,12 @@ __device__ unsigned long long gdf_trace[16384 * 8];
 // scales of the operands are applied to the fp32 accumulators in the epilogue, GemmParams::mx_rowscale / mx_colscale).  A K-tile is 128
 // fp8 values = the same 128 bytes per row as 64 halves, so staging, swizzle and the 8-phase schedule are unchanged: the host passes lda /
 // K in 2-byte units; a lane's 32-byte fragment of the K = 128 MFMA is the two adjacent 16-byte chunks 2 fk, 2 fk + 1 of its row.
-template <int MODE, int BM, int BN, int STAGES, bool GEGLU, bool DIT, bool BF = false, bool QKN = false, bool SPLIT = false, bool MX = false>
+// GNS: the epilogue also emits per-channel GroupNorm partial sums of the stored fp16 image (GemmParams::gn_partial; VAE convs only)
+template <int MODE, int BM, int BN, int STAGES, bool GEGLU, bool DIT, bool BF = false, bool QKN = false, bool SPLIT = false, bool MX = false,
+          bool GNS = false>
 __device__ __forceinline__ void gemm_body(const GemmParams& p) {
   static_assert(!BF || DIT, "bf16 operands exist on the MMDiT path only");
+  static_assert(!GNS || (!DIT && !GEGLU && !SPLIT && !MX && BN >= 128 && BN != 320), "GroupNorm partial sums: plain 64-row wave tiles only");
   static_assert(!MX || (DIT && STAGES == 8 && !SPLIT && !QKN && !GEGLU), "fp8 operands: the 256x256 two-group MMDiT kernel only");
   constexpr int NW = BM / 32;                    // waves per workgroup (4 or 8)
   // waves along N (the GEGLU form of the 256x320 tile uses 4x2 waves of 64x160: an EVEN number of 16-column fragments,
@@ -919,6 +922,9 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
     if (DIT && p.rv_tok) return row % p.rows_per_sample;
     return row / p.rows_per_sample;
   };
+  float gsum[GNS ? 8 : 1], gsq[GNS ? 8 : 1];           // GNS: sum x / sum x^2 of this lane's 8 columns over the rows it stores
+#pragma unroll
+  for (int e = 0; e < (GNS ? 8 : 1); ++e) gsum[e] = gsq[e] = 0.f;
 #pragma unroll
   for (int ps = 0; ps < PASSES; ++ps) {
     // ---- prefetch this pass's residual / row-vector operands (overlaps the LDS staging below) ----
@@ -1104,6 +1110,10 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
               for (int e = 0; e < 8; ++e) hv[e] = act16<DIT, BF>(v[it][e] * o_sc);
             }
             *(f16x8*)(out16 + (size_t)rowi[it] * p.ldo16 + col) = hv;
+            if constexpr (GNS) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) { const float x = v[it][e] * o_sc; gsum[e] += x; gsq[e] += x * x; }
+            }
           }
         if (SPLIT && p.o16_lo > 0) {                     // split operand for the consumer GEMM: lo = e16(v - hi)
 #pragma unroll
@@ -1148,6 +1158,28 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_sched_barrier(0);                   // keep the next pass's prefetch from being hoisted (VGPR pressure)
   }
+  if constexpr (GNS) {
+    // the wave tile is one 64-row statistics slab: combine the RPI lanes that hold the same 8 columns through the (idle) staging
+    // rows of this wave, then one 64-byte store per column chunk: gn_partial[slab][col .. col+7][sum, sum of squares]
+    static_assert(WTM == 64 && PR * SLD >= 64 * 16, "one slab per wave tile");
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { st[lane * 16 + e] = gsum[e]; st[lane * 16 + 8 + e] = gsq[e]; }
+    __builtin_amdgcn_wave_barrier();
+    if (lane < LPR && full && p.gn_partial) {
+      float a[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) a[e] = 0.f;
+#pragma unroll
+      for (int r = 0; r < RPI; ++r)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) a[e] += st[(r * LPR + lane) * 16 + e];
+      const int slab = (m0 + wm * WTM) >> 6;
+      f32x4* gp = (f32x4*)(p.gn_partial + ((size_t)slab * p.N + col) * 2);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) gp[q] = f32x4{a[2 * q], a[8 + 2 * q], a[2 * q + 1], a[8 + 2 * q + 1]};
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
   GDF_TR(4);
   if constexpr (!PERSIST) break;
   vb += gridDim.x;
@@ -1162,6 +1194,11 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
 template <int MODE, int BM, int BN, int STAGES, bool GEGLU>
 __global__ __launch_bounds__(BM * 2, 2) void gemm_kernel(const GemmParams p) {
   gemm_body<MODE, BM, BN, STAGES, GEGLU, false>(p);
+}
+// 3x3 conv whose epilogue also writes GroupNorm partial sums (GemmParams::gn_partial; the VAE op programs)
+template <int MODE, int BM, int BN, int STAGES>
+__global__ __launch_bounds__(BM * 2, 2) void gemm_gn_kernel(const GemmParams p) {
+  gemm_body<MODE, BM, BN, STAGES, false, false, false, false, false, false, true>(p);
 }
 // the same tiles with split fp16 hi + lo operands ("precise" plans)
 template <int MODE, int BM, int BN, int STAGES, bool GEGLU>
@@ -1202,7 +1239,8 @@ static int persist_wgs() {
   return n;
 }
 
-template <int MODE, int BM, int BN, int STAGES, bool GEGLU, bool DIT = false, bool BF = false, bool QKN = false, bool SPLIT = false, bool MX = false>
+template <int MODE, int BM, int BN, int STAGES, bool GEGLU, bool DIT = false, bool BF = false, bool QKN = false, bool SPLIT = false, bool MX = false,
+          bool GNS = false>
 static hipError_t launch_t(const GemmParams& p, hipStream_t s) {
   const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
   const int smem = (STAGES >= 8 ? 2 : STAGES) * (BM * 128 + BN * 128);
@@ -1210,6 +1248,7 @@ static hipError_t launch_t(const GemmParams& p, hipStream_t s) {
   {
     const void* fn;
     if constexpr (MX) fn = (const void*)gemm_mx_kernel<BM, BN, STAGES>;
+    else if constexpr (GNS) fn = (const void*)gemm_gn_kernel<MODE, BM, BN, STAGES>;
     else if constexpr (DIT && SPLIT) fn = (const void*)gemm_dit_split_kernel<BM, BN, STAGES, BF, QKN>;
     else if constexpr (DIT) fn = (const void*)gemm_dit_kernel<BM, BN, STAGES, BF, QKN>;
     else if constexpr (SPLIT) fn = (const void*)gemm_split_kernel<MODE, BM, BN, STAGES, GEGLU>;
@@ -1235,6 +1274,7 @@ static hipError_t launch_t(const GemmParams& p, hipStream_t s) {
   if (STAGES == 8 && gx > pw && !(p.batch > 1)) gx = pw;   // persistent: one workgroup per CU walks the tiles
   const dim3 grid(gx, (STAGES == 2 && p.splitk > 1) ? p.splitk : p.batch > 1 ? p.batch : 1);
   if constexpr (MX) hipLaunchKernelGGL((gemm_mx_kernel<BM, BN, STAGES>), grid, dim3(BM * 2), smem, s, q);
+  else if constexpr (GNS) hipLaunchKernelGGL((gemm_gn_kernel<MODE, BM, BN, STAGES>), grid, dim3(BM * 2), smem, s, q);
   else if constexpr (DIT && SPLIT) hipLaunchKernelGGL((gemm_dit_split_kernel<BM, BN, STAGES, BF, QKN>), grid, dim3(BM * 2), smem, s, q);
   else if constexpr (DIT) hipLaunchKernelGGL((gemm_dit_kernel<BM, BN, STAGES, BF, QKN>), grid, dim3(BM * 2), smem, s, q);
   else if constexpr (SPLIT) hipLaunchKernelGGL((gemm_split_kernel<MODE, BM, BN, STAGES, GEGLU>), grid, dim3(BM * 2), smem, s, q);
@@ -1337,7 +1377,8 @@ const char* gemm_kernel_name(const GemmParams& p) {
   else if (v == 825) { bm = 256; bn = 256; st = 8; } else if (v == 932) { bm = 256; bn = 320; st = 9; } else if (v == 826) { bm = 256; bn = 256; st = 8; }
   if (p.mode == A_CONV_SMALLC && v != 160) { bm = 128; bn = 128; st = 2; }
   char tmp[64];
-  if (p.dit && p.mx) snprintf(tmp, sizeof tmp, "gemm_mx_kernel<256, 256, 8>");
+  if (p.gn_partial && !p.dit) snprintf(tmp, sizeof tmp, "gemm_gn_kernel<%d, %d, %d, %d>", p.mode, bm, bn, st);
+  else if (p.dit && p.mx) snprintf(tmp, sizeof tmp, "gemm_mx_kernel<256, 256, 8>");
   else if (p.dit) snprintf(tmp, sizeof tmp, "%s<%d, %d, %d, %s, %s>", is_dit_split(p) ? "gemm_dit_split_kernel" : "gemm_dit_kernel", v == 128 ? 128 : 256, (v == 1256 || v == 8256) ? 256 : 128, v == 8256 ? 8 : v == 2128 ? 3 : 2, p.bf16 ? "true" : "false", p.qkn_nq ? "true" : "false");
   else snprintf(tmp, sizeof tmp, "%s<%d, %d, %d, %d, %s>", is_split(p) ? "gemm_split_kernel" : "gemm_kernel", p.mode, bm, bn, st, p.geglu ? "true" : "false");
   // interned: the returned pointer stays valid for the life of the library (plan build time only, mutex-protected)
@@ -1347,6 +1388,15 @@ const char* gemm_kernel_name(const GemmParams& p) {
   for (const std::string& n : names) if (n == tmp) return n.c_str();
   names.emplace_back(tmp);
   return names.back().c_str();
+}
+
+// GroupNorm partial sums from the epilogue: plain 3x3 convs on the tiles whose wave tile is 64 rows (128x128, 256x128 ring, 256x256 two-group)
+int gemm_gn_slab_rows(const GemmParams& p) {
+  if ((p.mode != A_CONV3 && p.mode != A_CONV_SMALLC) || p.dit || p.geglu || p.splitk > 1 || p.batch > 1 || is_split(p) || p.bn == 16) return 0;
+  if ((p.M % 64) != 0 || (p.N % 8) != 0) return 0;
+  const int v = pick_variant(p);
+  if (p.mode == A_CONV_SMALLC) return v != 160 ? 64 : 0;                 // conv_in: the 128x128 tile
+  return (v == 128 || v == 256 || v == 826) ? 64 : 0;
 }
 
 hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {
@@ -1360,6 +1410,13 @@ hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {
   const int v = pick_variant(p);
   if (v != 16 && ((p.geglu ? p.N / 2 : p.N) % 8) != 0) return hipErrorInvalidValue;   // ragged N only in the BN = 16 variant
   if (p.bf16 && !p.dit) return hipErrorInvalidValue;                                      // bf16 exists on the MMDiT path only
+  if (p.gn_partial) {                                                                     // GroupNorm partial sums from the epilogue (VAE convs)
+    if (gemm_gn_slab_rows(p) != 64 || !p.out16) return hipErrorInvalidValue;
+    if (p.mode == A_CONV_SMALLC) return launch_t<A_CONV_SMALLC, 128, 128, 2, false, false, false, false, false, false, true>(p, s);
+    if (v == 826) return launch_t<A_CONV3, 256, 256, 8, false, false, false, false, false, false, true>(p, s);
+    if (v == 256) return launch_t<A_CONV3, 256, 128, 3, false, false, false, false, false, false, true>(p, s);
+    return launch_t<A_CONV3, 128, 128, 2, false, false, false, false, false, false, true>(p, s);
+  }
   if (p.dit) {
     if (p.mode != A_DENSE || p.geglu || p.batch > 1) return hipErrorInvalidValue;
     if (p.qkn_nq && ((v != 8256 && v != 1256) || (p.qkn_nq % 128) != 0)) return hipErrorInvalidValue;   // one head per 128-column wave tile

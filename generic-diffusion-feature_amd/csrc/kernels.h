@@ -136,8 +136,16 @@ struct GemmParams {
   int mx;
   const float* mx_rowscale;
   const float* mx_colscale;
+  // GROUPNORM STATISTICS FROM THE PRODUCER (VAE op programs; 3x3 convs on the tiles gemm_gn_slab_rows() accepts): besides storing
+  // out16, the epilogue sums x and x^2 of the stored values (v * out16_scale) per output channel over slabs of gemm_gn_slab_rows()
+  // consecutive rows and writes them as gn_partial[(row / slab_rows) * N + c][2] — the layout launch_gn_finalize() reads, so the
+  // GroupNorm that consumes the tensor needs no statistics pass of its own (a full HBM read of a 1-4 GB tensor at 1024^2).
+  // Requires M % slab_rows == 0 and (rows per sample) % slab_rows == 0.  nullptr = off (every UNet / MMDiT plan).
+  float* gn_partial;
 };
 hipError_t launch_gemm(const GemmParams& p, hipStream_t s);
+// rows per statistics slab if launch_gemm can run `p` (shape, mode, epilogue form) with gn_partial set, else 0
+int gemm_gn_slab_rows(const GemmParams& p);
 // Deterministic split-K for problems with few output tiles and a long K (the 8x8-level 3x3 convs of SD1.5: 160 tiles of 128x128,
 // K = 11520..23040): gemm_splitk_factor() > 1 says it pays; the caller provides `splitk * M * N` floats of workspace, the GEMM
 // launch writes one raw partial-sum slab per K range and splitk_reduce_kernel sums them in a fixed order and applies the epilogue.
@@ -182,6 +190,12 @@ hipError_t launch_gn_stats(const half_t* x16, const float* x32, int ld, int B, i
                            const float* gamma, const float* beta, float* partial, float* ab, hipStream_t s, int x_lo = 0);
 hipError_t launch_gn_apply(const half_t* x16, const float* x32, int ld, int B, int HW, int C,
                            const float* ab, int silu, half_t* y, hipStream_t s, int x_lo = 0, int ldy = 0, int y_lo = 0);
+// the second stage of launch_gn_stats alone: `partial` = [B][nslab][C][2] per-slab channel sums (sum x, sum x^2) produced by a GEMM
+// epilogue (GemmParams::gn_partial) -> ab
+// `fold`: scratch of gn_fold_floats(B, nslab, C) floats (0 = none needed) for the pre-reduction of many short slabs
+size_t gn_fold_floats(int B, int nslab, int C);
+hipError_t launch_gn_finalize(const float* partial, int nslab, int B, int HW, int C, int G, float eps, const float* gamma,
+                              const float* beta, float* ab, float* fold, hipStream_t s);
 // single-launch GroupNorm (+SiLU) for small feature maps; gn_fused_slab(...) != 0 says whether it applies
 int gn_fused_slab(int B, int HW, int C, int G);
 hipError_t launch_gn_fused(const half_t* x16, const float* x32, int ld, int B, int HW, int C, int G, float eps, const float* gamma,

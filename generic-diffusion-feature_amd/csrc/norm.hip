@@ -155,6 +155,59 @@ hipError_t launch_gn_stats(const half_t* x16, const float* x32, int ld, int B, i
   return hipGetLastError();
 }
 
+// Many short slabs (a GEMM epilogue emits one per 64 rows: 16384 per sample at 1024^2) are first folded into <= GN_FOLD slabs per sample
+// with fully coalesced row reads; gn_finalize_kernel's per-group gather over all of them took 46-68 us per GroupNorm (poorly coalesced
+// 32-byte pieces, 128 workgroups), about a third of the statistics pass it replaces.
+static constexpr int GN_FOLD = 128;
+__global__ __launch_bounds__(256) void gn_fold_kernel(const float* partial, int nslab, int per, int C2, float* out) {
+  __shared__ double red[256 * 4];
+  const int b = blockIdx.y, j = blockIdx.x, nout = gridDim.x;
+  const int s0 = j * per, s1 = min(nslab, s0 + per);
+  const int tpr = min(256, C2 / 4), rg = 256 / tpr;      // threads per slab row (4 floats each), row groups working in parallel
+  const int tc = threadIdx.x % tpr, tr = threadIdx.x / tpr;
+  for (int c0 = 0; c0 < C2; c0 += 1024) {                // (C2 <= 1024 for every GroupNorm of the models here: one trip)
+    const int c = c0 + tc * 4;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    if (tr < rg && c < C2) {
+      int sl = s0 + tr;
+      for (; sl + 7 * rg < s1; sl += 8 * rg) {            // eight independent row loads in flight per thread
+        f32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = *(const f32x4*)(partial + ((size_t)b * nslab + sl + u * rg) * C2 + c);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { a0 += (double)v[u][0]; a1 += (double)v[u][1]; a2 += (double)v[u][2]; a3 += (double)v[u][3]; }
+      }
+      for (; sl < s1; sl += rg) {
+        const f32x4 v = *(const f32x4*)(partial + ((size_t)b * nslab + sl) * C2 + c);
+        a0 += (double)v[0]; a1 += (double)v[1]; a2 += (double)v[2]; a3 += (double)v[3];
+      }
+    }
+    red[threadIdx.x * 4 + 0] = a0; red[threadIdx.x * 4 + 1] = a1; red[threadIdx.x * 4 + 2] = a2; red[threadIdx.x * 4 + 3] = a3;
+    __syncthreads();
+    if (tr == 0 && c < C2) {                              // fixed combine order: deterministic
+      for (int g = 1; g < rg; ++g) {
+        a0 += red[(g * tpr + tc) * 4 + 0]; a1 += red[(g * tpr + tc) * 4 + 1]; a2 += red[(g * tpr + tc) * 4 + 2]; a3 += red[(g * tpr + tc) * 4 + 3];
+      }
+      *(f32x4*)(out + ((size_t)b * nout + j) * C2 + c) = f32x4{(float)a0, (float)a1, (float)a2, (float)a3};
+    }
+    __syncthreads();
+  }
+}
+
+size_t gn_fold_floats(int B, int nslab, int C) { return nslab > 2 * GN_FOLD ? (size_t)B * GN_FOLD * C * 2 : 0; }
+
+hipError_t launch_gn_finalize(const float* partial, int nslab, int B, int HW, int C, int G, float eps, const float* gamma,
+                              const float* beta, float* ab, float* fold, hipStream_t s) {
+  if (C % G || nslab < 1 || (C & 1)) return hipErrorInvalidValue;
+  if (fold && gn_fold_floats(B, nslab, C) && (2 * C) % 4 == 0 && (2 * C >= 1024 ? (2 * C) % 1024 == 0 : 256 % (2 * C / 4) == 0)) {
+    const int per = (nslab + GN_FOLD - 1) / GN_FOLD, nout = (nslab + per - 1) / per;
+    hipLaunchKernelGGL(gn_fold_kernel, dim3(nout, B), dim3(256), 0, s, partial, nslab, per, 2 * C, fold);
+    partial = fold; nslab = nout;
+  }
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(G, B), dim3(256), 0, s, partial, nslab, HW, C, G, eps, gamma, beta, ab);
+  return hipGetLastError();
+}
+
 __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* x16, const float* x32, int ld, int HW, int C,
                                                        const float* ab, int silu, half_t* y, int rows_per_block, int x_lo, int ldy,
                                                        int y_lo) {

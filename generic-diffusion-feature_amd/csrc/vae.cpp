@@ -162,8 +162,18 @@ struct VB : PlanBuilder {
       Epi e; e.bias = wt(v.conv_in.b); e.has_bias = true; out_to(e, cur);
       const Ref Wr = wt(v.conv_in.w); const int N = boc[0];
       const size_t M = (size_t)Bn * H * W;
+      size_t gp = NPOS;                                    // GroupNorm partial sums of conv_in's output (builder.h conv3, gn_epi)
+      {
+        GemmParams gk{}; gk.M = (int)M; gk.N = N; gk.K = 128; gk.mode = A_CONV_SMALLC;
+        const int sr = (gn_epi && e.has_o16) ? gemm_gn_slab_rows(gk) : 0;
+        if (sr > 0 && (H * W) % sr == 0) {
+          cur.gp_rows = sr; cur.gp_bytes = M / sr * (size_t)N * 8;
+          cur.gp_alloc = gp = dry ? 0 : ar.alloc(cur.gp_bytes);
+        }
+      }
       op("vae_conv_in", 2.0 * (double)M * N * 9 * d.in_channels, [=](const Bind& b, hipStream_t s) {
         GemmParams g{};
+        if (gp != NPOS) g.gn_partial = (float*)b.ws(gp);
         g.A = (const half_t*)b.ws(x8); g.lda = 8; g.a_bytes = (uint32_t)(M * 16);
         g.M = (int)M; g.N = N; g.K = 128; g.mode = A_CONV_SMALLC; g.H = H; g.W = W; g.OH = H; g.OW = W; g.stride = 1; g.Cin = 8;
         g.Wt = (const half_t*)b.p(Wr); g.w_bytes = (uint32_t)((size_t)N * 128 * 2);
@@ -184,7 +194,7 @@ struct VB : PlanBuilder {
         Act nxt = new_act(boc[lv], hh / 2, ww / 2, true);
         Epi e; e.bias = wt(v.downsamplers[lv].b); e.has_bias = true; e.pad0 = 1; out_to(e, nxt);
         reads_image(e, cur);
-        conv3("vae_downsample", cur.h, cur.ld, cur.C, hh, ww, 2, false, v.downsamplers[lv], e);     // downsampling.py:141-152
+        conv3("vae_downsample", cur.h, cur.ld, cur.C, hh, ww, 2, false, v.downsamplers[lv], e, 0, &nxt);     // downsampling.py:141-152
         free_act(cur);
         cur = nxt; hh /= 2; ww /= 2;
       }
@@ -264,7 +274,7 @@ struct VB : PlanBuilder {
         Act nxt = new_act(co, hh * 2, ww * 2, true);
         Epi e; e.bias = wt(v.upsamplers[i].b); e.has_bias = true; out_to(e, nxt);
         reads_image(e, cur);
-        conv3("vae_upsample", cur.h, cur.ld, cur.C, hh, ww, 1, true, v.upsamplers[i], e);    // upsampling.py:176-193
+        conv3("vae_upsample", cur.h, cur.ld, cur.C, hh, ww, 1, true, v.upsamplers[i], e, 0, &nxt);    // upsampling.py:176-193
         free_act(cur);
         cur = nxt; hh *= 2; ww *= 2;
       }
@@ -280,6 +290,13 @@ struct VB : PlanBuilder {
 };
 
 }  // namespace
+
+// GroupNorm statistics from the producing conv's epilogue (builder.h gn_epi; round 4).  At 1024^2 every VAE activation is a 1-4 GB tensor that
+// no cache holds, so the separate statistics pass is a full HBM read; GDF_VAE_GN_EPI=0 restores it (same-process A/B, tools/bench_vae.py).
+static bool gn_from_epilogue() {
+  const char* e = getenv("GDF_VAE_GN_EPI");
+  return !(e && e[0] == '0');
+}
 
 Model* vae_model_create(const gdf_vae_desc& d) {
   if (d.n_levels < 1 || d.n_levels > GDF_MAX_LEVELS || d.in_channels < 1 || d.in_channels > 8 || d.latent_channels < 1 ||
@@ -321,6 +338,7 @@ int vae_plan_build(const Model& m, Plan& P, int batch, int img_h, int img_w, boo
   // fp32 masters; its fp16 images (GroupNorm input, shortcut / downsample conv operand) and the resnet-internal conv1 output
   // are stored scaled by 2^-6 (max magnitude 4.2e6), exactly undone by their consumers (builder.h act_scale).
   b.act_scale = 1.0f / 64.0f;
+  b.gn_epi = gn_from_epilogue();
   b.build(img_h, img_w);
   P.ws_bytes = b.ar.peak + 256;
   return GDF_OK;
@@ -399,6 +417,7 @@ int vae_dec_plan_build(const Model& m, Plan& P, int batch, int lat_h, int lat_w,
   VB b(m, P, dry, P.opts);
   b.Bn = chunk;
   b.act_scale = 1.0f / 64.0f;          // fp16 range control of the stream images, as in the encoder (vae_plan_build)
+  b.gn_epi = gn_from_epilogue();
   b.build_decoder(lat_h, lat_w);
   P.ws_bytes = b.ar.peak + 256;
   return GDF_OK;

@@ -174,3 +174,33 @@ def test_feature_extractor_vae_out(version, img, monkeypatch):
                                                        scaling_factor=float(df.pipe.vae.config.scaling_factor))
     torch.cuda.synchronize()
     assert torch.equal(img2, out)
+
+
+def test_vae_groupnorm_statistics_from_conv_epilogue(monkeypatch):
+    """Round 4: the 3x3 convs of the VAE op programs emit the per-channel GroupNorm partial sums of the image they store
+    (GemmParams::gn_partial), so the consuming GroupNorm runs `gn_finalize` instead of a statistics pass over the tensor.
+    Same results as the separate pass (GDF_VAE_GN_EPI=0) and as the fp32 oracle; the op program must actually use it."""
+    from components.native import NativeVAEEncoder
+    channels, img, batch = (64, 128, 256, 256), 256, 2          # level 0: 256 x 256 pixels = 1024 slabs of 64 rows per sample (folded to 128)
+    arch = VR.tiny_arch(channels)
+    P = VR.synth_params(arch, seed=0)
+    g = torch.Generator().manual_seed(3)
+    image = (torch.rand(batch, 3, img, img, generator=g) * 2 - 1).half().float()
+    cfg = dict(in_channels=3, latent_channels=4, block_out_channels=channels, layers_per_block=2, use_quant_conv=1)
+    kw = dict(eps=None, noise=None, scaling_factor=1.0, noise_a=1.0, noise_b=0.0, input_scale=1.0)
+    outs, names = {}, {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("GDF_VAE_GN_EPI", flag)
+        enc = NativeVAEEncoder(cfg, device="cuda:0")
+        enc.load_vae_state_dict({k: v.half() for k, v in P.items()})
+        out, prof = enc.encode(image, profile=True, **kw)
+        torch.cuda.synchronize()
+        outs[flag] = out.float().cpu()
+        names[flag] = [n for n, *_ in prof]
+    assert "gn_finalize" not in names["0"] and names["0"].count("gn_stats") > 4
+    assert names["1"].count("gn_finalize") >= 6, names["1"]                 # conv_in, both convs of the level-0 / level-1 resnets, the downsamplers
+    ref = VR.prepare_latents(P, arch, image, None, None, 1.0, 1.0, 0.0, 1.0)
+    e1, e0, d = rel_l2(outs["1"], ref), rel_l2(outs["0"], ref), rel_l2(outs["1"], outs["0"])
+    print(f"[vae gn-epilogue] vs oracle: epilogue statistics {e1:.2e}, separate pass {e0:.2e}; between the two {d:.2e}")
+    assert e1 < 3e-3 and e0 < 3e-3
+    assert d < 2e-3            # the epilogue sums the fp32 values before the fp16 rounding of the stored image, the separate pass the rounded image
