@@ -146,6 +146,14 @@ __device__ unsigned long long gdf_trace[16384 * 8];
 // fp8 values = the same 128 bytes per row as 64 halves, so staging, swizzle and the 8-phase schedule are unchanged: the host passes lda /
 // K in 2-byte units; a lane's 32-byte fragment of the K = 128 MFMA is the two adjacent 16-byte chunks 2 fk, 2 fk + 1 of its row.
 // GNS: the epilogue also emits per-channel GroupNorm partial sums of the stored fp16 image (GemmParams::gn_partial; VAE convs only)
+// Order of the MFMAs of a register tile: "snake" — the column index runs backwards on every other row, so that exactly ONE operand register
+// changes between consecutive MFMAs (row-major changes both at every row change).  At the power cap the rate follows the energy:
+// tools/micro/energy.hip mfma-order: 1930 (snake) vs 1913 (row-major) vs 1849 TFLOP/s (both operands change every time).  -DGDF_MMA_ROWMAJOR: A/B.
+#if defined(GDF_MMA_ROWMAJOR)
+#define GDF_SNAKE(row, j, n) (j)
+#else
+#define GDF_SNAKE(row, j, n) ((((row) & 1) != 0) ? (n) - 1 - (j) : (j))
+#endif
 template <int MODE, int BM, int BN, int STAGES, bool GEGLU, bool DIT, bool BF = false, bool QKN = false, bool SPLIT = false, bool MX = false,
           bool GNS = false>
 __device__ __forceinline__ void gemm_body(const GemmParams& p) {
@@ -413,7 +421,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
 #pragma unroll
     for (int i = 0; i < FM; ++i)
 #pragma unroll
-      for (int j = 0; j < FN; ++j) acc[i][j] = mfma16<BF>(af[i], bf[j], acc[i][j]);
+      for (int jj = 0; jj < FN; ++jj) { const int j = GDF_SNAKE(i, jj, FN); acc[i][j] = mfma16<BF>(af[i], bf[j], acc[i][j]); }
   };
   // compile-time off for the 256x320 variant: its 160 accumulator VGPRs leave no room for the second code path
   constexpr bool EARLY_OK = (NW == 8) && (FM * FN <= 16);
@@ -528,8 +536,10 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
 #pragma unroll
           for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < FNH; ++j)
+            for (int jj = 0; jj < FNH; ++jj) {
+              const int j = GDF_SNAKE(i + kk, jj, FNH);
               acc[AH * 2 + i][BH * FNH + j] = mfma16<BF>(a8[AH * 2 + i][kk], b8[j][kk], acc[AH * 2 + i][BH * FNH + j]);
+            }
       }
     };
     auto bar = [&]() {
@@ -683,8 +693,10 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int j = 0; j < 5; ++j)
+          for (int jj = 0; jj < 5; ++jj) {
+            const int j = GDF_SNAKE(i + kk, jj, 5);
             acc[Q * 2 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a4[i][kk], b10[j][kk], acc[Q * 2 + i][j], 0, 0, 0);
+          }
     };
     auto bar = [&]() {
       __builtin_amdgcn_sched_barrier(0);
@@ -737,8 +749,10 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
 #pragma unroll
           for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 5; ++j)
+            for (int jj = 0; jj < 5; ++jj) {
+              const int j = GDF_SNAKE(i + kk, jj, 5);
               acc[H * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a8[i][kk], b10[j][kk], acc[H * 4 + i][j], 0, 0, 0);
+            }
       };
       auto ktile = [&](int kt, const int cur) {                 // ring [A0][A1][B0][B1], loop unrolled by two: see STAGES == 8
         rd_ball(cur); rd_ah(cur, 0); stage_b(kt + 1, cur ^ 1, B2); stage_a(kt + 1, cur ^ 1, 2); stage_a(kt + 1, cur ^ 1, 3); lgkm0();

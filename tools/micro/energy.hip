@@ -94,6 +94,35 @@ __global__ __launch_bounds__(512, 2) void mfma_kernel(const f16x8* __restrict__ 
   for (int i = 0; i < NA; ++i) for (int j = 0; j < NB; ++j) for (int r = 0; r < 4; ++r) s += acc[i][j][r];
   if (s == 12345.f) out[0] = s;
 }
+// Does the ORDER of the MFMAs of a register tile matter for power?  4 x 8 fragments, 32 accumulators, the same 32 products per trip:
+//   MODE 0 row-major (a[i] fixed for 8 MFMAs, b changes every time, both change at a row change)     <- the GEMM kernels' order
+//   MODE 1 snake (exactly one operand changes between consecutive MFMAs)
+//   MODE 2 diagonal (BOTH operands change at every MFMA)
+//   MODE 3 one fixed pair a[0], b[0] for all 32 accumulators (no operand change at all; random values)
+template <int MODE>
+__global__ __launch_bounds__(512, 2) void mfma_order_kernel(const f16x8* __restrict__ in, float* out, int iters) {
+  constexpr int NA = 4, NB = 8;
+  f16x8 a[NA], b[NB];
+  for (int i = 0; i < NA; ++i) a[i] = in[(threadIdx.x * 7 + i * 131 + blockIdx.x) & 4095];
+  for (int j = 0; j < NB; ++j) b[j] = in[(threadIdx.x * 13 + j * 257 + blockIdx.x * 3 + 1024) & 4095];
+  f32x4 acc[NA][NB];
+  for (int i = 0; i < NA; ++i) for (int j = 0; j < NB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int k = 0; k < NA * NB; ++k) {
+      int i, j;
+      if (MODE == 0) { i = k / NB; j = k % NB; }
+      else if (MODE == 1) { i = k / NB; j = (i & 1) ? NB - 1 - k % NB : k % NB; }
+      else if (MODE == 2) { i = k % NA; j = (k % NA + k / NA) % NB; }
+      else { i = k / NB; j = k % NB; }
+      acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(MODE == 3 ? a[0] : a[i], MODE == 3 ? b[0] : b[j], acc[i][j], 0, 0, 0);
+    }
+    asm volatile("" : "+v"(a[0]), "+v"(b[0]));
+  }
+  float s = 0;
+  for (int i = 0; i < NA; ++i) for (int j = 0; j < NB; ++j) for (int r = 0; r < 4; ++r) s += acc[i][j][r];
+  if (s == 12345.f) out[0] = s;
+}
 __global__ __launch_bounds__(512, 2) void spin_kernel(int iters) {
   for (int it = 0; it < iters; ++it) __builtin_amdgcn_s_sleep(32);
 }
@@ -171,7 +200,7 @@ static void run(const char* name, Sampler& S, F launch, double units_per_launch,
   printf("%-44s %8.1f W %6.0f MHz  %10.3f %s\n", name, w, mhz, rate / 1e12, unit); fflush(stdout);
 }
 
-int main() {
+int main(int argc, char** argv) {
   Sampler S;
   printf("hwmon cards matched to HIP device 0: %zu (%s)\n", S.pw.size(), S.pw.empty() ? "-" : S.pw[0].c_str());
   const size_t big = 8ull << 30;
@@ -182,6 +211,18 @@ int main() {
   f16x8* zer; CK(hipMalloc(&zer, 4096 * 16)); CK(hipMemset(zer, 0, 4096 * 16));
   CK(hipFuncSetAttribute((const void*)lds_read_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
 
+  if (argc > 1 && !strcmp(argv[1], "mfma-order")) {
+    const double fl = 512.0 * 8 * 32 * 16384 * 4000;
+    run("idle spin (s_sleep), 512 WGs", S, [&] { hipLaunchKernelGGL(spin_kernel, dim3(512), dim3(512), 0, 0, 20000); }, 0, "-");
+    for (int rep = 0; rep < 2; ++rep) {
+      run("MFMA 4x8 tile, row-major order", S, [&] { hipLaunchKernelGGL((mfma_order_kernel<0>), dim3(512), dim3(512), 0, 0, rnd, (float*)out, 4000); }, fl, "TFLOP/s");
+      run("MFMA 4x8 tile, snake order", S, [&] { hipLaunchKernelGGL((mfma_order_kernel<1>), dim3(512), dim3(512), 0, 0, rnd, (float*)out, 4000); }, fl, "TFLOP/s");
+      run("MFMA 4x8 tile, diagonal (both change)", S, [&] { hipLaunchKernelGGL((mfma_order_kernel<2>), dim3(512), dim3(512), 0, 0, rnd, (float*)out, 4000); }, fl, "TFLOP/s");
+      run("MFMA one fixed random operand pair", S, [&] { hipLaunchKernelGGL((mfma_order_kernel<3>), dim3(512), dim3(512), 0, 0, rnd, (float*)out, 4000); }, fl, "TFLOP/s");
+      run("MFMA 4x8 tile, row-major, zero operands", S, [&] { hipLaunchKernelGGL((mfma_order_kernel<0>), dim3(512), dim3(512), 0, 0, zer, (float*)out, 4000); }, fl, "TFLOP/s");
+    }
+    return 0;
+  }
   run("idle spin (s_sleep), 512 WGs", S, [&] { hipLaunchKernelGGL(spin_kernel, dim3(512), dim3(512), 0, 0, 20000); }, 0, "-");
   const int WG = 2048;
   { const size_t slice = (1ull << 20) / 16 / 8;      // 8 KB per WG x 2048 = 16 MB total; each XCD's 256 WGs touch 2 MB: L2-resident
