@@ -107,6 +107,9 @@ __device__ unsigned long long gdf_attn_trace[8192 * 8];
 #else                           // experiment: no priorities
 #define GDF_ATTN_PRIO_MFMA(x)
 #endif
+// (Round 4, measured and rejected: v_pk_fma_f32 / v_pk_add_f32 (inline asm: the compiler scalarises a <2 x float> fma whose lanes are extracted) for the
+// softmax's scale-and-shift and row sum, halving those 96 VALU instructions per tile: 731-740 vs 755-760 TFLOP/s at D = 64, 910 vs 957-969 on the Flux joint
+// shape — the opaque asm blocks cost the scheduler more than the issue slots save.)
 // NW = waves per workgroup (4, or 8: twice the query rows share every staged K / V tile)
 // (Measured and rejected: an explicit ping-pong — 8 waves, the two waves of a SIMD one workgroup barrier apart, iteration =
 // softmax phase | barrier | PV(t) + QK^T(t+1) phase | barrier — which is what lifts the GEMM main loops.  Here the two phases
