@@ -528,8 +528,10 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int j = 0; j < FNH; ++j)
+          for (int jj = 0; jj < FNH; ++jj) {
+            const int j = GDF_SNAKE(i, jj, FNH);
             acc[AH * 2 + i][BH * FNH + j] = mfma_mx8(a8[AH * 2 + i][0], a8[AH * 2 + i][1], b8[j][0], b8[j][1], acc[AH * 2 + i][BH * FNH + j]);
+          }
       } else {
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
