@@ -255,7 +255,27 @@ def main():
                          "four); --precise = every operand class split (fp16 hi + lo, K doubled); --precise selective | plain | stream,attn_out ...")
     ap.add_argument("--no-extras", action="store_true", help="skip the plans / other_configs / e2e legs (N = 1 only run them)")
     ap.add_argument("--profile-ops", action="store_true", help="print a per-op time table (extra synchronising pass)")
+    ap.add_argument("--e2e", action="store_true",
+                    help="N = 1: time FeatureExtractor.extract(image_type='tensors') instead of the UNet step — VAE encode + sample + noise-add + "
+                         "UNet + hooks on synthetic 1024^2 images resident in HBM, --steps batches; prints its own JSON line (the default line "
+                         "carries the same measurement as its `e2e` block)")
     args = ap.parse_args()
+
+    if args.e2e:                                    # the product call end to end; not BASELINE.json's metric: a separate line
+        if int(os.environ.get("WORLD_SIZE", "1")) != 1 or args.gpus != 1 or args.version != "xl":
+            sys.exit("--e2e is a single-GPU SDXL measurement")
+        import torch
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_extra as BX
+        dev = torch.device("cuda:0"); torch.cuda.set_device(dev)
+        img = args.img or 1024
+        blk = BX.e2e_block(dev, "xl", args.batch, img, PRACTICAL["xl"], steps=max(2, args.steps))
+        print(json.dumps({"metric": "images/sec FeatureExtractor.extract end to end (VAE encode + noise-add + UNet + hooks), SDXL %d^2 single-timestep" % img,
+                          "value": blk["extract_images_per_s"], "unit": "images/s", "n_gpus": 1, "steps": max(2, args.steps), "warmup": 3,
+                          "ms_per_step": blk["extract_ms_per_batch"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16",
+                          "data": "synthetic", "config": {"workload": "FeatureExtractor.extract(image_type='tensors'), batch %d, t=100, hooks=config_xl_practical, "
+                                                           "images resident in HBM" % args.batch, "global_batch": args.batch}, "e2e": blk}))
+        return
 
     if args.version == "flux":                    # BASELINE configs[4]: same JSON schema, single GPU (tools/bench_flux.py)
         sys.argv = [sys.argv[0], "--steps", str(args.steps), "--warmup", str(args.warmup)] + (["--dtype", args.flux_dtype]) + \
