@@ -264,12 +264,11 @@ def main():
     if args.e2e:                                    # the product call end to end; not BASELINE.json's metric: a separate line
         if int(os.environ.get("WORLD_SIZE", "1")) != 1 or args.gpus != 1 or args.version != "xl":
             sys.exit("--e2e is a single-GPU SDXL measurement")
-        import torch
         sys.path.insert(0, os.path.join(ROOT, "tools"))
-        import bench_extra as BX
+        import bench_extra as BX_e2e                 # (a function-level `import torch` / `import ... as BX` here would shadow the names used below)
         dev = torch.device("cuda:0"); torch.cuda.set_device(dev)
         img = args.img or 1024
-        blk = BX.e2e_block(dev, "xl", args.batch, img, PRACTICAL["xl"], steps=max(2, args.steps))
+        blk = BX_e2e.e2e_block(dev, "xl", args.batch, img, PRACTICAL["xl"], steps=max(2, args.steps))
         print(json.dumps({"metric": "images/sec FeatureExtractor.extract end to end (VAE encode + noise-add + UNet + hooks), SDXL %d^2 single-timestep" % img,
                           "value": blk["extract_images_per_s"], "unit": "images/s", "n_gpus": 1, "steps": max(2, args.steps), "warmup": 3,
                           "ms_per_step": blk["extract_ms_per_batch"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16",
