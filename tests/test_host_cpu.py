@@ -397,3 +397,25 @@ def test_operand_plan_selection_table_and_masks():
         assert worst <= N.AUTO_BOUND, (f, worst)
         if any(i.endswith("-map") or i == "unet-out" for i in ids):
             assert m != 0, f
+
+
+def test_bench_main_has_no_function_level_import_shadowing_module_names():
+    """A function-level `import torch` anywhere inside bench.main() makes `torch` a local of the WHOLE function: every use before that
+    statement raises UnboundLocalError — on the default path, which the CPU suite cannot run (round 4: the --e2e branch did exactly that)."""
+    import ast
+    import os
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")).read()
+    tree = ast.parse(src)
+    top = set()
+    for n in tree.body:
+        if isinstance(n, (ast.Import, ast.ImportFrom)):
+            top.update((a.asname or a.name).split(".")[0] for a in n.names)
+    assert "torch" in top
+    for fn in (n for n in ast.walk(tree) if isinstance(n, ast.FunctionDef)):
+        inner = set()
+        for n in ast.walk(fn):
+            if isinstance(n, (ast.Import, ast.ImportFrom)):
+                inner.update((a.asname or a.name).split(".")[0] for a in n.names if not (isinstance(n, ast.Import) and "." in a.name and not a.asname and a.name.split(".")[0] in top and False))
+        # `import torch.distributed as dist` binds only `dist`; a bare `import torch.x` would bind `torch`
+        bad = {m for m in inner if m in top and m in ("torch", "os", "sys", "json", "time", "argparse")}
+        assert not bad, (fn.name, bad)
