@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the hot path: SDXL 1024^2 single-timestep feature extraction (BASELINE.json configs[2]).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 16] [--version xl]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 16] [--version xl]      (N > 1: starts its N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -288,9 +288,16 @@ def main():
     share_gpu = os.environ.get("GDF_BENCH_SHARE_GPU", "0") == "1"
     if share_gpu:
         local = 0
+    from components import dist as D
+    if D.needs_self_launch(args.gpus):
+        # The front door for N ranks (BASELINE configs[3]): `python3 bench.py --gpus N ...` started as ONE plain process starts its N
+        # ranks itself — ordinary child processes with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, rendezvous on 127.0.0.1 — and
+        # exits with their code; rank 0 inherits stdout, so its single JSON line is this command's output.  Nothing above this line
+        # touches the GPU (device_count() does not initialise it), nothing is exec'd over a process that did.
+        if not share_gpu and torch.cuda.device_count() < args.gpus:
+            sys.exit(f"--gpus {args.gpus} needs {args.gpus} visible GPUs, torch.cuda.device_count() = {torch.cuda.device_count()}")
+        sys.exit(D.self_launch(os.path.abspath(__file__), sys.argv[1:], args.gpus))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
         sys.exit(f"--gpus {args.gpus} does not match WORLD_SIZE={world}: one rank per GPU")
     # fail fast, before anything initialises a GPU (device_count() does not): N ranks need N visible GPUs
     if not share_gpu and torch.cuda.device_count() < max(1, args.gpus):
@@ -309,6 +316,9 @@ def main():
         if dist.get_world_size() != args.gpus:
             sys.exit(f"process group reports {dist.get_world_size()} ranks, --gpus {args.gpus}")
 
+    if os.environ.get("GDF_TEST_FAIL_RANK") == str(rank) and world > 1:
+        sys.exit(3)                        # test hook: a rank dying AFTER the rendezvous (the others sit in a collective) must fail the whole job
+    group = D.group_evidence(dev)          # backend, ranks that answered one all_reduce, the PCI bus id of every rank's device
     from components.native import NativeUNet
     import ctypes as C
     cfg = _cfg(args.version)
@@ -320,7 +330,6 @@ def main():
     unet = NativeUNet(cfg, device=dev, stream_fp32=not args.fp16_stream, early_exit=args.early_exit,
                       precise=None if args.precise is None else (False if args.precise == "plain" else args.precise))
     t0 = time.time()
-    from components import dist as D
     if rank == 0:
         unet.init_synthetic(seed=0)
     torch.cuda.synchronize()
@@ -444,7 +453,7 @@ def main():
                       else "images/sec feature-extract, SD1.5 512^2 single-timestep",
             "value": round(ips, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f16", "data": "synthetic", "rccl": group,
             "timed_region": {"path": ("hipGraph replay (product default), event-record nodes around the dominant kernel"
                                       if (plan.graph and launches_in_region == args.steps and fails_in_region == 0) else
                                       "eager launches (GDF_HIP_GRAPH=0)" if not plan.graph else
@@ -466,6 +475,10 @@ def main():
                        "model_tflops_per_s": round(ips * (fl_img - kv_img * (B - 1) / B) / 1e12, 1),
                        "shared_ctx_kv_gflop_per_image_not_executed": round(kv_img * (B - 1) / B / 1e9, 1),
                        "weights_init_s": round(t_init, 1), "weights_broadcast_s": round(t_bcast, 3),
+                       "weights_broadcast_gb_per_s": round(unet.weight_blob().numel() / 1e9 / t_bcast, 1) if world > 1 and t_bcast > 0 else None,
+                       "launched_by": ("bench.py itself (components/dist.py self_launch)" if os.environ.get("GDF_SELF_LAUNCHED") == "1" else
+                                       "torch.distributed.run" if world > 1 else "single process"),
+                       "max_inflight_forwards": int(os.environ.get("GDF_MAX_INFLIGHT", "4" if world > 1 else "0")),
                        "per_rank_ms_per_step": {"min": round(per_rank_ms[0], 3), "max": round(per_rank_ms[-1], 3)}},
             "roofline": {"bound": "mfma", "kernel": dominant, "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_stale": traffic_stale,

@@ -12,7 +12,8 @@ The reference's own script also runs unchanged against this package (it only nee
 this version overlaps the device->host copies of batch i with the extraction of batch i+1 through pinned buffers.
 
 Data-parallel (one process per GPU, no collective in the loop):
-    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 extract_feature.py ...
+    python3 extract_feature.py --gpus 8 ...          (starts its 8 ranks itself: components/dist.py self_launch)
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 extract_feature.py ...   (equivalent)
 rank r extracts the contiguous slice shard_range(len(images), r, W) of the sorted image list and writes its own files
 (<split><GLOBAL index> names, so the output directory is identical to a single-process run); rank 0 alone reads / generates
 the denoiser weights and broadcasts the flat device arena once over RCCL (components/dist.py).
@@ -66,6 +67,9 @@ def parse_args(argv=None):
                         "a class list such as stream,attn_out")
     p.add_argument('--early_exit', action='store_true',
                    help='native extension (not in the reference CLI): stop the denoiser forward after the last requested layer (same files, less work)')
+    p.add_argument('--gpus', type=int, default=1,
+                   help='native extension (not in the reference CLI): data-parallel over N GPUs of this node.  Started as a plain process '
+                        '(`python3 extract_feature.py --gpus 8 ...`) the script starts its N ranks itself; under torchrun it must equal WORLD_SIZE')
     return p.parse_args(argv)
 
 
@@ -88,6 +92,7 @@ class HostWriter:
         if self.stream is not None:
             self.stream.wait_stream(torch.cuda.current_stream())
         ctx = torch.cuda.stream(self.stream) if self.stream is not None else _null()
+        originals = [v for v in feats.values() if torch.is_tensor(v)]      # what the extractor handed out (aggregation rebinds `feats`)
         with ctx:
             if self.args.aggregate_output:                      # reference :113-125; device tensors: resize_concat_kernel
                 from components.postproc import resize_concat
@@ -103,13 +108,17 @@ class HostWriter:
         ev = torch.cuda.Event() if self.stream is not None else None
         if ev is not None:
             ev.record(self.stream)
-            # the D2H copies read the hook buffers on THIS stream: announce it, so that the extractor may recycle the buffers as soon as
-            # `feats` is dropped (components/native.py release_after — the record_stream() of the native hook buffers)
+            # the D2H copies (and resize_concat) read the hook buffers on THIS stream: announce it, so that the extractor may recycle the
+            # buffers as soon as `feats` is dropped (components/native.py release_after — the record_stream() of the native hook buffers);
+            # tensors that come from the caching allocator instead (pooled / aggregated features, the concat result) get record_stream()
+            seen = originals + [v for v in feats.values() if torch.is_tensor(v)]
             try:
                 from components.native import release_after
-                release_after([v for v in feats.values() if torch.is_tensor(v)], self.stream)
+                rest = release_after(seen, self.stream)
             except ImportError:
-                pass
+                rest = [v for v in seen if v.is_cuda]
+            for v in rest:
+                v.record_stream(self.stream)
         self.pending = (host, names, ev)
 
     def flush(self):
@@ -165,6 +174,15 @@ def main(argv=None):
     args = parse_args(argv)
     if args.precise is not None and (args.version == 'flux' or args.version.startswith('pixart')):
         raise SystemExit("--precise: split-operand plans exist for the UNet versions ('1-5', '2-1', 'xl', 'pgv2') only")
+    # the front door for N ranks: a plain `python3 extract_feature.py --gpus N ...` starts one child process per GPU (this parent never
+    # touches the GPU) and exits with their code; under torchrun (WORLD_SIZE set) the ranks arrive here directly
+    from components import dist as D
+    if D.needs_self_launch(args.gpus):
+        if os.environ.get("GDF_SHARE_GPU", "0") != "1" and torch.cuda.device_count() < args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} needs {args.gpus} visible GPUs, torch.cuda.device_count() = {torch.cuda.device_count()}")
+        raise SystemExit(D.self_launch(os.path.abspath(__file__), sys.argv[1:] if argv is None else list(argv), args.gpus))
+    if args.gpus > 1 and int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE={os.environ.get('WORLD_SIZE')}: one rank per GPU")
     rank, world, device = init_data_parallel()
     os.makedirs(args.output_dir, exist_ok=True)
     if rank == 0:

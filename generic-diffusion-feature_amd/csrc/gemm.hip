@@ -1181,7 +1181,9 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) { st[lane * 16 + e] = gsum[e]; st[lane * 16 + 8 + e] = gsq[e]; }
     __builtin_amdgcn_wave_barrier();
-    if (lane < LPR && full && p.gn_partial) {
+    // (M % 64 == 0 is required, so a wave tile lies entirely inside or entirely outside the matrix: in the last M tile of a 128- / 256-row
+    //  workgroup the waves whose 64 rows start at or beyond M own NO slab and must not store — M/64 slabs are allocated)
+    if (lane < LPR && full && p.gn_partial && m0 + wm * WTM < p.M) {
       float a[16];
 #pragma unroll
       for (int e = 0; e < 16; ++e) a[e] = 0.f;

@@ -611,10 +611,19 @@ int plan_build(const Model& m, Plan& P, int batch, int H, int W, int n_ctx, cons
   }
   const bool precise = opts.reserved[1] != 0;
   if (precise && !opts.stream_fp32) { set_error("a precise plan needs the fp32 master stream (stream_fp32 = 1)"); return GDF_ERR_ARG; }
-  for (int lv = 0; lv < L; ++lv) {   // 32-bit buffer offsets: the widest row (concat / GEGLU inner / qkv) must stay < 2 GiB
-    const size_t r = (size_t)batch * (H >> lv) * (W >> lv), c = m.arch.block_out_channels[lv];
-    if (r * c * 4 * 2 * (precise ? 2 : 1) >= (1ull << 31)) {
-      set_error("batch*H*W too large for 32-bit buffer offsets; split the batch"); return GDF_ERR_UNSUPPORTED;
+  // 32-bit buffer offsets: the widest row of a level must stay < 2 GiB.  Widest rows: the GEGLU inner tensor (4C, doubled when ITS class is
+  // split), the fused q|k|v output (3C, never split) — both only where the level has attention — and the skip-concat buffers of the up path
+  // (<= 3C, doubled when the STREAM class is split).  The limit follows the classes the mask actually splits (any non-zero mask
+  // used to halve it, which refused SDXL 1024^2 B = 26..34 calls under the selective preset although their widest rows are not split).
+  {
+    const int split = opts.reserved[1] == 1 ? PlanBuilder::SP_ALL : ((opts.reserved[1] >> 8) & PlanBuilder::SP_ALL);
+    for (int lv = 0; lv < L; ++lv) {
+      const size_t r = (size_t)batch * (H >> lv) * (W >> lv), c = m.arch.block_out_channels[lv];
+      size_t widest = 3 * ((split & PlanBuilder::SP_STREAM) ? 2 : 1);                                   // concat [hi | lo]
+      if (m.arch.has_attn[lv] || lv == L - 1) widest = std::max<size_t>(widest, std::max<size_t>(3, 4 * ((split & PlanBuilder::SP_FF_INNER) ? 2 : 1)));
+      if (r * c * 2 * widest >= (1ull << 31)) {
+        set_error("batch*H*W too large for 32-bit buffer offsets; split the batch"); return GDF_ERR_UNSUPPORTED;
+      }
     }
   }
   P.batch = batch; P.H = H; P.W = W; P.n_ctx = n_ctx; P.opts = opts;

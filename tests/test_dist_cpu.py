@@ -95,3 +95,57 @@ def test_shard_range_partitions():
             assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+_RANK_SCRIPT = r'''
+import json, os, sys
+sys.path.insert(0, sys.argv[1])
+import torch.distributed as dist
+from components import dist as D
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+assert os.environ["GDF_SELF_LAUNCHED"] == "1" and os.environ["LOCAL_RANK"] == str(rank) and os.environ["MASTER_ADDR"] == "127.0.0.1"
+if len(sys.argv) > 2 and sys.argv[2] == "fail" and rank == 1:
+    sys.exit(7)                                   # a rank that dies before the rendezvous: the job must come down, not hang
+dist.init_process_group("gloo", rank=rank, world_size=world)
+ev = D.group_evidence(None)
+print("noise from rank", rank)                     # only rank 0's stdout is the command's stdout
+if rank == 0:
+    print(json.dumps(ev))
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_self_launch_front_door(tmp_path):
+    """`python3 bench.py --gpus N` / `extract_feature.py --gpus N` start their N ranks themselves (components/dist.py self_launch):
+    torchrun-compatible environment, rank 0 owns stdout, every rank answers the evidence all_reduce, a failing rank fails the job."""
+    import json
+    import subprocess
+    pkg = os.path.join(ROOT, "generic-diffusion-feature_amd")
+    script = tmp_path / "rank.py"
+    script.write_text(_RANK_SCRIPT)
+    drv = ("import sys; sys.path.insert(0, %r); from components import dist as D; "
+           "assert D.needs_self_launch(3) and not D.needs_self_launch(1); "
+           "sys.exit(D.self_launch(%r, sys.argv[1:], 3, timeout_s=120))" % (pkg, str(script)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, "-c", drv, pkg], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = [l for l in r.stdout.splitlines() if l.strip()]
+    ev = json.loads([l for l in out if l.startswith("{")][0])
+    assert ev["world_size"] == 3 and ev["ranks_seen"] == [0, 1, 2] and ev["backend"] == "gloo"
+    assert "noise from rank 0" in r.stdout and "noise from rank 1" not in r.stdout and "noise from rank 1" in r.stderr
+    r = subprocess.run([sys.executable, "-c", drv, pkg, "fail"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 7 and "rank 1 exited with code 7" in r.stderr
+    # inside a rank (WORLD_SIZE set) the front door stays shut
+    r = subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, %r); from components import dist as D; "
+                        "sys.exit(int(D.needs_self_launch(4)))" % pkg], env=dict(env, WORLD_SIZE="4", RANK="0"), timeout=120)
+    assert r.returncode == 0
+
+
+def test_bench_front_door_refuses_without_gpus():
+    """No GPU here: `python3 bench.py --gpus 2` must fail fast in the PARENT (device_count() < N) without starting ranks or touching a GPU."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "GDF_BENCH_SHARE_GPU")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], env=env, capture_output=True, text=True, timeout=300)
+    if torch.cuda.device_count() < 2:
+        assert r.returncode != 0 and "needs 2 visible GPUs" in r.stderr and "self_launch" not in r.stderr

@@ -133,9 +133,10 @@ def test_four_rank_cli_with_empty_shard_and_vae_out(tmp_path):
     env = dict(os.environ, GDF_SYNTHETIC_WEIGHTS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable] + base + ["--output_dir", str(tmp_path / "one")], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
-                        "--master-port", str(_free_port())] + base + ["--output_dir", str(tmp_path / "four")],
-                       env=dict(env, GDF_SHARE_GPU="1"), capture_output=True, text=True, timeout=900)
+    # plain `python3 extract_feature.py --gpus 4 ...` (no torchrun): the CLI starts its four ranks itself (components/dist.py self_launch)
+    env4 = {k: v for k, v in dict(env, GDF_SHARE_GPU="1").items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable] + base + ["--gpus", "4", "--output_dir", str(tmp_path / "four")],
+                       env=env4, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     one, four = _tree(tmp_path / "one"), _tree(tmp_path / "four")
     assert sorted(one) == sorted(four) and len(one) == 6                     # 2 layers x 3 images
@@ -143,16 +144,32 @@ def test_four_rank_cli_with_empty_shard_and_vae_out(tmp_path):
         assert np.array_equal(one[k].view(np.uint16), four[k].view(np.uint16)), k
 
 
+def test_bench_front_door_failure_is_nonzero():
+    """a rank that dies after the rendezvous (the other one is waiting in a collective) brings the whole self-launched job down: non-zero
+    exit code, no JSON line, no orphaned rank"""
+    env = {k: v for k, v in dict(os.environ, GDF_BENCH_SHARE_GPU="1", GDF_TEST_FAIL_RANK="1").items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--version", "1-5", "--batch", "2",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 3 and not [l for l in r.stdout.splitlines() if l.startswith("{")], (r.returncode, r.stderr[-1500:])
+    assert "rank 1 exited with code 3" in r.stderr
+
+
 def test_four_rank_bench_line():
     """bench.py --gpus 4 on one GPU (GDF_BENCH_SHARE_GPU=1): the line carries the broadcast time and the per-rank step times, and the whole-job
     value is 4 ranks x batch x steps / the slowest rank's time."""
     env = dict(os.environ, GDF_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
-                        "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "2", "--warmup", "1",
+    env = {k: v for k, v in env.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    # the command shape the driver uses: PLAIN python3 bench.py --gpus N (no torchrun) — bench.py starts its four ranks itself
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "2", "--warmup", "1",
                         "--version", "1-5", "--batch", "2", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
-    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                                   # ONE JSON line on stdout: rank 0's
+    line = json.loads(lines[0])
     c = line["config"]
+    g = line["rccl"]
+    assert g["world_size"] == 4 and g["ranks_seen"] == [0, 1, 2, 3] and g["backend"] == "gloo"      # (share-GPU test hook: gloo; RCCL on a real node)
+    assert c["launched_by"].startswith("bench.py itself") and c["max_inflight_forwards"] == 4 and c["weights_broadcast_gb_per_s"] > 0
     assert line["n_gpus"] == 4 and line["scaling"] == "weak" and c["global_batch"] == 8 and line["value"] > 0
     assert c["weights_broadcast_s"] >= 0 and 0 < c["per_rank_ms_per_step"]["min"] <= c["per_rank_ms_per_step"]["max"]
     assert abs(line["value"] - 8 * 1e3 / c["per_rank_ms_per_step"]["max"]) < 0.02 * line["value"]

@@ -204,3 +204,38 @@ def test_vae_groupnorm_statistics_from_conv_epilogue(monkeypatch):
     print(f"[vae gn-epilogue] vs oracle: epilogue statistics {e1:.2e}, separate pass {e0:.2e}; between the two {d:.2e}")
     assert e1 < 3e-3 and e0 < 3e-3
     assert d < 2e-3            # the epilogue sums the fp32 values before the fp16 rounding of the stored image, the separate pass the rounded image
+
+
+@pytest.mark.parametrize("img,batch", [(320, 1), (320, 3), (192, 2)])
+def test_vae_gn_epilogue_ragged_last_tile(img, batch, monkeypatch):
+    """image sizes that are odd multiples of 64 give conv levels whose row count M is a multiple of 64 but NOT of the
+    128- / 256-row workgroup tile (320^2, batch 1: the 40 x 40 level has M = 1600 = 12.5 tiles of 128).  The waves of the last tile whose
+    64 rows start beyond M own no statistics slab and must not store one (they used to write N * 8 bytes past the M / 64 slabs).
+    Encode AND decode with the statistics epilogue must equal the separate-pass build and the fp32 oracle."""
+    from components.native import NativeVAEEncoder, NativeVAEDecoder
+    channels = (64, 128, 256, 256)
+    arch = VR.tiny_arch(channels)
+    P, PD = VR.synth_params(arch, seed=0), VR.synth_dec_params(arch, seed=0)
+    g = torch.Generator().manual_seed(5)
+    image = (torch.rand(batch, 3, img, img, generator=g) * 2 - 1).half().float()
+    lat = img // 8
+    z = torch.randn(batch, 4, lat, lat, generator=g).half().float()
+    cfg = dict(in_channels=3, latent_channels=4, block_out_channels=channels, layers_per_block=2, use_quant_conv=1)
+    kw = dict(eps=None, noise=None, scaling_factor=1.0, noise_a=1.0, noise_b=0.0, input_scale=1.0)
+    enc_out, dec_out = {}, {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("GDF_VAE_GN_EPI", flag)
+        enc = NativeVAEEncoder(cfg, device="cuda:0")
+        enc.load_vae_state_dict({k: v.half() for k, v in P.items()})
+        dec = NativeVAEDecoder(cfg, device="cuda:0")
+        dec.load_vae_state_dict({k: v.half() for k, v in PD.items()})
+        for _ in range(2):                                   # twice: a stray store of the first run would corrupt the second one's inputs
+            e = enc.encode(image, **kw)
+            d = dec.decode(z, None, scaling_factor=1.0)
+        torch.cuda.synchronize()
+        enc_out[flag], dec_out[flag] = e.float().cpu(), d.float().cpu()
+    ref_e = VR.prepare_latents(P, arch, image, None, None, 1.0, 1.0, 0.0, 1.0)
+    ref_d = VR.decode(PD, arch, z)
+    for flag in ("0", "1"):
+        assert rel_l2(enc_out[flag], ref_e) < 3e-3 and rel_l2(dec_out[flag], ref_d) < 3e-3, (flag, rel_l2(enc_out[flag], ref_e), rel_l2(dec_out[flag], ref_d))
+    assert rel_l2(enc_out["1"], enc_out["0"]) < 2e-3 and rel_l2(dec_out["1"], dec_out["0"]) < 2e-3
