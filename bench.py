@@ -247,7 +247,7 @@ def main():
                     help="xl = BASELINE headline (configs[2]); 1-5 = configs[1]; flux = configs[4] (single GPU, tools/bench_flux.py)")
     ap.add_argument("--img", type=int, default=0, help="image size (default 1024 for xl, 512 for 1-5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--flux-dtype", default="bfloat16", choices=("bfloat16", "float16", "bfloat16x2", "fp8-mx"), help="--version flux only")
+    ap.add_argument("--flux-dtype", default="bfloat16", choices=("bfloat16", "float16", "bfloat16x2", "fp8-mx", "float16s", "auto"), help="--version flux only")
     ap.add_argument("--fp16-stream", action="store_true", help="disable the fp32 master of the residual stream")
     ap.add_argument("--early-exit", action="store_true", help="opt-in: stop after the last requested hook")
     ap.add_argument("--precise", nargs="?", const="precise", default=None,
@@ -404,7 +404,7 @@ def main():
         out = step()
     torch.cuda.synchronize(); barrier()
     dt = time.perf_counter() - t0
-    power = sampler.finish(t0, t0 + dt) if sampler is not None else None
+    power = sampler.finish(t0, t0 + dt, images=B * args.steps) if sampler is not None else None
     st_after = plan.graph_stats()
     cap_in_region = st_after[0] - st_before[0]
     launches_in_region = st_after[1] - st_before[1]

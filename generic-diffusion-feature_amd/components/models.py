@@ -297,7 +297,7 @@ class SyntheticFluxPipe:
         self.device = device
         self._cfg = dict(cfg or FLUX_CONFIGS["flux"])
         self.n_txt = n_txt
-        self.transformer = _fill(NativeFluxTransformer(self._cfg, device=device), lambda m: m.init_synthetic(seed))
+        self.transformer = _fill(NativeFluxTransformer(self._cfg, device=device, compute_dtype=flux_compute_dtype()), lambda m: m.init_synthetic(seed))
         self.unet = self.transformer               # reference models.py:169 `pipe.unet = pipe.transformer`
         empty = types.SimpleNamespace(parameters=lambda: iter(()), to=lambda *a, **k: None)
         self.vae = types.SimpleNamespace(parameters=lambda: iter(()), config=types.SimpleNamespace(scaling_factor=0.3611, shift_factor=0.1159))
@@ -362,6 +362,13 @@ class SyntheticFluxPipe:
         return None
 
 
+def flux_compute_dtype():
+    """Arithmetic of the Flux transformer behind FeatureExtractor: 'auto' (round 5 default: fp16 operands with range scaling, every hook within
+    1e-3 of the fp32 reference at the bf16 mode's speed; NativeFluxTransformer) unless GDF_FLUX_DTYPE names another mode ('bfloat16' = the
+    reference's own dtype, 'bfloat16x2', 'float16', 'fp8-mx')."""
+    return os.environ.get("GDF_FLUX_DTYPE", "") or "auto"
+
+
 def _native_flux_from_diffusers(pipe, device):
     """Swap pipe.transformer (diffusers FluxTransformer2DModel, bf16) for the native MMDiT with the same weights."""
     c = pipe.transformer.config
@@ -369,7 +376,7 @@ def _native_flux_from_diffusers(pipe, device):
                attention_head_dim=c.attention_head_dim, num_attention_heads=c.num_attention_heads,
                joint_attention_dim=c.joint_attention_dim, pooled_projection_dim=c.pooled_projection_dim,
                guidance_embeds=int(bool(c.guidance_embeds)), axes_dims_rope=tuple(c.axes_dims_rope), mlp_ratio=4)
-    net = NativeFluxTransformer(cfg, device=device)
+    net = NativeFluxTransformer(cfg, device=device, compute_dtype=flux_compute_dtype())
     _fill(net, lambda m: m.load_state_dict(pipe.transformer.state_dict()))
     pipe.transformer = net
     pipe.unet = net

@@ -460,7 +460,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_kernel(const AttnParams p) 
   if constexpr (STG) if ((p.ldo & 7) == 0) {
 #pragma unroll
     for (int w = 0; w < QW; ++w) {
-      const float inv = 1.0f / half_sum(l_run[w]);
+      const float inv = (p.o_scale != 0.f ? p.o_scale : 1.0f) / half_sum(l_run[w]);
 #pragma unroll
       for (int db = 0; db < NDB; ++db)
 #pragma unroll
@@ -487,7 +487,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_kernel(const AttnParams p) 
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int w = 0; w < QW; ++w) {
-        const float inv = 1.0f / half_sum(l_run[w]);
+        const float inv = (p.o_scale != 0.f ? p.o_scale : 1.0f) / half_sum(l_run[w]);
 #pragma unroll
         for (int db = 0; db < NDB; ++db)
 #pragma unroll
@@ -516,7 +516,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_kernel(const AttnParams p) 
 #pragma unroll
   for (int w = 0; w < QW; ++w) {
     const float l_tot = half_sum(l_run[w]);
-    const float inv = 1.0f / l_tot;
+    const float inv = (p.o_scale != 0.f ? p.o_scale : 1.0f) / l_tot;
     if (q_ok[w]) {
       _Float16* op = p.o + seg_row(b, q_row[w], p.Sq, p.seg_T, p.B, p.Sq) * p.ldo + head * D;
 #pragma unroll
@@ -931,13 +931,14 @@ __global__ __launch_bounds__(LW ? 320 : 256, OCC) void attn_map_kernel(const Att
         if (d0 < D) {
           f16x4 hv;
           const bool pbf = p.o_lo > 0 && p.o_pair_bf16;
+          const float osc = p.o_scale != 0.f ? p.o_scale : 1.0f;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) hv[e] = (!BF && pbf) ? pair_hi(o[db][rq * 4 + e], true) : out16<BF>(o[db][rq * 4 + e]);
+          for (int e = 0; e < 4; ++e) hv[e] = (!BF && pbf) ? pair_hi(o[db][rq * 4 + e] * osc, true) : out16<BF>(o[db][rq * 4 + e] * osc);
           *(f16x4*)(op + d0) = hv;
           if (!BF && p.o_lo > 0) {
             f16x4 lv;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) lv[e] = pair_lo(o[db][rq * 4 + e], pbf);
+            for (int e = 0; e < 4; ++e) lv[e] = pair_lo(o[db][rq * 4 + e] * osc, pbf);
             *(f16x4*)(op + d0 + p.o_lo) = lv;
           }
         }

@@ -233,12 +233,13 @@ struct PlanBuilder {
   }
   // coalesced hook store: fp16 copy of `rows x C` from (src, ld)
   // s_lo > 0: the source is a split pair (hook = fp16(hi + lo)); src_bf: element type of the source (-1 = the model's)
-  void hook_copy(int slot, Ref src, int ld, size_t nrows, int C, int s_lo = 0, int src_bf = -1) {
+  // scale != 1: the source holds scale^-1-scaled values (range-scaled fp16 image): hook = fp16(scale * src)
+  void hook_copy(int slot, Ref src, int ld, size_t nrows, int C, int s_lo = 0, int src_bf = -1, float scale = 1.0f) {
     if (slot < 0) return;
     P.hooks[slot].copied = true;
     const int bf = src_bf >= 0 ? src_bf : m.bf16, sat = (m.kind == 1);   // MMDiT hooks: bf16 or range-critical fp16 source -> saturating fp16
     op("hook_store", 0, [=](const Bind& b, hipStream_t s) {
-      return launch_copy2d((const half_t*)b.p(src), nullptr, ld, (half_t*)b.hook(slot), C, (int)nrows, C, s, bf, sat, s_lo);
+      return launch_copy2d((const half_t*)b.p(src), nullptr, ld, (half_t*)b.hook(slot), C, (int)nrows, C, s, bf, sat, s_lo, scale);
     });
     hook_done();
   }
@@ -470,7 +471,8 @@ struct PlanBuilder {
       if (w.has_sc) { e.res32 = ws(sc); e.has_r32 = true; e.ldres = w.cout; }
       else residual_from(e, x);
       out_to(e, y);
-      conv3("res_conv2", ws(n2), w.cout * px, w.cout, x.H, x.W, 1, false, w.c2, e, slo * w.cout, &y);
+      // (statistics only into an activation that OWNS its buffer and is therefore released through free_act: a concat-slice view never is)
+      conv3("res_conv2", ws(n2), w.cout * px, w.cout, x.H, x.W, 1, false, w.c2, e, slo * w.cout, (m.kind != 0 || y.h_alloc != NPOS) ? &y : nullptr);
       if (e.aux_slot >= 0) hook_done();
     }
     untmp(n2, img_bytes(n, w.cout, SP_RES));

@@ -126,8 +126,8 @@ struct FB : PlanBuilder {   // Flux op program
   MxA alloc8(size_t n, int K) { MxA q; q.lda8 = K; q.a8 = ws(tmp(n * (size_t)K)); q.ascale = ws(tmp(n * 4)); return q; }
   static MxA rows8(const MxA& q, size_t r0) { MxA o = q; o.a8.off += r0 * (size_t)q.lda8; o.ascale.off += r0 * 4; return o; }
   // image-token hook from a 16-bit matrix; s_lo > 0: a split pair; src_bf: element type (-1 = the model's)
-  void hook_rows16(const std::string& id, Ref src, int ld, int C, int s_lo = 0, int src_bf = -1) {
-    hook_copy(want(id, C, gh, gw), src, ld, NS, C, s_lo, src_bf);
+  void hook_rows16(const std::string& id, Ref src, int ld, int C, int s_lo = 0, int src_bf = -1, float scale = 1.0f) {
+    hook_copy(want(id, C, gh, gw), src, ld, NS, C, s_lo, src_bf, scale);
   }
   void hook_rows32(const std::string& id, Ref src, int ld, int C) {      // ... from the fp32 stream
     const int slot = want(id, C, gh, gw);
@@ -160,7 +160,7 @@ struct FB : PlanBuilder {   // Flux op program
   }
   // cross_slot / self_slot: hook slots of `cross-map` (B, heads, S, T) / `self-map` (B, heads, S, S) or -1
   // (FluxAttnStoreProcessor, components/attention.py:493-502: image queries only, split by key)
-  void joint_attention(size_t qkv, Ref o, int ldo, int cross_slot = -1, int self_slot = -1, int o_lo = 0) {
+  void joint_attention(size_t qkv, Ref o, int ldo, int cross_slot = -1, int self_slot = -1, int o_lo = 0, float o_scale = 0.f) {
     const int C = f.C, D = f.D, heads = C / D, Bq = Bn, Sj = T + S, Tq = T, bf = m.x2 ? 0 : m.bf16, pbf = m.x2;
     const Ref q = ws(qkv), k = ws(qkv + (size_t)C * 2), v = ws(qkv + (size_t)2 * C * 2);
     op("joint_attn", 4.0 * (double)Bn * heads * Sj * (double)Sj * D, [=](const Bind& b, hipStream_t s) {
@@ -168,7 +168,7 @@ struct FB : PlanBuilder {   // Flux op program
       a.q = (const half_t*)b.p(q); a.ldq = 3 * C; a.k = (const half_t*)b.p(k); a.ldk = 3 * C;
       a.v = (const half_t*)b.p(v); a.ldv = 3 * C; a.o = (half_t*)b.p(o); a.ldo = ldo;
       a.B = Bq; a.heads = heads; a.Sq = Sj; a.Sk = Sj; a.D = D; a.scale = 1.0f / sqrtf((float)D);
-      a.kv_bstride = Sj; a.seg_T = Tq; a.bf16 = bf; a.o_lo = o_lo; a.o_pair_bf16 = pbf;
+      a.kv_bstride = Sj; a.seg_T = Tq; a.bf16 = bf; a.o_lo = o_lo; a.o_pair_bf16 = pbf; a.o_scale = o_scale;
       a.map = self_slot >= 0 ? (half_t*)b.hook(self_slot) : nullptr;
       a.map2 = cross_slot >= 0 ? (half_t*)b.hook(cross_slot) : nullptr;
       return launch_attention(a, s);
@@ -271,6 +271,11 @@ struct FB : PlanBuilder {   // Flux op program
       gemm("context_embedder", Ref{BUF_CTX, 0}, d.joint_attention_dim, nt, f.ctx_emb, C, d.joint_attention_dim, 0, e); }
 
     const int X = px(), x2 = m.x2;                                                  // 'bfloat16x2': operand rows hold [hi | lo]
+    // 'float16s': fp16 operands everywhere; the one operand class without an a-priori bound — the MLP hidden tensors gelu(ff_in(.)) — is stored
+    // scaled by hs = 2^-8 (fp16 mantissa, range +-1.7e7, absolute resolution 1.5e-5 below 0.016) and the consuming GEMM multiplies its
+    // accumulators by 1 / hs.  The single blocks contract over [attn | mlp] rows in ONE GEMM, so their attention output carries the same scale.
+    const float hs = m.hid_scale, ihs = hs != 0.f ? 1.0f / hs : 0.f;
+    const float hk = hs != 0.f ? ihs : 1.0f;                                        // factor that turns a scaled buffer back into a hook
     const bool f8 = m.fp8 != 0;                                                     // 'fp8-mx': the large linears multiply e4m3 operands
     const size_t ln_b = nr * C * 2 * X, qkv_b = nr * 3 * C * 2;
     // ================= double (MMDiT) blocks =================
@@ -327,12 +332,12 @@ struct FB : PlanBuilder {   // Flux op program
       adaln("adaln", nt, ns, w.mod + 3 * C, w.mod + 4 * C, S, 0, 0, ws(nx), f8 ? &nx8 : nullptr);
       hook_rows16(bid + "-norm-out", ws(nx), C * X, C, x2 * C);
       const size_t inner = tmp(ns * hid * 2 * X);
-      { Epi e = plain(w.ff1); e.act = 1; e.out16 = ws(inner); e.has_o16 = true; e.ldo16 = hid * X; e.o16_lo = x2 * hid;
+      { Epi e = plain(w.ff1); e.act = 1; e.out16 = ws(inner); e.has_o16 = true; e.ldo16 = hid * X; e.o16_lo = x2 * hid; e.out16_scale = hs;
         gemm("ff_in", ws(nx), C * X, ns, w.ff1, hid, C, 0, e, x2 * C, f8 ? &nx8 : nullptr); }
       if (f8) free8(nx8, ns);
-      hook_rows16(bid + "-ffn-inner", ws(inner), hid * X, hid, x2 * hid);            // attention.py:1255-1257
+      hook_rows16(bid + "-ffn-inner", ws(inner), hid * X, hid, x2 * hid, -1, hk);    // attention.py:1255-1257
       { const MxA in8 = f8 ? quant8(ws(inner), hid, ns, hid) : MxA{};
-        Epi e = gated(w.ff2, nt, w.mod + 5 * C, S); gemm("ff_out", ws(inner), hid * X, ns, w.ff2, C, hid, 0, e, x2 * hid, f8 ? &in8 : nullptr);
+        Epi e = gated(w.ff2, nt, w.mod + 5 * C, S); e.acc_scale = ihs; gemm("ff_out", ws(inner), hid * X, ns, w.ff2, C, hid, 0, e, x2 * hid, f8 ? &in8 : nullptr);
         if (f8) free8(in8, ns); }
       untmp(inner, ns * hid * 2 * X);
       hook_rows16(bid + "-out", ws(nx), C * X, C, x2 * C);
@@ -343,12 +348,12 @@ struct FB : PlanBuilder {   // Flux op program
       const MxA ne8 = f8 ? alloc8(nt, C) : MxA{};
       adaln("adaln_txt", 0, nt, w.cmod + 3 * C, w.cmod + 4 * C, T, 0, 0, ws(ne), f8 ? &ne8 : nullptr);
       const size_t cin = tmp(nt * hid * 2 * X);
-      { Epi e = plain(w.cff1); e.act = 1; e.out16 = ws(cin); e.has_o16 = true; e.ldo16 = hid * X; e.o16_lo = x2 * hid;
+      { Epi e = plain(w.cff1); e.act = 1; e.out16 = ws(cin); e.has_o16 = true; e.ldo16 = hid * X; e.o16_lo = x2 * hid; e.out16_scale = hs;
         gemm("ff_context_in", ws(ne), C * X, nt, w.cff1, hid, C, 0, e, x2 * C, f8 ? &ne8 : nullptr); }
       if (f8) free8(ne8, nt);
       untmp(ne, nt * C * 2 * X);
       { const MxA ci8 = f8 ? quant8(ws(cin), hid, nt, hid) : MxA{};
-        Epi e = gated(w.cff2, 0, w.cmod + 5 * C, T); gemm("ff_context_out", ws(cin), hid * X, nt, w.cff2, C, hid, 0, e, x2 * hid, f8 ? &ci8 : nullptr);
+        Epi e = gated(w.cff2, 0, w.cmod + 5 * C, T); e.acc_scale = ihs; gemm("ff_context_out", ws(cin), hid * X, nt, w.cff2, C, hid, 0, e, x2 * hid, f8 ? &ci8 : nullptr);
         if (f8) free8(ci8, nt); }
       untmp(cin, nt * hid * 2 * X);
     }
@@ -367,7 +372,7 @@ struct FB : PlanBuilder {   // Flux op program
       { Epi e = plain(w.qkv); e.out16 = ws(qkv); e.has_o16 = true; e.ldo16 = 3 * C; e.out_f16 = x2;
         if (fuse) qkn(e, w.nq, w.nk, 0, T, (int)nt, T, S);
         gemm("attn_qkv", ws(ln), C * X, nr, w.qkv, 3 * C, C, 0, e, x2 * C, f8 ? &ln8 : nullptr); }
-      { Epi e = plain(w.mlp); e.act = 1; e.out16 = ws(cat + (size_t)C * 2); e.has_o16 = true; e.ldo16 = CK * X; e.o16_lo = x2 * CK;   // :95
+      { Epi e = plain(w.mlp); e.act = 1; e.out16 = ws(cat + (size_t)C * 2); e.has_o16 = true; e.ldo16 = CK * X; e.o16_lo = x2 * CK; e.out16_scale = hs;   // :95
         gemm("proj_mlp", ws(ln), C * X, nr, w.mlp, hid, C, 0, e, x2 * C, f8 ? &ln8 : nullptr); }
       untmp(ln, ln_b);
       if (f8) free8(ln8, nr);
@@ -383,12 +388,12 @@ struct FB : PlanBuilder {   // Flux op program
       }
       int mc = -1, ms = -1;
       map_slots(bid, mc, ms);
-      joint_attention(qkv, ws(cat), CK * X, mc, ms, x2 * CK);                        // cat([attn_output, mlp], 2) in place (:103)
+      joint_attention(qkv, ws(cat), CK * X, mc, ms, x2 * CK, hs);                    // cat([attn_output, mlp], 2) in place (:103)
       untmp(qkv, qkv_b);
-      hook_rows16(bid + "-attn-out", ws(cat + nt * CK * 2 * X), CK * X, C, x2 * CK); // :2360-2361
+      hook_rows16(bid + "-attn-out", ws(cat + nt * CK * 2 * X), CK * X, C, x2 * CK, -1, hk); // :2360-2361
       if (cat_b < (1ull << 31)) {
         const MxA c8 = f8 ? quant8(ws(cat), CK, nr, CK) : MxA{};                     // [attn | mlp] rows as e4m3, one scale per row
-        Epi e = gated(w.out, 0, w.mod + 2 * C, T, nt, S); gemm("proj_out", ws(cat), CK * X, nr, w.out, C, CK, 0, e, x2 * CK, f8 ? &c8 : nullptr);   // :104-106
+        Epi e = gated(w.out, 0, w.mod + 2 * C, T, nt, S); e.acc_scale = ihs; gemm("proj_out", ws(cat), CK * X, nr, w.out, C, CK, 0, e, x2 * CK, f8 ? &c8 : nullptr);   // :104-106
         if (f8) free8(c8, nr);
       } else {
         // the A operand is addressed through 32-bit buffer offsets (< 2 GiB): the pair form of [rows][C + hid] at batch 8 is 2.26 GB, so
@@ -432,12 +437,13 @@ Model* flux_model_create(const gdf_flux_desc& d) {
   if (d.in_channels % 64 || d.joint_attention_dim % 64 || d.pooled_projection_dim % 8) {
     set_error("in_channels / joint_attention_dim must be multiples of 64, pooled_projection_dim of 8"); return nullptr;
   }
-  if (d.compute_dtype != GDF_F16 && d.compute_dtype != GDF_BF16 && d.compute_dtype != GDF_BF16X2 && d.compute_dtype != GDF_FP8MX) {
-    set_error("compute_dtype must be GDF_F16, GDF_BF16, GDF_BF16X2 or GDF_FP8MX"); return nullptr;
+  if (d.compute_dtype != GDF_F16 && d.compute_dtype != GDF_BF16 && d.compute_dtype != GDF_BF16X2 && d.compute_dtype != GDF_FP8MX && d.compute_dtype != GDF_F16S) {
+    set_error("compute_dtype must be GDF_F16, GDF_F16S, GDF_BF16, GDF_BF16X2 or GDF_FP8MX"); return nullptr;
   }
   Model* m = new Model();
   m->kind = 1;
-  m->bf16 = d.compute_dtype != GDF_F16;
+  m->bf16 = d.compute_dtype != GDF_F16 && d.compute_dtype != GDF_F16S;
+  m->hid_scale = d.compute_dtype == GDF_F16S ? 1.0f / 256.0f : 0.f;
   m->x2 = d.compute_dtype == GDF_BF16X2;
   m->fp8 = d.compute_dtype == GDF_FP8MX;
   m->flux.d = d;

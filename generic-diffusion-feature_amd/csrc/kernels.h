@@ -173,6 +173,8 @@ struct AttnParams {
   int bf16;              // D = 128 only: q, k, v, o are bf16 (mfma_f32_32x32x16_bf16, P rounded to bf16); maps stay fp16
   int o_lo;              // > 0 ("precise" plans): o is written as a split (hi, lo) pair, lo at o + o_lo elements in the same row
   int o_pair_bf16;       // with o_lo > 0 and fp16 q / k / v (bf16 == 0): the pair is written as bf16 hi + bf16 lo (MMDiT 'bfloat16x2' plans)
+  float o_scale;         // != 0: o is stored multiplied by this power of two (MMDiT 'float16s' plans: the [attn | mlp] operand rows of the single
+                         // blocks share ONE fp16 range scale, undone on the consuming GEMM's accumulators)
 };
 hipError_t launch_attention(const AttnParams& p, hipStream_t s);
 
@@ -250,7 +252,7 @@ hipError_t launch_silu_vec(const float* x, float* out, long n, hipStream_t s);
 // src_bf16: s16 holds bf16; sat: clamp to the fp16 range instead of producing +-inf (hook stores of the bf16 / MMDiT path)
 // s_lo > 0: the 16-bit source is a split pair (lo s_lo elements after hi in the row): dst = fp16(hi + lo)
 hipError_t launch_copy2d(const half_t* s16, const float* s32, int lds_, half_t* dst, int ldd, int R, int C,
-                         hipStream_t s, int src_bf16 = 0, int sat = 0, int s_lo = 0);
+                         hipStream_t s, int src_bf16 = 0, int sat = 0, int s_lo = 0, float scale = 1.0f);   // scale != 1: dst = fp16(scale * src)
 // latents NCHW fp16 (B,Cin,H,W) -> NHWC padded to 8 channels (conv_in operand) and optional NHWC hook copy
 hipError_t launch_pack_latents(const half_t* x, int B, int Cin, int H, int W, half_t* nhwc8, half_t* hook_nhwc,
                                hipStream_t s);

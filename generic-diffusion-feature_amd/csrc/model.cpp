@@ -629,6 +629,10 @@ int plan_build(const Model& m, Plan& P, int batch, int H, int W, int n_ctx, cons
   P.batch = batch; P.H = H; P.W = W; P.n_ctx = n_ctx; P.opts = opts;
   B b(m, P, dry, opts);
   b.Bn = batch; b.n_ctx = n_ctx;
+  // row N1's statistics half: the resnet convs whose tile supports it (64-row wave tiles: N = 640 / 1280 levels) emit the GroupNorm partial sums
+  // of the image they store, and the consuming norm2 / Transformer2DModel.norm runs gn_finalize instead of a statistics pass.  Off by default:
+  // same-box A/B in profiles/r05_ab_unet_gn_stats_from_conv_epilogue.txt (GDF_UNET_GN_EPI=1 switches it on).
+  { static const bool on = [] { const char* e = getenv("GDF_UNET_GN_EPI"); return e && atoi(e) != 0; }(); b.gn_epi = on; }
   if (!dry) {
     std::unordered_set<std::string> known(m.hook_names.begin(), m.hook_names.end());
     for (int i = 0; i < n_ids; ++i)

@@ -92,6 +92,8 @@ struct Model {
   // Flux 'fp8-mx' (GDF_FP8MX): the arena additionally holds, for every [n][k] linear at byte offset w, its fp8 (e4m3) copy at f8_off + w / 2 and
   // the per-output-channel power-of-two scales (float[n]) at sc_off + w / 16 (both written when the parameter is set)
   int fp8 = 0; size_t f8_off = 0, sc_off = 0;
+  float hid_scale = 0.f;                       // Flux 'float16s' (GDF_F16S): the MLP hidden tensors (and the single blocks' [attn | mlp] operand rows) are stored
+                                               // as fp16 of (x * hid_scale), a power of two < 1 — fp16 mantissa, +-1.7e7 range; undone on the consumer's accumulators
   int x2 = 0;                                  // Flux 'bfloat16x2' (GDF_BF16X2): bf16 weights, activation operands as bf16 hi + lo pairs, fp16 attention internals
   int kind = 0;                                // 0: UNet2DConditionModel, 1: FluxTransformer2DModel, 2: AutoencoderKL encoder, 3: PixArt DiT, 4: AutoencoderKL decoder
   FluxW flux;

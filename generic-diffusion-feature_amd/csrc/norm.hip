@@ -412,7 +412,7 @@ hipError_t launch_layernorm(const half_t* x16, const float* x32, int ld, int R, 
 // (`bf`) and the fp16 result saturates at +-65504 instead of overflowing to inf (`sat`).
 template <bool CVT>
 __global__ __launch_bounds__(256) void copy2d_kernel(const half_t* s16, const float* s32, int lds_, half_t* dst, int ldd,
-                                                     long R, int C, int bf, int sat, int s_lo) {
+                                                     long R, int C, int bf, int sat, int s_lo, float scale) {
   if ((C & 7) == 0 && (lds_ & 7) == 0 && (ldd & 7) == 0) {
     const int CH = C / 8;
     const long total = R * CH;
@@ -434,7 +434,7 @@ __global__ __launch_bounds__(256) void copy2d_kernel(const half_t* s16, const fl
       }
       f16x8 o;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = (CVT && sat) ? f32_to_f16_sat(v[e]) : (_Float16)v[e];
+      for (int e = 0; e < 8; ++e) o[e] = (CVT && sat) ? f32_to_f16_sat(CVT ? v[e] * scale : v[e]) : (_Float16)(CVT ? v[e] * scale : v[e]);
       *(f16x8*)(dst + (size_t)r * ldd + c) = o;
     }
   } else {
@@ -444,21 +444,22 @@ __global__ __launch_bounds__(256) void copy2d_kernel(const half_t* s16, const fl
       const int c = (int)(i - r * C);
       float v = s32 ? s32[(size_t)r * lds_ + c] : e16_to_f32(s16[(size_t)r * lds_ + c], CVT && bf);
       if (CVT && s_lo > 0 && !s32) v += e16_to_f32(s16[(size_t)r * lds_ + c + s_lo], bf);
+      if (CVT) v *= scale;
       dst[(size_t)r * ldd + c] = (CVT && sat) ? f32_to_f16_sat(v) : (_Float16)v;
     }
   }
 }
 
 hipError_t launch_copy2d(const half_t* s16, const float* s32, int lds_, half_t* dst, int ldd, int R, int C,
-                         hipStream_t s, int src_bf16, int sat, int s_lo) {
+                         hipStream_t s, int src_bf16, int sat, int s_lo, float scale) {
   const long work = (long)R * ((C + 7) / 8);
   long blocks = (work + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   if (blocks < 1) blocks = 1;
-  if (src_bf16 || sat || s_lo > 0)
-    hipLaunchKernelGGL(copy2d_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, s16, s32, lds_, dst, ldd, (long)R, C, src_bf16, sat, s_lo);
+  if (src_bf16 || sat || s_lo > 0 || scale != 1.0f)
+    hipLaunchKernelGGL(copy2d_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, s16, s32, lds_, dst, ldd, (long)R, C, src_bf16, sat, s_lo, scale);
   else
-    hipLaunchKernelGGL(copy2d_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, s16, s32, lds_, dst, ldd, (long)R, C, 0, 0, 0);
+    hipLaunchKernelGGL(copy2d_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, s16, s32, lds_, dst, ldd, (long)R, C, 0, 0, 0, 1.0f);
   return hipGetLastError();
 }
 
@@ -546,7 +547,7 @@ __global__ __launch_bounds__(256) void small_linear_kernel(const float* x, int l
           for (int e = 0; e < 8; ++e) {
             float xv = xp[e];
             if (silu_in) xv = xv / (1.0f + expf(-xv));
-            acc[i] += xv * e16_to_f32(wv[e], wbf);
+            acc[i] = __builtin_fmaf(xv, e16_to_f32(wv[e], wbf), acc[i]);     // (explicit: the same rounding for every row, see the wide kernel)
           }
         }
       }
@@ -607,10 +608,17 @@ __global__ __launch_bounds__(256) void small_linear_wide_kernel(const float* x, 
 #pragma unroll
       for (int m = 0; m < 8; ++m) {
         const f32x4 a = *(const f32x4*)(xs + m * K + k), b = *(const f32x4*)(xs + m * K + k + 4);
+        // explicit fused multiply-adds in ONE fixed order (k ascending): `acc += a*w + b*w2` left the contraction to the compiler, which paired
+        // rows into packed instructions and rounded rows {0, 3} differently from rows {1, 2} — identical samples of one batch then got
+        // different time embeddings, the source of every batch-position difference of the UNet (tools/op_batch_position.py, round 5)
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
+          float t = acc[c][m];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) acc[c][m] += a[e] * wf[c][e] + b[e] * wf[c][4 + e];
+          for (int e = 0; e < 4; ++e) t = __builtin_fmaf(a[e], wf[c][e], t);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) t = __builtin_fmaf(b[e], wf[c][4 + e], t);
+          acc[c][m] = t;
         }
       }
     }

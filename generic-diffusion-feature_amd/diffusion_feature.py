@@ -36,6 +36,10 @@ class FeatureExtractor(nn.Module):
                  precise=None,     # native extension: operand plan of the UNet versions — None = 'auto' (the cheapest plan level that keeps
                                    # every REQUESTED layer within 1e-3 of the fp32 reference: plain fp16 operands / the selective split /
                                    # the full split), False = plain, True = full split, 'selective', or a class list ('stream,attn_out')
+                 verify=None,      # native extension: True (or GDF_VERIFY=1) = runtime self-check of the automatic operand plan on the first batch of
+                                   # every layer set: the chosen level and the full split are both run, the requested layers compared, and the level
+                                   # escalated (with one warning) when any differs by more than 9.5e-4 — the plan chooser's error table comes from
+                                   # synthetic weight statistics, real checkpoints may be heavier-tailed (components/native.py _verify_level)
                  early_exit=False, # native extension, OPT-IN: stop the denoiser forward after the last requested layer (the reference always runs the
                                    # whole forward and discards `noise_pred`; the returned features are bit-identical either way).  Ignored when
                                    # 'vae-out' (which needs the model output) is requested
@@ -68,6 +72,8 @@ class FeatureExtractor(nn.Module):
             native_vae_decoder(pipe, device)
         if early_exit and not self.store_vae_output and hasattr(pipe.unet, "early_exit"):
             pipe.unet.early_exit = True
+        if verify is not None and hasattr(pipe.unet, "_verify_level"):
+            pipe.unet.verify = bool(verify)
         if precise is not None:
             if hasattr(pipe.unet, "set_precise"):
                 pipe.unet.set_precise(precise)

@@ -26,7 +26,7 @@ typedef struct gdf_model gdf_model;
 typedef struct gdf_plan gdf_plan;
 
 enum { GDF_OK = 0, GDF_ERR_ARG = 1, GDF_ERR_HIP = 2, GDF_ERR_STATE = 3, GDF_ERR_UNSUPPORTED = 4 };
-enum { GDF_F16 = 0, GDF_F32 = 1, GDF_BF16 = 2, GDF_BF16X2 = 3, GDF_FP8MX = 4 /* 3, 4: gdf_flux_desc.compute_dtype only, see gdf_flux.h */ };
+enum { GDF_F16 = 0, GDF_F32 = 1, GDF_BF16 = 2, GDF_BF16X2 = 3, GDF_FP8MX = 4, GDF_F16S = 5 /* 3, 4, 5: gdf_flux_desc.compute_dtype only, see gdf_flux.h */ };
 
 #define GDF_MAX_LEVELS 4
 

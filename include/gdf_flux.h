@@ -51,6 +51,16 @@ typedef struct gdf_flux_desc {
                                    [hi | lo] x [W | W] (K doubled, weights read twice), and the attention internals (q, k after
                                    RMSNorm + RoPE, v, P) are fp16: every hook within 1e-3 of the fp32 reference at full depth
                                    (bf16: 3.4e-3) without leaving bf16's range on the residual / MLP path; about 1.7x the time.
+                                   GDF_F16S (5, round 5; the Python front end's 'auto' default): GDF_F16 made range-safe where the MMDiT has no
+                                   a-priori bound.  The residual streams are fp32 (all modes); LayerNorm outputs are bounded by
+                                   (1 + |scale|) sqrt(C) + |shift|, q / k are RMS-normalised, v and the attention output are hooked tensors
+                                   the reference itself hands out as fp16; the ONE remaining operand class — the MLP hidden tensors
+                                   gelu(ff_in(.)) (and with them the single blocks' [attn | mlp] operand rows) — is stored as fp16 of
+                                   x * 2^-8 (range +-1.7e7, fp16 mantissa) and the factor is undone on the consuming GEMM's fp32 accumulators.
+                                   fp16 operands carry 3 more mantissa bits than bf16: every hook within 1e-3 of the fp32 reference at full
+                                   depth (<= 4.6e-4 measured; bf16 3.4e-3) at the bf16 mode's speed.  Weights are bf16 checkpoint values cast
+                                   to fp16 (exact for 6.1e-5 <= |w| <= 65504; the Python loader checks the cast and falls back to
+                                   GDF_BF16X2 when a matrix does not survive it).
                                    GDF_FP8MX (4), OPT-IN and LOWER precision than the reference's bf16 (BASELINE.json configs[4]: "optional fp8
                                    MFMA"): as GDF_BF16, but the large linears (QKV, MLP, attention / block output projections) multiply
                                    OCP e4m3 operands with v_mfma_scale_f32_16x16x128_f8f6f4 — activations quantised per token, weights per

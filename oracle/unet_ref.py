@@ -451,50 +451,38 @@ def synth_params(arch, seed=0, dtype=torch.float32):
 
 
 def synth_params_heavy(arch, seed=0, dtype=torch.float32, sigma=0.5, n_outlier=3, outlier_gain=32.0):
-    """Heavy-tailed synthetic weights: what real SD checkpoints look like, which N(0, 1/fan_in) does not.
+    """Heavy-tailed synthetic weights: what real SD checkpoints look like and N(0, 1/fan_in) does not.
 
-    * every matrix / conv has LOG-NORMAL per-output-channel scales exp(sigma N) (rows of very different magnitude);
+    * every matrix / conv gets LOG-NORMAL per-output-channel scales exp(sigma N): rows of very different magnitude;
     * `n_outlier` fixed channels per width are OUTLIER channels of the residual stream: every layer that writes the stream (conv_in,
-      resnet conv2 / conv_shortcut, attn to_out.0, ff.net.2, proj_out, the down / upsampler convs) has those output rows multiplied
-      by `outlier_gain`, so the stream carries a few channels ~32x the others through the whole depth (the well-known massive
-      activations of diffusion / transformer checkpoints); the norm gammas of those channels are 1/8 as trained models compensate;
-    * norm gammas log-normal as well.
-    Same rounding contract as synth_params (fp16-representable values)."""
+      resnet conv2, attn to_out.0, ff.net.2, proj_out: the additive branches, whose inputs are normalised) has those output rows multiplied by
+      `outlier_gain`, so the stream carries a few channels ~32x the others through the whole depth (the massive activations of trained
+      diffusion / transformer checkpoints); the gammas of the norms that READ the stream are 1/8 on those channels, as trained
+      models compensate;
+    * all norm gammas log-normal (sigma 0.3).
+    Same rounding contract as synth_params: every value is fp16-representable."""
     g = torch.Generator().manual_seed(seed + 7919)
     P = synth_params(arch, seed=seed, dtype=torch.float32)
-    out_idx = {}
-
-    def outliers(c):
-        if c not in out_idx:
-            out_idx[c] = torch.randperm(c, generator=torch.Generator().manual_seed(1000 + c))[:n_outlier]
-        return out_idx[c]
-    writers = (".conv2.weight", ".conv_shortcut.weight", ".to_out.0.weight", ".ff.net.2.weight", ".proj_out.weight",
-               "samplers.0.conv.weight")
-    for name in list(P.keys()):
-        w = P[name]
-        is_norm = ".norm" in name or name.startswith("conv_norm_out")
-        if name.endswith(".weight") and not is_norm:
-            sc = torch.exp(sigma * torch.randn(w.shape[0], generator=g))
-            if name == "conv_in.weight" or name.endswith(writers):
-                sc[outliers(w.shape[0])] *= outlier_gain
-            w = w * sc.view(-1, *([1] * (w.dim() - 1)))
-        elif name.endswith(".weight"):
-            w = w * torch.exp(0.3 * torch.randn(w.shape[0], generator=g))
-            if "norm_out" not in name and w.shape[0] in out_idx or True:
-                idx = outliers(w.shape[0]) if w.shape[0] in (arch["block_out_channels"]) else None
-                if idx is not None and not name.endswith((".norm2.weight",)):
-                    pass
-        P[name] = w.half().to(dtype)
-    # norm gammas of the outlier channels of STREAM-reading norms (resnet norm1 over non-concat inputs, Transformer2DModel.norm, LayerNorms)
-    for name in list(P.keys()):
+    widths = set(arch["block_out_channels"])
+    idx = {c: torch.randperm(c, generator=torch.Generator().manual_seed(1000 + c))[:n_outlier] for c in widths}
+    # (the 1x1 shortcuts and the sampler convs READ the raw stream: its outlier channels pass through them without a gain of their own)
+    writers = (".conv2.weight", ".to_out.0.weight", ".ff.net.2.weight", ".proj_out.weight")
+    for name, w in list(P.items()):
         if not name.endswith(".weight"):
             continue
-        is_stream_norm = (name.endswith((".norm.weight", ".norm1.weight", ".norm3.weight")) and "transformer_blocks" in name) or \
-                         name.endswith(".attentions.0.norm.weight") or name.endswith(".norm.weight") or name == "conv_norm_out.weight"
-        if is_stream_norm and P[name].dim() == 1 and P[name].shape[0] in arch["block_out_channels"]:
-            w = P[name].clone()
-            w[outliers(w.shape[0])] *= 0.125
-            P[name] = w.half().to(dtype)
+        is_norm = ".norm" in name or name.startswith("conv_norm_out")
+        if not is_norm:
+            sc = torch.exp(sigma * torch.randn(w.shape[0], generator=g))
+            if (name == "conv_in.weight" or name.endswith(writers)) and w.shape[0] in widths:
+                sc[idx[w.shape[0]]] *= outlier_gain
+            w = w * sc.view(-1, *([1] * (w.dim() - 1)))
+        else:
+            w = w * torch.exp(0.3 * torch.randn(w.shape[0], generator=g))
+            reads_stream = not name.endswith(".norm2.weight") or "transformer_blocks" in name     # (resnet norm2 reads the conv1 output)
+            if reads_stream and w.shape[0] in widths:
+                w = w.clone()
+                w[idx[w.shape[0]]] *= 0.125
+        P[name] = w.half().to(dtype)
     return P
 
 

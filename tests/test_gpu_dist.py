@@ -174,3 +174,58 @@ def test_four_rank_bench_line():
     assert c["weights_broadcast_s"] >= 0 and 0 < c["per_rank_ms_per_step"]["min"] <= c["per_rank_ms_per_step"]["max"]
     assert abs(line["value"] - 8 * 1e3 / c["per_rank_ms_per_step"]["max"]) < 0.02 * line["value"]
     assert "plans" not in line and "e2e" not in line                         # the extra legs are single-GPU only
+
+
+def test_four_rank_cli_uneven_shards_bit_equal_to_one_process(tmp_path):
+    """MORE images than ranks, uneven shards.  SEVEN images over FOUR ranks (shards of 2, 2, 2, 1), batch size 2; the last
+    rank runs a batch-1 plan, as the single process does for its ragged last batch: every file must equal the single-process file bit for
+    bit.  (The VAE sampling / add_noise draws are per batch position, like the reference's `prepare_latents`, so the CLI cannot move an image
+    to another batch index without changing its latents; that the DENOISER gives identical bits at every batch index is asserted on
+    identical latents in test_per_sample_bits_do_not_depend_on_batch_index below and at SDXL B = 16 in test_gpu_fullsize.py.)"""
+    from PIL import Image
+    rs = np.random.RandomState(2)
+    (tmp_path / "imgs").mkdir()
+    names = "abcdefg"
+    for n in names:
+        Image.fromarray((rs.rand(64, 64, 3) * 255).astype(np.uint8)).save(tmp_path / "imgs" / f"{n}.png")
+    (tmp_path / "prompt.txt").write_text("a photo of a bird")
+    layers = {"up-level1-repeat2-res-out": True, "up-level2-repeat1-vit-block0-cross-q": True, "down-level0-repeat0-res-increment": True}
+    (tmp_path / "layers.json").write_text(json.dumps(layers))
+    base = [os.path.join(ROOT, "extract_feature.py"), "--layer", str(tmp_path / "layers.json"), "--version", "1-5", "--img_size", "128",
+            "--t", "100", "-b", "2", "--input_dir", str(tmp_path / "imgs" / "*.png"), "--prompt_file", str(tmp_path / "prompt.txt")]
+    env = {k: v for k, v in dict(os.environ, GDF_SYNTHETIC_WEIGHTS="1", HSA_ENABLE_IPC_MODE_LEGACY="0").items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable] + base + ["--output_dir", str(tmp_path / "one")], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([sys.executable] + base + ["--gpus", "4", "--output_dir", str(tmp_path / "four")], env=dict(env, GDF_SHARE_GPU="1"),
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    one, four = _tree(tmp_path / "one"), _tree(tmp_path / "four")
+    assert sorted(one) == sorted(four) and len(one) == 3 * 7
+    # shards: rank 0 = images 0-1, rank 1 = 2-3, rank 2 = 4-5 (batch-2 plans, like the single process's batches 0-1, 2-3, 4-5), rank 3 = image 6
+    # (a batch-1 plan; the single process ALSO runs image 6 as its last, ragged batch of one): every file must be bit-identical
+    for k in one:
+        assert np.array_equal(one[k].view(np.uint16), four[k].view(np.uint16)), k
+
+
+def test_per_sample_bits_do_not_depend_on_batch_index(monkeypatch):
+    """The same pre-noised latent at batch index 0, 1, 2 of a batch of three different latents (and alone in a batch whose other members
+    change) gives bit-identical features: the plan's kernels are per-sample position independent (round 5: the stacked time-embedding linear
+    used to round rows {0, 3} and {1, 2} of a batch differently — tools/op_batch_position.py)."""
+    monkeypatch.setenv("GDF_SYNTHETIC_WEIGHTS", "1")
+    import diffusion_feature
+    layer = {"down-level0-repeat0-res-increment": True, "up-level1-repeat1-vit-block0-cross-q": True, "up-level2-repeat2-res-out": True,
+             "mid-vit-block0-ffn-inner": True}
+    df = diffusion_feature.FeatureExtractor(layer=layer, version='1-5', img_size=256, device='cuda:0')
+    prompt = df.encode_prompt('a photo of a cat')
+    lat = [torch.randn(4, 32, 32, generator=torch.Generator().manual_seed(s)).half() for s in (0, 1, 2, 3)]
+    runs = {}
+    for order in ((0, 1, 2, 3), (3, 0, 1, 2), (2, 3, 0, 1), (1, 2, 3, 0)):
+        x = torch.stack([lat[i] for i in order])
+        f = df.extract(prompt, batch_size=4, image=x, image_type='latents', t=100)
+        torch.cuda.synchronize()
+        runs[order] = {k: v.clone() for k, v in f.items()}
+    base = runs[(0, 1, 2, 3)]
+    for order, f in runs.items():
+        for pos, i in enumerate(order):
+            for k in layer:
+                assert torch.equal(f[k][pos], base[k][i]), (order, pos, k)

@@ -361,7 +361,7 @@ def test_every_layer_config_of_the_reference_is_served():
 def test_operand_plan_selection_table_and_masks():
     """Round 4: the operand plan is chosen per hook set (components/native.py choose_split) from the committed CPU-emulation table
     (components/operand_error_table.json, tools/operand_subsets.py): plain fp16 operands when every requested hook's emulated error is
-    <= 9.5e-4, else the architecture's selective preset, else the full split.  Every shipped layer config lands on a level whose emulated
+    <= AUTO_BOUND (9.3e-4 since round 5), else the light level (only `gnv` split), else the architecture's selective preset, else the full split.  Every shipped layer config lands on a level whose emulated
     worst hook is within the bound; the BASELINE headline hooks stay on the plain plan."""
     import glob
     import json
@@ -375,7 +375,10 @@ def test_operand_plan_selection_table_and_masks():
     for ver, fam in (("xl", "xl"), ("pgv2", "xl"), ("1-5", "1-5"), ("2-1", "1-5")):
         assert N.arch_family(N.ARCH_CONFIGS[ver]) == fam
     assert N.choose_split(N.ARCH_CONFIGS["xl"], bench.PRACTICAL["xl"]) == 0               # the headline runs plain fp16 operands
-    assert N.choose_split(N.ARCH_CONFIGS["1-5"], bench.PRACTICAL["1-5"]) == 0
+    # SD1.5's practical `self-k` measures 9.70e-4 on the plain plan (3.0 % under the contract): it is handed to the LIGHT level (9.1e-4)
+    assert N.choose_split(N.ARCH_CONFIGS["1-5"], bench.PRACTICAL["1-5"]) == N.SPLIT_LIGHT == N.SPLIT_CLASSES["gnv"]
+    assert N.choose_split(N.ARCH_CONFIGS["1-5"], bench.PRACTICAL["1-5"][:3]) == 0
+    assert N.AUTO_BOUND <= 9.3e-4
     worst_xl = max(tab["xl"]["hooks"], key=lambda h: tab["xl"]["hooks"][h][0])
     assert worst_xl.endswith("ffn-inner") and tab["xl"]["hooks"][worst_xl][0] > 1e-3 > tab["xl"]["hooks"][worst_xl][1]
     assert N.choose_split(N.ARCH_CONFIGS["xl"], [worst_xl]) == N.SELECTIVE_BY_ARCH["xl"]
@@ -391,8 +394,8 @@ def test_operand_plan_selection_table_and_masks():
         ids = [k for k, v in json.load(open(f)).items() if v]
         ver = "xl" if ("_xl_" in f or "_pg_" in f) else "1-5"
         m = N.choose_split(N.ARCH_CONFIGS[ver], ids)
-        assert m in (0, N.SELECTIVE_BY_ARCH[ver]), f                                       # no shipped config needs the full split
-        col = 0 if m == 0 else 1
+        assert m in (0, N.SPLIT_LIGHT, N.SELECTIVE_BY_ARCH[ver]), f                        # no shipped config needs the full split
+        col = 0 if m == 0 else (2 if m == N.SPLIT_LIGHT else 1)                            # columns: plain, selective, light
         worst = max((tab[ver]["hooks"][i][col] for i in ids if i in tab[ver]["hooks"]), default=0.0)
         assert worst <= N.AUTO_BOUND, (f, worst)
         if any(i.endswith("-map") or i == "unet-out" for i in ids):

@@ -46,8 +46,21 @@ def _rd(p):
         return None
 
 
+def _max_sclk_mhz(h):
+    """highest shader-clock DPM level of the card behind hwmon dir `h` (pp_dpm_sclk: '0: 132Mhz\n1: 2400Mhz *'), None if unreadable"""
+    try:
+        with open(os.path.join(os.path.dirname(os.path.dirname(h)), "pp_dpm_sclk")) as f:
+            v = [int(l.split(":")[1].strip().lower().split("mhz")[0]) for l in f.read().splitlines() if ":" in l]
+        return max(v) if v else None
+    except Exception:
+        return None
+
+
 class PowerSampler(threading.Thread):
-    def __init__(self, dev_index=0, dt=0.02):
+    """hwmon power / clock sampling.  The sensor averages over ~0.5 s, so a 100-ms cadence loses nothing and wakes the interpreter 10x per
+    second instead of 50x (a 20-ms Python thread contends for the GIL with the launching thread inside the timed region)."""
+
+    def __init__(self, dev_index=0, dt=0.1):
         super().__init__(daemon=True)
         self.h = _hwmon(dev_index)
         self.dt = dt
@@ -62,7 +75,7 @@ class PowerSampler(threading.Thread):
             self.rows.append((time.perf_counter(), _rd(pw), _rd(fq)))
             time.sleep(self.dt)
 
-    def finish(self, t0, t1):
+    def finish(self, t0, t1, images=None):
         self.stop_flag = True
         if self.is_alive():
             self.join()
@@ -74,8 +87,10 @@ class PowerSampler(threading.Thread):
         cap = _rd(os.path.join(self.h, "power1_cap"))
         w = [r[1] / 1e6 for r in rows]
         f = [r[2] / 1e6 for r in rows if r[2]]
-        return {"watts_avg": round(sum(w) / len(w), 1), "watts_max": round(max(w), 1), "cap_watts": round(cap / 1e6, 1) if cap else None,
-                "sclk_mhz_avg": round(sum(f) / len(f)) if f else None, "sclk_mhz_max": 2400, "samples": len(rows),
+        wavg = sum(w) / len(w)
+        return {"watts_avg": round(wavg, 1), "watts_max": round(max(w), 1), "cap_watts": round(cap / 1e6, 1) if cap else None,
+                "sclk_mhz_avg": round(sum(f) / len(f)) if f else None, "sclk_mhz_max": _max_sclk_mhz(self.h), "samples": len(rows),
+                "joules_per_image": round(wavg * (t1 - t0) / images, 2) if images else None,
                 "note": "hwmon power1_input / freq1_input of this card over the last 75 % of the timed region: every MFMA kernel of the step runs at "
                         "the package power cap with the shader clock throttled (profiles/r04_power_per_kernel.txt), so images/s follow ENERGY per "
                         "image, not cycles"}
@@ -124,7 +139,10 @@ def _unet_inputs(cfg, B, lat, img, dev, seed=7):
     return x, t, ctx, txt, tid
 
 
-def other_configs_block(dev, flops_fn, practical, budget_s=45.0):
+FLUX_EXTRA_DTYPES = ["auto"]      # round 5: the product default (fp16 operands + range-scaled MLP hidden tensors)
+
+
+def other_configs_block(dev, flops_fn, practical, budget_s=75.0):
     from components.native import NativeUNet, ARCH_CONFIGS, FLUX_CONFIGS, NativeFluxTransformer
     out = {}
     t_start = time.time()
@@ -147,12 +165,18 @@ def other_configs_block(dev, flops_fn, practical, budget_s=45.0):
         torch.cuda.empty_cache()
     except Exception as e:                                     # an extra leg must never cost the headline line
         out["sd15_error"] = repr(e)[:300]
-    # ---- BASELINE configs[4]: Flux.1-dev MMDiT 1024^2, bf16, batch 8 (tools/bench_flux.py is the full per-model bench) ----
-    if time.time() - t_start < budget_s:
+    # ---- BASELINE configs[4]: Flux.1-dev MMDiT 1024^2, batch 8, every shipped arithmetic mode (tools/bench_flux.py is the full per-model bench):
+    # bf16 = the reference's dtype (hooks <= 3.4e-3 at full depth), bfloat16x2 = bf16 hi + lo operand pairs (<= 1.8e-4), fp8-mx = the optional
+    # e4m3 MFMA leg (<= 7.5e-2, opt-in, lower precision) ----
+    for dt_name in ("bfloat16", "bfloat16x2", "fp8-mx") + tuple(FLUX_EXTRA_DTYPES):
+        tag = "flux_dev_1024_%s_b8_config_c5" % {"bfloat16": "bf16"}.get(dt_name, dt_name.replace("-", "_"))
+        if time.time() - t_start > budget_s:
+            out[tag] = "skipped: budget"
+            continue
         try:
             from oracle.flux_ref import flops_per_image, latent_image_ids, ARCH_FLUX_DEV      # FLOP model + id helper only (not measured)
             cfg = dict(FLUX_CONFIGS["flux"])
-            net = NativeFluxTransformer(cfg, device=dev, compute_dtype="bfloat16")
+            net = NativeFluxTransformer(cfg, device=dev, compute_dtype=dt_name)
             t0 = time.time(); net.init_synthetic(seed=0); torch.cuda.synchronize(); t_w = time.time() - t0
             B, grid, T = 8, 64, 512
             S = grid * grid
@@ -167,17 +191,63 @@ def other_configs_block(dev, flops_fn, practical, budget_s=45.0):
             ids = [f"vit-block{i}-out" for i in picks] + [f"vit-block{i}-q" for i in picks]
             step = lambda: net.forward_raw(x, enc, pooled, ts, img_ids, txt_ids, guidance=gd, hook_ids=ids, grid=(grid, grid))
             steps = 2
-            dt = _time_steps(step, steps, 2)
+            dt = _time_steps(step, steps, 2 if dt_name == "bfloat16" else 1)
             fl_img = flops_per_image(dict(ARCH_FLUX_DEV), S, T)
-            out["flux_dev_1024_bf16_b8_config_c5"] = {"images_per_s": round(B * steps / dt, 2), "ms_per_step": round(1e3 * dt / steps, 1), "hooks": len(ids),
-                                                      "model_tflops_per_s": round(B * steps / dt * fl_img / 1e12, 1), "weights_init_s": round(t_w, 1),
-                                                      "steps": steps, "dtype": "bf16"}
-            del net
+            out[tag] = {"images_per_s": round(B * steps / dt, 2), "ms_per_step": round(1e3 * dt / steps, 1), "hooks": len(ids),
+                        "model_tflops_per_s": round(B * steps / dt * fl_img / 1e12, 1), "weights_init_s": round(t_w, 1),
+                        "steps": steps, "dtype": dt_name,
+                        "worst_hook_error_full_depth": {"bfloat16": "3.4e-3", "bfloat16x2": "1.8e-4", "fp8-mx": "7.5e-2 (opt-in, lower precision)",
+                                                        "float16": "4.6e-4", "auto": "<= 8.5e-4 asserted (the FeatureExtractor default)"}.get(dt_name, "see tests/test_gpu_fullsize.py")}
+            del net, step
             torch.cuda.empty_cache()
         except Exception as e:
-            out["flux_error"] = repr(e)[:300]
+            out[tag.replace("config_c5", "error")] = repr(e)[:300]
+    # ---- PixArt-Sigma-XL-2 1024^2 (28 blocks, 4096 image + 300 caption tokens), batch 4: SURVEY §8(f) rank 4 ----
+    if time.time() - t_start < budget_s:
+        try:
+            from components.native import NativePixArtTransformer, PIXART_CONFIGS
+            from oracle.pixart_ref import ARCH_PIXART_SIGMA, flops_per_image as pix_flops       # FLOP model only
+            net = NativePixArtTransformer(PIXART_CONFIGS["pixart-sigma"], device=dev).init_synthetic(0)
+            B, T = 4, 300
+            g = torch.Generator(device=dev).manual_seed(1)
+            x = torch.randn(B, 4, 128, 128, device=dev, generator=g).half()
+            enc = torch.randn(B, T, 4096, device=dev, generator=g).half()
+            mask = (torch.arange(T, device=dev)[None] < 120).expand(B, T).to(torch.int64)
+            tt = torch.full((B,), 100.0, device=dev)
+            ids = [f"vit-block{i}-out" for i in (6, 13, 20, 27)]
+            step = lambda: net.forward_raw(x, enc, tt, mask, hook_ids=ids)
+            steps = 3
+            dt = _time_steps(step, steps, 2)
+            fl = pix_flops(ARCH_PIXART_SIGMA, 4096, T)
+            out["pixart_sigma_1024_b4"] = {"images_per_s": round(B * steps / dt, 2), "ms_per_step": round(1e3 * dt / steps, 2), "hooks": len(ids),
+                                           "model_tflops_per_s": round(B * steps / dt * fl / 1e12, 1), "steps": steps, "dtype": "f16"}
+            del net, step
+            torch.cuda.empty_cache()
+        except Exception as e:
+            out["pixart_error"] = repr(e)[:300]
     else:
-        out["flux_dev_1024_bf16_b8_config_c5"] = "skipped: budget"
+        out["pixart_sigma_1024_b4"] = "skipped: budget"
+    # ---- `vae-out`: scheduler step + AutoencoderKL decoder at 1024^2, batch 16 (reference diffusion_feature.py:477-485) ----
+    if time.time() - t_start < budget_s:
+        try:
+            from components.native import NativeVAEDecoder, VAE_CONFIGS
+            from oracle.vae_ref import ARCH_SD_VAE, dec_flops_per_image                        # FLOP model only
+            dec = NativeVAEDecoder(VAE_CONFIGS["sd"], device=dev).init_synthetic(1)
+            B = 16
+            g = torch.Generator(device=dev).manual_seed(2)
+            lat = torch.randn(B, 4, 128, 128, device=dev, generator=g).half(); npred = torch.randn(B, 4, 128, 128, device=dev, generator=g).half()
+            step = lambda: dec.decode(lat, npred, c_sample=1.0, c_eps=-0.4, scaling_factor=0.13025)
+            steps = 2
+            dt = _time_steps(step, steps, 1)
+            fl = dec_flops_per_image(ARCH_SD_VAE, 1024)
+            out["vae_out_decode_1024_b16"] = {"images_per_s": round(B * steps / dt, 2), "ms_per_batch": round(1e3 * dt / steps, 1),
+                                              "model_tflops_per_s": round(B * steps / dt * fl / 1e12, 1), "steps": steps, "dtype": "f16 operands, fp32 stream"}
+            del dec, step
+            torch.cuda.empty_cache()
+        except Exception as e:
+            out["vae_out_error"] = repr(e)[:300]
+    else:
+        out["vae_out_decode_1024_b16"] = "skipped: budget"
     out["seconds"] = round(time.time() - t_start, 1)
     return out
 

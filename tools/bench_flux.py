@@ -63,7 +63,7 @@ def main():
     ap.add_argument("--hooks", default="practical", choices=("practical", "all", "none"))
     ap.add_argument("--profile-ops", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--dtype", default="bfloat16", choices=("bfloat16", "float16", "bfloat16x2", "fp8-mx"),
+    ap.add_argument("--dtype", default="bfloat16", choices=("bfloat16", "float16", "bfloat16x2", "fp8-mx", "float16s", "auto"),
                     help="element type of weights / activations / MFMA operands (the reference loads Flux in bfloat16)")
     args = ap.parse_args()
     if not torch.cuda.is_available():
@@ -127,7 +127,8 @@ def main():
            "unit": "images/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(1e3 * dt / args.steps, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": {"bfloat16": "bf16", "float16": "f16", "bfloat16x2": "bf16 hi+lo operand pairs (fp16 attention internals)",
-                     "fp8-mx": "fp8-mx (e4m3 operands in the large linears: LOWER than the reference's bf16; opt-in)"}[args.dtype], "data": "synthetic",
+                     "fp8-mx": "fp8-mx (e4m3 operands in the large linears: LOWER than the reference's bf16; opt-in)",
+                     "float16s": "f16 (range-scaled MLP hidden tensors)", "auto": "f16 (range-scaled MLP hidden tensors; the FeatureExtractor default)"}[args.dtype], "data": "synthetic",
            "config": {"workload": f"Flux MMDiT ({args.layers} double + {args.single_layers} single blocks, 24 heads x 128), "
                                   f"{S}+{T} tokens, batch {B}, hooks={args.hooks} ({len(out[1])} ids, "
                                   f"{hook_bytes / B / 1e6:.1f} MB/img)",
@@ -140,6 +141,8 @@ def main():
                                      "count algorithmic FLOPs); q / k / v / P fp16" if args.dtype == "bfloat16x2" else
                                      "QKV / MLP / output-projection GEMMs on OCP e4m3 operands (v_mfma_scale_f32_16x16x128_f8f6f4; activations quantised "
                                      "per token, weights per output channel, power-of-two scales), everything else bf16" if args.dtype == "fp8-mx" else
+                                     "fp16 MFMA operands (bf16 checkpoint values cast to fp16, cast checked at load), MLP hidden tensors stored x 2^-8 "
+                                     "(GDF_F16S: no operand class without a range bound)" if args.dtype in ("float16s", "auto") else
                                      "fp16 MFMA operands / weights / activations (reference: bf16)")
                                     + ", fp32 accumulate, fp32 residual stream, fp16 hooks (saturating)"},
            "roofline": {"bound": "mfma", "kernel": dominant, "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS,
