@@ -198,7 +198,7 @@ def test_flux_tiny_all_hooks_vs_oracle(dt):
                         I["img_ids"], I["txt_ids"], I["guidance"], store=st)
     net, out, hooks = _run_native(arch, P, I, FR.hook_ids(arch, maps=True), 8, dt)
     assert net.hook_names() == FR.hook_ids(arch, maps=True)
-    assert out.dtype == TDT[dt]
+    assert out.dtype == net.io_dtype == (torch.float16 if dt in ('float16', 'float16s', 'auto') else torch.bfloat16)
     assert hooks["vit-block0-cross-map"].shape == (2, 2, 64, 24) and hooks["vit-block3-self-map"].shape == (2, 2, 64, 64)
     assert list(hooks.keys()) == list(st.feats.keys())
     worst = rel_l2(out, y)
