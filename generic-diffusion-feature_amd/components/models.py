@@ -186,6 +186,7 @@ def native_prepare_latents(pipe, image, timestep, batch_size, num_images_per_pro
 
 
 class SyntheticPipe:
+    synthetic_weights = True                      # seeded N(0, 1/fan_in) weights: the statistics the operand-plan table was made on
     """Offline stand-in for the diffusers img2img pipeline object (`pipe`) used by FeatureExtractor."""
 
     def __init__(self, version, device, seed=0, stream_fp32=True):
@@ -280,6 +281,7 @@ class SyntheticPixartPipe(SyntheticPipe):
 
 
 class SyntheticFluxPipe:
+    synthetic_weights = True
     """Offline stand-in for the reference's PATCHED FluxImg2ImgPipeline as `FeatureExtractor.extract` drives it
     (`pipe(image=..., prompt=..., strength=t/1000, guidance_scale=1)`, diffusion_feature.py:246-254): true-architecture
     MMDiT (NativeFluxTransformer, seeded random weights) + deterministic stand-ins for the T5/CLIP encoders and the

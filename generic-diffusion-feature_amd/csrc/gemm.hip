@@ -1335,7 +1335,14 @@ static int pick_variant_any(const GemmParams& p) {
     return (p.N % 128 == 0 && (long)((p.M + 255) / 256) * (p.N / 128) >= 256) ? 2128 : 128;   // PixArt: C = 1152 = 9 x 128
   }
   if (p.bn == 16) return 16;
-  if (p.splitk > 1) return (p.N % 160 == 0 && p.N % 128 != 0) ? 160 : 128;      // split-K lives in the 2-stage ring tiles
+  if (p.splitk > 1) {                                                            // split-K lives in the 2-stage ring tiles
+    static const int force = [] { const char* e = getenv("GDF_SPLITK_TILE"); return e ? atoi(e) : 0; }();   // diagnostics: 128 | 160
+    if (force == 160 && p.N % 160 == 0) return 160;
+    if (force == 128 && p.N % 128 == 0) return 128;
+    // round 5: the 128x160 tile whenever it divides N (SD1.5's 8x8 level, N = 1280: 750 / 891 vs 715 / 824 TFLOP/s at K = 11520 / 23040,
+    // tools/bench_conv_small_m.py); gemm_splitk_factor counts its tiles the same way
+    return (p.N % 160 == 0) ? 160 : 128;
+  }
   if (p.variant) return p.variant;
   const long tiles256 = (long)((p.M + 255) / 256) * ((p.N + 127) / 128);
   const long tiles320 = (long)((p.M + 255) / 256) * ((p.N + 319) / 320);
@@ -1579,7 +1586,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p, 
 int gemm_splitk_factor(const GemmParams& p) {
   static const int off = [] { const char* e = getenv("GDF_SPLITK"); return e && atoi(e) == 0; }();     // diagnostics: GDF_SPLITK=0
   if (off || p.dit || p.geglu || p.bn == 16 || p.batch > 1 || p.mode == A_CONV_SMALLC || p.variant || (p.N % 128) || (p.K % BK)) return 1;
-  const long tiles = (long)((p.M + 127) / 128) * (p.N / 128);
+  const long tiles = (long)((p.M + 127) / 128) * ((p.N % 160 == 0) ? p.N / 160 : p.N / 128);       // (the split tile: pick_variant_any)
   const int nk = p.K / BK;
   const int S1 = p.cus > 0 ? p.cus : 256;
   if (tiles >= S1 || nk < 64) return 1;

@@ -9,6 +9,7 @@ the layer-selection config surface (JSON path | dict | None) and the version / d
 In scope is the single-timestep path (no `denoising_from`, ControlNet, DDIM inversion: SURVEY.md §2).
 """
 import copy
+import os
 
 import torch
 import torch.nn as nn
@@ -36,7 +37,8 @@ class FeatureExtractor(nn.Module):
                  precise=None,     # native extension: operand plan of the UNet versions — None = 'auto' (the cheapest plan level that keeps
                                    # every REQUESTED layer within 1e-3 of the fp32 reference: plain fp16 operands / the selective split /
                                    # the full split), False = plain, True = full split, 'selective', or a class list ('stream,attn_out')
-                 verify=None,      # native extension: True (or GDF_VERIFY=1) = runtime self-check of the automatic operand plan on the first batch of
+                 verify=None,      # native extension (None = ON for real checkpoints, OFF for GDF_SYNTHETIC_WEIGHTS pipelines; GDF_VERIFY=0/1 overrides):
+                                   # True = runtime self-check of the automatic operand plan on the first batch of
                                    # every layer set: the chosen level and the full split are both run, the requested layers compared, and the level
                                    # escalated (with one warning) when any differs by more than 9.5e-4 — the plan chooser's error table comes from
                                    # synthetic weight statistics, real checkpoints may be heavier-tailed (components/native.py _verify_level)
@@ -72,7 +74,13 @@ class FeatureExtractor(nn.Module):
             native_vae_decoder(pipe, device)
         if early_exit and not self.store_vae_output and hasattr(pipe.unet, "early_exit"):
             pipe.unet.early_exit = True
-        if verify is not None and hasattr(pipe.unet, "_verify_level"):
+        if hasattr(pipe.unet, "_verify_level"):
+            # verify=None: ON for real checkpoints (their weight statistics are not the synthetic ones the plan chooser's table was made on:
+            # heavy-tailed weights put the plain plan at 1.8e-3 where the table says 9e-4, profiles/r05_heavy_tailed_plan_levels.txt), OFF for
+            # the seeded synthetic pipelines (the table's own statistics, asserted per hook in tests/test_gpu_fullsize.py); GDF_VERIFY=0 / 1 overrides
+            env = os.environ.get("GDF_VERIFY", "")
+            if verify is None:
+                verify = (env not in ("", "0")) if env != "" else not getattr(pipe, "synthetic_weights", False)
             pipe.unet.verify = bool(verify)
         if precise is not None:
             if hasattr(pipe.unet, "set_precise"):
