@@ -24,6 +24,9 @@ typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
 #define LDS_AS __attribute__((address_space(3)))
 
 static constexpr int KT = 64;     // keys per tile
+#if !defined(GDF_ATTN_PV16_DEFAULT)
+#define GDF_ATTN_PV16_DEFAULT true    // P V on mfma_f32_16x16x32_f16 for D = 40 / 72 / 80 (attn_kernel<..., PV16>): same-box A/B of round 5: D = 40 564 -> 604 (B = 32: 589 -> 640), D = 72 674 -> 715, D = 80 659 -> 703 TFLOP/s (profiles/r05_ab_attn_pv16.txt); GDF_ATTN_PV16=0 restores the 32x32x16 form
+#endif
 
 // ---- element type of q / k / v / o: fp16, or bf16 for a bf16 MMDiT model (BF; the 16-byte fragments are only containers) ----
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -122,9 +125,17 @@ __device__ unsigned long long gdf_attn_trace[8192 * 8];
 // (16 MFMAs + 64 v_exp: 727 cycles against 533 and 644 alone).  The loop's bound is therefore MFMA + plain-VALU + LDS-read issue
 // time, and the lever is the instruction count, not the placement.)
 // OCC = workgroups per CU the register budget is sized for (2; 1 only in the GDF_ATTN_QW4 experiment below)
-template <int D, int QW, int NW = 4, bool BF = false, int OCC = 2>
+// PV16 (round 5, head dims whose 16-row padding is smaller than their 32-row padding: 40 -> 48 instead of 64, 72 / 80 -> 80 instead of 96): O^T += V^T P^T on
+// mfma_f32_16x16x32_f16.  The S^T accumulator of the 32x32x16 score MFMAs keeps queries 0-15 in lane rows 0 / 2 and queries 16-31 in rows 1 / 3 (a row = 16
+// lanes); one v_permlane16_swap per pair of packed P registers (X = keys {0-3, 8-11} + 4 lh, Y = keys {16-19, 24-27} + 4 lh of a 32-key block) turns them into
+// X' = [X.r0, Y.r0, X.r2, Y.r2] = the four 8-key groups of queries 0-15 and Y' = the same for queries 16-31: exactly the B-operand layout of the 16x16x32
+// instruction.  The key order inside the contraction is free, so the V^T fragment is simply read in the order the groups hold (row bases 0, 16, 4, 20 of the block).
+template <int D, int QW, int NW = 4, bool BF = false, int OCC = 2, bool PV16 = false>
 __global__ __launch_bounds__(NW * 64, OCC) void attn_kernel(const AttnParams p) {
   GDF_AT_ENTRY
+  static_assert(!PV16 || !BF, "the 16-row P V form is fp16 only");
+  typedef float f32x4_t __attribute__((ext_vector_type(4)));
+  constexpr int ND16 = (D + 15) / 16;            // 16-row blocks of O^T (PV16)
   constexpr int NT = NW * 64;                    // threads per workgroup
   constexpr int DQK = (D + 15) / 16 * 16;        // contraction length of QK^T, padded
   constexpr int DV = (D + 31) / 32 * 32;         // output rows of O^T, padded
@@ -188,15 +199,23 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_kernel(const AttnParams p) 
     }
   }
 
-  f32x16 o[QW][NDB];
+  f32x16 o[QW][PV16 ? 1 : NDB];
+  f32x4_t o16[QW][PV16 ? ND16 : 1][2];            // PV16: [d block of 16][query half]: lane (q = 16 qh + lane % 16, d = 16 db + 4 (lane / 16) + j)
   float m_run[QW], l_run[QW];
 #pragma unroll
   for (int w = 0; w < QW; ++w) {
     m_run[w] = -INFINITY; l_run[w] = 0.f;
+    if constexpr (PV16) {
 #pragma unroll
-    for (int i = 0; i < NDB; ++i)
+      for (int i = 0; i < ND16; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) o[w][i][r] = 0.f;
+        for (int h = 0; h < 2; ++h) o16[w][i][h] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    } else {
+#pragma unroll
+      for (int i = 0; i < NDB; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[w][i][r] = 0.f;
+    }
   }
   const float sl2 = p.scale * 1.44269504088896340736f;    // softmax(x*scale) via exp2
 
@@ -300,6 +319,10 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_kernel(const AttnParams p) 
   const int i16 = lane & 15;
   LDS_AS const char* kl = (LDS_AS const char*)&sK[0][0] + (lq * LDR + 8 * lh) * 2;
   LDS_AS const char* vl = (LDS_AS const char*)&sV[0][0] + ((4 * lh + (i16 >> 2)) * LDV + 16 * ((lane >> 4) & 1) + (i16 & 3) * 4) * 2;
+  if constexpr (PV16) {
+    const int g4 = lane >> 4;                      // 8-key group of the 16x16x32 A operand: row base 16 (g & 1) + 4 (g >> 1) of the 32-key block
+    vl = (LDS_AS const char*)&sV[0][0] + ((16 * (g4 & 1) + 4 * (g4 >> 1) + (i16 >> 2)) * LDV + (i16 & 3) * 4) * 2;
+  }
   asm volatile("" : "+v"(kl), "+v"(vl));
   for (int t = 0; t < ntiles; ++t) {
     const int BUF = t & 1;
@@ -323,6 +346,15 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_kernel(const AttnParams p) 
     for (int i = 0; i < PD; ++i) kq[i] = rdk(i);
     // the first V^T fragments of this tile are fetched here as well: they land during the softmax
     auto rdv = [&](int i) -> f16x8 {             // step i -> (s4 = i / NDB, db = i % NDB)
+      if constexpr (PV16) {                      // step i -> (kb = i / ND16, db = i % ND16): V[32 kb + base(g) + {0..3, 8..11}][16 db + lane % 16]
+        const int kb = i / ND16, db = i - kb * ND16;
+        LDS_AS const char* vp = vlt + (32 * kb * LDV + db * 16) * 2;
+        const fp16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((LDS_AS fp16x4_t*)vp);
+        const fp16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((LDS_AS fp16x4_t*)(vp + 8 * LDV * 2));
+        union { fp16x4_t q[2]; f16x8 h; } vf;
+        vf.q[0] = lo; vf.q[1] = hi;
+        return vf.h;
+      }
       const int s4 = i / NDB, db = i - s4 * NDB;
 #if defined(GDF_ATTN_ABLATE) && (GDF_ATTN_ABLATE & 32)
       return qf[0][(s4 + db) % NS];                      // diagnostics: no V^T fragment reads
@@ -352,7 +384,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_kernel(const AttnParams p) 
       }
       if (i + PD < NQK) kq[i % PD] = rdk(i + PD);
     }
-    constexpr int NPV = 4 * NDB;                 // V^T fragments per tile
+    constexpr int NPV = PV16 ? 2 * ND16 : 4 * NDB;   // V^T fragments per tile
     f16x8 vq[PD];
 #pragma unroll
     for (int i = 0; i < PD; ++i) vq[i] = rdv(i);
@@ -405,7 +437,19 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_kernel(const AttnParams p) 
           pf[w][kb * 2 + (r >> 3)][r & 7] = h2[0];
           pf[w][kb * 2 + (r >> 3)][(r & 7) + 1] = h2[1];
         }
-      if (m_new != m_run[w]) {
+      if constexpr (PV16) {
+        // the accumulators of a lane belong to the queries lane % 16 (+ 16): their factors live in the even / odd lane row of the same column
+        if (__builtin_amdgcn_ballot_w64(m_new != m_run[w]) != 0) {
+          const float alpha = (m_new != m_run[w]) ? __builtin_amdgcn_exp2f(m_run[w] - m_new) : 1.0f;
+          l_run[w] *= alpha;
+          const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(alpha), __float_as_uint(alpha), false, false);
+          const float a0 = __uint_as_float(sw[0]), a1 = __uint_as_float(sw[1]);
+#pragma unroll
+          for (int i = 0; i < ND16; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { o16[w][i][0][r] *= a0; o16[w][i][1][r] *= a1; }
+        }
+      } else if (m_new != m_run[w]) {
         const float alpha = __builtin_amdgcn_exp2f(m_run[w] - m_new);   // raw v_exp_f32; first tile: exp2(-inf) = 0
         l_run[w] *= alpha;
 #pragma unroll
@@ -420,6 +464,35 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_kernel(const AttnParams p) 
     // ---- O^T += V^T P^T : 4 steps of 16 (relabelled) keys; every V^T fragment feeds QW query blocks ----
     GDF_AT(1);
     GDF_ATTN_PRIO_MFMA(1);
+    if constexpr (PV16) {
+      // P: S^T layout -> 16x16x32 B operands (one permlane16_swap per packed register pair, see the kernel's header comment)
+      f16x8 pa[QW][2], pb[QW][2];                // [key block of 32]: queries 0-15 / 16-31 of the wave's 32-query block
+#pragma unroll
+      for (int w = 0; w < QW; ++w)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+          typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+          const u32x4 x = __builtin_bit_cast(u32x4, pf[w][2 * kb]), y = __builtin_bit_cast(u32x4, pf[w][2 * kb + 1]);
+          u32x4 xa, ya;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const auto sw = __builtin_amdgcn_permlane16_swap(x[r], y[r], false, false);
+            xa[r] = sw[0]; ya[r] = sw[1];
+          }
+          pa[w][kb] = __builtin_bit_cast(f16x8, xa); pb[w][kb] = __builtin_bit_cast(f16x8, ya);
+        }
+#pragma unroll
+      for (int i = 0; i < NPV; ++i) {
+        const int kb = i / ND16, db = i - kb * ND16;
+        const f16x8 vf = vq[i % PD];
+#pragma unroll
+        for (int w = 0; w < QW; ++w) {
+          o16[w][db][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pa[w][kb], o16[w][db][0], 0, 0, 0);
+          o16[w][db][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pb[w][kb], o16[w][db][1], 0, 0, 0);
+        }
+        if (i + PD < NPV) vq[i % PD] = rdv(i + PD);
+      }
+    } else {
 #pragma unroll
     for (int i = 0; i < NPV; ++i) {
       const int s4 = i / NDB, db = i - s4 * NDB;
@@ -428,6 +501,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_kernel(const AttnParams p) 
       for (int w = 0; w < QW; ++w)
         o[w][db] = mfma32<BF>(vf, pf[w][s4], o[w][db]);
       if (i + PD < NPV) vq[i % PD] = rdv(i + PD);
+    }
     }
 
     GDF_ATTN_PRIO_MFMA(0);
@@ -457,7 +531,33 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_kernel(const AttnParams p) 
   // The accumulators hold O^T (lane = query column): stored directly, every lane would write 8 bytes into a different row.
   // Each wave transposes its QBW x D block through the (now idle) K / V staging memory instead, so that the global stores
   // are 16 bytes per lane and whole D-wide rows per group of D/8 lanes.
+  // PV16: a lane's accumulators belong to the queries lane % 16 (+ 16); their 1 / l lives in the even / odd lane row of the same column
+  float inv16[QW][2];
+  if constexpr (PV16) {
+#pragma unroll
+    for (int w = 0; w < QW; ++w) {
+      const float invq = (p.o_scale != 0.f ? p.o_scale : 1.0f) / half_sum(l_run[w]);
+      const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(invq), __float_as_uint(invq), false, false);
+      inv16[w][0] = __uint_as_float(sw[0]); inv16[w][1] = __uint_as_float(sw[1]);
+    }
+  }
   if constexpr (STG) if ((p.ldo & 7) == 0) {
+    if constexpr (PV16) {
+#pragma unroll
+      for (int w = 0; w < QW; ++w)
+#pragma unroll
+        for (int db = 0; db < ND16; ++db)
+#pragma unroll
+          for (int qh = 0; qh < 2; ++qh) {
+            const int d0 = db * 16 + 4 * (lane >> 4);
+            if (d0 < D) {
+              f16x4 hv;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) hv[e] = pbf ? pair_hi(o16[w][db][qh][e] * inv16[w][qh], true) : out16<BF>(o16[w][db][qh][e] * inv16[w][qh]);
+              *(f16x4*)(stg + (w * 32 + 16 * qh + i16) * RSH + d0) = hv;
+            }
+          }
+    } else {
 #pragma unroll
     for (int w = 0; w < QW; ++w) {
       const float inv = (p.o_scale != 0.f ? p.o_scale : 1.0f) / half_sum(l_run[w]);
@@ -474,6 +574,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_kernel(const AttnParams p) 
           }
         }
     }
+    }
     __builtin_amdgcn_wave_barrier();                            // same-wave LDS RAW across lanes: DS ops of one wave execute in order
 #pragma unroll
     for (int it = 0; it < (QBW + RPIO - 1) / RPIO; ++it) {
@@ -485,6 +586,22 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_kernel(const AttnParams p) 
     if (!BF && p.o_lo > 0) {
       // split operand for the out-projection of a "precise" plan: lo = fp16(O - fp16(O)), staged and stored like the hi half
       __builtin_amdgcn_wave_barrier();
+      if constexpr (PV16) {
+#pragma unroll
+        for (int w = 0; w < QW; ++w)
+#pragma unroll
+          for (int db = 0; db < ND16; ++db)
+#pragma unroll
+            for (int qh = 0; qh < 2; ++qh) {
+              const int d0 = db * 16 + 4 * (lane >> 4);
+              if (d0 < D) {
+                f16x4 lv;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) lv[e] = pair_lo(o16[w][db][qh][e] * inv16[w][qh], pbf);
+                *(f16x4*)(stg + (w * 32 + 16 * qh + i16) * RSH + d0) = lv;
+              }
+            }
+      } else {
 #pragma unroll
       for (int w = 0; w < QW; ++w) {
         const float inv = (p.o_scale != 0.f ? p.o_scale : 1.0f) / half_sum(l_run[w]);
@@ -501,6 +618,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_kernel(const AttnParams p) 
             }
           }
       }
+      }
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int it = 0; it < (QBW + RPIO - 1) / RPIO; ++it) {
@@ -511,6 +629,34 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_kernel(const AttnParams p) 
       }
     }
     GDF_AT_EXIT;
+    return;
+  }
+  if constexpr (PV16) {
+#pragma unroll
+    for (int w = 0; w < QW; ++w)
+#pragma unroll
+      for (int qh = 0; qh < 2; ++qh) {
+        const int qr = qb * QBLK + wave * QBW + w * 32 + 16 * qh + i16;       // query row of this lane's column
+        if (qr < p.Sq) {
+          _Float16* op = p.o + seg_row(b, qr, p.Sq, p.seg_T, p.B, p.Sq) * p.ldo + head * D;
+#pragma unroll
+          for (int db = 0; db < ND16; ++db) {
+            const int d0 = db * 16 + 4 * (lane >> 4);
+            if (d0 < D) {
+              f16x4 hv;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) hv[e] = pbf ? pair_hi(o16[w][db][qh][e] * inv16[w][qh], true) : out16<BF>(o16[w][db][qh][e] * inv16[w][qh]);
+              *(f16x4*)(op + d0) = hv;
+              if (p.o_lo > 0) {
+                f16x4 lv;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) lv[e] = pair_lo(o16[w][db][qh][e] * inv16[w][qh], pbf);
+                *(f16x4*)(op + d0 + p.o_lo) = lv;
+              }
+            }
+          }
+        }
+      }
     return;
   }
 #pragma unroll
@@ -985,6 +1131,19 @@ static hipError_t launch_d(const AttnParams& p, hipStream_t s) {
       return hipGetLastError();
     }
 #endif
+    // round 5: P V on mfma_f32_16x16x32_f16 where the 16-row padding of D is smaller than the 32-row one (40 / 72 / 80); GDF_ATTN_PV16=0 / 1: A/B switch
+    constexpr bool pv16c = !BF && ((D + 15) / 16 * 16 < (D + 31) / 32 * 32);
+    static const bool pv16 = [] { const char* e = getenv("GDF_ATTN_PV16"); return e ? atoi(e) != 0 : GDF_ATTN_PV16_DEFAULT; }();
+    if (pv16c && pv16) {
+      if (can2 && p.Sq >= 512 && 1.00 * fill(nb2, 512) >= 0.80 * fill(nb1, 512)) {
+        const int nqb = (p.Sq + 255) / 256;
+        hipLaunchKernelGGL((attn_kernel<D, can2 ? 2 : 1, 4, false, 2, pv16c>), dim3(p.B * p.heads * nqb), dim3(256), 0, s, p);
+      } else {
+        const int nqb = (p.Sq + 127) / 128;
+        hipLaunchKernelGGL((attn_kernel<D, 1, 4, false, 2, pv16c>), dim3(p.B * p.heads * nqb), dim3(256), 0, s, p);
+      }
+      return hipGetLastError();
+    }
     if (!BF && can2 && p.Sq >= 512 && 1.00 * fill(nb2, 512) >= 0.80 * fill(nb1, 512)) {
       const int nqb = (p.Sq + 255) / 256;
       hipLaunchKernelGGL((attn_kernel<D, can2 ? 2 : 1>), dim3(p.B * p.heads * nqb), dim3(256), 0, s, p);
