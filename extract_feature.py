@@ -79,15 +79,41 @@ def sample_name(path, nested):
 
 
 class HostWriter:
-    """Device -> pinned host -> .npy, one batch behind the GPU."""
+    """Device -> pinned host -> .npy, behind the GPU: the D2H copies run on a side stream, the np.save calls on a writer thread (round 5: the
+    main thread used to write the previous batch's files itself — 15.7 MB per SDXL image through single-threaded np.save — before it could
+    launch the next extract: 68 vs 74 img/s end to end).  At most `depth` batches are pending; flush() waits for all of them and re-raises
+    a writer error."""
 
-    def __init__(self, args):
+    def __init__(self, args, depth=2):
+        import queue
+        import threading
         self.args = args
-        self.pending = None
         self.stream = torch.cuda.Stream() if torch.cuda.is_available() else None
+        self.q = queue.Queue(maxsize=depth)
+        self.err = None
+        self.thread = threading.Thread(target=self._work, daemon=True)
+        self.thread.start()
+
+    def _work(self):
+        while True:
+            item = self.q.get()
+            try:
+                if item is None:
+                    return
+                if self.err is None:
+                    self._write(*item)
+            except BaseException as e:               # surfaced in the main thread by submit() / flush()
+                self.err = e
+            finally:
+                self.q.task_done()
+
+    def _check(self):
+        if self.err is not None:
+            e, self.err = self.err, None
+            raise e
 
     def submit(self, feats, names):
-        self.flush()
+        self._check()
         host = {}
         if self.stream is not None:
             self.stream.wait_stream(torch.cuda.current_stream())
@@ -119,13 +145,19 @@ class HostWriter:
                 rest = [v for v in seen if v.is_cuda]
             for v in rest:
                 v.record_stream(self.stream)
-        self.pending = (host, names, ev)
+        self.q.put((host, names, ev))                            # blocks while `depth` batches are still being written
 
     def flush(self):
-        if self.pending is None:
-            return
-        host, names, ev = self.pending
-        self.pending = None
+        self.q.join()
+        self._check()
+
+    def close(self):
+        self.q.join()
+        self.q.put(None)
+        self.thread.join()
+        self._check()
+
+    def _write(self, host, names, ev):
         if ev is not None:
             ev.synchronize()
         a = self.args
@@ -225,7 +257,7 @@ def main(argv=None):
             writer.submit(feats, names)
             if rank == 0:
                 print(f'{min(i + len(chunk), hi) - lo}/{hi - lo}', end='\r')
-    writer.flush()
+    writer.close()
     if world > 1:
         import torch.distributed as dist
         dist.barrier()

@@ -38,5 +38,6 @@ def run(nstreams, B):
     print(json.dumps(r), flush=True)
     del nets; torch.cuda.empty_cache()
 
-for ns, B in ((1, 16), (2, 8), (2, 16), (4, 4), (1, 32), (3, 8)):
+ap2 = [(1, 16), (2, 8), (2, 16), (4, 4), (1, 32), (3, 8)] if a.version == "xl" else [(1, 32), (2, 32), (2, 16), (3, 32), (1, 64)]
+for ns, B in ap2:
     run(ns, B)

@@ -312,7 +312,7 @@ def e2e_block(dev, version, B, img, practical_ids, steps=4):
             nbytes = sum(os.path.getsize(os.path.join(dp, f)) for dp, _, fs in os.walk(tmp) for f in fs)
             out["with_npy_output_images_per_s"] = round(B * steps / dtw, 2)
             out["npy_mb_per_image"] = round(nbytes / (B * (steps + 2)) / 1e6, 2)
-            out["npy_note"] = "extract_feature.HostWriter (pinned D2H on a side stream, np.save per layer and image to a tmpfs directory, one batch behind)"
+            out["npy_note"] = "extract_feature.HostWriter (pinned D2H on a side stream, np.save per layer and image to a tmpfs directory on a writer thread, at most two batches behind)"
         finally:
             shutil.rmtree(tmp, ignore_errors=True)
     del df
