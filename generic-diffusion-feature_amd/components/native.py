@@ -177,7 +177,10 @@ def arch_family(cfg):
     return None
 
 
-def choose_split(cfg, hook_ids):
+RES_EXPONENT = 0.13      # error ~ (table resolution / resolution)^0.13 below the table's resolution (see choose_split)
+
+
+def choose_split(cfg, hook_ids, lat=None):
     """The cheapest operand-class mask under which every requested hook stays within BASELINE.json's 1e-3 of the fp32 reference:
     0 (plain fp16 operands) -> SPLIT_LIGHT -> the architecture's selective preset -> SPLIT_ALL.  Decided from components/operand_error_table.json (per-hook
     error of the CPU oracle with exactly the plan's operand classes rounded to fp16, tools/operand_subsets.py): a level is accepted when
@@ -196,6 +199,16 @@ def choose_split(cfg, hook_ids):
             _ERR_TABLE = {}
     tab = _ERR_TABLE.get(fam, {}).get("hooks") if fam else None
     sel = SELECTIVE_BY_ARCH.get(fam, SPLIT_SELECTIVE)
+    # The table was emulated at the BASELINE resolution (latent 128 for the SDXL family, 64 for SD1.5).  Smaller grids average the operand
+    # rounding over fewer elements: measured on hardware (tests/test_gpu_fullsize.py ragged-shape test) the selective plan's worst hook goes
+    # 8.2e-4 -> 9.1e-4 from 1024^2 to 448^2 (x 1.11 for 2.29x fewer rows per side), the plain plan's median 7.8e-4 -> 8.2e-4: the table values are
+    # scaled by (table lat / lat)^0.13 when the call's latent grid is smaller (never down-scaled for larger grids).
+    scale = 1.0
+    if lat and fam:
+        lat_t = float(_ERR_TABLE.get(fam, {}).get("lat", 0) or 0)
+        if lat_t > 0 and lat < lat_t:
+            scale = (lat_t / float(lat)) ** RES_EXPONENT
+    bound = AUTO_BOUND / scale
     level = 0                                            # 0 plain, 1 light, 2 selective, 3 full
     for h in ids:
         if h.endswith("-map"):
@@ -208,12 +221,12 @@ def choose_split(cfg, hook_ids):
             risky = h.endswith(("ffn-inner", "unet-out", "-q", "-k", "-v")) or (fam != "xl" and h.endswith(("-out", "res-increment")))
             level = max(level, 2 if risky else 0)
             continue
-        if row[0] <= AUTO_BOUND:
+        if row[0] <= bound:
             continue
-        if len(row) > 2 and row[2] <= AUTO_BOUND:        # columns: plain, selective, light
+        if len(row) > 2 and row[2] <= bound:             # columns: plain, selective, light
             level = max(level, 1)
             continue
-        level = max(level, 2 if row[1] <= AUTO_BOUND else 3)
+        level = max(level, 2 if row[1] <= bound else 3)
         if level == 3:
             break
     return (0, SPLIT_LIGHT, sel, SPLIT_ALL)[level]
@@ -773,13 +786,13 @@ class NativeUNet(_NativeModel):
         self.split = 0 if self.auto_split else split_mask(spec)
         return self
 
-    def split_for(self, hook_ids):
+    def split_for(self, hook_ids, lat=None):
         if getattr(self, "auto_split", False):
             # (split plans need the fp32 master of the stream: the opt-out fp16-stream mode keeps plain operands)
             if not self.stream_fp32:
                 return 0
             esc = self._escalated.get(tuple(hook_ids))
-            return esc if esc is not None else choose_split(self.cfg, hook_ids)
+            return esc if esc is not None else choose_split(self.cfg, hook_ids, lat)
         return self.split
 
     def _verify_level(self, run, ids, out):
@@ -829,7 +842,7 @@ class NativeUNet(_NativeModel):
 
     # ---- plans ------------------------------------------------------------------------------------
     def _plan(self, batch, h, w, n_ctx, hook_ids, shared_ctx=False, split=None):
-        split = self.split_for(hook_ids) if split is None else split
+        split = self.split_for(hook_ids, lat=min(h, w)) if split is None else split
         key = (batch, h, w, n_ctx, tuple(hook_ids), self.stream_fp32, self.early_exit, bool(shared_ctx), split, self.cus)
         p = self._plans.get(key)
         if p is None:
@@ -873,7 +886,7 @@ class NativeUNet(_NativeModel):
         if ctx.shape[0] != B or ctx.shape[2] != self.cfg["cross_attention_dim"]:
             raise ValueError("encoder_hidden_states shape mismatch")
         ids = list(hook_ids) if hook_ids is not None else self.requested_ids()
-        self.last_split = self.split_for(ids)
+        self.last_split = self.split_for(ids, lat=min(H, W))
         plan = self._plan(B, H, W, ctx.shape[1], ids, shared_ctx, self.last_split)
         f16, f32 = torch.float16, torch.float32
         call = self._launch(plan, self.lib.gdf_forward, self.lib.gdf_plan_profile, "forward", profile)

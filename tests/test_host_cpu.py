@@ -379,6 +379,16 @@ def test_operand_plan_selection_table_and_masks():
     assert N.choose_split(N.ARCH_CONFIGS["1-5"], bench.PRACTICAL["1-5"]) == N.SPLIT_LIGHT == N.SPLIT_CLASSES["gnv"]
     assert N.choose_split(N.ARCH_CONFIGS["1-5"], bench.PRACTICAL["1-5"][:3]) == 0
     assert N.AUTO_BOUND <= 9.3e-4
+    # the table is emulated at the BASELINE resolution; smaller latent grids average the rounding over fewer elements (measured x 1.11 from 1024^2 to
+    # 448^2): the chooser scales the table by (table lat / lat)^0.13 there, so a hook near the bound climbs a level at low resolution and never drops one
+    near = [h for h, r in tab["xl"]["hooks"].items() if 8.8e-4 <= r[0] <= N.AUTO_BOUND]
+    assert near and all(N.choose_split(N.ARCH_CONFIGS["xl"], [h], lat=128) == 0 for h in near)
+    assert all(N.choose_split(N.ARCH_CONFIGS["xl"], [h], lat=32) != 0 for h in near)
+    assert N.choose_split(N.ARCH_CONFIGS["xl"], bench.PRACTICAL["xl"], lat=256) == N.choose_split(N.ARCH_CONFIGS["xl"], bench.PRACTICAL["xl"], lat=128) == 0
+    for ids in (bench.PRACTICAL["xl"], near[:3], ["unet-out"]):
+        lv = [N.choose_split(N.ARCH_CONFIGS["xl"], ids, lat=l) for l in (128, 96, 64, 32, 16)]
+        order = {0: 0, N.SPLIT_LIGHT: 1, N.SELECTIVE_BY_ARCH["xl"]: 2, N.SPLIT_ALL: 3}
+        assert [order[x] for x in lv] == sorted(order[x] for x in lv), lv               # monotone: never a cheaper level at a smaller grid
     worst_xl = max(tab["xl"]["hooks"], key=lambda h: tab["xl"]["hooks"][h][0])
     assert worst_xl.endswith("ffn-inner") and tab["xl"]["hooks"][worst_xl][0] > 1e-3 > tab["xl"]["hooks"][worst_xl][1]
     assert N.choose_split(N.ARCH_CONFIGS["xl"], [worst_xl]) == N.SELECTIVE_BY_ARCH["xl"]
