@@ -180,6 +180,28 @@ def arch_family(cfg):
 RES_EXPONENT = 0.13      # error ~ (table resolution / resolution)^0.13 below the table's resolution (see choose_split)
 
 
+def table_scale(cfg, lat=None):
+    """Factor applied to the operand-error table for THIS model and latent grid (>= 1; choose_split compares table x factor with AUTO_BOUND)."""
+    global _ERR_TABLE
+    fam = arch_family(cfg)
+    if _ERR_TABLE is None:
+        import json
+        try:
+            _ERR_TABLE = json.load(open(os.path.join(_HERE, "operand_error_table.json")))
+        except Exception:
+            _ERR_TABLE = {}
+    scale = 1.0
+    if fam == "1-5" and (tuple(cfg.get("heads", ())) != (8, 8, 8, 8) or cfg.get("cross_attention_dim") != 768):
+        # SD2.1-base borrows the SD1.5 table (same topology, 64-wide heads, linear projections, cross dim 1024): measured at true widths its hooks
+        # sit up to 7.8 % above the table where SD1.5's own sit 4.5 % above (tests/test_gpu_fullsize.py::test_sd21_512_plan_levels_borrow_the_sd15_table)
+        scale = 1.04
+    if lat and fam:
+        lat_t = float(_ERR_TABLE.get(fam, {}).get("lat", 0) or 0)
+        if lat_t > 0 and lat < lat_t:
+            scale *= (lat_t / float(lat)) ** RES_EXPONENT
+    return scale
+
+
 def choose_split(cfg, hook_ids, lat=None):
     """The cheapest operand-class mask under which every requested hook stays within BASELINE.json's 1e-3 of the fp32 reference:
     0 (plain fp16 operands) -> SPLIT_LIGHT -> the architecture's selective preset -> SPLIT_ALL.  Decided from components/operand_error_table.json (per-hook
@@ -203,11 +225,7 @@ def choose_split(cfg, hook_ids, lat=None):
     # rounding over fewer elements: measured on hardware (tests/test_gpu_fullsize.py ragged-shape test) the selective plan's worst hook goes
     # 8.2e-4 -> 9.1e-4 from 1024^2 to 448^2 (x 1.11 for 2.29x fewer rows per side), the plain plan's median 7.8e-4 -> 8.2e-4: the table values are
     # scaled by (table lat / lat)^0.13 when the call's latent grid is smaller (never down-scaled for larger grids).
-    scale = 1.0
-    if lat and fam:
-        lat_t = float(_ERR_TABLE.get(fam, {}).get("lat", 0) or 0)
-        if lat_t > 0 and lat < lat_t:
-            scale = (lat_t / float(lat)) ** RES_EXPONENT
+    scale = table_scale(cfg, lat)
     bound = AUTO_BOUND / scale
     level = 0                                            # 0 plain, 1 light, 2 selective, 3 full
     for h in ids:
