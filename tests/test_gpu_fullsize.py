@@ -90,7 +90,7 @@ def _check(errs, floor, bound, floor_mult=1.15, floor_abs=2e-5):
     assert not bad, bad[:10]
 
 
-def _plain_plan_contract(fam, arch, errs, tag, level_mask=0):
+def _plain_plan_contract(fam, arch, errs, tag, level_mask=0, product=True):
     """the automatic chooser hands a hook to the plan level `level_mask` (0 = the PLAIN plan, SPLIT_LIGHT = only the `gnv`
     class split) when its emulated error under that level (components/operand_error_table.json) is <= AUTO_BOUND.  `errs` = measured error of
     every hook under that level on hardware.  Asserted: EVERY hook h with choose_split([h]) == level_mask — i.e. every hook a user may request
@@ -100,7 +100,7 @@ def _plain_plan_contract(fam, arch, errs, tag, level_mask=0):
     from components.native import choose_split, table_scale, _HERE
     import components.native as _N
     cfg = cfg_from_oracle_arch(arch)
-    AUTO_BOUND = _N.AUTO_BOUND / table_scale(cfg)          # the bound this MODEL's table values are compared with (SD2.1 borrows SD1.5's table x 1.04)
+    AUTO_BOUND = _N.auto_bound(cfg) / table_scale(cfg)          # the bound this MODEL's table values are compared with (SD2.1 borrows SD1.5's table x 1.04)
     table = json.load(open(os.path.join(_HERE, "operand_error_table.json")))[fam]["hooks"]
     col = 0 if level_mask == 0 else 2
     accepted = [h for h in errs if not h.endswith("-map") and choose_split(cfg, [h]) == level_mask]
@@ -116,7 +116,9 @@ def _plain_plan_contract(fam, arch, errs, tag, level_mask=0):
         json.dump({"errs": errs, "accepted": accepted, "auto_bound": AUTO_BOUND}, open(os.path.join(dump, f"plan_level_{level_mask}_errs_{tag}.json"), "w"))
     bad = [(h, errs[h]) for h in accepted if not errs[h] <= 0.97e-3]
     assert not bad, sorted(bad, key=lambda kv: -kv[1])[:10]
-    assert AUTO_BOUND * max(ratio.values()) <= 0.97e-3, (AUTO_BOUND, max(ratio.values()))       # the bound leaves >= 3 % to 1e-3 at the measured offset
+    # on the table's own kind of inputs: the bound leaves >= 3 % to 1e-3 even if the worst offset met the largest accepted table value
+    # (product=False: inputs chosen to differ from the table's, where the per-hook assertion above is the contract and the offsets are what is being measured)
+    assert not product or AUTO_BOUND * max(ratio.values()) <= 0.97e-3, (AUTO_BOUND, max(ratio.values()))
 
 
 def _light_level_errs(arch, P, run, ref, ids):
@@ -644,3 +646,29 @@ def test_sd21_512_plan_levels_borrow_the_sd15_table():
     ev = sorted(errs_a.values())
     print(f"[sd2.1 512^2 B=2 AUTO -> selective split] median {ev[len(ev) // 2]:.2e} worst {ev[-1]:.2e}")
     _check(errs_a, None, lambda kd: 1.0e-3)
+
+
+def test_sdxl_plan_level_contract_on_other_inputs():
+    """The operand-error table was emulated on ONE seeded sample / prompt at t = 100.  The per-hook contract of the plain and light levels
+    (_plain_plan_contract) on DIFFERENT inputs: two other samples with two other prompts at t = 500, true SDXL 1024^2, B = 2."""
+    _threads()
+    from components.native import SPLIT_LIGHT
+    arch = R.ARCHS["xl"]
+    P = R.synth_params(arch, seed=0)
+    I = R.synth_inputs(arch, 2, 128, seed=23, same_prompt=False)
+    I["timestep"] = torch.tensor([500.0])
+    ids = [i for i in R.stored_hook_ids(arch) if not i.endswith("-map")]
+    ref = _oracle(arch, P, I, ids)
+    g = lambda k: I[k].cuda()
+    run = lambda u: u.forward_raw(g("sample"), g("timestep"), g("ctx"), g("text_embeds"), g("time_ids"), hook_ids=ids)[1]
+    u = _native(arch, P)
+    hooks = run(u)
+    torch.cuda.synchronize()
+    errs = {k: max(_rel_each(hooks[k], ref[k])) for k in ids}
+    ev = sorted(errs.values())
+    print(f"\n[sdxl 1024^2 B=2, other samples / prompts, t=500, plain] median {ev[len(ev) // 2]:.2e} worst {ev[-1]:.2e}; below 1e-3: {sum(e < 1e-3 for e in ev)}")
+    del hooks, u
+    torch.cuda.empty_cache()
+    _plain_plan_contract("xl", arch, errs, "sdxl_b2_other_inputs", product=False)
+    errs_l = _light_level_errs(arch, P, run, ref, ids)
+    _plain_plan_contract("xl", arch, errs_l, "sdxl_b2_other_inputs", SPLIT_LIGHT, product=False)
