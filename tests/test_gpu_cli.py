@@ -88,3 +88,32 @@ def test_output_stage_matches_reference_files_on_gpu(tmp_path):
     from test_host_cpu import _run_output_stage, check_output_stage
     got, want = _run_output_stage(tmp_path, "cuda")
     check_output_stage(got, want)
+
+
+def test_cli_loader_threads_equal_the_serial_input_loop(tmp_path, monkeypatch):
+    """Round 5: the CLI decodes / resizes / normalises the next batches on loader threads (extract_feature.BatchLoader) while the GPU works; the
+    threads run FeatureExtractor.preprocess_image — the serial path's own function — so `--loader_threads 0` (the reference's serial loop) and the
+    default give byte-identical files.  Five images, batch 2: a ragged last batch and more batches than the prefetch depth."""
+    monkeypatch.setenv("GDF_SYNTHETIC_WEIGHTS", "1")
+    sys.path.insert(0, ROOT)
+    import extract_feature as cli
+    from PIL import Image
+    layers = _setup(tmp_path)
+    rs = np.random.RandomState(3)
+    for n in ("d", "e"):
+        Image.fromarray((rs.rand(150, 130, 3) * 255).astype(np.uint8)).save(tmp_path / "imgs" / f"{n}.png")
+    base = ["--layer", str(tmp_path / "layers.json"), "--version", "1-5", "--img_size", "256", "--t", "100", "-b", "2",
+            "--input_dir", str(tmp_path / "imgs" / "*.png"), "--prompt_file", str(tmp_path / "prompt.txt")]
+    cli.main(base + ["--output_dir", str(tmp_path / "serial"), "--loader_threads", "0"])
+    cli.main(base + ["--output_dir", str(tmp_path / "threads")])
+    cli.main(base + ["--output_dir", str(tmp_path / "one"), "--loader_threads", "1"])
+    for k in layers:
+        for i in range(5):
+            a = np.load(tmp_path / "serial" / k / f"train{i}.npy")
+            for other in ("threads", "one"):
+                b = np.load(tmp_path / other / k / f"train{i}.npy")
+                assert a.dtype == b.dtype and np.array_equal(a.view(np.uint16), b.view(np.uint16)), (k, i, other)
+    # a file that cannot be decoded surfaces as an error of the batch it belongs to, not as a hang
+    (tmp_path / "imgs" / "zz_broken.png").write_bytes(b"not an image")
+    with pytest.raises(Exception):
+        cli.main(base + ["--output_dir", str(tmp_path / "bad")])

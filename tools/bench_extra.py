@@ -315,6 +315,55 @@ def e2e_block(dev, version, B, img, practical_ids, steps=4):
             out["npy_note"] = "extract_feature.HostWriter (pinned D2H on a side stream, np.save per layer and image to a tmpfs directory on a writer thread, at most two batches behind)"
         finally:
             shutil.rmtree(tmp, ignore_errors=True)
+        # the CLI's WHOLE loop from image files: JPEG decode + resize + normalise (host) -> VAE encode + UNet + hooks -> D2H -> .npy, with the
+        # reference's serial input side (load the batch, then extract) and with the loader threads of round 5 (extract_feature.BatchLoader)
+        try:
+            out["cli_from_jpeg_files"] = _cli_from_files(df, prompts, B, img, cli, argparse)
+        except Exception as e:
+            out["cli_from_jpeg_files"] = {"error": repr(e)[:200]}
     del df
     torch.cuda.empty_cache()
     return out
+
+
+def _cli_from_files(df, prompts, B, img, cli, argparse, n_images=64):
+    import glob
+    import numpy as np
+    from PIL import Image
+    tmp = tempfile.mkdtemp(prefix="gdf_cli_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        rs = np.random.RandomState(0)
+        base = (rs.rand(160, 160, 3) * 255).astype(np.uint8)
+        for i in range(n_images):
+            Image.fromarray(np.roll(base, i, 0)).resize((1280, 960), Image.BICUBIC).save(os.path.join(tmp, f"img{i:04d}.jpg"), quality=92)
+        paths = sorted(glob.glob(os.path.join(tmp, "*.jpg")))
+        threads = min(16, os.cpu_count() or 1)
+
+        def run(thr, tag):
+            w = cli.HostWriter(argparse.Namespace(output_dir=os.path.join(tmp, tag), aggregate_output=False, sample_name_first=False))
+            starts = list(range(0, len(paths), B))
+            loader = cli.BatchLoader(paths, starts, len(paths), B, df.preprocess_image, thr) if thr > 0 else None
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            with torch.no_grad():
+                for i in starts:
+                    chunk = paths[i:i + B]
+                    if loader is not None:
+                        feats = df.extract(prompts, len(chunk), loader.get(i), image_type="tensors", t=100)
+                        loader.done(i)
+                    else:
+                        feats = df.extract(prompts, len(chunk), [Image.open(p) for p in chunk], t=100)
+                    w.submit(feats, [f"train{i + j}" for j in range(len(chunk))])
+                    del feats
+            if loader is not None:
+                loader.close()
+            w.close(); torch.cuda.synchronize()
+            return time.perf_counter() - t0
+        run(threads, "warm")
+        dt_t = run(threads, "thr")
+        dt_s = run(0, "ser")
+        return {"images": n_images, "source": "1280x960 JPEG q92 files on tmpfs, resized to %dx%d" % (img, img), "host_cpus": os.cpu_count(),
+                "loader_threads": threads, "images_per_s": round(n_images / dt_t, 2), "serial_input_loop_images_per_s": round(n_images / dt_s, 2),
+                "note": "extract_feature.py's loop: BatchLoader (decode / resize / normalise on threads, pinned fp16 batch buffers) -> FeatureExtractor.extract -> "
+                        "HostWriter (pinned D2H, np.save on threads); `serial_input_loop` = the reference's order (load the batch, then extract), same files bit for bit"}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
