@@ -52,7 +52,9 @@ try:
         return dt, files
 
     run(0 if a.images <= 32 else a.threads)          # warm-up: plans, graphs, pinned pools
+    os.environ["GDF_PREPROCESS_THREADS"] = "0"               # the reference's loop: one image after the other, then the GPU
     dt0, f0 = run(0)
+    os.environ.pop("GDF_PREPROCESS_THREADS")
     dt1, f1 = run(a.threads)
     same = len(f0) == len(f1) and all(np.array_equal(np.load(x).view(np.uint16), np.load(y).view(np.uint16)) for x, y in zip(f0[::7], f1[::7]))
     out.update({"serial_input_images_per_s": round(a.images / dt0, 2), "loader_threads": a.threads, "loader_threads_images_per_s": round(a.images / dt1, 2),

@@ -360,7 +360,15 @@ def _cli_from_files(df, prompts, B, img, cli, argparse, n_images=64):
             return time.perf_counter() - t0
         run(threads, "warm")
         dt_t = run(threads, "thr")
-        dt_s = run(0, "ser")
+        old_env = os.environ.get("GDF_PREPROCESS_THREADS")
+        os.environ["GDF_PREPROCESS_THREADS"] = "0"             # the reference's loop: one image after the other, then the GPU
+        try:
+            dt_s = run(0, "ser")
+        finally:
+            if old_env is None:
+                os.environ.pop("GDF_PREPROCESS_THREADS", None)
+            else:
+                os.environ["GDF_PREPROCESS_THREADS"] = old_env
         return {"images": n_images, "source": "1280x960 JPEG q92 files on tmpfs, resized to %dx%d" % (img, img), "host_cpus": os.cpu_count(),
                 "loader_threads": threads, "images_per_s": round(n_images / dt_t, 2), "serial_input_loop_images_per_s": round(n_images / dt_s, 2),
                 "note": "extract_feature.py's loop: BatchLoader (decode / resize / normalise on threads, pinned fp16 batch buffers) -> FeatureExtractor.extract -> "
