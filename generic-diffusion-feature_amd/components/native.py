@@ -608,6 +608,27 @@ class _Plan:
         return out, feats, ret
 
 
+_T_CACHE = {}
+
+
+def _timestep_on_device(timestep, B, dev):
+    """(B,) float32 device tensor of the timestep(s).  A HOST timestep (number / CPU tensor: what FeatureExtractor passes since round 5) is
+    looked up in a small cache of device constants — a pageable host -> device copy is stream ordered and would block the host until the
+    previous forward has finished; a device tensor is used as it is."""
+    if torch.is_tensor(timestep) and timestep.is_cuda:
+        t = timestep.to(dev).float().reshape(-1)
+        return t.expand(B) if t.numel() == 1 else t
+    vals = tuple(float(v) for v in torch.as_tensor(timestep).reshape(-1).tolist())
+    key = (vals, B, str(dev))
+    t = _T_CACHE.get(key)
+    if t is None:
+        if len(_T_CACHE) > 256:
+            _T_CACHE.clear()
+        t = torch.tensor(vals, dtype=torch.float32, device=dev)
+        t = _T_CACHE[key] = (t.expand(B) if t.numel() == 1 else t).contiguous()
+    return t
+
+
 class _NativeModel:
     """Shared surface of the libgdf model wrappers: weights in / hook names out (include/gdf.h model functions)."""
 
@@ -899,9 +920,7 @@ class NativeUNet(_NativeModel):
         dev = self.device
         B, _, H, W = sample.shape
         ctx = encoder_hidden_states
-        t = torch.as_tensor(timestep, device=dev).float().reshape(-1)
-        if t.numel() == 1:
-            t = t.expand(B)
+        t = _timestep_on_device(timestep, B, dev)
         txt = tid = None
         if self.cfg["addition_embed_text_time"]:
             if text_embeds is None or time_ids is None:
@@ -1102,8 +1121,7 @@ class NativeFluxTransformer(_NativeModel):
                 raise ValueError(f"{S} image tokens do not form a square grid; pass grid=(h, w)")
             grid = (g, g)
         x, enc, pooled = hidden_states, encoder_hidden_states, pooled_projections
-        t = torch.as_tensor(timestep, device=dev).float().reshape(-1)
-        t = t.expand(B) if t.numel() == 1 else t
+        t = _timestep_on_device(timestep, B, dev)
         gd = None
         if self.cfg["guidance_embeds"]:
             if guidance is None:
@@ -1400,8 +1418,7 @@ class NativePixArtTransformer(_NativeModel):
         dev = self.device
         B, cin, H, W = hidden_states.shape
         x, enc = hidden_states, encoder_hidden_states
-        t = torch.as_tensor(timestep, device=dev).float().reshape(-1)
-        t = t.expand(B) if t.numel() == 1 else t
+        t = _timestep_on_device(timestep, B, dev)
         T = enc.shape[1]
         if cin != self.cfg["in_channels"] or tuple(enc.shape) != (B, T, self.cfg["caption_channels"]):
             raise ValueError("pixart input shape mismatch")

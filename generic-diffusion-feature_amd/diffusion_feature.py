@@ -204,19 +204,27 @@ class FeatureExtractor(nn.Module):
             if pooled is not None:
                 pooled = pooled.repeat(batch_size, 1, 1).squeeze(1)                      # :275
 
-        # timestep selection through the scheduler, as the reference does (:288-295)
+        # timestep selection through the scheduler, as the reference does (:288-295) — but the scheduler's bookkeeping stays on the HOST
+        # (round 5).  With the timestep table on the device (the reference passes device=device) every `int(t)` / `index_for_timestep` /
+        # `sigmas[i]` of the scheduler is a device -> host read that waits for the GPU work queued before it: extract() spent 214 of its
+        # 225 ms blocked (tools/profile_extract_host.py) and could not queue the UNet behind the VAE.  The values are the same integers.
         self.pipe.scheduler = copy.deepcopy(self.scheduler_backup)
-        self.pipe.scheduler.set_timesteps(1000, device=device)
-        timesteps, _ = self.pipe.get_timesteps(1000, t / 1000, device)
+        self.pipe.scheduler.set_timesteps(1000, device='cpu')
+        timesteps, _ = self.pipe.get_timesteps(1000, t / 1000, 'cpu')
         latent_timestep = timesteps[:1].repeat(batch_size)
         t = timesteps[:1]
 
         added_cond_kwargs = {}
         if self.version in ('xl', 'pgv2'):                                               # :324-354
-            add_time_ids = _get_add_time_ids(self.pipe, (self.img_size, self.img_size), (0, 0),
-                                             (self.img_size, self.img_size), dtype=prompt_embeds.dtype)
-            added_cond_kwargs = {"text_embeds": pooled.to(device),
-                                 "time_ids": add_time_ids.to(device).repeat(batch_size, 1)}
+            # (cached on the device per batch size: a pageable host -> device copy is stream ordered, i.e. it blocks the host until the
+            #  previous forward has finished)
+            key = (self.img_size, batch_size, str(prompt_embeds.dtype), str(device))
+            cache = self.__dict__.setdefault('_time_ids_cache', {})
+            if key not in cache:
+                add_time_ids = _get_add_time_ids(self.pipe, (self.img_size, self.img_size), (0, 0),
+                                                 (self.img_size, self.img_size), dtype=prompt_embeds.dtype)
+                cache[key] = add_time_ids.to(device).repeat(batch_size, 1)
+            added_cond_kwargs = {"text_embeds": pooled.to(device), "time_ids": cache[key]}
 
         if image_type == 'latents':
             latents = image.to(device)
