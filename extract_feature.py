@@ -191,7 +191,7 @@ class BatchLoader:
     FeatureExtractor.preprocess_image per image: 20-45 ms of host time per 1024^2 JPEG, 0.3-0.7 s per batch of 16 against 0.22 s of GPU work — the
     reference's serial loop, and this CLI until round 5, leave the GPU idle for it).  get(i) returns the (B, 3, S, S) tensor of the batch that
     starts at image i, in order; exceptions of a worker surface there.
-    With a GPU the workers write fp16 straight into one of `depth + 1` rotating PINNED batch buffers (the VAE stage consumes fp16; the serial path's
+    With a GPU the workers write fp16 straight into one of `depth + 2` rotating PINNED batch buffers (the VAE stage consumes fp16; the serial path's
     `copy_` performs the same round-to-nearest conversion), so the upload is one asynchronous DMA instead of a pageable fp32 copy; done(i) records the
     event after which batch i's buffer may be overwritten."""
 
@@ -202,7 +202,10 @@ class BatchLoader:
         import threading
         self.lock = threading.Lock()
         self.pinned = torch.cuda.is_available()
-        self.bufs, self.events, self.slot_of = [None] * (depth + 1), [None] * (depth + 1), {}
+        # depth + 2 buffers: the batch submitted during get(i) reuses the buffer of batch i - 2, whose forward has long finished (with depth + 1
+        # it would be batch i - 1's, i.e. the forward that has just been queued: the main thread would wait for it)
+        self.nbuf = depth + 2
+        self.bufs, self.events, self.slot_of = [None] * self.nbuf, [None] * self.nbuf, {}
         self.futs = {}
         self.next = 0
         for _ in range(depth):
@@ -228,9 +231,9 @@ class BatchLoader:
             k = self.next
             i = self.starts[k]
             self.next += 1
-            slot = k % (self.depth + 1) if self.pinned else None
+            slot = k % self.nbuf if self.pinned else None
             if slot is not None and self.events[slot] is not None:
-                self.events[slot].synchronize()                     # the upload of the batch that used this buffer three batches ago has finished
+                self.events[slot].synchronize()                     # the batch that used this buffer (depth + 2 batches ago) has been consumed
             self.slot_of[i] = slot
             self.futs[i] = [self.pool.submit(self._one, p, slot, j) for j, p in enumerate(self.paths[i:min(i + self.bs, self.hi)])]
 
