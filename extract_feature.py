@@ -69,7 +69,7 @@ def parse_args(argv=None):
                    help='native extension (not in the reference CLI): stop the denoiser forward after the last requested layer (same files, less work)')
     p.add_argument('--loader_threads', type=int, default=-1,
                    help='native extension (not in the reference CLI): threads that decode + resize + normalise the NEXT batches while the GPU works on the current '
-                        'one (PIL and numpy release the GIL).  -1 = min(16, host CPUs); 0 = the reference\'s serial loop (load, then extract)')
+                        'one (PIL and numpy release the GIL).  -1 = min(32, half of this rank\'s share of the host CPUs); 0 = the reference\'s serial loop (load, then extract)')
     p.add_argument('--gpus', type=int, default=1,
                    help='native extension (not in the reference CLI): data-parallel over N GPUs of this node.  Started as a plain process '
                         '(`python3 extract_feature.py --gpus 8 ...`) the script starts its N ranks itself; under torchrun it must equal WORLD_SIZE')
@@ -324,7 +324,9 @@ def main(argv=None):
 
     writer = HostWriter(args)
     starts = list(range(lo, hi, args.batch_size))
-    n_thr = min(16, os.cpu_count() or 1) if args.loader_threads < 0 else args.loader_threads
+    # default: up to 32 loader threads, but never more than half of this rank's share of the host CPUs (8 ranks on a 256-CPU node: 16 each)
+    ranks_here = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1") or 1))
+    n_thr = min(32, max(2, (os.cpu_count() or 2) // (2 * ranks_here))) if args.loader_threads < 0 else args.loader_threads
     # flux / hunyuan pipelines take PIL images (reference :246-254); the UNet / PixArt versions go through df.preprocess_image, which is what the
     # loader threads run — the SAME function the serial path calls, so the latents are bit-identical either way
     prefetch = n_thr > 0 and args.version not in ('flux', 'hunyuan') and not args.show_all_layers
