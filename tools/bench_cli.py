@@ -14,7 +14,9 @@ import extract_feature as cli
 from PIL import Image
 
 ap = argparse.ArgumentParser(); ap.add_argument("--images", type=int, default=96); ap.add_argument("--threads", type=int, default=min(16, os.cpu_count() or 1))
-ap.add_argument("--batch", type=int, default=16); ap.add_argument("--src", type=int, default=1280, help="side of the source JPEGs (resized to 1024)")
+ap.add_argument("--batch", type=int, default=16); ap.add_argument("--src", type=int, default=1280, help="side of the source JPEGs (resized to --img)")
+ap.add_argument("--version", default="xl"); ap.add_argument("--img", type=int, default=0)
+ap.add_argument("--no-write", action="store_true", help="diagnostics: drop the features instead of handing them to HostWriter")
 a = ap.parse_args()
 tmp = tempfile.mkdtemp(prefix="gdf_cli_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
 try:
@@ -24,10 +26,12 @@ try:
         im = Image.fromarray(np.roll(base, i, 0)).resize((a.src, int(a.src * 0.75)), Image.BICUBIC)
         im.save(os.path.join(tmp, f"img{i:04d}.jpg"), quality=92)
     paths = sorted(glob.glob(os.path.join(tmp, "*.jpg")))
-    ids = ["up-level0-repeat0-vit-block7-out", "up-level0-repeat0-vit-block5-out", "up-level1-repeat0-vit-block0-cross-q", "up-level1-repeat0-vit-block0-out"]
-    df = diffusion_feature.FeatureExtractor({k: True for k in ids}, "xl", device="cuda:0", img_size=1024)
+    import bench as BB
+    ids = BB.PRACTICAL[a.version]
+    img_size = a.img or (1024 if a.version == "xl" else 512)
+    df = diffusion_feature.FeatureExtractor({k: True for k in ids}, a.version, device="cuda:0", img_size=img_size)
     prompts = df.encode_prompt("a photo of a cat")
-    out = {"images": a.images, "batch": a.batch, "source": f"{a.src}x{int(a.src * 0.75)} JPEG q92", "host_cpus": os.cpu_count()}
+    out = {"version": a.version, "img_size": img_size, "images": a.images, "batch": a.batch, "source": f"{a.src}x{int(a.src * 0.75)} JPEG q92", "host_cpus": os.cpu_count()}
 
     def run(threads):
         odir = os.path.join(tmp, f"out{threads}")
@@ -43,7 +47,9 @@ try:
                     loader.done(i)
                 else:
                     feats = df.extract(prompts, len(chunk), [Image.open(p) for p in chunk], t=100)
-                w.submit(feats, [f"train{i + j}" for j in range(len(chunk))])
+                if not a.no_write:
+                    w.submit(feats, [f"train{i + j}" for j in range(len(chunk))])
+                del feats
         if loader is not None:
             loader.close()
         w.close(); torch.cuda.synchronize()
