@@ -182,7 +182,7 @@ class FeatureExtractor(nn.Module):
             if stock:
                 tr.single_forward = True
             try:
-                self.pipe(image=[i.resize((self.img_size, self.img_size)).convert("RGB") for i in image],
+                self.pipe(image=_map_threads(lambda i: i.resize((self.img_size, self.img_size)).convert("RGB"), list(image)),
                           prompt=prompts, strength=t / 1000, guidance_scale=1)
             except SingleForwardDone:
                 pass
