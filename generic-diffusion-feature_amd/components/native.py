@@ -858,14 +858,25 @@ class NativeUNet(_NativeModel):
         sel = SELECTIVE_BY_ARCH.get(arch_family(self.cfg), SPLIT_SELECTIVE)
         levels = [0, SPLIT_LIGHT, sel, SPLIT_ALL]
         ladder = levels[levels.index(cur):] if cur in levels else [cur, SPLIT_ALL]                  # the levels from the chosen one upwards
-        ref = run(SPLIT_ALL)
+        try:
+            ref = run(SPLIT_ALL)
+        except RuntimeError as e:
+            # the reference plan does not exist at this size (32-bit buffer offsets: the full split halves the largest batch) or does not fit in
+            # memory: the check cannot run; say so once and keep the table's choice
+            import warnings
+            warnings.warn(f"gdf verify: skipped for this layer set ({str(e)[:120]}); verify on a smaller batch to check the automatic operand plan "
+                          "against these weights", RuntimeWarning, stacklevel=3)
+            return out
         seen = {}
         for m in ladder:
             if m == SPLIT_ALL:
                 out = ref
                 break
             if m != cur:
-                out = run(m)
+                try:
+                    out = run(m)
+                except RuntimeError:
+                    continue
             worst = 0.0
             for k in ids:
                 r = ref[1][k].float()
