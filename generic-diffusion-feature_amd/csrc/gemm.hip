@@ -158,7 +158,7 @@ template <int MODE, int BM, int BN, int STAGES, bool GEGLU, bool DIT, bool BF = 
           bool GNS = false>
 __device__ __forceinline__ void gemm_body(const GemmParams& p) {
   static_assert(!BF || DIT, "bf16 operands exist on the MMDiT path only");
-  static_assert(!GNS || (!DIT && !GEGLU && !SPLIT && !MX && BN >= 128 && BN != 320), "GroupNorm partial sums: plain 64-row wave tiles only");
+  static_assert(!GNS || (!DIT && !GEGLU && !SPLIT && !MX && BN >= 128), "GroupNorm partial sums: plain epilogues, one statistics slab per wave tile (WTM rows)");
   static_assert(!MX || (DIT && STAGES == 8 && !SPLIT && !QKN && !GEGLU), "fp8 operands: the 256x256 two-group MMDiT kernel only");
   constexpr int NW = BM / 32;                    // waves per workgroup (4 or 8)
   // waves along N (the GEGLU form of the 256x320 tile uses 4x2 waves of 64x160: an EVEN number of 16-column fragments,
@@ -1177,11 +1177,11 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
   if constexpr (GNS) {
     // the wave tile is one 64-row statistics slab: combine the RPI lanes that hold the same 8 columns through the (idle) staging
     // rows of this wave, then one 64-byte store per column chunk: gn_partial[slab][col .. col+7][sum, sum of squares]
-    static_assert(WTM == 64 && PR * SLD >= 64 * 16, "one slab per wave tile");
+    static_assert((WTM == 64 || WTM == 128) && PR * SLD >= 64 * 16, "one slab per wave tile");
 #pragma unroll
     for (int e = 0; e < 8; ++e) { st[lane * 16 + e] = gsum[e]; st[lane * 16 + 8 + e] = gsq[e]; }
     __builtin_amdgcn_wave_barrier();
-    // (M % 64 == 0 is required, so a wave tile lies entirely inside or entirely outside the matrix: in the last M tile of a 128- / 256-row
+    // (M % WTM == 0 is required, so a wave tile lies entirely inside or entirely outside the matrix: in the last M tile of a 128- / 256-row
     //  workgroup the waves whose 64 rows start at or beyond M own NO slab and must not store — M/64 slabs are allocated)
     if (lane < LPR && full && p.gn_partial && m0 + wm * WTM < p.M) {
       float a[16];
@@ -1191,7 +1191,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
       for (int r = 0; r < RPI; ++r)
 #pragma unroll
         for (int e = 0; e < 16; ++e) a[e] += st[(r * LPR + lane) * 16 + e];
-      const int slab = (m0 + wm * WTM) >> 6;
+      const int slab = (m0 + wm * WTM) / WTM;            // slabs of WTM rows: 64 (128x128, 128x160, 256x128, 256x256 tiles) or 128 (256x320: 2 x 4 waves of 128 x 80)
       f32x4* gp = (f32x4*)(p.gn_partial + ((size_t)slab * p.N + col) * 2);
 #pragma unroll
       for (int q = 0; q < 4; ++q) gp[q] = f32x4{a[2 * q], a[8 + 2 * q], a[2 * q + 1], a[8 + 2 * q + 1]};
@@ -1421,7 +1421,8 @@ int gemm_gn_slab_rows(const GemmParams& p) {
   if ((p.M % 64) != 0 || (p.N % 8) != 0) return 0;
   const int v = pick_variant(p);
   if (p.mode == A_CONV_SMALLC) return v != 160 ? 64 : 0;                 // conv_in: the 128x128 tile
-  return (v == 128 || v == 256 || v == 826) ? 64 : 0;
+  if (v == 932) return (p.M % 128) == 0 ? 128 : 0;                       // round 5: 256x320 two-group (the UNet's N = 320 k convs): 128-row wave tiles
+  return (v == 128 || v == 160 || v == 256 || v == 826) ? 64 : 0;
 }
 
 hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {
@@ -1436,8 +1437,10 @@ hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {
   if (v != 16 && ((p.geglu ? p.N / 2 : p.N) % 8) != 0) return hipErrorInvalidValue;   // ragged N only in the BN = 16 variant
   if (p.bf16 && !p.dit) return hipErrorInvalidValue;                                      // bf16 exists on the MMDiT path only
   if (p.gn_partial) {                                                                     // GroupNorm partial sums from the epilogue (VAE convs)
-    if (gemm_gn_slab_rows(p) != 64 || !p.out16) return hipErrorInvalidValue;
+    if (gemm_gn_slab_rows(p) == 0 || !p.out16) return hipErrorInvalidValue;
     if (p.mode == A_CONV_SMALLC) return launch_t<A_CONV_SMALLC, 128, 128, 2, false, false, false, false, false, false, true>(p, s);
+    if (v == 932) return launch_t<A_CONV3, 256, 320, 9, false, false, false, false, false, false, true>(p, s);
+    if (v == 160) return launch_t<A_CONV3, 128, 160, 2, false, false, false, false, false, false, true>(p, s);
     if (v == 826) return launch_t<A_CONV3, 256, 256, 8, false, false, false, false, false, false, true>(p, s);
     if (v == 256) return launch_t<A_CONV3, 256, 128, 3, false, false, false, false, false, false, true>(p, s);
     return launch_t<A_CONV3, 128, 128, 2, false, false, false, false, false, false, true>(p, s);

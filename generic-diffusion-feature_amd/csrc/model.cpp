@@ -629,18 +629,12 @@ int plan_build(const Model& m, Plan& P, int batch, int H, int W, int n_ctx, cons
   P.batch = batch; P.H = H; P.W = W; P.n_ctx = n_ctx; P.opts = opts;
   B b(m, P, dry, opts);
   b.Bn = batch; b.n_ctx = n_ctx;
-  // row N1's statistics half: the resnet convs whose tile supports it (64-row wave tiles: N = 640 / 1280 levels) emit the GroupNorm partial sums
-  // of the image they store, and the consuming norm2 / Transformer2DModel.norm runs gn_finalize instead of a statistics pass.  Off by default:
-  // same-box A/B in profiles/r05_ab_unet_gn_stats_from_conv_epilogue.txt (GDF_UNET_GN_EPI=1 switches it on).
-  { static const bool on = [] { const char* e = getenv("GDF_UNET_GN_EPI"); return e && atoi(e) != 0; }(); b.gn_epi = on; }
-  if (!dry) {
-    std::unordered_set<std::string> known(m.hook_names.begin(), m.hook_names.end());
-    for (int i = 0; i < n_ids; ++i)
-      if (ids[i] && known.count(ids[i])) P.requested.insert(ids[i]);     // unknown ids silently ignored
-    b.remaining = (int)P.requested.size();
-    for (auto& s : P.requested) if (s.find("map") != std::string::npos) P.want_maps = true;   // diffusion_feature.py:72-77
-    if (opts.early_exit && b.remaining == 0) b.stop = true;
-  }
+  // row N1's statistics half (round 5, ON by default): the resnet convs emit the GroupNorm partial sums of the fp16 image they store (gemm_body<..., GNS>:
+  // one [slab of 64 / 128 rows][channel][sum, sum of squares] record per wave tile, now also on the 256x320 and 128x160 tiles the UNet's convs run on), and
+  // the consuming norm2 / Transformer2DModel.norm runs gn_fold + gn_finalize instead of a statistics pass over the tensor (16 of SDXL's 26 statistics passes).
+  // Same-box A/B, three alternations each (profiles/r05_ab_unet_gn_stats_from_conv_epilogue.txt): SDXL B = 16 +0.4-0.6 %, SD1.5 B = 32 +0.5-0.6 %.
+  // GDF_UNET_GN_EPI=0 restores the separate passes.
+  { static const bool on = [] { const char* e = getenv("GDF_UNET_GN_EPI"); return e ? atoi(e) != 0 : true; }(); b.gn_epi = on; }
   b.build(H, W);
   if (b.bad) return GDF_ERR_UNSUPPORTED;
   P.ws_bytes = b.ar.peak + 256;
