@@ -635,6 +635,14 @@ int plan_build(const Model& m, Plan& P, int batch, int H, int W, int n_ctx, cons
   // Same-box A/B, three alternations each (profiles/r05_ab_unet_gn_stats_from_conv_epilogue.txt): SDXL B = 16 +0.4-0.6 %, SD1.5 B = 32 +0.5-0.6 %.
   // GDF_UNET_GN_EPI=0 restores the separate passes.
   { static const bool on = [] { const char* e = getenv("GDF_UNET_GN_EPI"); return e ? atoi(e) != 0 : true; }(); b.gn_epi = on; }
+  if (!dry) {
+    std::unordered_set<std::string> known(m.hook_names.begin(), m.hook_names.end());
+    for (int i = 0; i < n_ids; ++i)
+      if (ids[i] && known.count(ids[i])) P.requested.insert(ids[i]);     // unknown ids silently ignored
+    b.remaining = (int)P.requested.size();
+    for (auto& s : P.requested) if (s.find("map") != std::string::npos) P.want_maps = true;   // diffusion_feature.py:72-77
+    if (opts.early_exit && b.remaining == 0) b.stop = true;
+  }
   b.build(H, W);
   if (b.bad) return GDF_ERR_UNSUPPORTED;
   P.ws_bytes = b.ar.peak + 256;
