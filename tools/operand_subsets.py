@@ -144,10 +144,12 @@ def main():
     ap.add_argument("--out"); ap.add_argument("--check", action="append", default=[])
     ap.add_argument("--threads", type=int, default=8)
     ap.add_argument("--classes", default=",".join(ALL))
+    ap.add_argument("--heavy", action="store_true", help="heavy-tailed weights (oracle/unet_ref.py synth_params_heavy, outlier gain 16) instead of N(0, 1/fan_in)")
     a = ap.parse_args()
     torch.set_num_threads(a.threads)
     arch = R.ARCHS[a.ver]
-    P = R.synth_params(arch, seed=0); I = R.synth_inputs(arch, 1, a.lat, seed=1)
+    P = R.synth_params_heavy(arch, seed=0, outlier_gain=16.0) if a.heavy else R.synth_params(arch, seed=0)
+    I = R.synth_inputs(arch, 1, a.lat, seed=1)
     ids = [i for i in R.stored_hook_ids(arch) if not i.endswith("-map")]
     fine = any(c in dict(FINE_CLASSES) for c in a.classes.split(","))
     cls_of = classify(P, fine)
