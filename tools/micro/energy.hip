@@ -123,6 +123,28 @@ __global__ __launch_bounds__(512, 2) void mfma_order_kernel(const f16x8* __restr
   for (int i = 0; i < NA; ++i) for (int j = 0; j < NB; ++j) for (int r = 0; r < 4; ++r) s += acc[i][j][r];
   if (s == 12345.f) out[0] = s;
 }
+// Does the SHAPE of the MFMA matter for power?  The same 128 accumulator registers per lane as the 4 x 8 tile of 16x16x32 above, held as 2 x 4 tiles of
+// 32x32x16 (each operand register then feeds 32 output columns instead of 16), walked in snake order.
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+template <int NA, int NB>
+__global__ __launch_bounds__(512, 2) void mfma32_kernel(const f16x8* __restrict__ in, float* out, int iters) {
+  f16x8 a[NA], b[NB];
+  for (int i = 0; i < NA; ++i) a[i] = in[(threadIdx.x * 7 + i * 131 + blockIdx.x) & 4095];
+  for (int j = 0; j < NB; ++j) b[j] = in[(threadIdx.x * 13 + j * 257 + blockIdx.x * 3 + 1024) & 4095];
+  f32x16_t acc[NA][NB];
+  for (int i = 0; i < NA; ++i) for (int j = 0; j < NB; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int k = 0; k < NA * NB; ++k) {
+      const int i = k / NB, j = (i & 1) ? NB - 1 - k % NB : k % NB;
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    asm volatile("" : "+v"(a[0]), "+v"(b[0]));
+  }
+  float s = 0;
+  for (int i = 0; i < NA; ++i) for (int j = 0; j < NB; ++j) for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+  if (s == 12345.f) out[0] = s;
+}
 __global__ __launch_bounds__(512, 2) void spin_kernel(int iters) {
   for (int it = 0; it < iters; ++it) __builtin_amdgcn_s_sleep(32);
 }
@@ -221,6 +243,17 @@ int main(int argc, char** argv) {
       run("MFMA one fixed random operand pair", S, [&] { hipLaunchKernelGGL((mfma_order_kernel<3>), dim3(512), dim3(512), 0, 0, rnd, (float*)out, 4000); }, fl, "TFLOP/s");
       run("MFMA 4x8 tile, row-major, zero operands", S, [&] { hipLaunchKernelGGL((mfma_order_kernel<0>), dim3(512), dim3(512), 0, 0, zer, (float*)out, 4000); }, fl, "TFLOP/s");
     }
+    return 0;
+  }
+  if (argc > 1 && !strcmp(argv[1], "mfma-shape")) {
+    const double fl16 = 512.0 * 8 * 32 * 16384 * 4000, fl32 = 512.0 * 8 * 8 * 32768 * 8000;
+    run("idle spin (s_sleep), 512 WGs", S, [&] { hipLaunchKernelGGL(spin_kernel, dim3(512), dim3(512), 0, 0, 20000); }, 0, "-");
+    for (int rep = 0; rep < 3; ++rep) {
+      run("MFMA 16x16x32 f16, 4x8 tile, snake, random", S, [&] { hipLaunchKernelGGL((mfma_order_kernel<1>), dim3(512), dim3(512), 0, 0, rnd, (float*)out, 4000); }, fl16, "TFLOP/s");
+      run("MFMA 32x32x16 f16, 2x4 tile, snake, random", S, [&] { hipLaunchKernelGGL((mfma32_kernel<2, 4>), dim3(512), dim3(512), 0, 0, rnd, (float*)out, 8000); }, fl32, "TFLOP/s");
+    }
+    run("MFMA 16x16x32 f16, 4x8 tile, snake, zeros", S, [&] { hipLaunchKernelGGL((mfma_order_kernel<1>), dim3(512), dim3(512), 0, 0, zer, (float*)out, 4000); }, fl16, "TFLOP/s");
+    run("MFMA 32x32x16 f16, 2x4 tile, snake, zeros", S, [&] { hipLaunchKernelGGL((mfma32_kernel<2, 4>), dim3(512), dim3(512), 0, 0, zer, (float*)out, 8000); }, fl32, "TFLOP/s");
     return 0;
   }
   run("idle spin (s_sleep), 512 WGs", S, [&] { hipLaunchKernelGGL(spin_kernel, dim3(512), dim3(512), 0, 0, 20000); }, 0, "-");
