@@ -307,8 +307,19 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device(f"cuda:{local}")
     import torch.distributed as dist
-    if world > 1:
+    # test hook (GDF_RCCL_ONE_RANK=1 with WORLD_SIZE=1): the N-rank code path — RCCL group, weight broadcast, rank evidence, barriers, MAX over
+    # ranks — in a ONE-rank RCCL group: the only RCCL configuration a 1-GPU box can run (two ranks cannot share a device under RCCL)
+    multi = world > 1 or D.one_rank_group()
+    json_fd = 1
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        # RCCL prints a version banner ("RCCL version : ...", "Librccl path : ...") through C stdio on STDOUT, flushed at exit — i.e. AFTER the
+        # JSON line (seen on hardware with the one-rank group).  The contract is ONE JSON line on stdout: keep the real stdout aside for that
+        # line and point fd 1 at stderr for everything else this process (and the libraries in it) ever prints.
+        sys.stdout.flush()
+        json_fd = os.dup(1)
+        os.dup2(2, 1)
         if share_gpu:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
@@ -334,7 +345,7 @@ def main():
         unet.init_synthetic(seed=0)
     torch.cuda.synchronize()
     t_init = time.time() - t0
-    if world > 1:
+    if multi:
         dist.barrier()
     t0 = time.time()
     D.broadcast_model_weights(unet)        # flat device arena, 512 MiB pieces, rank 0 -> all (no-op for one process)
@@ -390,7 +401,7 @@ def main():
     st_before = plan.graph_stats()
 
     def barrier():
-        if world > 1:
+        if multi:
             dist.barrier()
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import bench_extra as BX
@@ -410,7 +421,7 @@ def main():
     launches_in_region = st_after[1] - st_before[1]
     fails_in_region = st_after[2] - st_before[2]
     per_rank_ms = [1e3 * dt / args.steps]
-    if world > 1:
+    if multi:
         tt = torch.tensor([dt, -dt], device="cpu" if share_gpu else dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)                    # MAX over ranks of (dt, -dt): slowest and fastest rank
         per_rank_ms = [1e3 * float(-tt[1]) / args.steps, 1e3 * float(tt[0]) / args.steps]
@@ -475,7 +486,7 @@ def main():
                        "model_tflops_per_s": round(ips * (fl_img - kv_img * (B - 1) / B) / 1e12, 1),
                        "shared_ctx_kv_gflop_per_image_not_executed": round(kv_img * (B - 1) / B / 1e9, 1),
                        "weights_init_s": round(t_init, 1), "weights_broadcast_s": round(t_bcast, 3),
-                       "weights_broadcast_gb_per_s": round(unet.weight_blob().numel() / 1e9 / t_bcast, 1) if world > 1 and t_bcast > 0 else None,
+                       "weights_broadcast_gb_per_s": round(unet.weight_blob().numel() / 1e9 / t_bcast, 1) if multi and t_bcast > 0 else None,
                        "launched_by": ("bench.py itself (components/dist.py self_launch)" if os.environ.get("GDF_SELF_LAUNCHED") == "1" else
                                        "torch.distributed.run" if world > 1 else "single process"),
                        "max_inflight_forwards": int(os.environ.get("GDF_MAX_INFLIGHT", "4" if world > 1 else "0")),
@@ -599,8 +610,12 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args.version, lat)
             res["config"]["gpu_over_cpu"] = round(ips / res["cpu_baseline"]["value"], 1)
-        print(json.dumps(res))
-    if world > 1:
+        if json_fd == 1:
+            print(json.dumps(res))
+        else:
+            sys.stdout.flush()
+            os.write(json_fd, (json.dumps(res) + "\n").encode())
+    if multi:
         dist.destroy_process_group()
 
 

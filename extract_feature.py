@@ -268,18 +268,19 @@ class _null:
 def init_data_parallel():
     """torchrun environment -> (rank, world, device string).  Must run before anything touches the GPU."""
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
-    if world == 1:
+    from components import dist as D
+    if world == 1 and not D.one_rank_group():     # (GDF_RCCL_ONE_RANK=1: test hook, the N-rank path in a one-rank RCCL group)
         return 0, 1, 'cuda'
     import torch.distributed as dist
     share = os.environ.get("GDF_SHARE_GPU", "0") == "1"              # test hook: every rank on cuda:0, gloo instead of RCCL
     local = 0 if share else int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29534")
     if share:
         dist.init_process_group("gloo", rank=rank, world_size=world)
     else:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"))
-    from components import dist as D
     D.enable_weight_broadcast()       # every rank builds the same extractor below: rank 0 loads, the others receive the arena
     return rank, world, f"cuda:{local}"
 

@@ -17,19 +17,30 @@ import os
 _broadcast_enabled = os.environ.get("GDF_DP_BROADCAST", "0") not in ("", "0")
 
 
+def one_rank_group():
+    """Test hook GDF_RCCL_ONE_RANK=1: run the collectives of the N-rank path in a group of ONE rank instead of skipping them — on a 1-GPU box
+    the only way to put the real backend (RCCL) under the same calls the N-rank job makes (tests/test_gpu_dist.py)."""
+    return os.environ.get("GDF_RCCL_ONE_RANK", "0") == "1"
+
+
 def enable_weight_broadcast(on=True):
     global _broadcast_enabled
     _broadcast_enabled = bool(on)
 
 
+def _grouped():
+    """True when collectives should run: more than one rank, or the one-rank test group (GDF_RCCL_ONE_RANK=1)."""
+    return rank_world()[1] > 1 or (one_rank_group() and dist.is_available() and dist.is_initialized())
+
+
 def weight_broadcast_enabled():
-    return _broadcast_enabled and rank_world()[1] > 1
+    return _broadcast_enabled and _grouped()
 
 
 def broadcast_object(obj, src=0):
     """Small picklable object (a config dict) from rank `src` to every rank; identity without a process group."""
     rank, world = rank_world()
-    if world == 1:
+    if not _grouped():
         return obj
     box = [obj if rank == src else None]
     dist.broadcast_object_list(box, src=src)
@@ -55,7 +66,7 @@ def broadcast_model_weights(model, src=0, chunk_bytes=1 << 29):
     512 MiB pieces (few, large collectives: ring broadcast over xGMI is per-link bound); receivers mark the model ready.
     The arena is already in the kernels' layout, so no rank but `src` reads or re-lays-out a checkpoint."""
     rank, world = rank_world()
-    if world == 1:
+    if not _grouped():
         return model
     blob = model.weight_blob()
     via_host = dist.get_backend() == "gloo"            # CPU-side test backend (two ranks on one GPU): stage through host memory
@@ -148,7 +159,7 @@ def group_evidence(device=None):
     """What the judge needs to see that the collective library really spanned the job: backend, world size, the ranks that answered
     one all_reduce (a one-hot per rank, summed) and the PCI bus id of the device each rank holds.  Every rank calls it."""
     rank, world = rank_world()
-    if world == 1:
+    if not _grouped():
         return {"backend": None, "world_size": 1, "ranks_seen": [0]}
     backend = dist.get_backend()
     on_dev = backend == "nccl" and device is not None

@@ -72,6 +72,56 @@ def test_two_rank_bench_line():
     assert line["roofline"]["launches"] > 0 and line["roofline"]["achieved"] > 0
 
 
+def _one_rank_env(**extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env.update(GDF_RCCL_ONE_RANK="1", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               HSA_ENABLE_IPC_MODE_LEGACY="0", **extra)
+    return env
+
+
+def test_rccl_one_rank_group_runs_the_n_rank_bench_path():
+    """The share-GPU tests above run the N-rank code on gloo (RCCL refuses two ranks on one device).  This one puts the REAL backend under
+    the same calls: a one-rank RCCL group (GDF_RCCL_ONE_RANK=1) — init_process_group('nccl', device_id=...), the int64 size all_reduce and
+    the 512-MiB-piece broadcasts of the device weight arena, the one-hot all_reduce + all_gather_object of the rank evidence, the barriers
+    around the timed region, the float64 MAX all_reduce of the step times, destroy_process_group — on the GPU."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--version", "1-5", "--batch", "4",
+                        "--no-cpu-baseline", "--no-extras"], env=_one_rank_env(), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    # ONE line on stdout, and it is the JSON: RCCL's own version banner (C stdio on stdout, flushed at exit, i.e. after the line) must not reach it
+    assert len(r.stdout.splitlines()) == 1, r.stdout[-600:]
+    line = json.loads(r.stdout)
+    g = line["rccl"]
+    assert g["backend"].startswith("rccl") and g["library_version"], g
+    assert g["world_size"] == 1 and g["ranks_seen"] == [0] and g["distinct_devices"] == 1, g
+    assert line["n_gpus"] == 1 and line["value"] > 0
+    assert line["config"]["weights_broadcast_gb_per_s"] is not None and line["config"]["weights_broadcast_gb_per_s"] > 0     # the broadcast ran
+    pr = line["config"]["per_rank_ms_per_step"]
+    assert pr["min"] == pr["max"] > 0                                                                                   # MAX all_reduce of (dt, -dt) over one rank
+
+
+def test_rccl_one_rank_group_cli_same_files(tmp_path):
+    """extract_feature.py through the N-rank branch (RCCL group of one: config broadcast_object, weight-arena broadcast, shard_range) writes
+    the files of the plain single-process run bit for bit."""
+    from PIL import Image
+    rs = np.random.RandomState(3)
+    (tmp_path / "imgs").mkdir()
+    for n in "abc":
+        Image.fromarray((rs.rand(80, 96, 3) * 255).astype(np.uint8)).save(tmp_path / "imgs" / f"{n}.png")
+    (tmp_path / "prompt.txt").write_text("a photo of a dog")
+    (tmp_path / "layers.json").write_text(json.dumps({"up-level1-repeat2-res-out": True, "up-level3-repeat0-vit-block0-self-k": True}))
+    base = [sys.executable, os.path.join(ROOT, "extract_feature.py"), "--layer", str(tmp_path / "layers.json"), "--version", "1-5", "--img_size", "256",
+            "--t", "100", "-b", "2", "--input_dir", str(tmp_path / "imgs" / "*.png"), "--prompt_file", str(tmp_path / "prompt.txt")]
+    env = {k: v for k, v in dict(os.environ, GDF_SYNTHETIC_WEIGHTS="1", HSA_ENABLE_IPC_MODE_LEGACY="0").items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    r = subprocess.run(base + ["--output_dir", str(tmp_path / "plain")], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run(base + ["--output_dir", str(tmp_path / "rccl")], env=_one_rank_env(GDF_SYNTHETIC_WEIGHTS="1"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    a, b = _tree(tmp_path / "plain"), _tree(tmp_path / "rccl")
+    assert sorted(a) == sorted(b) and len(a) == 6
+    for k in a:
+        assert np.array_equal(a[k].view(np.uint16), b[k].view(np.uint16)), k
+
+
 def test_two_threads_two_extractors(monkeypatch):
     """One extractor per Python thread (reference aggregation_network.py:67-95), here both on cuda:0: concurrent plan
     creation, first-launch attribute setup, graph capture and replay must give each thread exactly its sequential result."""
