@@ -3,14 +3,15 @@
 import ctypes as C, os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 vp, ci = C.c_void_p, C.c_int
-names = {0: "full", 1: "no K/V traffic", 2: "no softmax math", 3: "no K/V traffic, no softmax", 5: "no K/V traffic, no barrier", 7: "MFMA + LDS reads only", 8: "no global loads (LDS stores kept)", 16: "no LDS stores (global loads kept)", 128: "no v_exp_f32 (rest of the softmax kept)", 100: "full, no s_setprio", 102: "full, softmax at prio 1", 200: "previous build (libgdf_attn_old.so)"}
+names = {0: "full", 1: "no K/V traffic", 2: "no softmax math", 3: "no K/V traffic, no softmax", 5: "no K/V traffic, no barrier", 7: "MFMA + LDS reads only", 8: "no global loads (LDS stores kept)", 16: "no LDS stores (global loads kept)", 128: "no v_exp_f32 (rest of the softmax kept)", 100: "full, no s_setprio", 102: "full, softmax at prio 1", 300: "score / P V MFMAs issued as 16x16x32 (GDF_ATTN_FAKE16)", 200: "previous build (libgdf_attn_old.so)"}
 shapes = [("sdxl_4096", 16, 10, 4096, 64), ("sdxl_1024", 16, 20, 1024, 64), ("flux_d128", 4, 24, 4608, 128)]
 only = [int(x) for x in sys.argv[1:]]
+ITERS = int(os.environ.get("ITERS", "10"))      # long loops (300+) let the power cap settle: what an energy A/B needs
 _w = torch.randn(8192, 8192, device='cuda').half()
 for _ in range(200): _w @ _w          # clock ramp: the first kernels of a process run at a lower clock
 torch.cuda.synchronize()
 for a in (only or (0, 1, 2, 3, 5, 7, 8, 16, 100, 102)):
-    path = os.path.join(ROOT, "generic-diffusion-feature_amd", "libgdf.so") if a == 0 else os.path.join(ROOT, "tools/micro/build", f"libgdf_attn_abl{a}.so" if a not in (100, 102, 200) else "libgdf_attn_old.so" if a == 200 else f"libgdf_attn_prio{a - 100}.so")
+    path = os.path.join(ROOT, "generic-diffusion-feature_amd", "libgdf.so") if a == 0 else os.path.join(ROOT, "tools/micro/build", "libgdf_attn_fake16.so" if a == 300 else f"libgdf_attn_abl{a}.so" if a not in (100, 102, 200) else "libgdf_attn_old.so" if a == 200 else f"libgdf_attn_prio{a - 100}.so")
     L = C.CDLL(path)
     L.gdf_op_attention.restype = ci
     L.gdf_op_attention.argtypes = [vp, ci, vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, ci, vp, vp]
@@ -24,8 +25,8 @@ for a in (only or (0, 1, 2, 3, 5, 7, 8, 16, 100, 102)):
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(10): fn()
+        for _ in range(ITERS): fn()
         e1.record(); torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / 10
+        ms = e0.elapsed_time(e1) / ITERS
         row.append(f"{name}: {ms:7.4f} ms {4.0 * B * h * S * S * D / ms / 1e9:7.1f}")
     print(f"{names[a]:30s} " + "   ".join(row), flush=True)
