@@ -202,6 +202,9 @@ class BatchLoader:
         import threading
         self.lock = threading.Lock()
         self.pinned = torch.cuda.is_available()
+        # the CUDA device is per THREAD and a new thread starts on device 0: the workers allocate their pinned buffers under THIS rank's device,
+        # or every rank of an N-GPU job would open a context on GPU 0 for its host allocator
+        self.dev = torch.cuda.current_device() if self.pinned else None
         # depth + 2 buffers: the batch submitted during get(i) reuses the buffer of batch i - 2, whose forward has long finished (with depth + 1
         # it would be batch i - 1's, i.e. the forward that has just been queued: the main thread would wait for it)
         self.nbuf = depth + 2
@@ -222,7 +225,8 @@ class BatchLoader:
             with self.lock:
                 buf = self.bufs[slot]
                 if buf is None or tuple(buf.shape[1:]) != tuple(x.shape[1:]):
-                    buf = self.bufs[slot] = torch.empty((self.bs,) + tuple(x.shape[1:]), dtype=torch.float16, pin_memory=True)
+                    with torch.cuda.device(self.dev):
+                        buf = self.bufs[slot] = torch.empty((self.bs,) + tuple(x.shape[1:]), dtype=torch.float16, pin_memory=True)
         buf[j].copy_(x[0])
         return None
 
