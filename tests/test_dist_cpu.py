@@ -149,3 +149,39 @@ def test_bench_front_door_refuses_without_gpus():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], env=env, capture_output=True, text=True, timeout=300)
     if torch.cuda.device_count() < 2:
         assert r.returncode != 0 and "needs 2 visible GPUs" in r.stderr and "self_launch" not in r.stderr
+
+
+def _one_rank_worker(rank, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), GDF_RCCL_ONE_RANK="1")
+    from components import dist as D
+    before = (D._grouped(), D.group_evidence()["backend"])             # hook set but no group yet: the collectives stay skipped
+    dist.init_process_group("gloo", rank=0, world_size=1)
+
+    class Arena:
+        def __init__(self):
+            self.blob = torch.arange(700, dtype=torch.uint8)
+            self.ready = True
+
+        def weight_blob(self):
+            return self.blob
+
+        def set_ready(self):
+            self.ready = True
+    ar = Arena()
+    D.broadcast_model_weights(ar, chunk_bytes=256)                      # three pieces through the backend, not the world == 1 short-cut
+    ev = D.group_evidence()
+    D.enable_weight_broadcast()
+    torch.save({"before": before, "grouped": D._grouped(), "ev": ev, "obj": D.broadcast_object({"a": 1}), "blob": ar.blob,
+                "enabled": D.weight_broadcast_enabled()}, os.path.join(out, "one.pt"))
+    dist.destroy_process_group()
+
+
+def test_one_rank_group_hook_runs_the_collectives(tmp_path):
+    """GDF_RCCL_ONE_RANK=1 (the hook the GPU tests use to put RCCL itself under the N-rank code on a 1-GPU box): with a one-rank group the
+    world == 1 short-cuts are NOT taken; without a group the hook changes nothing."""
+    mp.spawn(_one_rank_worker, args=(29500 + (os.getpid() + 977) % 2000, str(tmp_path)), nprocs=1, join=True)
+    r = torch.load(os.path.join(tmp_path, "one.pt"), weights_only=False)
+    assert r["before"] == (False, None)
+    assert r["grouped"] and r["enabled"]
+    assert r["ev"]["backend"] == "gloo" and r["ev"]["world_size"] == 1 and r["ev"]["ranks_seen"] == [0]
+    assert r["obj"] == {"a": 1} and torch.equal(r["blob"], torch.arange(700, dtype=torch.uint8))
