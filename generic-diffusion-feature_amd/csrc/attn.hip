@@ -130,10 +130,15 @@ __device__ unsigned long long gdf_attn_trace[8192 * 8];
 // lanes); one v_permlane16_swap per pair of packed P registers (X = keys {0-3, 8-11} + 4 lh, Y = keys {16-19, 24-27} + 4 lh of a 32-key block) turns them into
 // X' = [X.r0, Y.r0, X.r2, Y.r2] = the four 8-key groups of queries 0-15 and Y' = the same for queries 16-31: exactly the B-operand layout of the 16x16x32
 // instruction.  The key order inside the contraction is free, so the V^T fragment is simply read in the order the groups hold (row bases 0, 16, 4, 20 of the block).
-template <int D, int QW, int NW = 4, bool BF = false, int OCC = 2, bool PV16 = false>
+// QKP (round 5, AttnParams::q_lo / kv_lo > 0, the full-split plans): q, k and v arrive as split fp16 pairs (hi, lo = fp16(x - hi), lo at +q_lo / +kv_lo elements
+// in the same row) and the kernel contracts over them: S^T = K_hi Q_hi^T + K_hi Q_lo^T + K_lo Q_hi^T, O^T += (V_hi^T + V_lo^T) P^T.  The fp16 STORAGE of q / k / v in
+// front of the softmax is the one rounding no GEMM operand class removes; with peaked softmaxes (heavy-tailed weight statistics) it is the whole floor of the
+// full split (DESIGN.md 3.9 h: 8.0e-4 on the worst hook by itself).  2.5 x the MFMAs (3 x Q K^T, 2 x P V); K_lo / V_lo tiles are staged like K / V.
+template <int D, int QW, int NW = 4, bool BF = false, int OCC = 2, bool PV16 = false, bool QKP = false>
 __global__ __launch_bounds__(NW * 64, OCC) void attn_kernel(const AttnParams p) {
   GDF_AT_ENTRY
   static_assert(!PV16 || !BF, "the 16-row P V form is fp16 only");
+  static_assert(!QKP || (!PV16 && !BF), "split q / k / v pairs: fp16, 32x32x16 form");
   typedef float f32x4_t __attribute__((ext_vector_type(4)));
   constexpr int ND16 = (D + 15) / 16;            // 16-row blocks of O^T (PV16)
   constexpr int NT = NW * 64;                    // threads per workgroup
@@ -156,6 +161,8 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_kernel(const AttnParams p) 
   // double-buffered K / V tiles: one barrier per tile
   __shared__ __attribute__((aligned(16))) _Float16 sK[2][KT * LDR];
   __shared__ __attribute__((aligned(16))) _Float16 sV[2][KT * LDV];
+  __shared__ __attribute__((aligned(16))) _Float16 sKl[2][QKP ? KT * LDR : 8];     // QKP: the lo halves of the K / V tiles
+  __shared__ __attribute__((aligned(16))) _Float16 sVl[2][QKP ? KT * LDV : 8];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nqb = (p.Sq + QBLK - 1) / QBLK;
@@ -169,6 +176,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_kernel(const AttnParams p) 
   bool q_ok[QW];
   // ---- Q fragments (B operand of S^T = K Q^T): Q[q][16 s + 8 lh .. +8] ----
   f16x8 qf[QW][NS];
+  f16x8 qfl[QKP ? QW : 1][QKP ? NS : 1];                   // QKP: the lo halves of the Q fragments
 #pragma unroll
   for (int w = 0; w < QW; ++w) {
     q_row[w] = qb * QBLK + wave * QBW + w * 32 + lq;       // query index inside the sequence
@@ -195,6 +203,11 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_kernel(const AttnParams p) 
         f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
         if (q_ok[w] && d0 < D) v = *(const f16x8*)(qp + d0);
         qf[w][s] = v;
+        if constexpr (QKP) {
+          f16x8 vl = {0, 0, 0, 0, 0, 0, 0, 0};
+          if (q_ok[w] && d0 < D) vl = *(const f16x8*)(qp + p.q_lo + d0);
+          qfl[w][s] = vl;
+        }
       }
     }
   }
@@ -235,6 +248,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_kernel(const AttnParams p) 
   const uint32_t ldk = (uint32_t)p.ldk, ldv = (uint32_t)p.ldv;
 
   f16x8 kreg[NCH], vreg[NCH];
+  f16x8 klreg[QKP ? NCH : 1], vlreg[QKP ? NCH : 1];
   auto gload = [&](int t) {
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
@@ -248,7 +262,15 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_kernel(const AttnParams p) 
         if (!PADDED || ch * 8 < D) {
           kk = *(const f16x8*)(kbase + (r * ldk + (uint32_t)(ch * 8)));
           vv = *(const f16x8*)(vbase + (r * ldv + (uint32_t)(ch * 8)));
+          if constexpr (QKP) {
+            klreg[c] = *(const f16x8*)(kbase + p.kv_lo + (r * ldk + (uint32_t)(ch * 8)));
+            vlreg[c] = *(const f16x8*)(vbase + p.kv_lo + (r * ldv + (uint32_t)(ch * 8)));
+          }
+        } else if constexpr (QKP) {
+          klreg[c] = kk; vlreg[c] = kk;
         }
+      } else if constexpr (QKP) {
+        klreg[c] = kk; vlreg[c] = kk;
       }
       kreg[c] = kk; vreg[c] = vv;
     }
@@ -261,6 +283,10 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_kernel(const AttnParams p) 
       if ((KT * CPR) % NT == 0 || idx < KT * CPR) {
         *(f16x8*)(&sK[buf][row * LDR + ch * 8]) = kreg[c];
         *(f16x8*)(&sV[buf][row * LDV + ch * 8]) = vreg[c];
+        if constexpr (QKP) {
+          *(f16x8*)(&sKl[buf][row * LDR + ch * 8]) = klreg[c];
+          *(f16x8*)(&sVl[buf][row * LDV + ch * 8]) = vlreg[c];
+        }
       }
     }
   };
@@ -296,6 +322,10 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_kernel(const AttnParams p) 
     for (int c = 0; c < NCH; ++c) {
       kreg[c] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rsK, kvo[c], sk, 0));
       vreg[c] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rsV, vvo[c], sv, 0));
+      if constexpr (QKP) {
+        klreg[c] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rsK, kvo[c] + (uint32_t)p.kv_lo * 2u, sk, 0));
+        vlreg[c] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rsV, vvo[c] + (uint32_t)p.kv_lo * 2u, sv, 0));
+      }
     }
   };
   const bool fast_ok = FASTLD && seg_aligned && small_off;
@@ -334,11 +364,15 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_kernel(const AttnParams p) 
     // Fragment reads run PD steps ahead of the MFMAs that consume them (round 2: the compiler's order — read, wait, multiply —
     // exposed the LDS latency at every step; tools/trace_attn.py: QK^T 766 and PV 1622 cycles per tile for 512 cycles of MFMA each)
     f32x16 s[QW][2];
-    constexpr int NQK = NS * 2;                  // K fragments per tile, step i -> (st = i / 2, kb = i % 2): the key blocks alternate
+    constexpr int NQK = NS * 2 * (QKP ? 2 : 1);  // K fragments per tile, step i -> (st = i / 2, kb = i % 2): the key blocks alternate (QKP: then K_lo's)
     auto rdk = [&](int i) -> f16x8 {
 #if defined(GDF_ATTN_ABLATE) && (GDF_ATTN_ABLATE & 64)
       return qf[0][i % NS];                              // diagnostics: no K fragment reads
 #endif
+      if constexpr (QKP) if (i >= NS * 2) {              // steps NQK0 .. 2 NQK0 - 1: the same fragments of the K_lo tile
+        const int j = i - NS * 2;
+        return *(LDS_AS const f16x8*)(klt + ((LDS_AS const char*)&sKl[0][0] - (LDS_AS const char*)&sK[0][0]) + ((j & 1) * 32 * LDR + 16 * (j >> 1)) * 2);
+      }
       return *(LDS_AS const f16x8*)(klt + ((i & 1) * 32 * LDR + 16 * (i >> 1)) * 2);
     };
     f16x8 kq[PD];
@@ -355,13 +389,16 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_kernel(const AttnParams p) 
         vf.q[0] = lo; vf.q[1] = hi;
         return vf.h;
       }
-      const int s4 = i / NDB, db = i - s4 * NDB;
+      const bool vlo = QKP && i >= 4 * NDB;      // steps 4 NDB .. 8 NDB - 1: the same fragments of the V_lo tile
+      const int i0 = vlo ? i - 4 * NDB : i;
+      const int s4 = i0 / NDB, db = i0 - s4 * NDB;
 #if defined(GDF_ATTN_ABLATE) && (GDF_ATTN_ABLATE & 32)
       return qf[0][(s4 + db) % NS];                      // diagnostics: no V^T fragment reads
 #endif
       // V^T fragment: lane (d = db*32 + lq, lh) needs V[16 s4 + 4 lh + {0..3}][d] and V[16 s4 + 8 + 4 lh + {0..3}][d]
       // (row 4 lh + (i16 >> 2), column 16 ((lane >> 4) & 1) + 4 (i16 & 3) are in `vl`)
       LDS_AS const char* vp = vlt + (16 * s4 * LDV + db * 32) * 2;
+      if constexpr (QKP) if (vlo) vp += (LDS_AS const char*)&sVl[0][0] - (LDS_AS const char*)&sV[0][0];
       const fp16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((LDS_AS fp16x4_t*)vp);
       const fp16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((LDS_AS fp16x4_t*)(vp + 8 * LDV * 2));
       union { fp16x4_t q[2]; f16x8 h; } vf;              // pure register re-interpretation, no conversion
@@ -371,10 +408,22 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_kernel(const AttnParams p) 
     GDF_ATTN_PRIO_MFMA(1);
 #pragma unroll
     for (int i = 0; i < NQK; ++i) {
-      const int st = i >> 1, kb = i & 1;
+      const bool klo = QKP && i >= NS * 2;       // a K_lo fragment: contracts with Q_hi only (the lo x lo term is 2^-22 relative)
+      const int st = (klo ? i - NS * 2 : i) >> 1, kb = i & 1;
       const f16x8 kf = kq[i % PD];
 #pragma unroll
       for (int w = 0; w < QW; ++w) {
+        if constexpr (QKP) {
+          if (klo) { s[w][kb] = mfma32<BF>(kf, qf[w][st], s[w][kb]); continue; }
+          if (st == 0) {
+            const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            s[w][kb] = mfma32<BF>(kf, qfl[w][st], z);            // the small term first
+          } else {
+            s[w][kb] = mfma32<BF>(kf, qfl[w][st], s[w][kb]);
+          }
+          s[w][kb] = mfma32<BF>(kf, qf[w][st], s[w][kb]);
+          continue;
+        }
         if (st == 0) {
           const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
           s[w][kb] = mfma32<BF>(kf, qf[w][st], z);
@@ -384,7 +433,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_kernel(const AttnParams p) 
       }
       if (i + PD < NQK) kq[i % PD] = rdk(i + PD);
     }
-    constexpr int NPV = PV16 ? 2 * ND16 : 4 * NDB;   // V^T fragments per tile
+    constexpr int NPV = PV16 ? 2 * ND16 : 4 * NDB * (QKP ? 2 : 1);   // V^T fragments per tile (QKP: then V_lo's)
     f16x8 vq[PD];
 #pragma unroll
     for (int i = 0; i < PD; ++i) vq[i] = rdv(i);
@@ -495,7 +544,8 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_kernel(const AttnParams p) 
     } else {
 #pragma unroll
     for (int i = 0; i < NPV; ++i) {
-      const int s4 = i / NDB, db = i - s4 * NDB;
+      const int i0 = (QKP && i >= 4 * NDB) ? i - 4 * NDB : i;
+      const int s4 = i0 / NDB, db = i0 - s4 * NDB;
       const f16x8 vf = vq[i % PD];
 #pragma unroll
       for (int w = 0; w < QW; ++w)
@@ -1131,6 +1181,16 @@ static hipError_t launch_d(const AttnParams& p, hipStream_t s) {
       return hipGetLastError();
     }
 #endif
+    // split q / k / v pairs (AttnParams::q_lo / kv_lo, the full-split UNet plans): 8 waves x 32 query rows share the four staged tiles (K, K_lo, V, V_lo), one
+    // workgroup per CU; head dims whose tiles do not fit (160) or do not split evenly over 512 threads use 4 waves / fall through to the hi halves
+    if constexpr (!BF && D <= 80 && D >= 40) {
+      if (p.q_lo > 0 && p.kv_lo > 0) {
+        constexpr int W8 = (KT * ((D + 31) / 32 * 32 / 8)) % 512 == 0 ? 8 : 4;
+        const int nqb = (p.Sq + 32 * W8 - 1) / (32 * W8);
+        hipLaunchKernelGGL((attn_kernel<D, 1, W8, false, 1, false, true>), dim3(p.B * p.heads * nqb), dim3(64 * W8), 0, s, p);
+        return hipGetLastError();
+      }
+    }
     // round 5: P V on mfma_f32_16x16x32_f16 where the 16-row padding of D is smaller than the 32-row one (40 / 72 / 80); GDF_ATTN_PV16=0 / 1: A/B switch
     constexpr bool pv16c = !BF && ((D + 15) / 16 * 16 < (D + 31) / 32 * 32);
     static const bool pv16 = [] { const char* e = getenv("GDF_ATTN_PV16"); return e ? atoi(e) != 0 : GDF_ATTN_PV16_DEFAULT; }();

@@ -173,6 +173,9 @@ struct AttnParams {
   int bf16;              // D = 128 only: q, k, v, o are bf16 (mfma_f32_32x32x16_bf16, P rounded to bf16); maps stay fp16
   int o_lo;              // > 0 ("precise" plans): o is written as a split (hi, lo) pair, lo at o + o_lo elements in the same row
   int o_pair_bf16;       // with o_lo > 0 and fp16 q / k / v (bf16 == 0): the pair is written as bf16 hi + bf16 lo (MMDiT 'bfloat16x2' plans)
+  int q_lo, kv_lo;       // both > 0 (full-split plans, fp16 UNet attention with 40 <= D <= 80): q, k and v are split (hi, lo) pairs, lo at +q_lo (q) /
+                         // +kv_lo (k, v) elements in the same row; the kernel contracts over both halves (attn_kernel<..., QKP>).  Other head dims
+                         // read the hi halves only.
   float o_scale;         // != 0: o is stored multiplied by this power of two (MMDiT 'float16s' plans: the [attn | mlp] operand rows of the single
                          // blocks share ONE fp16 range scale, undone on the consuming GEMM's accumulators)
 };

@@ -242,7 +242,7 @@ struct B : PlanBuilder {   // UNet op program
 
   // ---- attention helper ---------------------------------------------------------------------------
   void attention(const char* name, Ref q, int ldq, Ref k, int ldk, Ref v, int ldv, Ref o, int ldo, int heads, int Sq,
-                 int Sk, int D, int map_slot, int kv_rows_per_batch = -1, int o_lo = 0) {
+                 int Sk, int D, int map_slot, int kv_rows_per_batch = -1, int o_lo = 0, int q_lo = 0, int kv_lo = 0) {
     if (kv_rows_per_batch < 0) kv_rows_per_batch = Sk;
     const int Bq = Bn;
     const double fl = 4.0 * (double)Bn * heads * Sq * Sk * D;
@@ -251,7 +251,7 @@ struct B : PlanBuilder {   // UNet op program
       a.q = (const half_t*)b.p(q); a.ldq = ldq; a.k = (const half_t*)b.p(k); a.ldk = ldk;
       a.v = (const half_t*)b.p(v); a.ldv = ldv; a.o = (half_t*)b.p(o); a.ldo = ldo;
       a.B = Bq; a.heads = heads; a.Sq = Sq; a.Sk = Sk; a.D = D; a.scale = 1.0f / sqrtf((float)D);
-      a.kv_bstride = kv_rows_per_batch; a.o_lo = o_lo;
+      a.kv_bstride = kv_rows_per_batch; a.o_lo = o_lo; a.q_lo = q_lo; a.kv_lo = kv_lo;
       a.map = map_slot >= 0 ? (half_t*)b.hook(map_slot) : nullptr;
       return launch_attention(a, s);
     });
@@ -283,17 +283,20 @@ struct B : PlanBuilder {   // UNet op program
       const size_t nb_lna = img_bytes(n, C, SP_LN_ATTN), nb_ao = img_bytes(n, C, SP_ATTN_OUT), nb_ao2 = img_bytes(n, C, SP_ATTN2_OUT), nb_lnf = img_bytes(n, C, SP_LN_FF);
       // --- self attention ---
       size_t ln = layernorm(tok, bw.ln1, SP_LN_ATTN);
-      const size_t qkv = tmp(n * 3 * C * 2);
-      { Epi e; e.out16 = ws(qkv); e.has_o16 = true; e.ldo16 = 3 * C; gemm("attn1_qkv", ws(ln), C * p_lna, n, bw.qkv, 3 * C, C, 0, e, s_lna * C); }
+      // SP_QKV: rows [q | k | v | q_lo | k_lo | v_lo] (the GEMM's pair output), the hooks read the hi halves = fp16(q), as always
+      const int s_qkv = spl(SP_QKV), lq = 3 * C * (1 + s_qkv);
+      const size_t qkv = tmp(n * (size_t)lq * 2);
+      { Epi e; e.out16 = ws(qkv); e.has_o16 = true; e.ldo16 = lq; e.o16_lo = s_qkv * 3 * C;
+        gemm("attn1_qkv", ws(ln), C * p_lna, n, bw.qkv, 3 * C, C, 0, e, s_lna * C); }
       untmp(ln, nb_lna);
-      hook_copy(want(bid + "-self-q", C, x.H, x.W), ws(qkv), 3 * C, n, C);                 // attention_processor.py:3291-3294
-      hook_copy(want(bid + "-self-k", C, x.H, x.W), ws(qkv + (size_t)C * 2), 3 * C, n, C);
-      hook_copy(want(bid + "-self-v", C, x.H, x.W), ws(qkv + (size_t)2 * C * 2), 3 * C, n, C);
+      hook_copy(want(bid + "-self-q", C, x.H, x.W), ws(qkv), lq, n, C);                 // attention_processor.py:3291-3294
+      hook_copy(want(bid + "-self-k", C, x.H, x.W), ws(qkv + (size_t)C * 2), lq, n, C);
+      hook_copy(want(bid + "-self-v", C, x.H, x.W), ws(qkv + (size_t)2 * C * 2), lq, n, C);
       size_t ao = tmp(nb_ao);
       const int ms = maps ? want_map(bid + "-self-map", heads, S, S) : (dry_map(bid + "-self-map"), -1);
-      attention("attn1", ws(qkv), 3 * C, ws(qkv + (size_t)C * 2), 3 * C, ws(qkv + (size_t)2 * C * 2), 3 * C, ws(ao), C * p_ao, heads,
-                S, S, D, ms, -1, s_ao * C);
-      untmp(qkv, n * 3 * C * 2);
+      attention("attn1", ws(qkv), lq, ws(qkv + (size_t)C * 2), lq, ws(qkv + (size_t)2 * C * 2), lq, ws(ao), C * p_ao, heads,
+                S, S, D, ms, -1, s_ao * C, s_qkv * 3 * C, s_qkv * 3 * C);
+      untmp(qkv, n * (size_t)lq * 2);
       { Epi e; e.bias = wt(bw.o1.b); e.has_bias = true; residual_from(e, tok); out_to(e, tok, false);
         gemm("attn1_out", ws(ao), C * p_ao, n, bw.o1, C, C, 0, e, s_ao * C); }
       untmp(ao, nb_ao);
@@ -302,21 +305,26 @@ struct B : PlanBuilder {   // UNet op program
       ln = layernorm(tok, bw.ln2, SP_LN_ATTN);
       // a hooked `cross-q` / `ffn-inner` is a whole contiguous tensor with one producer: the GEMM writes it straight into
       // the caller's hook buffer and the consumer reads it from there (no workspace copy, no hook_store pass)
+      // (SP_QKV: the query is a pair [q | q_lo] in workspace and a hooked `cross-q` a copy of its hi half)
       const int hq = want(bid + "-cross-q", C, x.H, x.W);
-      const size_t q2 = hq >= 0 ? 0 : tmp(nb);
-      const Ref q2r = hq >= 0 ? Ref{BUF_HOOK0 + hq, 0} : ws(q2);
-      { Epi e; e.out16 = q2r; e.has_o16 = true; e.ldo16 = C; gemm("attn2_q", ws(ln), C * p_lna, n, bw.q2, C, C, 0, e, s_lna * C); }
+      const bool q2_direct = hq >= 0 && !s_qkv;
+      const size_t q2 = q2_direct ? 0 : tmp(nb * (1 + s_qkv));
+      const Ref q2r = q2_direct ? Ref{BUF_HOOK0 + hq, 0} : ws(q2);
+      { Epi e; e.out16 = q2r; e.has_o16 = true; e.ldo16 = C * (1 + s_qkv); e.o16_lo = s_qkv * C;
+        gemm("attn2_q", ws(ln), C * p_lna, n, bw.q2, C, C, 0, e, s_lna * C); }
       untmp(ln, nb_lna);
-      if (hq >= 0) hook_done();
+      if (q2_direct) hook_done();
+      else if (hq >= 0) hook_copy(hq, ws(q2), C * (1 + s_qkv), n, C);
       // text K/V: precomputed for all blocks by the grouped GEMM at the head of the plan; with one prompt repeated over
       // the batch (reference diffusion_feature.py:272, opts.reserved[0]) there is a single K/V set per block
       const bool shared = opt.reserved[0] != 0;
       const size_t kv = dry ? 0 : kv_bufs[bw.kv_group].first + (size_t)bw.kv_index * kv_bufs[bw.kv_group].second;
       ao = tmp(nb_ao2);
       const int mc = maps ? want_map(bid + "-cross-map", heads, S, n_ctx) : (dry_map(bid + "-cross-map"), -1);
-      attention("attn2", q2r, C, ws(kv), 2 * C, ws(kv + (size_t)C * 2), 2 * C, ws(ao), C * p_ao2, heads, S, n_ctx, D, mc,
-                shared ? 0 : n_ctx, s_ao2 * C);
-      if (hq < 0) untmp(q2, nb);
+      // text K / V rows: [k | v] or, SP_QKV, [k | v | k_lo | v_lo] (the grouped GEMM's pair output)
+      attention("attn2", q2r, C * (1 + s_qkv), ws(kv), 2 * C * (1 + s_qkv), ws(kv + (size_t)C * 2), 2 * C * (1 + s_qkv), ws(ao), C * p_ao2, heads, S, n_ctx, D, mc,
+                shared ? 0 : n_ctx, s_ao2 * C, s_qkv * C, s_qkv * 2 * C);
+      if (!q2_direct) untmp(q2, nb * (1 + s_qkv));
       { Epi e; e.bias = wt(bw.o2.b); e.has_bias = true; residual_from(e, tok); out_to(e, tok, false);
         gemm("attn2_out", ws(ao), C * p_ao2, n, bw.o2, C, C, 0, e, s_ao2 * C); }
       untmp(ao, nb_ao2);
@@ -421,7 +429,8 @@ struct B : PlanBuilder {   // UNet op program
       const bool shared = opt.reserved[0] != 0;
       const size_t nkv = (size_t)(shared ? 1 : Bn) * n_ctx;
       for (const KvGroup& g : m.kv_groups) {
-        const size_t per = align_up(nkv * 2 * g.C * 2, 256);
+        const int kvp = spl(SP_QKV) ? 2 : 1;                      // SP_QKV: rows [k | v | k_lo | v_lo]
+        const size_t per = align_up(nkv * 2 * g.C * 2 * kvp, 256);
         const size_t off = tmp(per * g.count);
         kv_bufs.push_back({off, per});
         const Ref W = wt(g.base);
@@ -432,7 +441,7 @@ struct B : PlanBuilder {   // UNet op program
           gp.A = (const half_t*)b.base[BUF_CTX]; gp.lda = K; gp.a_bytes = (uint32_t)(nkv * K * 2);
           gp.M = (int)nkv; gp.N = N; gp.K = K; gp.mode = A_DENSE;
           gp.Wt = (const half_t*)b.p(W); gp.w_bytes = (uint32_t)((size_t)N * K * 2);
-          gp.out16 = (half_t*)b.ws(off); gp.ldo16 = N; gp.bn = 128; gp.rows_per_sample = 1;
+          gp.out16 = (half_t*)b.ws(off); gp.ldo16 = N * kvp; gp.o16_lo = kvp == 2 ? N : 0; gp.bn = 128; gp.rows_per_sample = 1;
           gp.batch = cnt; gp.w_bstride = wst; gp.o_bstride = ost;
           return launch_gemm(gp, s);
         });
@@ -612,7 +621,7 @@ int plan_build(const Model& m, Plan& P, int batch, int H, int W, int n_ctx, cons
   const bool precise = opts.reserved[1] != 0;
   if (precise && !opts.stream_fp32) { set_error("a precise plan needs the fp32 master stream (stream_fp32 = 1)"); return GDF_ERR_ARG; }
   // 32-bit buffer offsets: the widest row of a level must stay < 2 GiB.  Widest rows: the GEGLU inner tensor (4C, doubled when ITS class is
-  // split), the fused q|k|v output (3C, never split) — both only where the level has attention — and the skip-concat buffers of the up path
+  // split), the fused q|k|v output (3C, doubled when SP_QKV is split) — both only where the level has attention — and the skip-concat buffers of the up path
   // (<= 3C, doubled when the STREAM class is split).  The limit follows the classes the mask actually splits (any non-zero mask
   // used to halve it, which refused SDXL 1024^2 B = 26..34 calls under the selective preset although their widest rows are not split).
   {
@@ -620,7 +629,7 @@ int plan_build(const Model& m, Plan& P, int batch, int H, int W, int n_ctx, cons
     for (int lv = 0; lv < L; ++lv) {
       const size_t r = (size_t)batch * (H >> lv) * (W >> lv), c = m.arch.block_out_channels[lv];
       size_t widest = 3 * ((split & PlanBuilder::SP_STREAM) ? 2 : 1);                                   // concat [hi | lo]
-      if (m.arch.has_attn[lv] || lv == L - 1) widest = std::max<size_t>(widest, std::max<size_t>(3, 4 * ((split & PlanBuilder::SP_FF_INNER) ? 2 : 1)));
+      if (m.arch.has_attn[lv] || lv == L - 1) widest = std::max<size_t>(widest, std::max<size_t>(3 * ((split & PlanBuilder::SP_QKV) ? 2 : 1), 4 * ((split & PlanBuilder::SP_FF_INNER) ? 2 : 1)));
       if (r * c * 2 * widest >= (1ull << 31)) {
         set_error("batch*H*W too large for 32-bit buffer offsets; split the batch"); return GDF_ERR_UNSUPPORTED;
       }

@@ -111,6 +111,16 @@ int gdf_op_attention_split(const void* q, int ldq, const void* k, int ldk, const
   return fin(launch_attention(a, (hipStream_t)stream), "attention_split");
 }
 
+int gdf_op_attention_pair(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, int qkv_lo, void* o, int ldo, int o_lo, int B,
+                          int heads, int Sq, int Sk, int D, void* stream) {
+  if (qkv_lo <= 0 || (qkv_lo & 7)) return fin(hipErrorInvalidValue, "attention_pair");
+  AttnParams a{};
+  a.q = (const half_t*)q; a.ldq = ldq; a.k = (const half_t*)k; a.ldk = ldk; a.v = (const half_t*)v; a.ldv = ldv; a.q_lo = a.kv_lo = qkv_lo;
+  a.o = (half_t*)o; a.ldo = ldo; a.o_lo = o_lo; a.B = B; a.heads = heads; a.Sq = Sq; a.Sk = Sk; a.D = D; a.kv_bstride = Sk;
+  a.scale = 1.0f / sqrtf((float)D);
+  return fin(launch_attention(a, (hipStream_t)stream), "attention_pair");
+}
+
 int gdf_op_conv3x3_splitk(const void* x, int ld, int B, int H, int W, int Cin, const void* Wt, int Cout, const float* bias,
                           const float* rowvec, int stride, int ups, const float* res32, void* aux16, void* out16,
                           float* out32, int splitk, float* ws, void* stream) {

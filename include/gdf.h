@@ -93,9 +93,10 @@ typedef struct gdf_plan_opts {
                           contraction and every GroupNorm input is kept as a split fp16 pair hi + lo (22 mantissa bits) and
                           multiplied as [hi | lo] x [W | W] (K doubled, weights read twice) — removes the fp16-operand rounding
                           that bounds the default plans at ~1.0-1.3e-3 on `ffn-inner` / `unet-out`;
-                          about twice the GEMM / conv time.  Attention internals (q, k, v, P) stay fp16.
+                          about twice the GEMM / conv time.  Attention internals stay fp16 (P always; q, k, v unless the qkv class below is split).
                           Round 4: reserved[1] = (class mask << 8) keeps only the listed operand CLASSES split (csrc/builder.h SP_*: stream 1, gnv 2,
-                          ln_attn 4, attn_out 8, ln_ff 16, ff_inner 32, res 64, out 128, sampler 256, attn2_out 512, upsampler 1024); 1 = all.
+                          ln_attn 4, attn_out 8, ln_ff 16, ff_inner 32, res 64, out 128, sampler 256, attn2_out 512, upsampler 1024,
+                          qkv 2048 = round 5: self-attention q | k | v stored as pairs, the flash kernel contracts over both halves); 1 = all.
                           reserved[2] = cus: the plan will run on a stream restricted to this many CUs (gdf_stream_create_cu_mask):
                           tile selection, persistent grids and the XCD super-block order are sized for that partition. 0 = whole chip. */
 } gdf_plan_opts;

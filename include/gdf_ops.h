@@ -45,6 +45,12 @@ int gdf_op_groupnorm_split(const void* x16, int x_lo, const float* x32, int ld, 
 int gdf_op_attention_split(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* o, int ldo, int o_lo, int B,
                            int heads, int Sq, int Sk, int D, void* map, void* stream);
 
+/* q, k and v as split pairs (hi, lo = fp16(x - hi), lo at +qkv_lo elements in the same row: what a GEMM with o16_lo writes): the softmax sees
+ * q k^T contracted over both halves, O accumulates P (v_hi + v_lo) — the full-split UNet plans (attention_processor.py:3311-3313 in fp32 terms).
+ * Head dims 40 / 64 / 80; others read the hi halves only. */
+int gdf_op_attention_pair(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, int qkv_lo, void* o, int ldo, int o_lo, int B,
+                          int heads, int Sq, int Sk, int D, void* stream);
+
 /* Deterministic split-K form of gdf_op_conv3x3 (few output tiles, long K — the 8x8-level convs of SD1.5): the K range is cut
  * into `splitk` contiguous parts (0 = the plan builder's heuristic, gdf_op_splitk_factor), every part writes raw fp32 partial
  * sums to its own slab of `ws` (splitk * M * Cout floats, M = B * OH * OW), a second kernel adds the slabs in a fixed order and

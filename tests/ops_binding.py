@@ -19,6 +19,7 @@ OPS = {
     "gdf_op_layernorm_split": (ci, [vp, ci, ci, ci, fp, vp, vp, vp, ci, ci, vp]),
     "gdf_op_groupnorm_split": (ci, [vp, ci, vp, ci, ci, ci, ci, ci, fp, vp, vp, ci, vp, ci, ci, vp, vp]),
     "gdf_op_attention_split": (ci, [vp, ci, vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, ci, ci, vp, vp]),
+    "gdf_op_attention_pair": (ci, [vp, ci, vp, ci, vp, ci, ci, vp, ci, ci, ci, ci, ci, ci, ci, vp]),
     "gdf_op_attention": (ci, [vp, ci, vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, ci, vp, vp]),
     "gdf_op_groupnorm_scratch_bytes": (C.c_size_t, [ci, ci, ci]),
     "gdf_op_groupnorm": (ci, [vp, vp, ci, ci, ci, ci, ci, fp, vp, vp, ci, vp, vp, vp]),

@@ -454,3 +454,37 @@ def test_norms_and_attention_split_outputs():
     assert torch.equal(o[:, :Ca], o1)                                            # the hi half IS the plain output
     pa = o[:, :Ca].double().cpu() + o[:, Ca:].double().cpu()
     assert rel(pa, refa) < rel(o1, refa)                                         # the pair removes the output rounding (P stays fp16)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("D,S,gain", [(64, 512, 3.0), (64, 320, 1.0), (40, 448, 3.0), (80, 192, 3.0), (160, 64, 1.0)])
+def test_attention_over_split_qkv_pairs(D, S, gain):
+    """gdf_op_attention_pair (AttnParams::qkv_lo, attn_kernel<..., QKP>): q, k, v as (hi, lo) pairs in the row layout a GEMM with o16_lo writes,
+    [q | k | v | q_lo | k_lo | v_lo].  Against fp64 SDPA of the UNROUNDED q, k, v: the pair form removes the storage rounding in front of the
+    softmax (what remains is P in fp16 and the output rounding), the plain kernel on the hi halves does not — most visibly with peaked softmaxes
+    (`gain` scales q: larger logits).  D = 160 has no pair kernel (its four tiles do not fit in LDS): the call reads the hi halves."""
+    L = lib()
+    g = torch.Generator().manual_seed(D + S)
+    Bq, heads = 2, 3
+    Ca = heads * D
+    x = torch.randn(Bq * S, 3 * Ca, generator=g)
+    x[:, :Ca] *= gain
+    hi, lo = _split(x)
+    q, k, v = [t.double().view(Bq, S, heads, D).transpose(1, 2) for t in x.split(Ca, -1)]
+    ref = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(Bq * S, Ca)
+    pair = torch.cat([hi, lo], -1).cuda()                                        # ld = 6 Ca, lo at + 3 Ca
+    o_pair = torch.zeros(Bq * S, 2 * Ca, dtype=torch.half, device="cuda")
+    ok(L.gdf_op_attention_pair(P(pair), 6 * Ca, C_off(pair, Ca), 6 * Ca, C_off(pair, 2 * Ca), 6 * Ca, 3 * Ca, P(o_pair), 2 * Ca, Ca, Bq, heads, S, S, D,
+                               stream()), L)
+    o_plain = torch.zeros(Bq * S, 2 * Ca, dtype=torch.half, device="cuda")
+    ok(L.gdf_op_attention_split(P(pair), 6 * Ca, C_off(pair, Ca), 6 * Ca, C_off(pair, 2 * Ca), 6 * Ca, P(o_plain), 2 * Ca, Ca, Bq, heads, S, S, D, None,
+                                stream()), L)
+    torch.cuda.synchronize()
+    e_pair = rel(o_pair[:, :Ca].double().cpu() + o_pair[:, Ca:].double().cpu(), ref)
+    e_plain = rel(o_plain[:, :Ca].double().cpu() + o_plain[:, Ca:].double().cpu(), ref)
+    print(f"[attention pair] D={D} S={S} gain={gain}: plain (hi halves) {e_plain:.2e}  pair {e_pair:.2e}")
+    assert torch.isfinite(o_pair.float()).all()
+    if D == 160:
+        assert torch.equal(o_pair, o_plain)
+    else:
+        assert e_pair < 0.6 * e_plain and e_pair < 2.5e-4

@@ -514,7 +514,8 @@ def test_verify_escalates_plan_on_heavy_tailed_weights():
     key, seen, kept = uh.verify_log[0]
     assert len(uh.verify_log) == 1 and kept != 0 and seen[0] > 3e-3 and uh.last_split == kept and len(uh._plans) == n_plans
     # ending at the full split is reported for what it means: the check bounds the distance to the full split, not the full split's own error
-    assert ("outside the statistics" in str(msgs[0].message)) == (kept == 2047)
+    from components.native import SPLIT_ALL
+    assert ("outside the statistics" in str(msgs[0].message)) == (kept == SPLIT_ALL)
     _, want = run_native(native(arch, Ph, precise=kept), I, ids)
     ref = oracle_run(arch, Ph, I, ids)
     for k in ids:

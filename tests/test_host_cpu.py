@@ -366,7 +366,7 @@ def test_operand_plan_selection_table_and_masks():
     import glob
     import json
     from components import native as N
-    assert N.split_mask(None) == 0 and N.split_mask(False) == 0 and N.split_mask(True) == N.SPLIT_ALL == N.split_mask("precise") == 2047
+    assert N.split_mask(None) == 0 and N.split_mask(False) == 0 and N.split_mask(True) == N.SPLIT_ALL == N.split_mask("precise") == 4095
     assert N.split_mask("selective") == N.SPLIT_SELECTIVE == N.split_mask("stream,gnv,attn_out,out,sampler") == N.split_mask(395)
     with pytest.raises(ValueError):
         N.split_mask("stream,bogus")

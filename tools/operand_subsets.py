@@ -36,7 +36,7 @@ FINE_CLASSES = [("attn1_out", r"attn1\.to_out\.0\.weight$"), ("attn2_out", r"att
                 ("upsampler", r"upsamplers\.0\.conv\.weight$"), ("downsampler", r"downsamplers\.0\.conv\.weight$")]
 GN_CLASSES = [("gn_res1", r"resnets\.\d+\.norm1\.weight$"), ("gn_res2", r"resnets\.\d+\.norm2\.weight$"),
               ("gn_vit", r"attentions\.\d+\.norm\.weight$"), ("gn_out", r"^conv_norm_out\.weight$")]
-ALL = [c for c, _ in LIN_CLASSES] + [c for c, _ in GN_CLASSES] + ["qkv_store", "P"]
+ALL = [c for c, _ in LIN_CLASSES] + [c for c, _ in GN_CLASSES] + ["qkv_store", "P"]     # (--classes also takes qkv_self / qkv_cross: the two halves of qkv_store)
 
 
 def _r(x):
@@ -68,7 +68,8 @@ def rounding(cls_of, rounded, vec_rows=64):
         return gn(_r(x) if cls_of.get(id(w)) in rounded else x, g, w, b, eps)
 
     def attention(q, k, v, *a, **kw):
-        if "qkv_store" in rounded:
+        cross = q.shape[-2] != k.shape[-2]             # (the UNets' cross-attention has 77 text keys)
+        if "qkv_store" in rounded or ("qkv_cross" if cross else "qkv_self") in rounded:
             q, k, v = _r(q), _r(k), _r(v)
         scale = kw.get("scale") or q.shape[-1] ** -0.5
         p = sm(mm(q, k.transpose(-1, -2)) * scale, dim=-1)
@@ -95,7 +96,8 @@ def table(errs, title):
 # second run with --classes attn1_out,attn2_out,upsampler,downsampler and merged by merge_fine())
 PLAN_CLASSES = {"stream": ["shortcut", "proj_out", "gn_vit", "gn_res1", "gn_out"], "gnv": ["proj_in"], "ln_attn": ["qkv", "xq"],
                 "attn_out": ["attn1_out"], "attn2_out": ["attn2_out"], "sampler": ["downsampler"], "upsampler": ["upsampler"],
-                "ln_ff": ["geglu"], "ff_inner": ["ff_out"], "res": ["conv1", "conv2", "gn_res2"], "out": ["conv_out"]}
+                "ln_ff": ["geglu"], "ff_inner": ["ff_out"], "res": ["conv1", "conv2", "gn_res2"], "out": ["conv_out"],
+                "qkv": ["qkv_store"]}         # (round 5: q / k / v of the self- AND the cross-attention as pairs; qkv_self / qkv_cross are its halves)
 
 
 def merge_fine(res, fine):
