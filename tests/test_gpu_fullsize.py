@@ -10,8 +10,8 @@ Stated tolerances (north star: 1e-3):
     `*-map` (softmax of q k^T: exponentiates the q / k errors)                                        <= 1.5e-3
   * Flux widths: compute_dtype float16            <= 6e-4;   bfloat16 (the reference's dtype, 8 mantissa bits) <= 4e-3
   * SDXL config_xl_full maps (140 `*-map` ids, B = 1) <= 1.5e-3;  PixArt-Sigma widths <= 6e-4;  VAE encoder 1024^2 latents <= 1e-3
-  * PRECISE plans (opt-in, NativeUNet(precise=True) / GDF_PRECISE=1: split fp16 hi + lo activation operands, K doubled): EVERY hook
-    kind incl. `ffn-inner`, `unet-out` and the maps                                                  <= 1.0e-3   (the north star)
+  * PRECISE plans (opt-in, NativeUNet(precise=True) / GDF_PRECISE=1: split fp16 hi + lo activation operands, K doubled; round 5: q / k / v of
+    both attentions as pairs through the flash kernel): EVERY hook kind incl. `ffn-inner`, `unet-out`      <= 3e-4 (SDXL) / 6e-4 (SD1.5 incl. maps)
   * and for the UNets: every hook within 1.15x (+2e-5) of the fp16-OPERAND FLOOR (oracle/operand_floor.py) — the error of
     the fp32 oracle with nothing but its matmul operands rounded to fp16, i.e. what any fp16-MFMA implementation commits at
     best.  `ffn-inner` (h * gelu(g): the product of two GEMM outputs that each carry the stream error) and `unet-out` sit
@@ -185,7 +185,7 @@ def test_sdxl_1024_batch16_all_non_map_hooks():
     errs_p = {k: max(_rel_each(hooks[k], ref[k])) for k in ids}
     ev = sorted(errs_p.values())
     print(f"[sdxl 1024^2 B=16 PRECISE] hooks={len(ev)} median {ev[len(ev) // 2]:.2e} worst {ev[-1]:.2e}; below 1e-3: {sum(e < 1e-3 for e in ev)}")
-    _check(errs_p, None, lambda kd: 1.0e-3)
+    _check(errs_p, None, lambda kd: 3.0e-4)        # (round 5: q / k / v pairs in the full split: worst 1.9e-4; 4.9e-4 before)
     # ---- the PRODUCT DEFAULT ('auto', round 4): the plan level is chosen from the requested hooks — this set contains `ffn-inner` /
     # `unet-out`, so the selective split (stream images + GroupNorm-in-front-of-proj_in + attention outputs + conv_out operand) is picked,
     # and EVERY kind meets the north-star 1e-3 at ~0.9x the plain plan's speed (tools/bench_split.py); the headline's four hooks alone
@@ -265,7 +265,7 @@ def test_sd15_512_full_layer_set_with_maps_batch2_and_batch32():
     errs_p = {k: max(_rel_each(hooks[k], ref[k])) for k in ids}
     ev = sorted(errs_p.values())
     print(f"[sd1.5 512^2 B=2 PRECISE, 197 ids] median {ev[len(ev) // 2]:.2e} worst {ev[-1]:.2e}; below 1e-3: {sum(e < 1e-3 for e in ev)}")
-    _check(errs_p, None, lambda kd: 1.0e-3)
+    _check(errs_p, None, lambda kd: 6.0e-4)        # (incl. the maps, whose kernel reads the hi halves of q / k: worst 4.4e-4)
     del hooks
     torch.cuda.empty_cache()
     _, hooks = up.forward_raw(gb("sample"), gb("timestep"), gb("ctx"), hook_ids=ids, shared_ctx=True)
@@ -273,7 +273,7 @@ def test_sd15_512_full_layer_set_with_maps_batch2_and_batch32():
     errs_p32 = {k: max(_rel_each(hooks[k], ref[k][:1])) for k in ids}
     ev = sorted(errs_p32.values())
     print(f"[sd1.5 512^2 B=32 PRECISE, 197 ids] median {ev[len(ev) // 2]:.2e} worst {ev[-1]:.2e}")
-    _check(errs_p32, None, lambda kd: 1.0e-3)
+    _check(errs_p32, None, lambda kd: 6.0e-4)
     # ---- the PRODUCT DEFAULT ('auto'): this full layer set (maps, ffn-inner, unet-out) selects the SD1.5 selective split; every kind <= 1e-3 ----
     del hooks, up
     torch.cuda.empty_cache()

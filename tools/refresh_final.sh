@@ -17,7 +17,8 @@ for a, b in (("bench_line.json", "bench_line.json"), ("bench_line_selective.json
     shutil.copy(O + "/" + a, "profiles/%s_final_%s" % (TAG, b))
 shutil.copy(O + "/pmc_traffic.json", "profiles/pmc_traffic_current.json")
 s = open("DESIGN.md").read()
-s = re.sub(r"PMC file stamped with the final `csrc/` hash `[0-9a-f]{16}`", "PMC file stamped with the final `csrc/` hash `%s`" % sha, s)
+# only the paragraph of THIS round carries the current hash (earlier rounds keep theirs)
+s = re.sub(r"(profiles/%s_final_\*`; PMC file stamped with the final `csrc/` hash )`[0-9a-f]{16}`" % TAG, r"\g<1>`%s`" % sha, s)
 open("DESIGN.md", "w").write(s)
 d = json.loads(open(O + "/bench_line.json").read().strip().splitlines()[-1])
 print("copied; csrc", sha, "|", d["value"], "img/s", d["ms_per_step"], "ms", d["roofline"]["frac"], (d.get("power") or {}).get("watts_avg"), "W e2e", d["e2e"]["extract_images_per_s"])
