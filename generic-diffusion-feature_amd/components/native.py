@@ -161,6 +161,12 @@ SPLIT_SELECTIVE = (SPLIT_CLASSES["stream"] | SPLIT_CLASSES["gnv"] | SPLIT_CLASSE
 # plain-plan error sits just above the bound (SD1.5's practical `self-k`: 9.7e-4 plain, 9.1e-4 light) at a fraction of the selective preset's cost.
 SPLIT_LIGHT = SPLIT_CLASSES["gnv"]
 SELECTIVE_BY_ARCH = {"xl": SPLIT_SELECTIVE, "1-5": SPLIT_CLASSES["stream"] | SPLIT_CLASSES["gnv"] | SPLIT_CLASSES["out"] | SPLIT_CLASSES["sampler"]}
+# The DEEP level (round 5, only on verify's ladder, between the selective preset and the full split): selective + the q / k / v pairs + the GEGLU
+# projection's operand.  On heavy-tailed weight statistics the error is spread over every class, and the cheapest subset the per-class emulation
+# finds under 8e-4 is this one (tools/operand_subsets.py --heavy with the qkv class: 7.3e-4 at +34 % of the step, where the full split costs +75 %;
+# profiles/r05_heavy_tailed_operand_classes.txt).  The table never selects it: a layer set reaches it only when verify measured that the selective
+# preset is not enough for THESE weights.
+SPLIT_DEEP_EXTRA = SPLIT_CLASSES["qkv"] | SPLIT_CLASSES["ln_ff"]
 # emulated error above which the next plan level is chosen.  Round 5, measured at full size on hardware (tests/test_gpu_fullsize.py
 # _plain_plan_contract, profiles/r05_plain_plan_contract.txt): hooks whose emulated error is within 15 % of the bound measure 1.3-4.3 % (SDXL B = 16) /
 # 0-4.5 % (SD1.5) above the emulation; at 9.25e-4 the worst hook handed to the plain plan measures 9.5e-4 (SDXL) / 9.6e-4 (SD1.5): >= 4 % below 1e-3
@@ -852,7 +858,7 @@ class NativeUNet(_NativeModel):
         feature/components/feature_extractor.py:31-76 — here: within 1e-3 of it).  `run(mask)` -> (noise, hooks) of the same inputs under
         operand mask `mask`; `out` = the result of the level the table chose.  Compares every requested hook with the FULL split (itself
         <= 5e-4 from fp32 on every kind with benign weight statistics, tests/test_gpu_fullsize.py; the difference then over-estimates the
-        level's own error) and climbs plain -> light -> selective -> full until the worst relative L2 difference is <= verify_bound.
+        level's own error) and climbs plain -> light -> selective -> deep (selective + q / k / v pairs + the GEGLU operand) -> full until the worst relative L2 difference is <= verify_bound.
         Returns the result to hand out.
         What the check cannot see is the full split's own distance to fp32.  Until round 5 that was 0.7-1.5e-3 on the synthetic heavy-tailed
         statistics of oracle/unet_ref.py synth_params_heavy — the fp16 STORAGE of q / k / v in front of the (text cross-attention's) peaked
@@ -866,7 +872,7 @@ class NativeUNet(_NativeModel):
         if cur == SPLIT_ALL or not ids:
             return out
         sel = SELECTIVE_BY_ARCH.get(arch_family(self.cfg), SPLIT_SELECTIVE)
-        levels = [0, SPLIT_LIGHT, sel, SPLIT_ALL]
+        levels = [0, SPLIT_LIGHT, sel, sel | SPLIT_DEEP_EXTRA, SPLIT_ALL]
         ladder = levels[levels.index(cur):] if cur in levels else [cur, SPLIT_ALL]                  # the levels from the chosen one upwards
         try:
             ref = run(SPLIT_ALL)
