@@ -141,10 +141,12 @@ struct PlanBuilder {
          SP_SAMPLER = 256,   // (with SP_STREAM) the DOWNsampler convs contract over hi + lo of the stream image (else over hi only)
          SP_ATTN2_OUT = 512, // cross-attention outputs         -> attn2.to_out.0 operands (SP_ATTN_OUT: the self-attention outputs)
          SP_UPSAMPLER = 1024,// (with SP_STREAM) the UPsampler convs contract over hi + lo (two of the largest convs of the step)
-         SP_QKV = 2048,      // round 5: the self-attention q | k | v are stored as pairs and the flash kernel contracts over both halves
-                             // (AttnParams::qkv_lo): the fp16 STORAGE rounding in front of the softmax, the floor of the full split on
-                             // heavy-tailed weight statistics (DESIGN.md 3.9 h); 2.5 x the attention MFMAs
-         SP_ALL = 4095 };
+         SP_QKV = 2048,      // round 5: the SELF-attention q | k | v are stored as pairs and the flash kernel contracts over both halves
+                             // (AttnParams::q_lo / kv_lo): the fp16 STORAGE rounding in front of the softmax; 2.5 x the attention MFMAs
+         SP_XQKV = 4096,     // the same for the text CROSS-attention (its q and the grouped text K / V): 77 keys, < 1 % of the step — and by far the larger
+                             // half of that rounding (benign weights 4.0e-4 of the worst hook against 0.7e-4 for the self-attention, heavy-tailed
+                             // 8.0e-4 against 2.6e-4: DESIGN.md 3.9 h), so the selective and light presets carry it
+         SP_ALL = 8191 };
   bool gn_epi = false;        // VAE op programs: 3x3 convs emit the GroupNorm partial sums of their output (Act::gp_*)
   int split = 0;              // mask of the classes above
   bool precise = false;       // split != 0

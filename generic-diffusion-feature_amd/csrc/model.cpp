@@ -305,26 +305,27 @@ struct B : PlanBuilder {   // UNet op program
       ln = layernorm(tok, bw.ln2, SP_LN_ATTN);
       // a hooked `cross-q` / `ffn-inner` is a whole contiguous tensor with one producer: the GEMM writes it straight into
       // the caller's hook buffer and the consumer reads it from there (no workspace copy, no hook_store pass)
-      // (SP_QKV: the query is a pair [q | q_lo] in workspace and a hooked `cross-q` a copy of its hi half)
+      // (SP_XQKV: the query is a pair [q | q_lo] in workspace and a hooked `cross-q` a copy of its hi half)
+      const int s_xq = spl(SP_XQKV);
       const int hq = want(bid + "-cross-q", C, x.H, x.W);
-      const bool q2_direct = hq >= 0 && !s_qkv;
-      const size_t q2 = q2_direct ? 0 : tmp(nb * (1 + s_qkv));
+      const bool q2_direct = hq >= 0 && !s_xq;
+      const size_t q2 = q2_direct ? 0 : tmp(nb * (1 + s_xq));
       const Ref q2r = q2_direct ? Ref{BUF_HOOK0 + hq, 0} : ws(q2);
-      { Epi e; e.out16 = q2r; e.has_o16 = true; e.ldo16 = C * (1 + s_qkv); e.o16_lo = s_qkv * C;
+      { Epi e; e.out16 = q2r; e.has_o16 = true; e.ldo16 = C * (1 + s_xq); e.o16_lo = s_xq * C;
         gemm("attn2_q", ws(ln), C * p_lna, n, bw.q2, C, C, 0, e, s_lna * C); }
       untmp(ln, nb_lna);
       if (q2_direct) hook_done();
-      else if (hq >= 0) hook_copy(hq, ws(q2), C * (1 + s_qkv), n, C);
+      else if (hq >= 0) hook_copy(hq, ws(q2), C * (1 + s_xq), n, C);
       // text K/V: precomputed for all blocks by the grouped GEMM at the head of the plan; with one prompt repeated over
       // the batch (reference diffusion_feature.py:272, opts.reserved[0]) there is a single K/V set per block
       const bool shared = opt.reserved[0] != 0;
       const size_t kv = dry ? 0 : kv_bufs[bw.kv_group].first + (size_t)bw.kv_index * kv_bufs[bw.kv_group].second;
       ao = tmp(nb_ao2);
       const int mc = maps ? want_map(bid + "-cross-map", heads, S, n_ctx) : (dry_map(bid + "-cross-map"), -1);
-      // text K / V rows: [k | v] or, SP_QKV, [k | v | k_lo | v_lo] (the grouped GEMM's pair output)
-      attention("attn2", q2r, C * (1 + s_qkv), ws(kv), 2 * C * (1 + s_qkv), ws(kv + (size_t)C * 2), 2 * C * (1 + s_qkv), ws(ao), C * p_ao2, heads, S, n_ctx, D, mc,
-                shared ? 0 : n_ctx, s_ao2 * C, s_qkv * C, s_qkv * 2 * C);
-      if (!q2_direct) untmp(q2, nb * (1 + s_qkv));
+      // text K / V rows: [k | v] or, SP_XQKV, [k | v | k_lo | v_lo] (the grouped GEMM's pair output)
+      attention("attn2", q2r, C * (1 + s_xq), ws(kv), 2 * C * (1 + s_xq), ws(kv + (size_t)C * 2), 2 * C * (1 + s_xq), ws(ao), C * p_ao2, heads, S, n_ctx, D, mc,
+                shared ? 0 : n_ctx, s_ao2 * C, s_xq * C, s_xq * 2 * C);
+      if (!q2_direct) untmp(q2, nb * (1 + s_xq));
       { Epi e; e.bias = wt(bw.o2.b); e.has_bias = true; residual_from(e, tok); out_to(e, tok, false);
         gemm("attn2_out", ws(ao), C * p_ao2, n, bw.o2, C, C, 0, e, s_ao2 * C); }
       untmp(ao, nb_ao2);
@@ -429,7 +430,7 @@ struct B : PlanBuilder {   // UNet op program
       const bool shared = opt.reserved[0] != 0;
       const size_t nkv = (size_t)(shared ? 1 : Bn) * n_ctx;
       for (const KvGroup& g : m.kv_groups) {
-        const int kvp = spl(SP_QKV) ? 2 : 1;                      // SP_QKV: rows [k | v | k_lo | v_lo]
+        const int kvp = spl(SP_XQKV) ? 2 : 1;                     // SP_XQKV: rows [k | v | k_lo | v_lo]
         const size_t per = align_up(nkv * 2 * g.C * 2 * kvp, 256);
         const size_t off = tmp(per * g.count);
         kv_bufs.push_back({off, per});

@@ -96,7 +96,7 @@ typedef struct gdf_plan_opts {
                           about twice the GEMM / conv time.  Attention internals stay fp16 (P always; q, k, v unless the qkv class below is split).
                           Round 4: reserved[1] = (class mask << 8) keeps only the listed operand CLASSES split (csrc/builder.h SP_*: stream 1, gnv 2,
                           ln_attn 4, attn_out 8, ln_ff 16, ff_inner 32, res 64, out 128, sampler 256, attn2_out 512, upsampler 1024,
-                          qkv 2048 = round 5: self-attention q | k | v stored as pairs, the flash kernel contracts over both halves); 1 = all.
+                          qkv 2048 / xqkv 4096 = round 5: the self- / cross-attention q, k, v stored as pairs, the flash kernel contracts over both halves); 1 = all.
                           reserved[2] = cus: the plan will run on a stream restricted to this many CUs (gdf_stream_create_cu_mask):
                           tile selection, persistent grids and the XCD super-block order are sized for that partition. 0 = whole chip. */
 } gdf_plan_opts;

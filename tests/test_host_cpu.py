@@ -366,8 +366,8 @@ def test_operand_plan_selection_table_and_masks():
     import glob
     import json
     from components import native as N
-    assert N.split_mask(None) == 0 and N.split_mask(False) == 0 and N.split_mask(True) == N.SPLIT_ALL == N.split_mask("precise") == 4095
-    assert N.split_mask("selective") == N.SPLIT_SELECTIVE == N.split_mask("stream,gnv,attn_out,out,sampler") == N.split_mask(395)
+    assert N.split_mask(None) == 0 and N.split_mask(False) == 0 and N.split_mask(True) == N.SPLIT_ALL == N.split_mask("precise") == 8191
+    assert N.split_mask("selective") == N.SPLIT_SELECTIVE == N.split_mask("stream,gnv,attn_out,out,sampler,xqkv") == N.split_mask(395 | 4096)
     with pytest.raises(ValueError):
         N.split_mask("stream,bogus")
     tab = json.load(open(os.path.join(os.path.dirname(N.__file__), "operand_error_table.json")))
@@ -376,7 +376,7 @@ def test_operand_plan_selection_table_and_masks():
         assert N.arch_family(N.ARCH_CONFIGS[ver]) == fam
     assert N.choose_split(N.ARCH_CONFIGS["xl"], bench.PRACTICAL["xl"]) == 0               # the headline runs plain fp16 operands
     # SD1.5's practical `self-k` measures 9.70e-4 on the plain plan (3.0 % under the contract): it is handed to the LIGHT level (9.1e-4)
-    assert N.choose_split(N.ARCH_CONFIGS["1-5"], bench.PRACTICAL["1-5"]) == N.SPLIT_LIGHT == N.SPLIT_CLASSES["gnv"]
+    assert N.choose_split(N.ARCH_CONFIGS["1-5"], bench.PRACTICAL["1-5"]) == N.SPLIT_LIGHT == N.SPLIT_CLASSES["gnv"] | N.SPLIT_CLASSES["xqkv"]
     assert N.choose_split(N.ARCH_CONFIGS["1-5"], bench.PRACTICAL["1-5"][:3]) == 0
     assert N.AUTO_BOUND <= 9.3e-4
     # the table is emulated at the BASELINE resolution; smaller latent grids average the rounding over fewer elements (measured x 1.11 from 1024^2 to

@@ -97,7 +97,8 @@ def table(errs, title):
 PLAN_CLASSES = {"stream": ["shortcut", "proj_out", "gn_vit", "gn_res1", "gn_out"], "gnv": ["proj_in"], "ln_attn": ["qkv", "xq"],
                 "attn_out": ["attn1_out"], "attn2_out": ["attn2_out"], "sampler": ["downsampler"], "upsampler": ["upsampler"],
                 "ln_ff": ["geglu"], "ff_inner": ["ff_out"], "res": ["conv1", "conv2", "gn_res2"], "out": ["conv_out"],
-                "qkv": ["qkv_store"]}         # (round 5: q / k / v of the self- AND the cross-attention as pairs; qkv_self / qkv_cross are its halves)
+                "qkv": ["qkv_self"], "xqkv": ["qkv_cross"]}       # (round 5: q / k / v pairs of the self- / cross-attention; the committed r04 runs hold the
+                # combined class qkv_store instead: predict() on those keeps it unless BOTH plan classes are split)
 
 
 def merge_fine(res, fine):
@@ -110,6 +111,8 @@ def merge_fine(res, fine):
 def predict(res, plan_classes):
     """per-hook error (relative L2 vs the fp32 oracle, hook storage included) of a plan that keeps `plan_classes` split: variances add"""
     keep = set(c for p in plan_classes for c in PLAN_CLASSES[p])
+    if "qkv_self" in keep and "qkv_cross" in keep:
+        keep.add("qkv_store")
     return {h: (res["store"][h] ** 2 + sum(e[h] ** 2 for c, e in res["classes"].items() if c not in keep)) ** 0.5 for h in res["store"]}
 
 
