@@ -354,10 +354,20 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_kernel(const AttnParams p) 
     vl = (LDS_AS const char*)&sV[0][0] + ((16 * (g4 & 1) + 4 * (g4 >> 1) + (i16 >> 2)) * LDV + (i16 & 3) * 4) * 2;
   }
   asm volatile("" : "+v"(kl), "+v"(vl));
+  // QKP: the same lane-dependent pointers into the K_lo / V_lo tiles
+  [[maybe_unused]] LDS_AS const char* kll = kl;
+  [[maybe_unused]] LDS_AS const char* vll = vl;
+  if constexpr (QKP) {
+    kll = (LDS_AS const char*)&sKl[0][0] + (lq * LDR + 8 * lh) * 2;
+    vll = (LDS_AS const char*)&sVl[0][0] + ((4 * lh + (i16 >> 2)) * LDV + 16 * ((lane >> 4) & 1) + (i16 & 3) * 4) * 2;
+    asm volatile("" : "+v"(kll), "+v"(vll));
+  }
   for (int t = 0; t < ntiles; ++t) {
     const int BUF = t & 1;
     LDS_AS const char* const klt = kl + BUF * (KT * LDR * 2);
     LDS_AS const char* const vlt = vl + BUF * (KT * LDV * 2);
+    [[maybe_unused]] LDS_AS const char* const kllt = kll + BUF * (KT * LDR * 2);
+    [[maybe_unused]] LDS_AS const char* const vllt = vll + BUF * (KT * LDV * 2);
     GDF_AT(3);
 
     // ---- S^T = K Q^T : two 32-key blocks; every K fragment feeds QW query blocks ----
@@ -371,7 +381,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_kernel(const AttnParams p) 
 #endif
       if constexpr (QKP) if (i >= NS * 2) {              // steps NQK0 .. 2 NQK0 - 1: the same fragments of the K_lo tile
         const int j = i - NS * 2;
-        return *(LDS_AS const f16x8*)(klt + ((LDS_AS const char*)&sKl[0][0] - (LDS_AS const char*)&sK[0][0]) + ((j & 1) * 32 * LDR + 16 * (j >> 1)) * 2);
+        return *(LDS_AS const f16x8*)(kllt + ((j & 1) * 32 * LDR + 16 * (j >> 1)) * 2);
       }
       return *(LDS_AS const f16x8*)(klt + ((i & 1) * 32 * LDR + 16 * (i >> 1)) * 2);
     };
@@ -397,8 +407,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_kernel(const AttnParams p) 
 #endif
       // V^T fragment: lane (d = db*32 + lq, lh) needs V[16 s4 + 4 lh + {0..3}][d] and V[16 s4 + 8 + 4 lh + {0..3}][d]
       // (row 4 lh + (i16 >> 2), column 16 ((lane >> 4) & 1) + 4 (i16 & 3) are in `vl`)
-      LDS_AS const char* vp = vlt + (16 * s4 * LDV + db * 32) * 2;
-      if constexpr (QKP) if (vlo) vp += (LDS_AS const char*)&sVl[0][0] - (LDS_AS const char*)&sV[0][0];
+      LDS_AS const char* vp = ((QKP && vlo) ? vllt : vlt) + (16 * s4 * LDV + db * 32) * 2;
       const fp16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((LDS_AS fp16x4_t*)vp);
       const fp16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((LDS_AS fp16x4_t*)(vp + 8 * LDV * 2));
       union { fp16x4_t q[2]; f16x8 h; } vf;              // pure register re-interpretation, no conversion
