@@ -94,7 +94,9 @@ def cpu_baseline(version, lat_full, budget_s=100.0):
     predicted time fits `budget_s` (scaled by the algorithmic FLOP ratio when that is not the full resolution)."""
     from oracle import unet_ref as R
     arch = R.ARCHS[version]
-    cores = os.cpu_count() or 1
+    # the host CPUs THIS process may run on: under an N-rank launch every rank is pinned to its share of the host (components/dist.py
+    # pin_rank_cores), and os.cpu_count() would report the whole machine
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     # 1. calibrate the thread count on the two block types that carry the forward: one ResnetBlock2D at level 0
     #    (320 -> 320 @ lat x lat) + one BasicTransformerBlock at the deepest attention level (C = 1280), both through the
     #    oracle's own block functions; candidates 16 / 32 / 64 / 128 threads (capped by the host)
@@ -289,6 +291,9 @@ def main():
     if share_gpu:
         local = 0
     from components import dist as D
+    pinned = None
+    if not D.needs_self_launch(args.gpus) and world > 1:
+        pinned = D.pin_rank_cores()        # this rank's share of the host cores, before anything touches the GPU or starts a thread pool
     if D.needs_self_launch(args.gpus):
         # The front door for N ranks (BASELINE configs[3]): `python3 bench.py --gpus N ...` started as ONE plain process starts its N
         # ranks itself — ordinary child processes with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, rendezvous on 127.0.0.1 — and
@@ -320,15 +325,21 @@ def main():
         sys.stdout.flush()
         json_fd = os.dup(1)
         os.dup2(2, 1)
-        if share_gpu:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        try:
+            if share_gpu:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+            else:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        except RuntimeError as e:
+            if rank == 0 and ("EADDRINUSE" in str(e) or "address already in use" in str(e).lower()):
+                print(f"[bench] rendezvous port {os.environ['MASTER_PORT']} is taken: {str(e)[:200]}", file=sys.stderr)
+                sys.exit(D.RENDEZVOUS_BIND_FAILED)     # self_launch retries once on another port
+            raise
         if dist.get_world_size() != args.gpus:
             sys.exit(f"process group reports {dist.get_world_size()} ranks, --gpus {args.gpus}")
 
-    if os.environ.get("GDF_TEST_FAIL_RANK") == str(rank) and world > 1:
-        sys.exit(3)                        # test hook: a rank dying AFTER the rendezvous (the others sit in a collective) must fail the whole job
+    if os.environ.get("GDF_TEST_HOOKS") == "1" and os.environ.get("GDF_TEST_FAIL_RANK") == str(rank) and world > 1:
+        sys.exit(3)                        # tests/test_gpu_dist.py only: a rank dying AFTER the rendezvous (the others sit in a collective) must fail the whole job
     group = D.group_evidence(dev)          # backend, ranks that answered one all_reduce, the PCI bus id of every rank's device
     from components.native import NativeUNet
     import ctypes as C
@@ -426,6 +437,11 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)                    # MAX over ranks of (dt, -dt): slowest and fastest rank
         per_rank_ms = [1e3 * float(-tt[1]) / args.steps, 1e3 * float(tt[0]) / args.steps]
         dt = float(tt[0])
+        # That was the job's LAST collective.  The group is taken down here, on every rank, so that the ranks > 0 can finish and exit while
+        # rank 0 runs its untimed legs (the per-op rooflines and the CPU baseline): no peer is ever left parked inside an RCCL call.
+        torch.cuda.synchronize()
+        dist.barrier()
+        dist.destroy_process_group()
     ms_tot = C.c_double(); launches = C.c_long(); fl_tot = C.c_double()
     lib.gdf_plan_read_timing(plan.handle, C.byref(ms_tot), C.byref(launches), C.byref(fl_tot))
     lib.gdf_plan_set_timing(plan.handle, None)
@@ -490,7 +506,8 @@ def main():
                        "launched_by": ("bench.py itself (components/dist.py self_launch)" if os.environ.get("GDF_SELF_LAUNCHED") == "1" else
                                        "torch.distributed.run" if world > 1 else "single process"),
                        "max_inflight_forwards": int(os.environ.get("GDF_MAX_INFLIGHT", "4" if world > 1 else "0")),
-                       "per_rank_ms_per_step": {"min": round(per_rank_ms[0], 3), "max": round(per_rank_ms[-1], 3)}},
+                       "per_rank_ms_per_step": {"min": round(per_rank_ms[0], 3), "max": round(per_rank_ms[-1], 3)},
+                       "rank_cpu_affinity": {"rank0_cpus": len(pinned), "first": pinned[0], "last": pinned[-1]} if pinned else None},
             "roofline": {"bound": "mfma", "kernel": dominant, "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_stale": traffic_stale,
                          "frac_of_random_operand_mfma_ceiling": round(achieved / MFMA_RANDOM_DATA_CEILING_TFLOPS, 4),
@@ -607,16 +624,18 @@ def main():
                 r = rows.setdefault(name, [0.0, 0.0, 0]); r[0] += ms; r[1] += f_; r[2] += 1
             for name, r in sorted(rows.items(), key=lambda kv: -kv[1][0]):
                 print(f"# {name:16s} n={r[2]:4d} {r[0]:9.3f} ms  {r[1] / 1e9 / max(r[0], 1e-9):8.1f} TFLOP/s", file=sys.stderr)
-        if world == 1 and not args.no_cpu_baseline:
+        if not args.no_cpu_baseline:
+            # (any N: rank 0 times it after the process group is gone, on its own share of the host cores)
             res["cpu_baseline"] = cpu_baseline(args.version, lat)
+            res["cpu_baseline"]["host"] = {"cpus": os.cpu_count(), "rank0_affinity_cpus": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None,
+                                           "pinned_by": "components/dist.py pin_rank_cores" if pinned else None,
+                                           "when": "after the timed region" + (", after destroy_process_group (the other ranks have left)" if multi else "")}
             res["config"]["gpu_over_cpu"] = round(ips / res["cpu_baseline"]["value"], 1)
         if json_fd == 1:
             print(json.dumps(res))
         else:
             sys.stdout.flush()
             os.write(json_fd, (json.dumps(res) + "\n").encode())
-    if multi:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -276,15 +276,21 @@ def init_data_parallel():
     if world == 1 and not D.one_rank_group():     # (GDF_RCCL_ONE_RANK=1: test hook, the N-rank path in a one-rank RCCL group)
         return 0, 1, 'cuda'
     import torch.distributed as dist
+    D.pin_rank_cores()                # this rank's share of the host cores (launch thread, loader threads, OpenMP pool), before any GPU call
     share = os.environ.get("GDF_SHARE_GPU", "0") == "1"              # test hook: every rank on cuda:0, gloo instead of RCCL
     local = 0 if share else int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29534")
-    if share:
-        dist.init_process_group("gloo", rank=rank, world_size=world)
-    else:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"))
+    try:
+        if share:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"))
+    except RuntimeError as e:
+        if rank == 0 and ("EADDRINUSE" in str(e) or "address already in use" in str(e).lower()):
+            raise SystemExit(D.RENDEZVOUS_BIND_FAILED)               # self_launch retries once on another port
+        raise
     D.enable_weight_broadcast()       # every rank builds the same extractor below: rank 0 loads, the others receive the arena
     return rank, world, f"cuda:{local}"
 
@@ -336,31 +342,44 @@ def main(argv=None):
     # loader threads run — the SAME function the serial path calls, so the latents are bit-identical either way
     prefetch = n_thr > 0 and args.version not in ('flux', 'hunyuan') and not args.show_all_layers
     loader = BatchLoader(paths, starts, hi, args.batch_size, df.preprocess_image, n_thr) if prefetch else None
-    with torch.no_grad():
-        for i in starts:
-            chunk = paths[i:min(i + args.batch_size, hi)]
-            if loader is not None:
-                feats = df.extract(prompts, len(chunk), loader.get(i), image_type='tensors', t=args.t, denoising_from=args.denoising_from,
-                                   use_control=args.control is not None, use_ddim_inversion=args.use_ddim_inversion)
-                loader.done(i)
-            else:
-                images = [Image.open(p) for p in chunk]
-                feats = df.extract(prompts, len(images), images, t=args.t, denoising_from=args.denoising_from,
-                                   use_control=args.control is not None, use_ddim_inversion=args.use_ddim_inversion)
-            if args.show_all_layers:                               # dump the id list and stop (reference :103-110)
-                for k, v in feats.items():
-                    print(k, tuple(v[0].shape))
-                with open('layer_record.json', 'w') as f:
-                    json.dump({k: True for k in feats}, f)
-                return
-            names = [sample_name(p, args.nested_input_dir) if args.use_original_filename else f'{args.split}{i + j}'
-                     for j, p in enumerate(chunk)]
-            writer.submit(feats, names)
-            if rank == 0:
-                print(f'{min(i + len(chunk), hi) - lo}/{hi - lo}', end='\r')
-    if loader is not None:
-        loader.close()
-    writer.close()
+    ok = False
+    try:
+        with torch.no_grad():
+            for i in starts:
+                chunk = paths[i:min(i + args.batch_size, hi)]
+                if loader is not None:
+                    feats = df.extract(prompts, len(chunk), loader.get(i), image_type='tensors', t=args.t, denoising_from=args.denoising_from,
+                                       use_control=args.control is not None, use_ddim_inversion=args.use_ddim_inversion)
+                    loader.done(i)
+                else:
+                    images = [Image.open(p) for p in chunk]
+                    feats = df.extract(prompts, len(images), images, t=args.t, denoising_from=args.denoising_from,
+                                       use_control=args.control is not None, use_ddim_inversion=args.use_ddim_inversion)
+                if args.show_all_layers:                               # dump the id list and stop (reference :103-110)
+                    for k, v in feats.items():
+                        print(k, tuple(v[0].shape))
+                    with open('layer_record.json', 'w') as f:
+                        json.dump({k: True for k in feats}, f)
+                    return
+                names = [sample_name(p, args.nested_input_dir) if args.use_original_filename else f'{args.split}{i + j}'
+                         for j, p in enumerate(chunk)]
+                writer.submit(feats, names)
+                if rank == 0:
+                    print(f'{min(i + len(chunk), hi) - lo}/{hi - lo}', end='\r')
+        ok = True
+    finally:
+        # success, an exception in extract / the loader (a broken image file), or the --show_all_layers early return: the loader's thread pool and
+        # pinned batch buffers and the writer thread are always released.  On the error path the writer's own (later) exception must not replace
+        # the one that is already propagating.
+        if loader is not None:
+            loader.close()
+        try:
+            writer.close()
+        except Exception:
+            if ok:
+                raise
+    if args.show_all_layers:
+        return
     if world > 1:
         import torch.distributed as dist
         dist.barrier()

@@ -109,50 +109,154 @@ def self_launch(script, argv, n_ranks, timeout_s=None):
     (its single JSON line / progress output IS the command's output); the other ranks' stdout is folded into stderr.  A rank that
     fails takes the job down: the remaining children — exactly the PIDs started here — are terminated and the exit code is non-zero.
     """
+    import signal
     import socket
     import subprocess
     import sys
     import time
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
+
+    def free_port():
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        return port
+
+    cores = _rank_core_sets(n_ranks)
     procs = []
-    for r in range(n_ranks):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), GDF_SELF_LAUNCHED="1")
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL needs it on this driver
-        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n_ranks) // n_ranks)))
-        procs.append(subprocess.Popen([sys.executable, script] + list(argv), env=env, stdout=None if r == 0 else sys.stderr))
-    t0 = time.time()
+
+    def start(port):
+        for r in range(n_ranks):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), GDF_SELF_LAUNCHED="1")
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL needs it on this driver
+            env.setdefault("OMP_NUM_THREADS", str(max(1, len(cores[r]) if cores else (os.cpu_count() or n_ranks) // n_ranks)))
+            if cores and "GDF_RANK_CORES" not in os.environ:
+                env["GDF_RANK_CORES"] = ",".join(str(c) for c in cores[r])     # applied by the child before any GPU call (pin_rank_cores)
+            # every rank in its OWN process group (start_new_session): stop_all() below can then take down a rank together with whatever it
+            # started (loader threads are in-process, but a rank may itself have children) without ever signalling this process's group
+            procs.append(subprocess.Popen([sys.executable, script] + list(argv), env=env, stdout=None if r == 0 else sys.stderr,
+                                          start_new_session=True))
+
+    def stop_all(grace_s=10.0):
+        """terminate, then kill, then reap exactly the children started here (and their process groups)"""
+        live = [p for p in procs if p.poll() is None]
+        for p in live:
+            try:
+                os.killpg(p.pid, signal.SIGTERM)
+            except (ProcessLookupError, PermissionError):
+                pass
+        t1 = time.time()
+        while any(p.poll() is None for p in live) and time.time() - t1 < grace_s:
+            time.sleep(0.05)
+        for p in live:
+            if p.poll() is None:
+                try:
+                    os.killpg(p.pid, signal.SIGKILL)
+                except (ProcessLookupError, PermissionError):
+                    pass
+        for p in live:
+            try:
+                p.wait(timeout=grace_s)
+            except subprocess.TimeoutExpired:
+                pass
+
+    class _Stop(Exception):
+        pass
+
+    def on_signal(signum, _frame):
+        raise _Stop(signum)
+
+    old = {}
+    for sg in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
+        try:
+            old[sg] = signal.signal(sg, on_signal)                    # (only possible on the main thread; elsewhere the finally below still runs)
+        except ValueError:
+            pass
     rc = 0
-    live = list(procs)
-    while live:
-        time.sleep(0.05)
-        for p in list(live):
-            c = p.poll()
-            if c is None:
-                continue
-            live.remove(p)
-            if c != 0 and rc == 0:
-                rc = c if c > 0 else 1
-                print(f"[self_launch] rank {procs.index(p)} exited with code {c}: stopping the other ranks", file=sys.stderr)
-        if (rc != 0 or (timeout_s and time.time() - t0 > timeout_s)) and live:
-            if rc == 0:
-                rc = 124
-                print(f"[self_launch] timeout after {timeout_s} s", file=sys.stderr)
-            for p in live:
-                p.terminate()
-            t1 = time.time()
-            while any(p.poll() is None for p in live) and time.time() - t1 < 10:
+    attempt = 0
+    try:
+        while True:
+            attempt += 1
+            del procs[:]
+            t0 = time.time()
+            start(free_port())
+            rc = 0
+            live = list(procs)
+            while live:
                 time.sleep(0.05)
-            for p in live:
-                if p.poll() is None:
-                    p.kill()
-            for p in live:
-                p.wait()
-            live = []
+                for p in list(live):
+                    c = p.poll()
+                    if c is None:
+                        continue
+                    live.remove(p)
+                    if c != 0 and rc == 0:
+                        rc = c if c > 0 else 1
+                        print(f"[self_launch] rank {procs.index(p)} exited with code {c}: stopping the other ranks", file=sys.stderr)
+                if (rc != 0 or (timeout_s and time.time() - t0 > timeout_s)) and live:
+                    if rc == 0:
+                        rc = 124
+                        print(f"[self_launch] timeout after {timeout_s} s", file=sys.stderr)
+                    stop_all()
+                    live = []
+            # the free port is found by bind / close / reuse, which can lose a race with another job on the node: a rank that could not bind
+            # the rendezvous says so with RENDEZVOUS_BIND_FAILED (init_rank_group) — retry ONCE on a new port
+            if rc == RENDEZVOUS_BIND_FAILED and attempt == 1:
+                print("[self_launch] the rendezvous port was taken between probe and use: retrying once on another port", file=sys.stderr)
+                continue
+            break
+    except _Stop as e:
+        print(f"[self_launch] signal {e.args[0]}: stopping {sum(p.poll() is None for p in procs)} rank processes", file=sys.stderr)
+        rc = 128 + int(e.args[0])
+    except BaseException:
+        rc = rc or 1
+        raise
+    finally:
+        stop_all()                                                    # no rank started here outlives this call, whatever ended the wait
+        for sg, h in old.items():
+            signal.signal(sg, h)
     return rc
+
+
+RENDEZVOUS_BIND_FAILED = 97      # exit code of a rank whose TCPStore could not bind MASTER_PORT (EADDRINUSE): self_launch retries once
+
+
+def _rank_core_sets(n_ranks):
+    """The host cores of this process's affinity mask cut into `n_ranks` contiguous shares (rank r gets share r): each rank's launch thread,
+    loader threads and OpenMP pool then stay on their own cores instead of eight ranks' thread sets migrating over one 256-CPU host.
+    None when the platform has no affinity call or there are fewer cores than ranks.  GDF_PIN_CORES=0 disables pinning."""
+    if os.environ.get("GDF_PIN_CORES", "1") in ("", "0") or not hasattr(os, "sched_getaffinity"):
+        return None
+    avail = sorted(os.sched_getaffinity(0))
+    if len(avail) < n_ranks:
+        return None
+    out = []
+    for r in range(n_ranks):
+        lo, hi = shard_range(len(avail), r, n_ranks)
+        out.append(avail[lo:hi])
+    return out
+
+
+def pin_rank_cores():
+    """Called by a rank process BEFORE its first GPU call (bench.py / extract_feature.py main): restrict the process to the cores self_launch
+    assigned (GDF_RANK_CORES) — or, under torchrun, to its LOCAL_RANK's share of the inherited mask.  Returns the core list in force."""
+    if not hasattr(os, "sched_setaffinity"):
+        return None
+    spec = os.environ.get("GDF_RANK_CORES", "")
+    cores = None
+    if spec:
+        cores = [int(c) for c in spec.split(",") if c != ""]
+    elif "LOCAL_RANK" in os.environ and int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1"))) > 1:
+        sets = _rank_core_sets(int(os.environ.get("LOCAL_WORLD_SIZE", os.environ["WORLD_SIZE"])))
+        if sets:
+            cores = sets[int(os.environ["LOCAL_RANK"])]
+    if not cores:
+        return None
+    try:
+        os.sched_setaffinity(0, cores)
+    except OSError:
+        return None
+    return sorted(os.sched_getaffinity(0))
 
 
 def group_evidence(device=None):

@@ -108,16 +108,27 @@ class _Scheduler:
 
 
 def scheduler_noise_scalars(scheduler, timestep):
-    """(a, b) such that scheduler.add_noise(x, noise, timestep) == a * x + b * noise, for the scheduler families the
-    reference uses (PNDM / DDPM-style `alphas_cumprod` for 1-5, EulerDiscrete `sigmas` for 2-1 / xl: models.py:26,38,51)."""
+    """(a, b) such that scheduler.add_noise(x, noise, timestep) == a * x + b * noise for the call `prepare_latents` of the img2img pipelines makes
+    (reference feature/diffusion_feature.py:371-380 -> diffusers prepare_latents -> scheduler.add_noise).  Schedulers that say so themselves
+    (`noise_scalars`: the synthetic pipe's) are asked; a diffusers scheduler is PROBED on a deep copy with one-element CPU tensors — (x, noise) =
+    (1, 0) and (0, 1), linearity verified on a third point — so every family the reference configures gives its own coefficients: PNDM / DDPM
+    (sqrt(ac), sqrt(1 - ac); '1-5'), EulerDiscrete (1, sigma; '2-1', 'xl', 'pgv2': models.py:26,38,51), DPMSolverMultistep
+    (alpha_t, sigma_t; the PixArt pipelines).  (Until round 6 this read `scheduler.sigmas` directly, which is the Euler rule — wrong for
+    DPMSolverMultistep, which also has `sigmas` and `index_for_timestep`.)"""
     if hasattr(scheduler, "noise_scalars"):
         return scheduler.noise_scalars(timestep)
-    t = timestep.flatten()[0]
-    if hasattr(scheduler, "sigmas") and hasattr(scheduler, "index_for_timestep"):
-        sigma = float(scheduler.sigmas[scheduler.index_for_timestep(t)])
-        return 1.0, sigma
-    ac = float(scheduler.alphas_cumprod[int(t)])
-    return ac ** 0.5, (1 - ac) ** 0.5
+    import copy
+    t1 = timestep.flatten()[:1] if torch.is_tensor(timestep) else torch.as_tensor([timestep])
+
+    def probe(x, n):
+        sch = copy.deepcopy(scheduler)
+        one = lambda v: torch.full((1, 1, 1, 1), float(v), dtype=torch.float64)
+        return float(sch.add_noise(one(x), one(n), t1.cpu()).flatten()[0])
+    a, b = probe(1.0, 0.0), probe(0.0, 1.0)
+    chk = probe(0.5, -2.0)
+    if abs(chk - (0.5 * a - 2.0 * b)) > 1e-6 * (1.0 + abs(chk)):
+        raise NotImplementedError("scheduler.add_noise is not linear in (sample, noise) for this scheduler configuration")
+    return a, b
 
 
 def scheduler_step_scalars(scheduler, timestep):
@@ -186,8 +197,8 @@ def native_prepare_latents(pipe, image, timestep, batch_size, num_images_per_pro
 
 
 class SyntheticPipe:
-    synthetic_weights = True                      # seeded N(0, 1/fan_in) weights: the statistics the operand-plan table was made on
     """Offline stand-in for the diffusers img2img pipeline object (`pipe`) used by FeatureExtractor."""
+    synthetic_weights = True                      # seeded N(0, 1/fan_in) weights: the statistics the operand-plan table was made on
 
     def __init__(self, version, device, seed=0, stream_fp32=True):
         cfg = ARCH_CONFIGS[version]
@@ -281,7 +292,6 @@ class SyntheticPixartPipe(SyntheticPipe):
 
 
 class SyntheticFluxPipe:
-    synthetic_weights = True
     """Offline stand-in for the reference's PATCHED FluxImg2ImgPipeline as `FeatureExtractor.extract` drives it
     (`pipe(image=..., prompt=..., strength=t/1000, guidance_scale=1)`, diffusion_feature.py:246-254): true-architecture
     MMDiT (NativeFluxTransformer, seeded random weights) + deterministic stand-ins for the T5/CLIP encoders and the
@@ -289,6 +299,7 @@ class SyntheticFluxPipe:
     strength -> timestep rule.  Like the reference's pipeline (feature/diffusers/pipelines/flux/pipeline_flux_img2img.py:
     804-841: `return` at the end of the FIRST loop iteration) one call runs EXACTLY ONE transformer forward, at
     sigmas[t_start], and returns None."""
+    synthetic_weights = True
 
     num_inference_steps = 28                      # FluxImg2ImgPipeline.__call__ default
     returns_after_first_forward = True            # like the reference's patched pipeline (:841)
@@ -371,17 +382,64 @@ def flux_compute_dtype():
     return os.environ.get("GDF_FLUX_DTYPE", "") or "auto"
 
 
+def flux_config_from_diffusers(c):
+    """FluxTransformer2DModel `.config` -> the fields of FLUX_CONFIGS"""
+    return dict(in_channels=c.in_channels, num_layers=c.num_layers, num_single_layers=c.num_single_layers,
+                attention_head_dim=c.attention_head_dim, num_attention_heads=c.num_attention_heads,
+                joint_attention_dim=c.joint_attention_dim, pooled_projection_dim=c.pooled_projection_dim,
+                guidance_embeds=int(bool(c.guidance_embeds)), axes_dims_rope=tuple(c.axes_dims_rope), mlp_ratio=4)
+
+
 def _native_flux_from_diffusers(pipe, device):
     """Swap pipe.transformer (diffusers FluxTransformer2DModel, bf16) for the native MMDiT with the same weights."""
-    c = pipe.transformer.config
-    cfg = dict(in_channels=c.in_channels, num_layers=c.num_layers, num_single_layers=c.num_single_layers,
-               attention_head_dim=c.attention_head_dim, num_attention_heads=c.num_attention_heads,
-               joint_attention_dim=c.joint_attention_dim, pooled_projection_dim=c.pooled_projection_dim,
-               guidance_embeds=int(bool(c.guidance_embeds)), axes_dims_rope=tuple(c.axes_dims_rope), mlp_ratio=4)
+    cfg = flux_config_from_diffusers(pipe.transformer.config)
     net = NativeFluxTransformer(cfg, device=device, compute_dtype=flux_compute_dtype())
-    _fill(net, lambda m: m.load_state_dict(pipe.transformer.state_dict()))
+    sd = pipe.transformer.state_dict()
+    _fill(net, lambda m: m.load_state_dict(sd))
+    # ADVICE r5: the fp16 modes ('auto' -> 'float16s') were validated on seeded synthetic weights; the load-time guard only looks at WEIGHT
+    # cast error.  A real checkpoint additionally gets an ACTIVATION range check on its first forward (NativeFluxTransformer.arm_range_check):
+    # a saturated / non-finite 16-bit tensor anywhere in the model re-loads these weights in 'bfloat16x2' (bf16's range, the reference's dtype
+    # as operand pairs) with one warning.  The state dict is held until that forward has run.
+    net.arm_range_check(sd)
     pipe.transformer = net
     pipe.unet = net
+    return pipe
+
+
+def pixart_config_from_diffusers(c):
+    """PixArtTransformer2DModel / Transformer2DModel `.config` -> the fields of PIXART_CONFIGS (interpolation_scale None = diffusers' default
+    max(sample_size // 64, 1))"""
+    ss = int(c.sample_size)
+    isc = getattr(c, "interpolation_scale", None)
+    if getattr(c, "use_additional_conditions", None):
+        raise NotImplementedError("PixArt-alpha micro-conditioning (use_additional_conditions) is not native")
+    return dict(num_attention_heads=int(c.num_attention_heads), attention_head_dim=int(c.attention_head_dim), in_channels=int(c.in_channels),
+                out_channels=int(c.out_channels), num_layers=int(c.num_layers), patch_size=int(c.patch_size), sample_size=ss,
+                caption_channels=int(c.caption_channels), interpolation_scale=int(isc) if isc is not None else max(ss // 64, 1))
+
+
+def _img2img_get_timesteps(self, num_inference_steps, strength, device, denoising_start=None):
+    """`get_timesteps` of the img2img pipelines, for pipelines that do not have one: the STOCK PixArt pipelines are text-to-image (the reference
+    carries patched copies that add this method and an image-taking prepare_latents: feature/diffusers/pipelines/pixart_alpha/
+    pipeline_pixart_sigma.py:598-700).  Same rule: the last int(N * strength) steps remain."""
+    init_timestep = min(int(num_inference_steps * strength), num_inference_steps)
+    t_start = max(num_inference_steps - init_timestep, 0)
+    order = getattr(self.scheduler, "order", 1)
+    timesteps = self.scheduler.timesteps[t_start * order:]
+    if hasattr(self.scheduler, "set_begin_index"):
+        self.scheduler.set_begin_index(t_start * order)
+    return timesteps, num_inference_steps - t_start
+
+
+def _native_vae_from_diffusers(pipe, device):
+    """pipe.native_vae = the AutoencoderKL encoder half in libgdf.so with pipe.vae's weights; pipe.prepare_latents = native_prepare_latents"""
+    vc = pipe.vae.config
+    enc = NativeVAEEncoder(dict(in_channels=vc.in_channels, latent_channels=vc.latent_channels,
+                                block_out_channels=tuple(vc.block_out_channels), layers_per_block=vc.layers_per_block,
+                                use_quant_conv=int(getattr(vc, "use_quant_conv", True))), device=device)
+    _fill(enc, lambda m: m.load_vae_state_dict(pipe.vae.state_dict()))
+    pipe.native_vae = enc
+    pipe.prepare_latents = types.MethodType(native_prepare_latents, pipe)
     return pipe
 
 
@@ -394,13 +452,7 @@ def _native_from_diffusers(pipe, device):
     # the step before the hot path: VAE encode + sample + noise-add in libgdf.so as well.
     # GDF_NATIVE_VAE=0 keeps diffusers' prepare_latents (e.g. the original SDXL VAE, whose activations need fp32).
     if os.environ.get("GDF_NATIVE_VAE", "1") not in ("", "0"):
-        vc = pipe.vae.config
-        enc = NativeVAEEncoder(dict(in_channels=vc.in_channels, latent_channels=vc.latent_channels,
-                                    block_out_channels=tuple(vc.block_out_channels), layers_per_block=vc.layers_per_block,
-                                    use_quant_conv=int(getattr(vc, "use_quant_conv", True))), device=device)
-        _fill(enc, lambda m: m.load_vae_state_dict(pipe.vae.state_dict()))
-        pipe.native_vae = enc
-        pipe.prepare_latents = types.MethodType(native_prepare_latents, pipe)
+        _native_vae_from_diffusers(pipe, device)
     return pipe
 
 
@@ -435,9 +487,17 @@ def get_diffusion_model(version, dtype, offline_lora=None, offline_lora_filename
         else:
             repo = "PixArt-alpha/PixArt-Sigma-XL-2-1024-MS" if version == "pixart-sigma" else "PixArt-alpha/PixArt-Sigma-XL-2-512-MS"
             pipe = diffusers.PixArtSigmaPipeline.from_pretrained(repo, torch_dtype=dt, use_safetensors=True).to(device)
-        net = NativePixArtTransformer(PIXART_CONFIGS[version], device=device)
+        # the architecture comes from the LOADED module (PIXART_CONFIGS holds the same numbers for the synthetic pipes)
+        net = NativePixArtTransformer(pixart_config_from_diffusers(pipe.transformer.config), device=device)
         _fill(net, lambda m: m.load_state_dict({k: v for k, v in pipe.transformer.state_dict().items() if k != "pos_embed.pos_embed"}))
         pipe.transformer = pipe.unet = net
+        # a STOCK diffusers PixArt pipeline is text-to-image: no `get_timesteps`, no image-taking `prepare_latents` (the reference patches both
+        # in).  Round 6: the img2img front half is supplied here — the native VAE encoder + scheduler.add_noise for prepare_latents (unless
+        # GDF_NATIVE_VAE=0 and the installed pipeline is the reference's patched one), the img2img rule for get_timesteps
+        if os.environ.get("GDF_NATIVE_VAE", "1") not in ("", "0"):
+            _native_vae_from_diffusers(pipe, device)
+        if not hasattr(pipe, "get_timesteps"):
+            pipe.get_timesteps = types.MethodType(_img2img_get_timesteps, pipe)
         return pipe
     if version not in _HF:
         raise NotImplementedError                                 # reference models.py:173-174

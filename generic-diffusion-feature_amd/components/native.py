@@ -820,7 +820,7 @@ class NativeUNet(_NativeModel):
         # split and compares the requested hooks; a level whose worst hook differs by more than VERIFY_BOUND is escalated (plain -> selective
         # -> full) for that hook set from then on, with one warning.
         self.verify = (os.environ.get("GDF_VERIFY", "0") not in ("", "0")) if verify is None else bool(verify)
-        self.verify_bound = float(os.environ.get("GDF_VERIFY_BOUND", "9.5e-4"))      # 1e-3 x margin 0.95
+        self.verify_bound = None         # None: sqrt(VERIFY_TARGET^2 - e_full(family)^2) (verify_accept_bound); a float overrides it
         self._escalated = {}             # tuple(hook ids) -> split mask found necessary by the self-check
         self._verified = set()
         self.verify_log = []             # [(hook ids tuple, {mask: worst difference to the full split}, mask kept)]
@@ -858,8 +858,9 @@ class NativeUNet(_NativeModel):
             # (split plans need the fp32 master of the stream: the opt-out fp16-stream mode keeps plain operands)
             if not self.stream_fp32:
                 return 0
-            esc = self._escalated.get(tuple(hook_ids))
-            return esc if esc is not None else choose_split(self.cfg, hook_ids, lat)
+            # (the escalation found by verify at ONE latent grid is OR-ed onto what the table picks for THIS grid — the masks are
+            #  nested, and a smaller grid / another batch may need more than the verified one did)
+            return self._escalated.get(tuple(hook_ids), 0) | choose_split(self.cfg, hook_ids, lat)
         return self.split
 
     def _verify_level(self, run, ids, out):
@@ -867,7 +868,9 @@ class NativeUNet(_NativeModel):
         feature/components/feature_extractor.py:31-76 — here: within 1e-3 of it).  `run(mask)` -> (noise, hooks) of the same inputs under
         operand mask `mask`; `out` = the result of the level the table chose.  Compares every requested hook with the FULL split (itself
         <= 5e-4 from fp32 on every kind with benign weight statistics, tests/test_gpu_fullsize.py; the difference then over-estimates the
-        level's own error) and climbs plain -> light -> selective -> deep (selective + q / k / v pairs + the GEGLU operand) -> full until the worst relative L2 difference is <= verify_bound.
+        level's own error) and climbs plain -> light -> selective -> deep (selective + q / k / v pairs + the GEGLU operand) -> every transformer-side class
+        -> everything but the ResBlock conv operands -> full until the worst relative L2 difference d satisfies d^2 + e_full^2 <= (0.97e-3)^2
+        (verify_accept_bound; e_full = the full split's own distance to fp32 for the family).
         Returns the result to hand out.
         What the check cannot see is the full split's own distance to fp32.  Until round 5 that was 0.7-1.5e-3 on the synthetic heavy-tailed
         statistics of oracle/unet_ref.py synth_params_heavy — the fp16 STORAGE of q / k / v in front of the (text cross-attention's) peaked
@@ -876,22 +879,36 @@ class NativeUNet(_NativeModel):
         tests/test_gpu_fullsize.py test_sdxl_heavy_tailed_full_split_is_a_reference, DESIGN.md 3.9 h).  Reaching the full split is still
         reported as "outside the statistics the plan table was built on"."""
         key = tuple(ids)
-        self._verified.add(key)
         cur = self.last_split
         if cur == SPLIT_ALL or not ids:
+            self._verified.add(key)
             return out
         sel = SELECTIVE_BY_ARCH.get(arch_family(self.cfg), SPLIT_SELECTIVE)
-        levels = [0, SPLIT_LIGHT, sel, sel | SPLIT_CLASSES["ln_ff"], sel | SPLIT_DEEP_EXTRA, SPLIT_ALL]
-        ladder = levels[levels.index(cur):] if cur in levels else [cur, SPLIT_ALL]                  # the levels from the chosen one upwards
+        deep = sel | SPLIT_DEEP_EXTRA
+        levels = [0, SPLIT_LIGHT, sel, sel | SPLIT_CLASSES["ln_ff"], deep,
+                  # round 6 (VERDICT r5 item 5): two more rungs below the full split — every transformer-side class, then everything but the
+                  # ResBlock conv operands (`res`: the most expensive class, a third of an SD1.5 step) — so that weights whose error is spread over
+                  # all classes (the heavy-tailed SD1.5 draw: 1.1-1.5e-3 on every rung up to `deep`) do not fall straight to the full split
+                  deep | SPLIT_CLASSES["attn_out"] | SPLIT_CLASSES["ff_inner"] | SPLIT_CLASSES["ln_attn"] | SPLIT_CLASSES["attn2_out"],
+                  SPLIT_ALL & ~SPLIT_CLASSES["res"], SPLIT_ALL]
+        ladder = levels[levels.index(cur):] if cur in levels else [cur] + [m for m in levels if (m & cur) == cur and m != cur]   # the levels from the chosen one upwards
+        plans_before = set(self._plans)
         try:
             ref = run(SPLIT_ALL)
         except RuntimeError as e:
             # the reference plan does not exist at this size (32-bit buffer offsets: the full split halves the largest batch) or does not fit in
-            # memory: the check cannot run; say so once and keep the table's choice
+            # memory: the check cannot run; say so once per call and keep the table's choice.  The layer set stays UNVERIFIED (ADVICE r5): the
+            # next forward of it — e.g. on the smaller batch the warning asks for — tries again.
             import warnings
             warnings.warn(f"gdf verify: skipped for this layer set ({str(e)[:120]}); verify on a smaller batch to check the automatic operand plan "
                           "against these weights", RuntimeWarning, stacklevel=3)
+            self._drop_plans(set(self._plans) - plans_before)
             return out
+        # Acceptance (round 6): the check sees d = the level's distance to the FULL SPLIT, not to fp32; the full split is itself e_full from fp32
+        # (measured per family on benign AND heavy-tailed weights, tests/test_gpu_fullsize.py).  The two are independent roundings, so a level is
+        # accepted when d^2 + e_full^2 <= target^2 with target = 0.97e-3 (3 % under the north star's 1e-3) — a constant 9.5e-4 guaranteed
+        # sqrt(9.5^2 + 2.7^2) = 9.9e-4 only.  GDF_VERIFY_BOUND overrides the resulting bound on d.
+        bound = self.verify_accept_bound()
         seen = {}
         for m in ladder:
             if m == SPLIT_ALL:
@@ -907,11 +924,12 @@ class NativeUNet(_NativeModel):
                 r = ref[1][k].float()
                 worst = max(worst, float((out[1][k].float() - r).norm() / (r.norm() + 1e-30)))
             seen[m] = worst
-            if worst <= self.verify_bound:
+            if worst <= bound:
                 break
         else:
             m = SPLIT_ALL
         kept = m
+        self._verified.add(key)                       # only after a COMPLETED comparison
         self.verify_log.append((key, seen, kept))
         if kept != cur:
             import warnings
@@ -920,11 +938,31 @@ class NativeUNet(_NativeModel):
             if kept == SPLIT_ALL:
                 tail = ("; every cheaper level differs from the full split by more than the bound: these weights are outside the statistics the plan "
                         "table was built on (the full split itself measures 2-4e-4 against fp32 on benign and on heavy-tailed synthetic weights)")
-            warnings.warn(f"gdf verify: operand plan {cur} differs from the full split by {seen.get(cur, float('nan')):.2e} (> {self.verify_bound:.1e}) on the "
+            warnings.warn(f"gdf verify: operand plan {cur} differs from the full split by {seen.get(cur, float('nan')):.2e} (> {bound:.2e}) on the "
                           f"requested layers with THESE weights; using plan {kept} for this layer set from now on "
                           f"(levels tried: { {k: '%.2e' % v for k, v in seen.items()} }){tail}", RuntimeWarning, stacklevel=3)
         self.last_split = kept
+        # the plans built only for the check (the full split's, the rungs tried and rejected) go away with their workspaces and hook sets; the
+        # kept level's plan stays (the next forward of this layer set replays it)
+        keep_split = kept
+        self._drop_plans({k for k in set(self._plans) - plans_before if k[8] != keep_split})
         return out
+
+    VERIFY_TARGET = 0.97e-3                                          # what a kept level must meet against fp32: 3 % under 1e-3
+    FULL_SPLIT_ERROR = {"xl": 2.7e-4, "1-5": 4.4e-4}                 # the full split's own measured distance to fp32, worst hook incl. maps
+
+    def verify_accept_bound(self):
+        env = os.environ.get("GDF_VERIFY_BOUND", "")
+        if env:
+            return float(env)
+        if getattr(self, "verify_bound", None) is not None:
+            return float(self.verify_bound)
+        e_full = self.FULL_SPLIT_ERROR.get(arch_family(self.cfg), 4.4e-4)
+        return (self.VERIFY_TARGET ** 2 - e_full ** 2) ** 0.5
+
+    def _drop_plans(self, keys):
+        for k in keys:
+            self._plans.pop(k, None)
 
     def _is_norm(self, name):
         return ".norm" in name or name.startswith("conv_norm_out")
@@ -1084,6 +1122,8 @@ class NativeFluxTransformer(_NativeModel):
         self.feature_store = None
         self.single_forward = False      # True: __call__ raises SingleForwardDone after one forward (stock diffusers pipelines)
         self.calls = 0                   # number of __call__ forwards so far (tests count one per pipe(...) call)
+        self._range_check_sd = None      # state dict held for the first-forward activation range check (arm_range_check)
+        self.range_check_log = None      # {"saturated": [(hook id, max |x|)], "mode_before": ..., "mode_after": ...} once the check has run
         self.config = types.SimpleNamespace(in_channels=cfg["in_channels"], guidance_embeds=bool(cfg["guidance_embeds"]),
                                             joint_attention_dim=cfg["joint_attention_dim"],
                                             pooled_projection_dim=cfg["pooled_projection_dim"])
@@ -1133,6 +1173,46 @@ class NativeFluxTransformer(_NativeModel):
                 self.cfg["compute_dtype"] = "bfloat16x2"
                 self._create()
         return super().load_state_dict(sd, strict)
+
+    # ---- activation range check of the fp16 modes on REAL checkpoints ----------------------------------------------
+    def arm_range_check(self, sd):
+        """Called by components/models.py for a checkpoint loaded from diffusers: if the model runs in an fp16 mode ('auto' / 'float16s' /
+        'float16'), its FIRST forward is preceded by a one-sample forward that stores EVERY hook of EVERY block (q, k, v, attention output,
+        modulated norm output, MLP hidden, block output: an image of each 16-bit tensor class of the MMDiT) and scans them for saturated
+        (|x| = 65504: the kernels' 16-bit stores clamp) or non-finite values.  Any hit means an activation of THIS checkpoint leaves the fp16
+        range somewhere the seeded synthetic weights never did: the weights in `sd` are re-loaded in 'bfloat16x2' (bf16's exponent range,
+        hi + lo operand pairs) with one warning.  `sd` is released after the check.  GDF_FLUX_RANGE_CHECK=0 disables it."""
+        if self.cfg["compute_dtype"] in ("auto", "float16s", "float16") and os.environ.get("GDF_FLUX_RANGE_CHECK", "1") not in ("", "0"):
+            self._range_check_sd = sd
+        return self
+
+    def _run_range_check(self, hidden_states, encoder_hidden_states, pooled_projections, timestep, img_ids, txt_ids, guidance, grid):
+        sd, self._range_check_sd = self._range_check_sd, None
+        first = lambda v: v[:1] if (torch.is_tensor(v) and v.dim() > 0 and v.shape[0] > 1) else v
+        ids = [h for h in self.hook_names() if not h.endswith("-map")]
+        ee, self.early_exit = self.early_exit, False
+        try:
+            out, hooks = self.forward_raw(first(hidden_states), first(encoder_hidden_states), first(pooled_projections), first(timestep), img_ids,
+                                          txt_ids, guidance=first(guidance) if guidance is not None else None, hook_ids=ids, grid=grid)
+        finally:
+            self.early_exit = ee
+        FP16_MAX = 65504.0
+        bad = []
+        for k, v in list(hooks.items()) + [("output", out)]:
+            m = float(v.float().abs().nan_to_num(nan=float("inf")).max())
+            if not m < FP16_MAX:
+                bad.append((k, m))
+        del hooks, out
+        self._plans.clear()
+        before = self.cfg["compute_dtype"]
+        if bad:
+            import warnings
+            warnings.warn(f"gdf flux: {len(bad)} 16-bit tensors of this checkpoint reach the end of the fp16 range in mode '{before}' (first: {bad[0][0]}, "
+                          f"max |x| = {bad[0][1]:.3g}); re-loading the weights in 'bfloat16x2' (bf16 operand pairs, bf16's range)", RuntimeWarning, stacklevel=3)
+            self.cfg["compute_dtype"] = "bfloat16x2"
+            self._create()
+            _NativeModel.load_state_dict(self, sd)
+        self.range_check_log = {"saturated": bad, "mode_before": before, "mode_after": self.cfg["compute_dtype"], "tensors_scanned": len(ids) + 1}
 
     def _plan(self, batch, gh, gw, n_txt, hook_ids):
         key = (batch, gh, gw, n_txt, tuple(hook_ids), self.early_exit)
@@ -1189,6 +1269,8 @@ class NativeFluxTransformer(_NativeModel):
                  controlnet_single_block_samples=None, return_dict=True, grid=None, **kwargs):
         if controlnet_block_samples is not None or controlnet_single_block_samples is not None or joint_attention_kwargs:
             raise NotImplementedError("ControlNet residuals / IP-adapter kwargs are outside the native hot path")
+        if self._range_check_sd is not None:
+            self._run_range_check(hidden_states, encoder_hidden_states, pooled_projections, timestep, img_ids, txt_ids, guidance, grid)
         ids = self.requested_ids()
         out, hooks = self.forward_raw(hidden_states, encoder_hidden_states, pooled_projections, timestep, img_ids, txt_ids,
                                       guidance=guidance, hook_ids=ids, grid=grid)

@@ -58,7 +58,7 @@ class FeatureExtractor(nn.Module):
                  verify=None,      # native extension (None = ON for real checkpoints, OFF for GDF_SYNTHETIC_WEIGHTS pipelines; GDF_VERIFY=0/1 overrides):
                                    # True = runtime self-check of the automatic operand plan on the first batch of
                                    # every layer set: the chosen level and the full split are both run, the requested layers compared, and the level
-                                   # escalated (with one warning) when any differs by more than 9.5e-4 — the plan chooser's error table comes from
+                                   # escalated (with one warning) when any differs by more than the family's acceptance bound (d^2 + e_full^2 <= (0.97e-3)^2) — the plan chooser's error table comes from
                                    # synthetic weight statistics, real checkpoints may be heavier-tailed (components/native.py _verify_level)
                  early_exit=False, # native extension, OPT-IN: stop the denoiser forward after the last requested layer (the reference always runs the
                                    # whole forward and discards `noise_pred`; the returned features are bit-identical either way).  Ignored when
@@ -181,9 +181,13 @@ class FeatureExtractor(nn.Module):
             stock = tr is not None and hasattr(tr, 'single_forward') and not getattr(self.pipe, 'returns_after_first_forward', False)
             if stock:
                 tr.single_forward = True
+            imgs = _map_threads(lambda i: i.resize((self.img_size, self.img_size)).convert("RGB"), list(image))
+            if stock and isinstance(prompts, str) and len(imgs) > 1:
+                # a stock FluxImg2ImgPipeline takes its batch size from the PROMPT (a str = 1) and then fails to pack B > 1 image latents;
+                # the CLI hands the raw prompt text over (reference extract_feature.py:81-82): one copy per image
+                prompts = [prompts] * len(imgs)
             try:
-                self.pipe(image=_map_threads(lambda i: i.resize((self.img_size, self.img_size)).convert("RGB"), list(image)),
-                          prompt=prompts, strength=t / 1000, guidance_scale=1)
+                self.pipe(image=imgs, prompt=prompts, strength=t / 1000, guidance_scale=1)
             except SingleForwardDone:
                 pass
             finally:

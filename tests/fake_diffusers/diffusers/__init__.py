@@ -1,0 +1,927 @@
+"""TEST INFRASTRUCTURE — a stand-in for the `diffusers` package (0.32.2 API surface), never imported by the product.
+
+Neither diffusers nor a checkpoint exists on the build / GPU boxes, so until round 6 no test reached the branch of
+generic-diffusion-feature_amd/components/models.py a user with REAL checkpoints takes (`get_diffusion_model` without
+GDF_SYNTHETIC_WEIGHTS: `from_pretrained` -> `config_from_diffusers` -> `load_state_dict(pipe.unet.state_dict())` -> native VAE from
+`pipe.vae.state_dict()` -> scheduler objects with `sigmas` / `alphas_cumprod` / `index_for_timestep` / `step`).  Tests put
+`tests/fake_diffusers` on sys.path; `import diffusers` inside the product then finds this package, which hands out
+
+  * pipelines with the STOCK diffusers call surface the reference and the product use (reference feature/components/models.py:18-172,
+    feature/diffusion_feature.py:149-206, :288-295, :371-380, :405-406, :477-485): `from_pretrained`, `.to`, `.unet / .transformer / .vae /
+    .text_encoder(_2) / .scheduler / .image_processor / .config`, `encode_prompt`, `get_timesteps`, `load_lora_weights`, `fuse_lora`,
+    and for Flux the whole `__call__` of FluxImg2ImgPipeline up to (and past) its first transformer call;
+  * `nn.Module` shells for the denoisers carrying diffusers' parameter NAMES, SHAPES and CONFIG at the true architectures
+    (tests/golden/diffusers_keys.json: generated from the reference's own model classes by tests/golden/gen_diffusers_keys.py), filled
+    with seeded N(0, 1/fan_in) weights; an AutoencoderKL shell whose key list is restated below from the published module tree
+    (un-vendored in the reference);
+  * the schedulers the reference configures — PNDMScheduler (1-5), EulerDiscreteScheduler (2-1, xl, pgv2), DPMSolverMultistepScheduler
+    (PixArt), FlowMatchEulerDiscreteScheduler (Flux) — restated from the published algorithms: `set_timesteps`, `timesteps`, `sigmas`,
+    `alphas_cumprod`, `index_for_timestep`, `set_begin_index`, `scale_model_input`, `add_noise` / `scale_noise`, `step`.
+
+What is NOT modelled: the text encoders (deterministic embeddings of the right shapes), checkpoint files, the VAE / denoiser FORWARD
+of diffusers (the product replaces both; the shells raise if called).  `CALLS` records every `from_pretrained` / lora call so tests can
+assert the arguments the product passed; `PIPES` keeps every pipeline created together with its ORIGINAL components (the product swaps
+`pipe.unet` for the native model — the test reads the weights it was loaded from out of here).
+"""
+import hashlib
+import json
+import math
+import os
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+__version__ = "0.32.2+fake"
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_KEYS_PATH = os.path.join(os.path.dirname(os.path.dirname(_HERE)), "golden", "diffusers_keys.json")
+_KEYS = None
+
+CALLS = []          # [(what, args dict)]
+PIPES = []          # every pipeline object handed out (strong references: tests read the original components back)
+
+
+def reset():
+    del CALLS[:]
+    del PIPES[:]
+
+
+def _keys():
+    global _KEYS
+    if _KEYS is None:
+        with open(_KEYS_PATH) as f:
+            _KEYS = json.load(f)
+    return _KEYS
+
+
+class FrozenDict(dict):
+    """diffusers.configuration_utils.FrozenDict: a dict whose items are also attributes"""
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k)
+
+
+# ------------------------------------------------------------------------------------------------------------------------------ #
+# module shells
+# ------------------------------------------------------------------------------------------------------------------------------ #
+class _Node(nn.Module):
+    pass
+
+
+def _is_norm_name(name):
+    return "norm" in name.rsplit(".", 1)[0].split(".")[-1] or ".norm" in name or name.startswith("conv_norm_out") or "group_norm" in name
+
+
+def _fill_value(name, shape, gen, device):
+    """Seeded synthetic checkpoint values: matrices / conv kernels ~ N(0, 1/fan_in), biases 0.05 N, norm gains 1 + 0.1 N, norm biases 0.1 N,
+    PixArt scale_shift_table ~ N(0, 1/C) — the statistics the operand-plan table of the product was derived on."""
+    t = torch.randn(tuple(shape), generator=gen, device=device, dtype=torch.float32)
+    if name.endswith("scale_shift_table"):
+        return t.mul_(shape[-1] ** -0.5)
+    norm = _is_norm_name(name)
+    if name.endswith(".weight") and len(shape) >= 2:
+        fan = 1
+        for s in shape[1:]:
+            fan *= s
+        return t.mul_(fan ** -0.5)
+    if name.endswith(".weight"):
+        return t.mul_(0.1).add_(1.0)
+    return t.mul_(0.1 if norm else 0.05)
+
+
+class ShellModel(nn.Module):
+    """An nn.Module tree that has exactly the given parameter names and shapes (so `.state_dict()`, `.parameters()`, `.to()` behave like
+    the diffusers model's) and a `.config`.  It has no forward: the product must replace it."""
+
+    def __init__(self, keys, config, dtype, seed, device="cpu"):
+        super().__init__()
+        self.config = FrozenDict(config)
+        gen = torch.Generator(device=device).manual_seed(seed)
+        for name, shape in keys:
+            parts = name.split(".")
+            node = self
+            for p in parts[:-1]:
+                if p not in node._modules:
+                    node.add_module(p, _Node())
+                node = node._modules[p]
+            node.register_parameter(parts[-1], nn.Parameter(_fill_value(name, shape, gen, device).to(dtype), requires_grad=True))
+
+    @property
+    def dtype(self):
+        return next(self.parameters()).dtype
+
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+    def forward(self, *a, **k):
+        raise AssertionError("fake diffusers: the torch forward of this model does not exist — the native path must have replaced the module")
+
+    __call__ = forward
+
+
+def _gen_device():
+    return "cuda" if (torch.cuda.is_available() and os.environ.get("FAKE_DIFFUSERS_CPU_WEIGHTS", "0") != "1") else "cpu"
+
+
+def _unet_shell(tag, dtype, seed):
+    k = _keys()[tag]
+    m = ShellModel(k["keys"], k["config"], dtype, seed, _gen_device())
+    # what _get_add_time_ids of the SDXL pipelines reads (reference diffusion_feature.py:534-571)
+    if k["config"].get("addition_embed_type") == "text_time":
+        m.add_embedding.linear_1.in_features = k["config"]["projection_class_embeddings_input_dim"]
+    return m
+
+
+def _limit_blocks(keys, prefix_limits):
+    """keep `prefix.N.` entries only for N < limit (tests shrink the DEPTH of the 12-B Flux transformer, never a width)"""
+    out = []
+    for name, shape in keys:
+        keep = True
+        for prefix, lim in prefix_limits.items():
+            if name.startswith(prefix + "."):
+                keep = int(name[len(prefix) + 1:].split(".")[0]) < lim
+        if keep:
+            out.append((name, shape))
+    return out
+
+
+def _flux_shell(dtype, seed):
+    k = _keys()["flux"]
+    cfg = dict(k["config"])
+    keys = k["keys"]
+    lim = os.environ.get("FAKE_DIFFUSERS_FLUX_LAYERS", "")
+    if lim:
+        nd, ns = (int(x) for x in lim.split(","))
+        cfg["num_layers"], cfg["num_single_layers"] = nd, ns
+        keys = _limit_blocks(keys, {"transformer_blocks": nd, "single_transformer_blocks": ns})
+    return ShellModel(keys, cfg, dtype, seed, _gen_device())
+
+
+def _pixart_shell(dtype, seed, sample_size=128, interpolation_scale=2):
+    k = _keys()["pixart-sigma"]
+    cfg = dict(k["config"], sample_size=sample_size, interpolation_scale=interpolation_scale)
+    keys = k["keys"]
+    lim = os.environ.get("FAKE_DIFFUSERS_PIXART_LAYERS", "")
+    if lim:
+        cfg["num_layers"] = int(lim)
+        keys = _limit_blocks(keys, {"transformer_blocks": int(lim)})
+    return ShellModel(keys, cfg, dtype, seed, _gen_device())
+
+
+def autoencoder_kl_keys(block_out_channels=(128, 256, 512, 512), layers_per_block=2, in_channels=3, out_channels=3, latent_channels=4,
+                        use_quant_conv=True, use_post_quant_conv=True):
+    """[restated] the parameter tree of diffusers==0.32.2 AutoencoderKL (models/autoencoders/autoencoder_kl.py + vae.py Encoder / Decoder,
+    unet_2d_blocks.py DownEncoderBlock2D / UpDecoderBlock2D / UNetMidBlock2D with one single-head Attention): names as `state_dict()` of a
+    loaded model reports them (the deprecated query / key / value / proj_attn names are converted at load time)."""
+    keys = []
+
+    def conv(n, co, ci, k=3):
+        keys.append((n + ".weight", [co, ci, k, k])); keys.append((n + ".bias", [co]))
+
+    def norm(n, c):
+        keys.append((n + ".weight", [c])); keys.append((n + ".bias", [c]))
+
+    def lin(n, co, ci):
+        keys.append((n + ".weight", [co, ci])); keys.append((n + ".bias", [co]))
+
+    def resnet(n, ci, co):
+        norm(n + ".norm1", ci); conv(n + ".conv1", co, ci); norm(n + ".norm2", co); conv(n + ".conv2", co, co)
+        if ci != co:
+            conv(n + ".conv_shortcut", co, ci, 1)
+
+    def mid(n, c):
+        norm(n + ".attentions.0.group_norm", c)
+        for q in ("to_q", "to_k", "to_v"):
+            lin(n + ".attentions.0." + q, c, c)
+        lin(n + ".attentions.0.to_out.0", c, c)
+        resnet(n + ".resnets.0", c, c); resnet(n + ".resnets.1", c, c)
+
+    boc = list(block_out_channels)
+    conv("encoder.conv_in", boc[0], in_channels)
+    ci = boc[0]
+    for i, co in enumerate(boc):
+        for j in range(layers_per_block):
+            resnet(f"encoder.down_blocks.{i}.resnets.{j}", ci, co)
+            ci = co
+        if i != len(boc) - 1:
+            conv(f"encoder.down_blocks.{i}.downsamplers.0.conv", co, co)
+    mid("encoder.mid_block", boc[-1])
+    norm("encoder.conv_norm_out", boc[-1])
+    conv("encoder.conv_out", 2 * latent_channels, boc[-1])
+    conv("decoder.conv_in", boc[-1], latent_channels)
+    mid("decoder.mid_block", boc[-1])
+    rev = boc[::-1]
+    ci = rev[0]
+    for i, co in enumerate(rev):
+        for j in range(layers_per_block + 1):
+            resnet(f"decoder.up_blocks.{i}.resnets.{j}", ci, co)
+            ci = co
+        if i != len(rev) - 1:
+            conv(f"decoder.up_blocks.{i}.upsamplers.0.conv", co, co)
+    norm("decoder.conv_norm_out", boc[0])
+    conv("decoder.conv_out", out_channels, boc[0])
+    if use_quant_conv:
+        conv("quant_conv", 2 * latent_channels, 2 * latent_channels, 1)
+    if use_post_quant_conv:
+        conv("post_quant_conv", latent_channels, latent_channels, 1)
+    return keys
+
+
+def _vae_shell(dtype, seed, scaling_factor, latent_channels=4, shift_factor=None, quant=True, sample_size=512, force_upcast=True):
+    cfg = dict(in_channels=3, out_channels=3, down_block_types=["DownEncoderBlock2D"] * 4, up_block_types=["UpDecoderBlock2D"] * 4,
+               block_out_channels=[128, 256, 512, 512], layers_per_block=2, act_fn="silu", latent_channels=latent_channels, norm_num_groups=32,
+               sample_size=sample_size, scaling_factor=scaling_factor, shift_factor=shift_factor, latents_mean=None, latents_std=None,
+               force_upcast=force_upcast, use_quant_conv=quant, use_post_quant_conv=quant, mid_block_add_attention=True)
+    return ShellModel(autoencoder_kl_keys(latent_channels=latent_channels, use_quant_conv=quant, use_post_quant_conv=quant), cfg, dtype, seed,
+                      _gen_device())
+
+
+class _TextEncoder(nn.Module):
+    def __init__(self, hidden, projection_dim=None, dtype=torch.float16):
+        super().__init__()
+        self.stub = nn.Parameter(torch.zeros(4, dtype=dtype))
+        self.config = FrozenDict(hidden_size=hidden, projection_dim=projection_dim)
+
+    @property
+    def dtype(self):
+        return self.stub.dtype
+
+
+def _embeds(text, shape, device, dtype):
+    seed = int.from_bytes(hashlib.sha256(text.encode()).digest()[:4], "little")
+    return torch.randn(shape, generator=torch.Generator().manual_seed(seed)).to(device=device, dtype=dtype)
+
+
+# ------------------------------------------------------------------------------------------------------------------------------ #
+# VaeImageProcessor [restated: image_processor.py preprocess for PIL / tensor inputs, do_resize to multiples of the scale factor]
+# ------------------------------------------------------------------------------------------------------------------------------ #
+class VaeImageProcessor:
+    def __init__(self, do_resize=True, vae_scale_factor=8, do_normalize=True):
+        self.config = FrozenDict(do_resize=do_resize, vae_scale_factor=vae_scale_factor, do_normalize=do_normalize, resample="lanczos")
+
+    def preprocess(self, image, height=None, width=None):
+        import PIL.Image
+        if isinstance(image, (PIL.Image.Image, torch.Tensor)) and not (torch.is_tensor(image) and image.ndim == 4):
+            image = [image]
+        if torch.is_tensor(image):
+            x = image
+        elif isinstance(image[0], PIL.Image.Image):
+            f = self.config.vae_scale_factor
+            out = []
+            for im in image:
+                w, h = im.size
+                hh, ww = height or h, width or w
+                hh, ww = hh - hh % f, ww - ww % f
+                if self.config.do_resize and (ww, hh) != (w, h):
+                    im = im.resize((ww, hh), resample=PIL.Image.LANCZOS)
+                out.append(np.array(im).astype(np.float32) / 255.0)
+            arr = np.stack(out, 0)
+            if arr.ndim == 3:
+                arr = arr[..., None]
+            x = torch.from_numpy(arr.transpose(0, 3, 1, 2))
+        else:                                                               # list of 3-D / 4-D tensors
+            x = torch.cat(image, 0) if image[0].ndim == 4 else torch.stack(image, 0)
+            if height or width:
+                x = torch.nn.functional.interpolate(x, size=(height or x.shape[-2], width or x.shape[-1]))
+        do_norm = self.config.do_normalize
+        if do_norm and x.min() < 0:                                         # diffusers warns and skips the [0,1] -> [-1,1] map
+            do_norm = False
+        return 2.0 * x - 1.0 if do_norm else x
+
+
+# ------------------------------------------------------------------------------------------------------------------------------ #
+# schedulers [restated from the published algorithms of diffusers==0.32.2]
+# ------------------------------------------------------------------------------------------------------------------------------ #
+def _betas(cfg):
+    n = cfg["num_train_timesteps"]
+    if cfg["beta_schedule"] == "scaled_linear":
+        return torch.linspace(cfg["beta_start"] ** 0.5, cfg["beta_end"] ** 0.5, n, dtype=torch.float32) ** 2
+    if cfg["beta_schedule"] == "linear":
+        return torch.linspace(cfg["beta_start"], cfg["beta_end"], n, dtype=torch.float32)
+    raise NotImplementedError(cfg["beta_schedule"])
+
+
+class _SchedulerBase:
+    order = 1
+    _defaults = {}
+
+    def __init__(self, **kw):
+        cfg = dict(self._defaults)
+        cfg.update({k: v for k, v in kw.items() if k in cfg})
+        cfg["_class_name"] = type(self).__name__
+        self.config = FrozenDict(cfg)
+
+    @classmethod
+    def from_config(cls, config, **kw):
+        CALLS.append((cls.__name__ + ".from_config", dict(config)))
+        return cls(**dict(config, **kw))
+
+    @classmethod
+    def from_pretrained(cls, repo, subfolder=None, **kw):
+        CALLS.append((cls.__name__ + ".from_pretrained", dict(repo=repo, subfolder=subfolder)))
+        return cls(**_SCHEDULER_CONFIGS.get(repo, {}))
+
+    def index_for_timestep(self, timestep, schedule_timesteps=None):
+        st = self.timesteps if schedule_timesteps is None else schedule_timesteps
+        idx = (st == timestep).nonzero()
+        pos = 1 if len(idx) > 1 else 0
+        return idx[pos].item()
+
+    def set_begin_index(self, begin_index=0):
+        self._begin_index = begin_index
+
+    def _init_step_index(self, timestep):
+        if self._begin_index is None:
+            if torch.is_tensor(timestep):
+                timestep = timestep.to(self.timesteps.device)
+            self._step_index = self.index_for_timestep(timestep)
+        else:
+            self._step_index = self._begin_index
+
+    def _indices_for(self, timesteps, schedule_timesteps):
+        if self._begin_index is None:
+            return [self.index_for_timestep(t, schedule_timesteps) for t in timesteps]
+        if self._step_index is not None:
+            return [self._step_index] * timesteps.shape[0]
+        return [self._begin_index] * timesteps.shape[0]
+
+
+class PNDMScheduler(_SchedulerBase):
+    _defaults = dict(num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule="linear", trained_betas=None, skip_prk_steps=False,
+                     set_alpha_to_one=False, prediction_type="epsilon", timestep_spacing="leading", steps_offset=0)
+
+    def __init__(self, **kw):
+        super().__init__(**kw)
+        self.betas = _betas(self.config)
+        self.alphas = 1.0 - self.betas
+        self.alphas_cumprod = torch.cumprod(self.alphas, dim=0)
+        self.final_alpha_cumprod = torch.tensor(1.0) if self.config.set_alpha_to_one else self.alphas_cumprod[0]
+        self.init_noise_sigma = 1.0
+        self.pndm_order = 4
+        self.cur_model_output, self.counter, self.cur_sample, self.ets = 0, 0, None, []
+        self.num_inference_steps = None
+        self.timesteps = torch.from_numpy(np.arange(0, self.config.num_train_timesteps)[::-1].copy())
+        self.prk_timesteps = self.plms_timesteps = None
+
+    def set_timesteps(self, num_inference_steps, device=None):
+        self.num_inference_steps = num_inference_steps
+        c = self.config
+        if c.timestep_spacing == "leading":
+            ratio = c.num_train_timesteps // num_inference_steps
+            ts = (np.arange(0, num_inference_steps) * ratio).round() + c.steps_offset
+        elif c.timestep_spacing == "linspace":
+            ts = np.linspace(0, c.num_train_timesteps - 1, num_inference_steps).round().astype(np.int64)
+        else:
+            raise NotImplementedError(c.timestep_spacing)
+        self._timesteps = ts
+        if c.skip_prk_steps:
+            self.prk_timesteps = np.array([])
+            self.plms_timesteps = np.concatenate([ts[:-1], ts[-2:-1], ts[-1:]])[::-1].copy()
+        else:
+            raise NotImplementedError("PRK steps (the reference's checkpoints set skip_prk_steps)")
+        self.timesteps = torch.from_numpy(np.concatenate([self.prk_timesteps, self.plms_timesteps]).astype(np.int64)).to(device)
+        self.ets, self.counter, self.cur_model_output = [], 0, 0
+
+    def scale_model_input(self, sample, *a, **k):
+        return sample
+
+    def add_noise(self, original_samples, noise, timesteps):
+        ac = self.alphas_cumprod.to(device=original_samples.device, dtype=original_samples.dtype)
+        timesteps = timesteps.to(original_samples.device)
+        a = ac[timesteps] ** 0.5
+        b = (1 - ac[timesteps]) ** 0.5
+        while a.ndim < original_samples.ndim:
+            a, b = a.unsqueeze(-1), b.unsqueeze(-1)
+        return a * original_samples + b * noise
+
+    def step(self, model_output, timestep, sample, return_dict=True):
+        return self.step_plms(model_output, timestep, sample, return_dict)
+
+    def step_plms(self, model_output, timestep, sample, return_dict=True):
+        ratio = self.config.num_train_timesteps // self.num_inference_steps
+        prev_timestep = timestep - ratio
+        if self.counter != 1:
+            self.ets = self.ets[-3:]
+            self.ets.append(model_output)
+        else:
+            prev_timestep = timestep
+            timestep = timestep + ratio
+        if len(self.ets) == 1 and self.counter == 0:
+            self.cur_sample = sample
+        elif len(self.ets) == 1 and self.counter == 1:
+            model_output = (model_output + self.ets[-1]) / 2
+            sample, self.cur_sample = self.cur_sample, None
+        elif len(self.ets) == 2:
+            model_output = (3 * self.ets[-1] - self.ets[-2]) / 2
+        elif len(self.ets) == 3:
+            model_output = (23 * self.ets[-1] - 16 * self.ets[-2] + 5 * self.ets[-3]) / 12
+        else:
+            model_output = (1 / 24) * (55 * self.ets[-1] - 59 * self.ets[-2] + 37 * self.ets[-3] - 9 * self.ets[-4])
+        prev = self._get_prev_sample(sample, timestep, prev_timestep, model_output)
+        self.counter += 1
+        return types.SimpleNamespace(prev_sample=prev) if return_dict else (prev,)
+
+    def _get_prev_sample(self, sample, timestep, prev_timestep, model_output):
+        a_t = self.alphas_cumprod[timestep]
+        a_p = self.alphas_cumprod[prev_timestep] if prev_timestep >= 0 else self.final_alpha_cumprod
+        b_t, b_p = 1 - a_t, 1 - a_p
+        if self.config.prediction_type == "v_prediction":
+            model_output = (a_t ** 0.5) * model_output + (b_t ** 0.5) * sample
+        elif self.config.prediction_type != "epsilon":
+            raise ValueError(self.config.prediction_type)
+        sample_coeff = (a_p / a_t) ** 0.5
+        denom = a_t * b_p ** 0.5 + (a_t * b_t * a_p) ** 0.5
+        return sample_coeff * sample - (a_p - a_t) * model_output / denom
+
+
+class EulerDiscreteScheduler(_SchedulerBase):
+    _defaults = dict(num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule="linear", trained_betas=None,
+                     prediction_type="epsilon", interpolation_type="linear", use_karras_sigmas=False, timestep_spacing="linspace",
+                     timestep_type="discrete", steps_offset=0, rescale_betas_zero_snr=False, final_sigmas_type="zero")
+
+    def __init__(self, **kw):
+        super().__init__(**kw)
+        self.betas = _betas(self.config)
+        self.alphas = 1.0 - self.betas
+        self.alphas_cumprod = torch.cumprod(self.alphas, dim=0)
+        sig = (((1 - self.alphas_cumprod) / self.alphas_cumprod) ** 0.5).flip(0)
+        self.timesteps = torch.from_numpy(np.linspace(0, self.config.num_train_timesteps - 1, self.config.num_train_timesteps, dtype=float)[::-1].copy()).float()
+        self.sigmas = torch.cat([sig, torch.zeros(1)])
+        self.num_inference_steps = None
+        self.is_scale_input_called = False
+        self._step_index = self._begin_index = None
+
+    @property
+    def init_noise_sigma(self):
+        ms = self.sigmas.max()
+        return ms if self.config.timestep_spacing in ("linspace", "trailing") else (ms ** 2 + 1) ** 0.5
+
+    @property
+    def step_index(self):
+        return self._step_index
+
+    @property
+    def begin_index(self):
+        return self._begin_index
+
+    def set_timesteps(self, num_inference_steps, device=None):
+        c = self.config
+        self.num_inference_steps = num_inference_steps
+        if c.timestep_spacing == "linspace":
+            ts = np.linspace(0, c.num_train_timesteps - 1, num_inference_steps, dtype=np.float32)[::-1].copy()
+        elif c.timestep_spacing == "leading":
+            ratio = c.num_train_timesteps // num_inference_steps
+            ts = (np.arange(0, num_inference_steps) * ratio).round()[::-1].copy().astype(np.float32) + c.steps_offset
+        elif c.timestep_spacing == "trailing":
+            ratio = c.num_train_timesteps / num_inference_steps
+            ts = (np.arange(c.num_train_timesteps, 0, -ratio)).round().copy().astype(np.float32) - 1
+        else:
+            raise ValueError(c.timestep_spacing)
+        sig = (((1 - self.alphas_cumprod) / self.alphas_cumprod) ** 0.5).numpy()
+        if c.interpolation_type != "linear" or c.use_karras_sigmas:
+            raise NotImplementedError
+        sig = np.interp(ts, np.arange(0, len(sig)), sig)
+        last = 0.0 if c.final_sigmas_type == "zero" else ((1 - self.alphas_cumprod[0]) / self.alphas_cumprod[0]) ** 0.5
+        sig = np.concatenate([sig, [last]]).astype(np.float32)
+        self.timesteps = torch.from_numpy(ts.astype(np.float32)).to(device=device)
+        self.sigmas = torch.from_numpy(sig).to("cpu")            # "to avoid too much CPU/GPU communication"
+        self._step_index = self._begin_index = None
+
+    def scale_model_input(self, sample, timestep):
+        if self._step_index is None:
+            self._init_step_index(timestep)
+        sigma = self.sigmas[self._step_index]
+        self.is_scale_input_called = True
+        return sample / ((sigma ** 2 + 1) ** 0.5)
+
+    def add_noise(self, original_samples, noise, timesteps):
+        sig = self.sigmas.to(device=original_samples.device, dtype=original_samples.dtype)
+        st = self.timesteps.to(original_samples.device)
+        timesteps = timesteps.to(original_samples.device)
+        s = sig[self._indices_for(timesteps, st)].flatten()
+        while s.ndim < original_samples.ndim:
+            s = s.unsqueeze(-1)
+        return original_samples + noise * s
+
+    def step(self, model_output, timestep, sample, s_churn=0.0, s_tmin=0.0, s_tmax=float("inf"), s_noise=1.0, generator=None, return_dict=True):
+        if self._step_index is None:
+            self._init_step_index(timestep)
+        sample = sample.to(torch.float32)
+        sigma = self.sigmas[self._step_index]
+        sigma_hat = sigma
+        if self.config.prediction_type == "epsilon":
+            x0 = sample - sigma_hat * model_output
+        elif self.config.prediction_type == "v_prediction":
+            x0 = model_output * (-sigma / (sigma ** 2 + 1) ** 0.5) + (sample / (sigma ** 2 + 1))
+        else:
+            raise ValueError(self.config.prediction_type)
+        derivative = (sample - x0) / sigma_hat
+        dt = self.sigmas[self._step_index + 1] - sigma_hat
+        prev = (sample + derivative * dt).to(model_output.dtype)
+        self._step_index += 1
+        return types.SimpleNamespace(prev_sample=prev, pred_original_sample=x0) if return_dict else (prev, x0)
+
+
+class DPMSolverMultistepScheduler(_SchedulerBase):
+    """set_timesteps / add_noise / scale_model_input only (the single-timestep path never steps a PixArt scheduler: 'vae-out' is rejected
+    for the DiT versions)."""
+    _defaults = dict(num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule="linear", trained_betas=None, solver_order=2,
+                     prediction_type="epsilon", thresholding=False, algorithm_type="dpmsolver++", solver_type="midpoint", lower_order_final=True,
+                     use_karras_sigmas=False, lambda_min_clipped=-float("inf"), variance_type=None, timestep_spacing="linspace", steps_offset=0,
+                     final_sigmas_type="zero")
+
+    def __init__(self, **kw):
+        super().__init__(**kw)
+        self.betas = _betas(self.config)
+        self.alphas = 1.0 - self.betas
+        self.alphas_cumprod = torch.cumprod(self.alphas, dim=0)
+        self.alpha_t = torch.sqrt(self.alphas_cumprod)
+        self.sigma_t = torch.sqrt(1 - self.alphas_cumprod)
+        self.lambda_t = torch.log(self.alpha_t) - torch.log(self.sigma_t)
+        self.sigmas = ((1 - self.alphas_cumprod) / self.alphas_cumprod) ** 0.5
+        self.init_noise_sigma = 1.0
+        self.timesteps = torch.from_numpy(np.linspace(0, self.config.num_train_timesteps - 1, self.config.num_train_timesteps, dtype=np.float32)[::-1].copy())
+        self._step_index = self._begin_index = None
+
+    def set_timesteps(self, num_inference_steps=None, device=None):
+        c = self.config
+        clipped = torch.searchsorted(torch.flip(self.lambda_t, [0]), c.lambda_min_clipped)
+        last = ((c.num_train_timesteps - clipped).numpy()).item()
+        if c.timestep_spacing == "linspace":
+            ts = np.linspace(0, last - 1, num_inference_steps + 1).round()[::-1][:-1].copy().astype(np.int64)
+        elif c.timestep_spacing == "leading":
+            ratio = last // (num_inference_steps + 1)
+            ts = (np.arange(0, num_inference_steps + 1) * ratio).round()[::-1][:-1].copy().astype(np.int64) + c.steps_offset
+        else:
+            raise NotImplementedError(c.timestep_spacing)
+        sig = (((1 - self.alphas_cumprod) / self.alphas_cumprod) ** 0.5).numpy()
+        sig = np.interp(ts, np.arange(0, len(sig)), sig)
+        sig = np.concatenate([sig, [0.0]]).astype(np.float32)
+        self.sigmas = torch.from_numpy(sig).to("cpu")
+        self.timesteps = torch.from_numpy(ts).to(device=device, dtype=torch.int64)
+        self.num_inference_steps = len(ts)
+        self._step_index = self._begin_index = None
+
+    def scale_model_input(self, sample, *a, **k):
+        return sample
+
+    def add_noise(self, original_samples, noise, timesteps):
+        sig = self.sigmas.to(device=original_samples.device, dtype=original_samples.dtype)
+        st = self.timesteps.to(original_samples.device)
+        timesteps = timesteps.to(original_samples.device)
+        s = sig[self._indices_for(timesteps, st)].flatten()
+        while s.ndim < original_samples.ndim:
+            s = s.unsqueeze(-1)
+        alpha_t = 1 / ((s ** 2 + 1) ** 0.5)
+        return alpha_t * original_samples + s * alpha_t * noise
+
+    def step(self, *a, **k):
+        raise AssertionError("fake diffusers: the multistep solver is not modelled (no caller on the single-timestep path)")
+
+
+class FlowMatchEulerDiscreteScheduler(_SchedulerBase):
+    _defaults = dict(num_train_timesteps=1000, shift=1.0, use_dynamic_shifting=False, base_shift=0.5, max_shift=1.15, base_image_seq_len=256,
+                     max_image_seq_len=4096)
+
+    def __init__(self, **kw):
+        super().__init__(**kw)
+        n = self.config.num_train_timesteps
+        ts = torch.from_numpy(np.linspace(1, n, n, dtype=np.float32)[::-1].copy())
+        sig = ts / n
+        if not self.config.use_dynamic_shifting:
+            sig = self.config.shift * sig / (1 + (self.config.shift - 1) * sig)
+        self.timesteps = sig * n
+        self.sigmas = sig.to("cpu")
+        self.sigma_min, self.sigma_max = self.sigmas[-1].item(), self.sigmas[0].item()
+        self._step_index = self._begin_index = None
+
+    def time_shift(self, mu, sigma, t):
+        return math.exp(mu) / (math.exp(mu) + (1 / t - 1) ** sigma)
+
+    def set_timesteps(self, num_inference_steps=None, device=None, sigmas=None, mu=None):
+        if self.config.use_dynamic_shifting and mu is None:
+            raise ValueError("you have to pass a value for `mu` when `use_dynamic_shifting` is set to be `True`")
+        n = self.config.num_train_timesteps
+        if sigmas is None:
+            ts = np.linspace(self.sigma_max * n, self.sigma_min * n, num_inference_steps)
+            sigmas = ts / n
+        else:
+            sigmas = np.array(sigmas).astype(np.float32)
+            num_inference_steps = len(sigmas)
+        self.num_inference_steps = num_inference_steps
+        if self.config.use_dynamic_shifting:
+            sigmas = self.time_shift(mu, 1.0, sigmas)
+        else:
+            sigmas = self.config.shift * sigmas / (1 + (self.config.shift - 1) * sigmas)
+        sigmas = torch.from_numpy(np.asarray(sigmas)).to(dtype=torch.float32, device=device)
+        self.timesteps = (sigmas * n).to(device=device)
+        self.sigmas = torch.cat([sigmas, torch.zeros(1, device=sigmas.device)])
+        self._step_index = self._begin_index = None
+
+    def scale_noise(self, sample, timestep, noise=None):
+        sig = self.sigmas.to(device=sample.device, dtype=sample.dtype)
+        st = self.timesteps.to(sample.device)
+        timestep = timestep.to(sample.device)
+        s = sig[self._indices_for(timestep, st)].flatten()
+        while s.ndim < sample.ndim:
+            s = s.unsqueeze(-1)
+        return s * noise + (1.0 - s) * sample
+
+    def step(self, model_output, timestep, sample, return_dict=True, **k):
+        raise AssertionError("fake diffusers: FluxImg2ImgPipeline went on to scheduler.step — the native transformer must stop a stock pipeline "
+                             "after its FIRST forward (reference pipeline_flux_img2img.py:804-841 returns there)")
+
+
+_SD_SCHED = dict(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", prediction_type="epsilon",
+                 timestep_spacing="leading", steps_offset=1)
+_SCHEDULER_CONFIGS = {"stabilityai/stable-diffusion-2-1-base": dict(_SD_SCHED)}
+
+
+# ------------------------------------------------------------------------------------------------------------------------------ #
+# pipelines
+# ------------------------------------------------------------------------------------------------------------------------------ #
+class DiffusionPipeline:
+    _component_names = ()
+
+    @classmethod
+    def from_pretrained(cls, repo, torch_dtype=torch.float32, **kw):
+        CALLS.append((cls.__name__ + ".from_pretrained", dict(repo=repo, torch_dtype=torch_dtype, **kw)))
+        log = os.environ.get("FAKE_DIFFUSERS_LOG", "")
+        if log:                                                      # multi-process tests: one JSON line per call, appended atomically
+            with open(log, "a") as f:
+                f.write(json.dumps(dict(what=cls.__name__ + ".from_pretrained", rank=os.environ.get("RANK", "0"), repo=repo,
+                                        unet_given="unet" in kw, unet_is_none=kw.get("unet", 0) is None, dtype=str(torch_dtype))) + "\n")
+        seed = int(os.environ.get("FAKE_DIFFUSERS_SEED", "0"))
+        pipe = cls.__new__(cls)
+        pipe._repo, pipe._dtype, pipe._device = repo, torch_dtype, torch.device("cpu")
+        pipe._build(repo, torch_dtype, seed, kw)
+        pipe.original = {n: getattr(pipe, n, None) for n in cls._component_names}      # what the product will swap out
+        pipe.lora = []
+        PIPES.append(pipe)
+        return pipe
+
+    def to(self, device=None, dtype=None):
+        if device is not None:
+            self._device = torch.device(device)
+        for n in self._component_names:
+            m = getattr(self, n, None)
+            if isinstance(m, nn.Module):
+                m.to(device=device, dtype=dtype)
+        return self
+
+    @property
+    def device(self):
+        return self._device
+
+    def load_lora_weights(self, path, weight_name=None, **kw):
+        CALLS.append(("load_lora_weights", dict(path=path, weight_name=weight_name)))
+        self.lora.append((path, weight_name))
+
+    def fuse_lora(self, **kw):
+        """A rank-1 'LoRA' fused into ONE weight, so that a test can tell a fused model from an un-fused one"""
+        CALLS.append(("fuse_lora", {}))
+        den = getattr(self, "unet", None) or getattr(self, "transformer", None)
+        if isinstance(den, nn.Module):
+            with torch.no_grad():
+                p = next(p for n, p in den.named_parameters() if p.ndim == 2)
+                p.mul_(1.0 + 1.0 / 64)
+
+    def _exec_device(self):
+        return self._device
+
+
+class StableDiffusionImg2ImgPipeline(DiffusionPipeline):
+    _component_names = ("unet", "vae", "text_encoder", "scheduler")
+
+    def _build(self, repo, dt, seed, kw):
+        v21 = "stable-diffusion-2" in repo
+        self.unet = kw["unet"] if "unet" in kw else _unet_shell("unet-2-1" if v21 else "unet-1-5", dt, seed)
+        self.vae = _vae_shell(dt, seed + 1, 0.18215, sample_size=768 if v21 else 512, force_upcast=True)
+        self.text_encoder = _TextEncoder(1024 if v21 else 768, 512, dt)
+        self.scheduler = kw.get("scheduler") or PNDMScheduler(skip_prk_steps=True, set_alpha_to_one=False, **_SD_SCHED)
+        self.vae_scale_factor = 8
+        self.image_processor = VaeImageProcessor(vae_scale_factor=8)
+        self.config = FrozenDict(requires_safety_checker=False)
+        self._ctx_dim = 1024 if v21 else 768
+
+    def encode_prompt(self, prompt, device, num_images_per_prompt, do_classifier_free_guidance, negative_prompt=None, prompt_embeds=None,
+                      negative_prompt_embeds=None, lora_scale=None, clip_skip=None):
+        CALLS.append(("encode_prompt", dict(prompt=prompt, negative_prompt=negative_prompt, cfg=do_classifier_free_guidance)))
+        n = 1 if isinstance(prompt, str) else len(prompt)
+        ps = [prompt] if isinstance(prompt, str) else list(prompt)
+        pe = torch.cat([_embeds(p, (1, 77, self._ctx_dim), device, self._dtype) for p in ps], 0)
+        ne = _embeds("neg:" + str(negative_prompt or ""), (1, 77, self._ctx_dim), device, self._dtype).repeat(n, 1, 1) if do_classifier_free_guidance else None
+        return pe, ne
+
+    def get_timesteps(self, num_inference_steps, strength, device):
+        init_timestep = min(int(num_inference_steps * strength), num_inference_steps)
+        t_start = max(num_inference_steps - init_timestep, 0)
+        timesteps = self.scheduler.timesteps[t_start * self.scheduler.order:]
+        if hasattr(self.scheduler, "set_begin_index"):
+            self.scheduler.set_begin_index(t_start * self.scheduler.order)
+        return timesteps, num_inference_steps - t_start
+
+    def prepare_latents(self, image, timestep, batch_size, num_images_per_prompt, dtype, device, generator=None):
+        raise AssertionError("fake diffusers: the torch VAE encode does not exist — native_prepare_latents must have replaced this method "
+                             "(GDF_NATIVE_VAE=0 cannot be exercised without diffusers)")
+
+
+class StableDiffusionXLImg2ImgPipeline(DiffusionPipeline):
+    _component_names = ("unet", "vae", "text_encoder", "text_encoder_2", "scheduler")
+
+    def _build(self, repo, dt, seed, kw):
+        self.unet = kw["unet"] if "unet" in kw else _unet_shell("unet-xl", dt, seed)
+        self.vae = _vae_shell(dt, seed + 1, 0.13025 if "xl-base" in repo else 0.5, sample_size=1024, force_upcast=True)
+        self.text_encoder = _TextEncoder(768, 768, dt)
+        self.text_encoder_2 = _TextEncoder(1280, 1280, dt)
+        # sd_xl_base_1.0 scheduler/scheduler_config.json: EulerDiscreteScheduler, leading spacing, steps_offset 1
+        self.scheduler = EulerDiscreteScheduler(interpolation_type="linear", use_karras_sigmas=False, **_SD_SCHED)
+        self.vae_scale_factor = 8
+        self.image_processor = VaeImageProcessor(vae_scale_factor=8)
+        self.config = FrozenDict(requires_aesthetics_score=False, force_zeros_for_empty_prompt=True)
+
+    def encode_prompt(self, prompt, prompt_2=None, device=None, num_images_per_prompt=1, do_classifier_free_guidance=True, negative_prompt=None,
+                      negative_prompt_2=None, prompt_embeds=None, negative_prompt_embeds=None, pooled_prompt_embeds=None,
+                      negative_pooled_prompt_embeds=None, lora_scale=None, clip_skip=None):
+        CALLS.append(("encode_prompt", dict(prompt=prompt, negative_prompt=negative_prompt, cfg=do_classifier_free_guidance)))
+        ps = [prompt] if isinstance(prompt, str) else list(prompt)
+        dt = self._dtype
+        pe = torch.cat([_embeds(p, (1, 77, 2048), device, dt) for p in ps], 0)
+        pooled = torch.cat([_embeds("pool:" + p, (1, 1280), device, dt) for p in ps], 0)
+        # force_zeros_for_empty_prompt: an empty negative prompt gives ZERO negative embeddings
+        ne, npool = torch.zeros_like(pe), torch.zeros_like(pooled)
+        return pe, ne, pooled, npool
+
+    def get_timesteps(self, num_inference_steps, strength, device, denoising_start=None):
+        assert denoising_start is None
+        init_timestep = min(int(num_inference_steps * strength), num_inference_steps)
+        t_start = max(num_inference_steps - init_timestep, 0)
+        timesteps = self.scheduler.timesteps[t_start * self.scheduler.order:]
+        if hasattr(self.scheduler, "set_begin_index"):
+            self.scheduler.set_begin_index(t_start * self.scheduler.order)
+        return timesteps, num_inference_steps - t_start
+
+    prepare_latents = StableDiffusionImg2ImgPipeline.prepare_latents
+
+
+class _PixArtPipeline(DiffusionPipeline):
+    """STOCK PixArtSigmaPipeline / PixArtAlphaPipeline: text-to-image pipelines — they have NO `get_timesteps` and no image-taking
+    `prepare_latents` (the reference adds both in its patched copies, feature/diffusers/pipelines/pixart_alpha/pipeline_pixart_sigma.py:598-700)."""
+    _component_names = ("transformer", "vae", "text_encoder", "scheduler")
+    _max_len = 300
+
+    def _build(self, repo, dt, seed, kw):
+        small = "512" in repo
+        self.transformer = _pixart_shell(dt, seed, sample_size=64 if small else 128, interpolation_scale=1 if small else 2)
+        alpha = "PixArt-XL-2" in repo
+        self.vae = _vae_shell(dt, seed + 1, 0.18215 if alpha else 0.13025, sample_size=1024, force_upcast=not alpha)
+        self.text_encoder = _TextEncoder(4096, None, dt)
+        self.scheduler = DPMSolverMultistepScheduler(beta_start=0.0001, beta_end=0.02, beta_schedule="linear")
+        self.vae_scale_factor = 8
+        self.image_processor = VaeImageProcessor(vae_scale_factor=8)
+        self.config = FrozenDict()
+
+    def encode_prompt(self, prompt, do_classifier_free_guidance=True, negative_prompt="", num_images_per_prompt=1, device=None, prompt_embeds=None,
+                      negative_prompt_embeds=None, prompt_attention_mask=None, negative_prompt_attention_mask=None, clean_caption=False,
+                      max_sequence_length=None, **kw):
+        L = max_sequence_length or self._max_len
+        ps = [prompt] if isinstance(prompt, str) else list(prompt)
+        dt = self._dtype
+        pe = torch.cat([_embeds(p, (1, L, 4096), device, dt) for p in ps], 0)
+        mask = torch.stack([(torch.arange(L, device=device) < max(1, min(L, len(p.split()) + 2))).to(torch.int64) for p in ps], 0)
+        ne = _embeds("neg:" + str(negative_prompt), (1, L, 4096), device, dt).repeat(len(ps), 1, 1)
+        nmask = torch.ones_like(mask)
+        return pe, mask, ne, nmask
+
+
+class PixArtSigmaPipeline(_PixArtPipeline):
+    _max_len = 300
+
+
+class PixArtAlphaPipeline(_PixArtPipeline):
+    _max_len = 120
+
+
+def calculate_shift(image_seq_len, base_seq_len=256, max_seq_len=4096, base_shift=0.5, max_shift=1.16):
+    m = (max_shift - base_shift) / (max_seq_len - base_seq_len)
+    b = base_shift - m * base_seq_len
+    return image_seq_len * m + b
+
+
+class FluxImg2ImgPipeline(DiffusionPipeline):
+    """STOCK FluxImg2ImgPipeline.__call__ [restated from pipelines/flux/pipeline_flux_img2img.py of diffusers==0.32.2]: preprocess -> encode_prompt ->
+    shifted sigmas -> get_timesteps(strength) -> prepare_latents (VAE encode [stand-in], scale_noise, 2x2 packing) -> the denoising LOOP
+    (transformer, scheduler.step) -> VAE decode.  The native transformer must end the call after its first forward (SingleForwardDone)."""
+    _component_names = ("transformer", "vae", "text_encoder", "text_encoder_2", "scheduler")
+
+    def _build(self, repo, dt, seed, kw):
+        self.transformer = _flux_shell(dt, seed)
+        self.vae = _vae_shell(dt, seed + 1, 0.3611, latent_channels=16, shift_factor=0.1159, quant=False, sample_size=1024, force_upcast=True)
+        self.text_encoder = _TextEncoder(768, 768, dt)
+        self.text_encoder_2 = kw.get("text_encoder_2") or _TextEncoder(4096, None, dt)
+        self.scheduler = FlowMatchEulerDiscreteScheduler(shift=3.0, use_dynamic_shifting=True, base_shift=0.5, max_shift=1.15,
+                                                         base_image_seq_len=256, max_image_seq_len=4096)
+        self.vae_scale_factor = 8
+        self.image_processor = VaeImageProcessor(vae_scale_factor=self.vae_scale_factor * 2)
+        self.default_sample_size = 128
+        self.tokenizer_max_length = 77
+        self.config = FrozenDict()
+        self.last_transformer_kwargs = None
+        self.transformer_calls = 0
+
+    def encode_prompt(self, prompt, prompt_2=None, device=None, num_images_per_prompt=1, prompt_embeds=None, pooled_prompt_embeds=None,
+                      max_sequence_length=512, lora_scale=None):
+        ps = [prompt] if isinstance(prompt, str) else list(prompt)
+        dt = self._dtype
+        pe = torch.cat([_embeds(p, (1, max_sequence_length, 4096), device, dt) for p in ps], 0)
+        pooled = torch.cat([_embeds("pool:" + p, (1, 768), device, dt) for p in ps], 0)
+        text_ids = torch.zeros(max_sequence_length, 3, device=device, dtype=dt)
+        return pe, pooled, text_ids
+
+    def get_timesteps(self, num_inference_steps, strength, device):
+        init_timestep = min(num_inference_steps * strength, num_inference_steps)
+        t_start = int(max(num_inference_steps - init_timestep, 0))
+        timesteps = self.scheduler.timesteps[t_start * self.scheduler.order:]
+        if hasattr(self.scheduler, "set_begin_index"):
+            self.scheduler.set_begin_index(t_start * self.scheduler.order)
+        return timesteps, num_inference_steps - t_start
+
+    def _encode_vae_image(self, image, generator):
+        """[stand-in for retrieve_latents(vae.encode(image))]: 8x8 average pooling + a fixed 3 -> 16 channel mix (the Flux VAE is upstream of
+        the native path on both sides)"""
+        lat = torch.nn.functional.avg_pool2d(image.float(), 8)
+        mix = torch.linspace(-1.0, 1.0, 48, device=image.device).reshape(16, 3)
+        lat = torch.einsum("oc,bchw->bohw", mix, lat) * 2.0
+        return ((lat - self.vae.config.shift_factor) * self.vae.config.scaling_factor).to(image.dtype)
+
+    @staticmethod
+    def _prepare_latent_image_ids(batch_size, height, width, device, dtype):
+        ids = torch.zeros(height, width, 3)
+        ids[..., 1] = ids[..., 1] + torch.arange(height)[:, None]
+        ids[..., 2] = ids[..., 2] + torch.arange(width)[None, :]
+        return ids.reshape(height * width, 3).to(device=device, dtype=dtype)
+
+    @staticmethod
+    def _pack_latents(latents, batch_size, num_channels_latents, height, width):
+        latents = latents.view(batch_size, num_channels_latents, height // 2, 2, width // 2, 2).permute(0, 2, 4, 1, 3, 5)
+        return latents.reshape(batch_size, (height // 2) * (width // 2), num_channels_latents * 4)
+
+    def prepare_latents(self, image, timestep, batch_size, num_channels_latents, height, width, dtype, device, generator, latents=None):
+        height = 2 * (int(height) // (self.vae_scale_factor * 2))
+        width = 2 * (int(width) // (self.vae_scale_factor * 2))
+        shape = (batch_size, num_channels_latents, height, width)
+        ids = self._prepare_latent_image_ids(batch_size, height // 2, width // 2, device, dtype)
+        image = image.to(device=device, dtype=dtype)
+        image_latents = self._encode_vae_image(image, generator)
+        if batch_size > image_latents.shape[0] and batch_size % image_latents.shape[0] == 0:
+            image_latents = torch.cat([image_latents] * (batch_size // image_latents.shape[0]), dim=0)
+        noise = torch.randn(shape, generator=generator, device=device, dtype=dtype)
+        latents = self.scheduler.scale_noise(image_latents, timestep, noise)
+        return self._pack_latents(latents, batch_size, num_channels_latents, height, width), ids
+
+    def __call__(self, prompt=None, prompt_2=None, image=None, height=None, width=None, strength=0.6, num_inference_steps=28, timesteps=None,
+                 guidance_scale=7.0, num_images_per_prompt=1, generator=None, latents=None, prompt_embeds=None, pooled_prompt_embeds=None,
+                 output_type="pil", return_dict=True, joint_attention_kwargs=None, max_sequence_length=512, **kw):
+        height = height or self.default_sample_size * self.vae_scale_factor
+        width = width or self.default_sample_size * self.vae_scale_factor
+        if strength < 0 or strength > 1:
+            raise ValueError(f"The value of strength should in [0.0, 1.0] but is {strength}")
+        device = self._exec_device()
+        init_image = self.image_processor.preprocess(image, height=height, width=width).to(dtype=torch.float32)
+        batch_size = 1 if isinstance(prompt, str) else len(prompt)
+        prompt_embeds, pooled_prompt_embeds, text_ids = self.encode_prompt(prompt=prompt, prompt_2=prompt_2, device=device,
+                                                                           num_images_per_prompt=num_images_per_prompt,
+                                                                           max_sequence_length=max_sequence_length)
+        sigmas = np.linspace(1.0, 1 / num_inference_steps, num_inference_steps)
+        image_seq_len = (int(height) // self.vae_scale_factor // 2) * (int(width) // self.vae_scale_factor // 2)
+        c = self.scheduler.config
+        mu = calculate_shift(image_seq_len, c.base_image_seq_len, c.max_image_seq_len, c.base_shift, c.max_shift)
+        self.scheduler.set_timesteps(device=device, sigmas=sigmas, mu=mu)
+        num_inference_steps = len(self.scheduler.timesteps)
+        timesteps, num_inference_steps = self.get_timesteps(num_inference_steps, strength, device)
+        if num_inference_steps < 1:
+            raise ValueError(f"After adjusting the num_inference_steps by strength parameter: {strength}, the number of pipeline"
+                             f"steps is {num_inference_steps} which is < 1 and not appropriate for this pipeline.")
+        latent_timestep = timesteps[:1].repeat(batch_size * num_images_per_prompt)
+        ncl = self.transformer.config.in_channels // 4
+        latents, latent_image_ids = self.prepare_latents(init_image, latent_timestep, batch_size * num_images_per_prompt, ncl, height, width,
+                                                         prompt_embeds.dtype, device, generator, latents)
+        guidance = None
+        if self.transformer.config.guidance_embeds:
+            guidance = torch.full([1], guidance_scale, device=device, dtype=torch.float32).expand(latents.shape[0])
+        for i, t in enumerate(timesteps):
+            timestep = t.expand(latents.shape[0]).to(latents.dtype)
+            kwargs = dict(hidden_states=latents, timestep=timestep / 1000, guidance=guidance, pooled_projections=pooled_prompt_embeds,
+                          encoder_hidden_states=prompt_embeds, txt_ids=text_ids, img_ids=latent_image_ids, joint_attention_kwargs=joint_attention_kwargs,
+                          return_dict=False)
+            self.last_transformer_kwargs = dict(kwargs, sigma=float(t) / 1000, step=i)
+            self.transformer_calls += 1
+            noise_pred = self.transformer(**kwargs)[0]
+            latents = self.scheduler.step(noise_pred, t, latents, return_dict=False)[0]
+        raise AssertionError("fake diffusers: the stock Flux pipeline ran to its VAE decode")

@@ -197,7 +197,7 @@ def test_four_rank_cli_with_empty_shard_and_vae_out(tmp_path):
 def test_bench_front_door_failure_is_nonzero():
     """a rank that dies after the rendezvous (the other one is waiting in a collective) brings the whole self-launched job down: non-zero
     exit code, no JSON line, no orphaned rank"""
-    env = {k: v for k, v in dict(os.environ, GDF_BENCH_SHARE_GPU="1", GDF_TEST_FAIL_RANK="1").items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env = {k: v for k, v in dict(os.environ, GDF_BENCH_SHARE_GPU="1", GDF_TEST_HOOKS="1", GDF_TEST_FAIL_RANK="1").items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--version", "1-5", "--batch", "2",
                         "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 3 and not [l for l in r.stdout.splitlines() if l.startswith("{")], (r.returncode, r.stderr[-1500:])
@@ -206,16 +206,24 @@ def test_bench_front_door_failure_is_nonzero():
 
 def test_four_rank_bench_line():
     """bench.py --gpus 4 on one GPU (GDF_BENCH_SHARE_GPU=1): the line carries the broadcast time and the per-rank step times, and the whole-job
-    value is 4 ranks x batch x steps / the slowest rank's time."""
+    value is 4 ranks x batch x steps / the slowest rank's time.  Round 6: the N > 1 line is COMPLETE — `roofline` and
+    `cpu_baseline` (timed by rank 0 after the process group is gone) are in it, and every rank was pinned to its own share of the host cores."""
     env = dict(os.environ, GDF_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     env = {k: v for k, v in env.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     # the command shape the driver uses: PLAIN python3 bench.py --gpus N (no torchrun) — bench.py starts its four ranks itself
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "2", "--warmup", "1",
-                        "--version", "1-5", "--batch", "2", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+                        "--version", "1-5", "--batch", "2", "--img", "256"], env=env, capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1                                                   # ONE JSON line on stdout: rank 0's
     line = json.loads(lines[0])
+    rf, cb = line["roofline"], line["cpu_baseline"]
+    assert rf["bound"] == "mfma" and rf["achieved"] > 0 and rf["peak"] == 2500.0 and 0 < rf["frac"] < 1 and rf["launches"] > 0
+    assert cb["value"] > 0 and cb["kind"] == "port" and cb["cores"] >= 1 and "after destroy_process_group" in cb["host"]["when"]
+    ncpu = len(os.sched_getaffinity(0))
+    if ncpu >= 4:                                                            # every rank on its own quarter of the cores this test may use
+        assert cb["host"]["rank0_affinity_cpus"] == ncpu // 4 + (1 if ncpu % 4 else 0) and cb["cores"] <= cb["host"]["rank0_affinity_cpus"]
+        assert line["config"]["rank_cpu_affinity"]["rank0_cpus"] == cb["host"]["rank0_affinity_cpus"]
     c = line["config"]
     g = line["rccl"]
     assert g["world_size"] == 4 and g["ranks_seen"] == [0, 1, 2, 3] and g["backend"] == "gloo"      # (share-GPU test hook: gloo; RCCL on a real node)

@@ -73,10 +73,20 @@ def _rep(I, B):
     return out
 
 
-def _check(errs, floor, bound, floor_mult=1.15, floor_abs=2e-5):
+def _margin(tag, errs, bound, extra=""):
+    """record the hook with the least spare room (err / bound) of a configuration for the driver-visible summary (tests/conftest.py)"""
+    import conftest
+    b = bound if callable(bound) else (lambda kd, _b=bound: _b)
+    k = max(errs, key=lambda h: errs[h] / b(kind_of(h)))
+    conftest.record_margin(tag, k, errs[k], b(kind_of(k)), extra)
+
+
+def _check(errs, floor, bound, floor_mult=1.15, floor_abs=2e-5, tag=None):
     """errs / floor: {id: worst-over-samples error}; bound(kind) -> absolute tolerance"""
     kinds = {}
     bad = []
+    if tag:
+        _margin(tag, errs, bound)
     for k, e in errs.items():
         kd = kind_of(k)
         kinds.setdefault(kd, []).append(e)
@@ -114,6 +124,9 @@ def _plain_plan_contract(fam, arch, errs, tag, level_mask=0, product=True):
     dump = os.environ.get("GDF_DUMP_ERRS")
     if dump:
         json.dump({"errs": errs, "accepted": accepted, "auto_bound": AUTO_BOUND}, open(os.path.join(dump, f"plan_level_{level_mask}_errs_{tag}.json"), "w"))
+    import conftest
+    conftest.record_margin(f"plan-level contract [{tag}] level {level_mask}: worst hook the chooser hands to this level ALONE", worst, errs[worst], 0.97e-3,
+                           extra=f"{len(accepted)} hooks at AUTO_BOUND {AUTO_BOUND:.2e}; hardware / emulation offset max {ratio[hmax]:.3f}")
     bad = [(h, errs[h]) for h in accepted if not errs[h] <= 0.97e-3]
     assert not bad, sorted(bad, key=lambda kv: -kv[1])[:10]
     # on the table's own kind of inputs: the bound leaves >= 3 % to 1e-3 even if the worst offset met the largest accepted table value
@@ -165,7 +178,7 @@ def test_sdxl_1024_batch16_all_non_map_hooks():
     ev = sorted(errs.values())
     print(f"\n[sdxl 1024^2 B=16] hooks={len(ev)} median {ev[len(ev) // 2]:.2e} worst {ev[-1]:.2e}; below 1e-3: {sum(e < 1e-3 for e in ev)}; "
           f"(sample, hook) pairs not bit-identical to sample 0: {n_differ} (first: {first_differ})")
-    _check(errs, floor, lambda kd: 1.3e-3 if kd in ("ffn-inner", "unet-out") else 1.0e-3)
+    _check(errs, floor, lambda kd: 1.3e-3 if kd in ("ffn-inner", "unet-out") else 1.0e-3, tag="SDXL 1024^2 B=16 plain plan, 472 non-map hooks (ffn-inner / unet-out: 1.3e-3)")
     _plain_plan_contract("xl", arch, errs, "sdxl_b16")
     assert n_differ == 0, (n_differ, first_differ)       # identical samples give identical bits at every batch position (round 5: small_linear_wide fix)
     from components.native import SPLIT_LIGHT
@@ -185,7 +198,7 @@ def test_sdxl_1024_batch16_all_non_map_hooks():
     errs_p = {k: max(_rel_each(hooks[k], ref[k])) for k in ids}
     ev = sorted(errs_p.values())
     print(f"[sdxl 1024^2 B=16 PRECISE] hooks={len(ev)} median {ev[len(ev) // 2]:.2e} worst {ev[-1]:.2e}; below 1e-3: {sum(e < 1e-3 for e in ev)}")
-    _check(errs_p, None, lambda kd: 3.0e-4)        # (round 5: q / k / v pairs in the full split: worst 1.9e-4; 4.9e-4 before)
+    _check(errs_p, None, lambda kd: 3.0e-4, tag="SDXL 1024^2 B=16 PRECISE (full split)")        # (round 5: q / k / v pairs in the full split: worst 1.9e-4; 4.9e-4 before)
     # ---- the PRODUCT DEFAULT ('auto', round 4): the plan level is chosen from the requested hooks — this set contains `ffn-inner` /
     # `unet-out`, so the selective split (stream images + GroupNorm-in-front-of-proj_in + attention outputs + conv_out operand) is picked,
     # and EVERY kind meets the north-star 1e-3 at ~0.9x the plain plan's speed (tools/bench_split.py); the headline's four hooks alone
@@ -202,7 +215,7 @@ def test_sdxl_1024_batch16_all_non_map_hooks():
     errs_a = {k: max(_rel_each(hooks[k], ref[k])) for k in ids}
     ev = sorted(errs_a.values())
     print(f"[sdxl 1024^2 B=16 AUTO -> selective split] hooks={len(ev)} median {ev[len(ev) // 2]:.2e} worst {ev[-1]:.2e}; below 1e-3: {sum(e < 1e-3 for e in ev)}")
-    _check(errs_a, None, lambda kd: 1.0e-3)
+    _check(errs_a, None, lambda kd: 1.0e-3, tag="SDXL 1024^2 B=16 AUTO -> selective split, 472 hooks")
 
 
 def test_sd15_512_full_layer_set_with_maps_batch2_and_batch32():
@@ -228,7 +241,7 @@ def test_sd15_512_full_layer_set_with_maps_batch2_and_batch32():
     errs = {k: max(_rel_each(hooks[k], ref[k])) for k in ids}
     ev = sorted(errs.values())
     print(f"\n[sd1.5 512^2 B=2, 197 ids] median {ev[len(ev) // 2]:.2e} worst {ev[-1]:.2e}; below 1e-3: {sum(e < 1e-3 for e in ev)}")
-    _check(errs, floor, bound)
+    _check(errs, floor, bound, tag="SD1.5 512^2 B=2 plain plan, 197 ids incl. maps")
     del hooks
     torch.cuda.empty_cache()
     # ---- the batch-32 plan of config C2 (56 GB of hooks) on sample 0 repeated ----
@@ -245,8 +258,8 @@ def test_sd15_512_full_layer_set_with_maps_batch2_and_batch32():
     ev = sorted(errs32.values())
     print(f"[sd1.5 512^2 B=32, 197 ids] median {ev[len(ev) // 2]:.2e} worst {ev[-1]:.2e}")
     floor0 = None      # (the floor above was taken over both samples; the absolute bounds are what is asserted at B = 32)
-    _check({k: errs32[k] for k in nm}, floor0, bound)
-    _check({k: errs32[k] for k in ids if k.endswith("-map")}, None, bound)
+    _check({k: errs32[k] for k in nm}, floor0, bound, tag="SD1.5 512^2 B=32 plain plan, non-map hooks")
+    _check({k: errs32[k] for k in ids if k.endswith("-map")}, None, bound, tag="SD1.5 512^2 B=32 plain plan, maps")
     _plain_plan_contract("1-5", arch, {k: errs[k] for k in nm}, "sd15_b2")
     _plain_plan_contract("1-5", arch, {k: errs32[k] for k in nm}, "sd15_b32")
     from components.native import SPLIT_LIGHT
@@ -265,7 +278,7 @@ def test_sd15_512_full_layer_set_with_maps_batch2_and_batch32():
     errs_p = {k: max(_rel_each(hooks[k], ref[k])) for k in ids}
     ev = sorted(errs_p.values())
     print(f"[sd1.5 512^2 B=2 PRECISE, 197 ids] median {ev[len(ev) // 2]:.2e} worst {ev[-1]:.2e}; below 1e-3: {sum(e < 1e-3 for e in ev)}")
-    _check(errs_p, None, lambda kd: 6.0e-4)        # (incl. the maps, whose kernel reads the hi halves of q / k: worst 4.4e-4)
+    _check(errs_p, None, lambda kd: 6.0e-4, tag="SD1.5 512^2 B=2 PRECISE, 197 ids")        # (incl. the maps, whose kernel reads the hi halves of q / k: worst 4.4e-4)
     del hooks
     torch.cuda.empty_cache()
     _, hooks = up.forward_raw(gb("sample"), gb("timestep"), gb("ctx"), hook_ids=ids, shared_ctx=True)
@@ -273,7 +286,7 @@ def test_sd15_512_full_layer_set_with_maps_batch2_and_batch32():
     errs_p32 = {k: max(_rel_each(hooks[k], ref[k][:1])) for k in ids}
     ev = sorted(errs_p32.values())
     print(f"[sd1.5 512^2 B=32 PRECISE, 197 ids] median {ev[len(ev) // 2]:.2e} worst {ev[-1]:.2e}")
-    _check(errs_p32, None, lambda kd: 6.0e-4)
+    _check(errs_p32, None, lambda kd: 6.0e-4, tag="SD1.5 512^2 B=32 PRECISE, 197 ids")
     # ---- the PRODUCT DEFAULT ('auto'): this full layer set (maps, ffn-inner, unet-out) selects the SD1.5 selective split; every kind <= 1e-3 ----
     del hooks, up
     torch.cuda.empty_cache()
@@ -285,7 +298,7 @@ def test_sd15_512_full_layer_set_with_maps_batch2_and_batch32():
     errs_a = {k: max(_rel_each(hooks[k], ref[k])) for k in ids}
     ev = sorted(errs_a.values())
     print(f"[sd1.5 512^2 B=2 AUTO -> selective split, 197 ids] median {ev[len(ev) // 2]:.2e} worst {ev[-1]:.2e}; below 1e-3: {sum(e < 1e-3 for e in ev)}")
-    _check(errs_a, None, lambda kd: 1.0e-3)
+    _check(errs_a, None, lambda kd: 1.0e-3, tag="SD1.5 512^2 B=2 AUTO -> selective split, 197 ids")
     del hooks
     torch.cuda.empty_cache()
     _, hooks = ua.forward_raw(gb("sample"), gb("timestep"), gb("ctx"), hook_ids=ids, shared_ctx=True)
@@ -293,7 +306,7 @@ def test_sd15_512_full_layer_set_with_maps_batch2_and_batch32():
     errs_a32 = {k: max(_rel_each(hooks[k], ref[k][:1])) for k in ids}
     ev = sorted(errs_a32.values())
     print(f"[sd1.5 512^2 B=32 AUTO -> selective split, 197 ids] median {ev[len(ev) // 2]:.2e} worst {ev[-1]:.2e}")
-    _check(errs_a32, None, lambda kd: 1.0e-3)
+    _check(errs_a32, None, lambda kd: 1.0e-3, tag="SD1.5 512^2 B=32 AUTO -> selective split, 197 ids")
 
 
 @pytest.mark.parametrize("dt", ["bfloat16", "float16", "bfloat16x2", "float16s"])
@@ -334,6 +347,8 @@ def test_flux_full_width_batch8(dt):
             errs["output"] = e_out
         worst = max(errs, key=errs.get)
         print(f"\n[flux widths B=8 {dt}, {len(ids)} hooks] worst {worst} = {errs[worst]:.2e}; output {e_out:.2e}")
+        if len(ids) == len(all_ids):
+            _margin(f"Flux widths 2+3 blocks B=8 {dt}, {len(ids)} hooks", errs, tol)
         assert errs[worst] <= tol, (worst, errs[worst])
         del hooks, out
 
@@ -403,6 +418,7 @@ def test_flux_dev_full_depth_config_c5_error_vs_depth():
         worst = max(errs, key=errs.get)
         lines.append(f"[{dt}] worst {worst} = {errs[worst]:.2e} (bound {bounds[dt]:.1e}); model output {e_out:.2e}")
         print("\n" + "\n".join(lines[-3:]))
+        _margin(f"FLUX.1-dev FULL depth 19+38, 4096+512 tokens, B=8, mode {dt}", errs, bounds[dt], extra=f"model output {e_out:.2e}")
         assert errs[worst] <= bounds[dt], (dt, worst, errs[worst])
         del hooks, out, net
         torch.cuda.empty_cache()
@@ -436,7 +452,7 @@ def test_sdxl_1024_full_layer_set_with_maps_batch1():
     errs = {k: max(_rel_each(hooks[k], ref[k])) for k in want}
     ev = sorted(errs.values())
     print(f"\n[sdxl 1024^2 B=1, {len(maps)} maps + {len(some)} other hooks] median {ev[len(ev) // 2]:.2e} worst {ev[-1]:.2e}")
-    _check(errs, None, lambda kd: 1.5e-3 if kd == "map" else (1.3e-3 if kd in ("ffn-inner", "unet-out") else 1.0e-3))
+    _check(errs, None, lambda kd: 1.5e-3 if kd == "map" else (1.3e-3 if kd in ("ffn-inner", "unet-out") else 1.0e-3), tag="SDXL 1024^2 B=1 plain plan, 140 maps + riders (maps: 1.5e-3)")
     # ---- PRECISE plan: the 140 maps (and the riders) <= 1e-3 ----
     del hooks, u
     torch.cuda.empty_cache()
@@ -446,7 +462,7 @@ def test_sdxl_1024_full_layer_set_with_maps_batch1():
     errs_p = {k: max(_rel_each(hooks[k], ref[k])) for k in want}
     ev = sorted(errs_p.values())
     print(f"[sdxl 1024^2 B=1 PRECISE, {len(maps)} maps + {len(some)} other hooks] median {ev[len(ev) // 2]:.2e} worst {ev[-1]:.2e}")
-    _check(errs_p, None, lambda kd: 1.0e-3)
+    _check(errs_p, None, lambda kd: 1.0e-3, tag="SDXL 1024^2 B=1 PRECISE, 140 maps + riders")
     # ---- the PRODUCT DEFAULT ('auto'): maps select the selective split; the 140 maps (and the riders) <= 1e-3 ----
     del hooks, up
     torch.cuda.empty_cache()
@@ -458,7 +474,7 @@ def test_sdxl_1024_full_layer_set_with_maps_batch1():
     errs_a = {k: max(_rel_each(hooks[k], ref[k])) for k in want}
     ev = sorted(errs_a.values())
     print(f"[sdxl 1024^2 B=1 AUTO -> selective split, {len(maps)} maps + {len(some)} other hooks] median {ev[len(ev) // 2]:.2e} worst {ev[-1]:.2e}")
-    _check(errs_a, None, lambda kd: 1.0e-3)
+    _check(errs_a, None, lambda kd: 1.0e-3, tag="SDXL 1024^2 B=1 AUTO -> selective split, 140 maps + riders")
 
 
 def test_pixart_sigma_full_width_batch4():
@@ -486,6 +502,7 @@ def test_pixart_sigma_full_width_batch4():
     errs["output"] = max(_rel_each(out, y))
     worst = max(errs, key=errs.get)
     print(f"\n[pixart-sigma widths B=4, {len(ids)} hooks] worst {worst} = {errs[worst]:.2e}")
+    _margin("PixArt-Sigma widths, 3 blocks, B=4", errs, 6.0e-4)
     assert errs[worst] <= 6.0e-4, (worst, errs[worst])
 
 
@@ -521,6 +538,7 @@ def test_pixart_sigma_full_depth_batch4():
     worst = max(errs, key=errs.get)
     print(f"\n[pixart-sigma full depth B=4, {len(ids)} hooks] block `out` by depth: " + " ".join(f"{b}:{e:.2e}" for b, e in enumerate(depth)))
     print(f"[pixart-sigma full depth] worst {worst} = {errs[worst]:.2e}; output {errs['output']:.2e}")
+    _margin("PixArt-Sigma FULL depth 28 blocks, 4096+300 tokens, B=4", errs, 1.0e-3)
     assert errs[worst] <= 1.0e-3, (worst, errs[worst])
 
 
@@ -547,6 +565,7 @@ def test_vae_encode_1024_batch2():
     torch.cuda.synchronize()
     e = rel_l2(got, ref)
     print(f"\n[vae 1024^2 B=2] rel L2 {e:.2e}")
+    _margin("VAE encode + sample + noise-add 1024^2 B=2 (latents)", {"latents": e}, 1e-3)
     assert got.shape == ref.shape == (2, 4, 128, 128) and e <= 1e-3, e
 
 
@@ -575,6 +594,7 @@ def test_vae_out_decode_1024_batch2():
     assert tuple(got.shape) == (2, 3, 1024, 1024)
     e = max(rel_l2(got[i:i + 1], ref) for i in range(2))
     print(f"\n[vae-out 1024^2 B=2] rel L2 {e:.2e}")
+    _margin("'vae-out': scheduler step + VAE decode 1024^2 B=2", {"vae-out": e}, 1e-3)
     assert e <= 1e-3, e
 
 
@@ -718,6 +738,46 @@ def test_sdxl_heavy_tailed_full_split_is_a_reference():
     print(f"[sdxl heavy-tailed x8, auto + verify] distances to the full split { {m: '%.2e' % v for m, v in seen.items()} } -> kept {kept}: worst {max(errs.values()):.2e} vs fp32")
     assert len([x for x in w if "gdf verify" in str(x.message)]) == 1
     from components.native import SPLIT_CLASSES
-    assert kept in (SELECTIVE_BY_ARCH["xl"] | SPLIT_CLASSES["ln_ff"], SELECTIVE_BY_ARCH["xl"] | SPLIT_DEEP_EXTRA) and seen[SELECTIVE_BY_ARCH["xl"]] > 9.5e-4
-    assert max(errs.values()) < 9.7e-4, max(errs, key=errs.get)
+    assert kept in (SELECTIVE_BY_ARCH["xl"] | SPLIT_CLASSES["ln_ff"], SELECTIVE_BY_ARCH["xl"] | SPLIT_DEEP_EXTRA) and seen[SELECTIVE_BY_ARCH["xl"]] > u.verify_accept_bound()
+    assert seen[kept] ** 2 + 2.7e-4 ** 2 <= 0.97e-3 ** 2 * (1 + 1e-9)          # round 6: d^2 + e_full^2 <= target^2, not a constant bound on d
+    assert max(errs.values()) <= 0.97e-3, max(errs, key=errs.get)
     assert abs(seen[kept] - max(errs.values())) < 1.5e-4          # the yardstick (distance to the full split) tracks the distance to fp32
+    _margin("SDXL 1024^2 B=1 HEAVY-TAILED x8 weights, auto + verify -> kept level %d" % kept, errs, 0.97e-3, extra=f"d to full split {seen[kept]:.2e}; full split itself {worst['full split']:.2e}")
+
+
+@pytest.mark.parametrize("ver,gain", [("xl", 16.0), ("xl", 32.0), ("1-5", 16.0)])
+def test_verify_ladder_on_heavy_tailed_weights(ver, gain):
+    """`verify` on heavy-tailed weight statistics at TRUE size, other outlier gains and the SD1.5 family.  Asserted: the level the
+    ladder keeps is within 0.97e-3 of the fp32 oracle on EVERY non-map hook (the acceptance rule d^2 + e_full^2 <= (0.97e-3)^2 is arithmetic, not a
+    constant), and on SD1.5 — whose heavy-tailed draw failed every rung of the round-5 ladder (1.1-1.5e-3) and fell to the full split — a rung
+    CHEAPER than the full split is kept."""
+    import warnings
+    from components.native import NativeUNet, SPLIT_ALL
+    _threads()
+    arch = R.ARCHS[ver]
+    lat = 128 if ver == "xl" else 64
+    P = R.synth_params_heavy(arch, seed=0, outlier_gain=gain)
+    I = R.synth_inputs(arch, 1, lat, seed=1)
+    ids = [i for i in R.stored_hook_ids(arch) if not i.endswith("-map")]
+    ref = _oracle(arch, P, I, ids)
+    g = lambda k: I[k].cuda() if k in I else None
+    u = NativeUNet(cfg_from_oracle_arch(arch), device="cuda:0", precise="auto", verify=True)
+    u.load_state_dict({k: v.half() for k, v in P.items()})
+    with warnings.catch_warnings(record=True):
+        warnings.simplefilter("always")
+        hooks = u.forward_raw(g("sample"), g("timestep"), g("ctx"), g("text_embeds"), g("time_ids"), hook_ids=ids)[1]
+        torch.cuda.synchronize()
+    key, seen, kept = u.verify_log[0]
+    errs = {k: max(_rel_each(hooks[k], ref[k])) for k in ids}
+    worst = max(errs, key=errs.get)
+    print(f"\n[{ver} heavy-tailed x{gain:g}, auto + verify] bound on d {u.verify_accept_bound():.3e}; distances to the full split "
+          f"{ {m: '%.2e' % v for m, v in seen.items()} } -> kept {kept}: worst {errs[worst]:.2e} ({worst}) vs fp32")
+    _margin(f"{'SDXL 1024^2' if ver == 'xl' else 'SD1.5 512^2'} B=1 HEAVY-TAILED x{gain:g} weights, auto + verify -> kept level {kept}", errs, 0.97e-3,
+            extra="levels tried " + " ".join(f"{m}:{v:.2e}" for m, v in seen.items()))
+    assert errs[worst] <= 0.97e-3, (worst, errs[worst])
+    if kept != SPLIT_ALL:
+        e_full = u.FULL_SPLIT_ERROR["xl" if ver == "xl" else "1-5"]
+        assert seen[kept] ** 2 + e_full ** 2 <= 0.97e-3 ** 2 * (1 + 1e-9)
+    if ver == "1-5":
+        assert kept != SPLIT_ALL, seen
+    assert {k[8] for k in u._plans} == {kept}                     # the check-only plans (full split, rejected rungs) are gone
