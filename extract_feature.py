@@ -70,6 +70,11 @@ def parse_args(argv=None):
     p.add_argument('--loader_threads', type=int, default=-1,
                    help='native extension (not in the reference CLI): threads that decode + resize + normalise the NEXT batches while the GPU works on the current '
                         'one (PIL and numpy release the GIL).  -1 = min(32, half of this rank\'s share of the host CPUs); 0 = the reference\'s serial loop (load, then extract)')
+    p.add_argument('--seed', type=int, default=None,
+                   help="native extension: seed of the VAE-sampling / add-noise draws.  Absent = the reference's behaviour (the global torch RNG: "
+                        "run- and partition-dependent with a real diffusers pipeline).  Given: the generator is re-seeded with seed + <index of the "
+                        "batch's first image> before every batch, so the features of an image depend only on (seed, batch start) — identical for "
+                        "any --gpus N whose shards are whole batches")
     p.add_argument('--gpus', type=int, default=1,
                    help='native extension (not in the reference CLI): data-parallel over N GPUs of this node.  Started as a plain process '
                         '(`python3 extract_feature.py --gpus 8 ...`) the script starts its N ranks itself; under torchrun it must equal WORLD_SIZE')
@@ -347,6 +352,8 @@ def main(argv=None):
         with torch.no_grad():
             for i in starts:
                 chunk = paths[i:min(i + args.batch_size, hi)]
+                if args.seed is not None:
+                    torch.manual_seed(args.seed + i)
                 if loader is not None:
                     feats = df.extract(prompts, len(chunk), loader.get(i), image_type='tensors', t=args.t, denoising_from=args.denoising_from,
                                        use_control=args.control is not None, use_ddim_inversion=args.use_ddim_inversion)

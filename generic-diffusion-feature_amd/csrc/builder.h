@@ -371,6 +371,16 @@ struct PlanBuilder {
     if (x.gp_alloc != NPOS && x.gp_rows > 0 && !from_f && x_lo == 0) {     // the producing conv left the per-slab channel sums: finalize only
       const size_t ab_b = (size_t)Bn * x.C * 8, ab = tmp(ab_b);
       const size_t gp = x.gp_alloc; const int nslab = HW / x.gp_rows;
+      // round 6: finalize + apply in one launch where the slab count needs no fold pass (GDF_GN_FINALIZE_APPLY=0: the two launches)
+      static const bool fa_on = [] { const char* e = getenv("GDF_GN_FINALIZE_APPLY"); return !e || atoi(e) != 0; }();
+      if (fa_on && gn_fold_floats(Bn, nslab, C) == 0 && gn_finalize_apply_slab(C, 32)) {
+        untmp(ab, ab_b);
+        op(silu ? "gn_finalize_apply_silu" : "gn_finalize_apply", 0, [=](const Bind& b, hipStream_t s) {
+          return launch_gn_finalize_apply((const float*)b.ws(gp), nslab, (const half_t*)b.p(xh), ld, Bq, HW, C, 32, eps, (const float*)b.p(g),
+                                          (const float*)b.p(bt), silu ? 1 : 0, (half_t*)b.ws(y), s, ldy, y_lo);
+        });
+        return y;
+      }
       const size_t fold_b = gn_fold_floats(Bn, nslab, C) * 4, fold = fold_b ? tmp(fold_b) : 0;
       op("gn_finalize", 0, [=](const Bind& b, hipStream_t s) {
         return launch_gn_finalize((const float*)b.ws(gp), nslab, Bq, HW, C, 32, eps, (const float*)b.p(g), (const float*)b.p(bt), (float*)b.ws(ab),

@@ -192,6 +192,13 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
   // Compiled as a loop only where the register budget has room for the loop-carried lane constants (256x320: 9-11 VGPRs spilled).
   constexpr bool PERSIST = (STAGES == 8);
   int vb = blockIdx.x;
+#if defined(GDF_STAGGER)                                        // diagnostics build (tools/build_variant.sh stagger -DGDF_STAGGER): the de-phasing experiment
+  if (p.stagger > 0 && (int)blockIdx.x < p.stagger_wgs) {      // (kernels.h GemmParams::stagger); uniform per workgroup
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long d = (unsigned long long)(p.stagger & 0xffffff) * (unsigned)((blockIdx.x >> 3) % (unsigned)(p.stagger >> 24));
+    while (__builtin_amdgcn_s_memrealtime() - t0 < d) __builtin_amdgcn_s_sleep(16);
+  }
+#endif
   do {
   GDF_TR(0); GDF_TR_ID();
   int tile_m, tile_n;
@@ -261,7 +268,13 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
     b_off[j] = (n < p.N) ? (uint32_t)n * ldb + (uint32_t)chunk * 16u : OOB;
   }
 
+#if defined(GDF_ABLATE_EPI) && GDF_ABLATE_EPI == 2
+  // diagnostics build (tools/ab_epilogue_bound.sh): NO main loop — the prologue / epilogue skeleton with every global load and store of the
+  // epilogue, on zero accumulators.  Results are garbage; the time per launch is the epilogue's (+ launch, prologue) alone.
+  const int nk = 0;
+#else
   const int nk = (MODE == A_CONV_SMALLC) ? 2 : p.K / BK;
+#endif
   // split-K (2-stage ring tiles only): this workgroup accumulates the K-tiles [kt0, kt1) and stores raw partial sums
   int kt0 = 0, kt1 = nk;
   if (STAGES == 2 && p.splitk > 1) {
@@ -857,8 +870,19 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
       if (++cur == 3) cur = 0;
     }
   }
+#if defined(GDF_ABLATE_EPI) && GDF_ABLATE_EPI == 2
+  wait_vmcnt<0>();
+#endif
   __syncthreads();   // all waves finished reading the last tile: LDS is free for epilogue staging
   GDF_TR(3);
+#if defined(GDF_ABLATE_EPI) && GDF_ABLATE_EPI == 1
+  // diagnostics build (tools/ab_epilogue_bound.sh): NO epilogue — the accumulators are kept alive and dropped.  Results are garbage; the
+  // time per launch is what a PERFECTLY overlapped epilogue would leave (the bound on any deferred-epilogue scheme).
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) asm volatile("" ::"v"(acc[i][j]));
+#else
 
   // ---- epilogue: per-wave staging of 32-row slabs through LDS ----
   // epilogue operands; the QKN instantiation (QKV projection: bias -> RMSNorm + RoPE -> 16-bit store) has none of the
@@ -1198,6 +1222,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
     }
     __builtin_amdgcn_wave_barrier();
   }
+#endif   // GDF_ABLATE_EPI == 1
   GDF_TR(4);
   if constexpr (!PERSIST) break;
   vb += gridDim.x;
@@ -1289,6 +1314,15 @@ static hipError_t launch_t(const GemmParams& p, hipStream_t s) {
   }
   int gx = tiles_m * tiles_n;
   const int pw = (p.cus > 0 && p.cus < persist_wgs()) ? p.cus : persist_wgs();
+  {
+    // de-phasing experiment (kernels.h GemmParams::stagger): GDF_STAGGER_US = delay in microseconds, applied to launches of >= GDF_STAGGER_MIN_ROUNDS
+    // (default 2) rounds of one-workgroup-per-CU tiles
+    static const float us = [] { const char* e = getenv("GDF_STAGGER_US"); return e ? (float)atof(e) : 0.f; }();
+    static const int min_rounds = [] { const char* e = getenv("GDF_STAGGER_MIN_ROUNDS"); return e ? atoi(e) : 2; }();
+    q.stagger = 0; q.stagger_wgs = 0;
+    static const int groups = [] { const char* e = getenv("GDF_STAGGER_GROUPS"); return e ? atoi(e) : 2; }();   // delay of workgroup b: ((b >> 3) % groups) x us
+    if (us > 0.f && groups > 1 && BM == 256 && pw < (1 << 30) && gx >= min_rounds * pw) { q.stagger = (int)(us * 100.f) | (groups << 24); q.stagger_wgs = pw; }
+  }
   if (STAGES == 8 && gx > pw && !(p.batch > 1)) gx = pw;   // persistent: one workgroup per CU walks the tiles
   const dim3 grid(gx, (STAGES == 2 && p.splitk > 1) ? p.splitk : p.batch > 1 ? p.batch : 1);
   if constexpr (MX) hipLaunchKernelGGL((gemm_mx_kernel<BM, BN, STAGES>), grid, dim3(BM * 2), smem, s, q);

@@ -142,6 +142,11 @@ struct GemmParams {
   // GroupNorm that consumes the tensor needs no statistics pass of its own (a full HBM read of a 1-4 GB tensor at 1024^2).
   // Requires M % slab_rows == 0 and (rows per sample) % slab_rows == 0.  nullptr = off (every UNet / MMDiT plan).
   float* gn_partial;
+  // DE-PHASING (round 6 experiment, compiled in by -DGDF_STAGGER only; set by launch_gemm from GDF_STAGGER_US / GDF_STAGGER_GROUPS; measured null: workgroup b of the FIRST
+  // round (b < stagger_wgs) waits ((b >> 3) % groups) x ticks of the 100-MHz realtime counter before its first tile (stagger = ticks | groups << 24),
+  // so that on a multi-round launch the CUs reach their epilogues at different times (tools/ab_stagger.sh,
+  // profiles/r06_ab_deferred_epilogue.txt)
+  int stagger, stagger_wgs;
 };
 hipError_t launch_gemm(const GemmParams& p, hipStream_t s);
 // rows per statistics slab if launch_gemm can run `p` (shape, mode, epilogue form) with gn_partial set, else 0
@@ -201,6 +206,10 @@ hipError_t launch_gn_apply(const half_t* x16, const float* x32, int ld, int B, i
 size_t gn_fold_floats(int B, int nslab, int C);
 hipError_t launch_gn_finalize(const float* partial, int nslab, int B, int HW, int C, int G, float eps, const float* gamma,
                               const float* beta, float* ab, float* fold, hipStream_t s);
+// statistics from the producer's epilogue -> finalize + apply (+SiLU) in ONE launch (round 6); gn_finalize_apply_slab(...) != 0 says whether it applies
+int gn_finalize_apply_slab(int C, int G);
+hipError_t launch_gn_finalize_apply(const float* partial, int nslab, const half_t* x16, int ld, int B, int HW, int C, int G, float eps,
+                                    const float* gamma, const float* beta, int silu, half_t* y, hipStream_t s, int ldy = 0, int y_lo = 0);
 // single-launch GroupNorm (+SiLU) for small feature maps; gn_fused_slab(...) != 0 says whether it applies
 int gn_fused_slab(int B, int HW, int C, int G);
 hipError_t launch_gn_fused(const half_t* x16, const float* x32, int ld, int B, int HW, int C, int G, float eps, const float* gamma,

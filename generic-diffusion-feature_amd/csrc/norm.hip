@@ -247,6 +247,112 @@ hipError_t launch_gn_apply(const half_t* x16, const float* x32, int ld, int B, i
   return hipGetLastError();
 }
 
+// Round 6 (the "apply half" of north_star's ResBlock fusion in the form that does not touch the conv's A path): the
+// statistics left by the producing conv's epilogue are finalised AND applied in ONE launch.  Workgroup (channel slab of whole groups,
+// row block, sample): pass 1 combines the per-slab channel sums of its SC channels (nslab x SC float2, coalesced, double accumulation,
+// fixed order: deterministic), the slab's groups become the affine table in LDS, pass 2 normalises (+SiLU) the block's rows.  Every row
+// block of a channel slab repeats pass 1 (nslab x SC x 8 bytes, L2 resident after the first) — the price of not needing a grid-wide
+// barrier; rows_per_block is chosen so that it stays below a quarter of the block's own traffic.
+__global__ __launch_bounds__(256) void gn_finalize_apply_kernel(const float* partial, int nslab, const half_t* x16, int ld, int HW, int C, int G,
+                                                                float eps, const float* gamma, const float* beta, int silu, half_t* y, int SC,
+                                                                int rows_per_block, int ldy, int y_lo) {
+  extern __shared__ double fa_red[];              // [RG][SC][2] doubles, then float ab[SC][2] behind them
+  const int b = blockIdx.z, c0 = blockIdx.x * SC;
+  const int RG = 256 / SC;                        // slab-row groups working in parallel (SC <= 256)
+  const int tc = threadIdx.x % SC, tg = threadIdx.x / SC;
+  double s = 0.0, q = 0.0;
+  if (tg < RG) {
+    for (int sl = tg; sl < nslab; sl += RG) {
+      const float2 pp = *(const float2*)(partial + (((size_t)b * nslab + sl) * C + c0 + tc) * 2);
+      s += (double)pp.x; q += (double)pp.y;
+    }
+    fa_red[(tg * SC + tc) * 2] = s; fa_red[(tg * SC + tc) * 2 + 1] = q;
+  }
+  __syncthreads();
+  float* ab = (float*)(fa_red + (size_t)RG * SC * 2);
+  const int cpg = C / G, ngs = SC / cpg;
+  if (threadIdx.x < ngs) {
+    double sum = 0.0, sq = 0.0;
+    for (int c = threadIdx.x * cpg; c < (threadIdx.x + 1) * cpg; ++c)
+      for (int g = 0; g < RG; ++g) { sum += fa_red[(g * SC + c) * 2]; sq += fa_red[(g * SC + c) * 2 + 1]; }
+    const double n = (double)HW * cpg;
+    const double mean = sum / n;
+    double var = sq / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    for (int c = threadIdx.x * cpg; c < (threadIdx.x + 1) * cpg; ++c) {
+      const float a = rstd * gamma[c0 + c];
+      ab[c * 2] = a;
+      ab[c * 2 + 1] = beta[c0 + c] - (float)mean * a;
+    }
+  }
+  __syncthreads();
+  const int LPR = SC / 8, RPP = 256 / LPR;
+  const int lc = threadIdx.x % LPR, tr = threadIdx.x / LPR;
+  if (tr >= RPP) return;
+  float a[8], bb[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { a[e] = ab[(lc * 8 + e) * 2]; bb[e] = ab[(lc * 8 + e) * 2 + 1]; }
+  const size_t rowbase = (size_t)b * HW;
+  const int r0 = blockIdx.y * rows_per_block, r1 = min(HW, r0 + rows_per_block);
+  int r = r0 + tr;
+  for (; r + 3 * RPP < r1; r += 4 * RPP) {                      // four rows in flight per thread
+    float v[4][8];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) load8(x16, nullptr, (rowbase + r + u * RPP) * ld + c0 + lc * 8, v[u], 0);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float t = v[u][e] * a[e] + bb[e];
+        if (silu) t = t / (1.0f + __expf(-t));
+        v[u][e] = t;
+      }
+      store8(y + (rowbase + r + u * RPP) * ldy + c0 + lc * 8, v[u], y_lo);
+    }
+  }
+  for (; r < r1; r += RPP) {
+    float v[8];
+    load8(x16, nullptr, (rowbase + r) * ld + c0 + lc * 8, v, 0);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float t = v[e] * a[e] + bb[e];
+      if (silu) t = t / (1.0f + __expf(-t));
+      v[e] = t;
+    }
+    store8(y + (rowbase + r) * ldy + c0 + lc * 8, v, y_lo);
+  }
+}
+
+// channels per workgroup of the finalize + apply kernel: whole groups, whole 16-byte chunks — the LARGEST such slab <= 256 channels that divides C
+// (C = 320 / 640 / 1280 -> 160: 320-byte row pieces; VAE C = 128 -> 128, 256 / 512 -> 256); 0 = not applicable
+int gn_finalize_apply_slab(int C, int G) {
+  if (C % 8 || C % G) return 0;
+  const int cpg = C / G;
+  int L = cpg;
+  while (L % 8) L += cpg;                                      // lcm(cpg, 8)
+  int best = 0;
+  for (int SC = L; SC <= 256; SC += L)
+    if (C % SC == 0) best = SC;
+  return best >= 32 ? best : 0;
+}
+
+hipError_t launch_gn_finalize_apply(const float* partial, int nslab, const half_t* x16, int ld, int B, int HW, int C, int G, float eps,
+                                    const float* gamma, const float* beta, int silu, half_t* y, hipStream_t s, int ldy, int y_lo) {
+  const int SC = gn_finalize_apply_slab(C, G);
+  if (!SC || nslab < 1) return hipErrorInvalidValue;
+  const int RG = 256 / SC;
+  // rows per block: the statistics pass (nslab x SC x 8 B) at most ~1/4 of the block's own 4 B/element, and >= 512 workgroups when the tensor allows
+  long rpb = ((long)nslab * 8 * 4 + 3) / 4;                    // rows such that rows * SC * 4 B = 4 x nslab * SC * 8 B
+  if (rpb < 256) rpb = 256;
+  while (rpb > 256 && (long)B * (C / SC) * ((HW + rpb - 1) / rpb) < 512) rpb /= 2;
+  if (rpb > HW) rpb = HW;
+  const size_t smem = (size_t)RG * SC * 2 * sizeof(double) + (size_t)SC * 2 * sizeof(float);
+  hipLaunchKernelGGL(gn_finalize_apply_kernel, dim3(C / SC, (unsigned)((HW + rpb - 1) / rpb), B), dim3(256), smem, s, partial, nslab, x16, ld, HW, C, G,
+                     eps, gamma, beta, silu, y, SC, (int)rpb, ldy > 0 ? ldy : C, y_lo);
+  return hipGetLastError();
+}
+
 // Small feature maps (<= 32 x 32 pixels): the three launches above are latency bound (1280 channels at 32^2, batch 16: 75 us for
 // 126 MB of traffic).  One workgroup per (sample, slab of whole groups) instead: pass 1 accumulates per-channel sums over the
 // slab's HW x SC block, the slab's group statistics are combined in double in LDS, pass 2 re-reads the block (L2 / MALL

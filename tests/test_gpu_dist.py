@@ -212,7 +212,7 @@ def test_four_rank_bench_line():
     env = {k: v for k, v in env.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     # the command shape the driver uses: PLAIN python3 bench.py --gpus N (no torchrun) — bench.py starts its four ranks itself
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "2", "--warmup", "1",
-                        "--version", "1-5", "--batch", "2", "--img", "256"], env=env, capture_output=True, text=True, timeout=1200)
+                        "--version", "1-5", "--batch", "2"], env=env, capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1                                                   # ONE JSON line on stdout: rank 0's

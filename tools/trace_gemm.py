@@ -38,6 +38,14 @@ def run(name, M, N, K, var, geglu=0, res=False):
     print(f"{name} {M}x{N}x{K}: {nwg} workgroups on {len(np.unique(cu))} CUs, span {us[:, 4].max():7.1f} us | first start spread {np.percentile(us[:, 0], 10):.1f}")
     print(f"    setup+issue {q(seg[:, 0])}  tile0 wait {q(seg[:, 1])}  main loop {q(seg[:, 2])}  epilogue {q(seg[:, 3])}  total {q(us[:, 4] - us[:, 0])}"
           + (f"  end->next start on the CU {q(np.array(gaps))}" if gaps else ""), flush=True)
+if len(sys.argv) > 1 and sys.argv[1] == "solo":
+    # round 6: is a tile's epilogue time CU-local (instructions / latency) or a share of a chip-wide resource?  The same tiles with 4 ... 768
+    # workgroups in flight: a CU-local epilogue takes the same time alone as in a full grid
+    for M in (256, 1024, 4096, 16384):
+        run("plain 932", M, 3840, 1280, 932)
+        run("res32 932", M, 1280, 1280, 932, res=True)
+        run("geglu 825", M, 10240, 1280, 825, 1)
+    sys.exit(0)
 for K in (64, 1280):
     run("geglu 825", 16384, 10240, K, 825, 1)
     run("plain 932", 16384, 3840, K, 932)
