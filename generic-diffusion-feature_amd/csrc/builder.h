@@ -371,14 +371,22 @@ struct PlanBuilder {
     if (x.gp_alloc != NPOS && x.gp_rows > 0 && !from_f && x_lo == 0) {     // the producing conv left the per-slab channel sums: finalize only
       const size_t ab_b = (size_t)Bn * x.C * 8, ab = tmp(ab_b);
       const size_t gp = x.gp_alloc; const int nslab = HW / x.gp_rows;
-      // round 6: finalize + apply in one launch where the slab count needs no fold pass (GDF_GN_FINALIZE_APPLY=0: the two launches)
-      static const bool fa_on = [] { const char* e = getenv("GDF_GN_FINALIZE_APPLY"); return !e || atoi(e) != 0; }();
-      if (fa_on && gn_fold_floats(Bn, nslab, C) == 0 && gn_finalize_apply_slab(C, 32)) {
+      // round 6: finalize + apply in ONE launch (after the fold pass where the producer left many short slabs) — built,
+      // measured on the same box, REJECTED: SDXL B = 16 144.3 vs 145.0 img/s, VAE encode 143.4 vs 148.2, SD1.5 B = 32 equal
+      // (profiles/r06_ab_gn_apply_after_fold.txt: every row block repeats the slab combine, and the apply pass loses its 64-row blocks' parallelism).
+      // OFF by default; GDF_GN_FINALIZE_APPLY=1 selects it (diagnostics)
+      static const bool fa_on = [] { const char* e = getenv("GDF_GN_FINALIZE_APPLY"); return e && atoi(e) != 0; }();
+      const bool need_fold = gn_fold_floats(Bn, nslab, C) != 0;
+      if (fa_on && gn_finalize_apply_slab(C, 32) && (!need_fold || gn_fold_ok(C))) {
         untmp(ab, ab_b);
+        const size_t fb = need_fold ? gn_fold_floats(Bn, nslab, C) * 4 : 0, fo = fb ? tmp(fb) : 0;
+        const int ns2 = need_fold ? gn_fold_out_slabs(nslab) : nslab;
+        if (need_fold) op("gn_fold", 0, [=](const Bind& b, hipStream_t s) { return launch_gn_fold((const float*)b.ws(gp), nslab, Bq, C, (float*)b.ws(fo), s); });
         op(silu ? "gn_finalize_apply_silu" : "gn_finalize_apply", 0, [=](const Bind& b, hipStream_t s) {
-          return launch_gn_finalize_apply((const float*)b.ws(gp), nslab, (const half_t*)b.p(xh), ld, Bq, HW, C, 32, eps, (const float*)b.p(g),
-                                          (const float*)b.p(bt), silu ? 1 : 0, (half_t*)b.ws(y), s, ldy, y_lo);
+          return launch_gn_finalize_apply(need_fold ? (const float*)b.ws(fo) : (const float*)b.ws(gp), ns2, (const half_t*)b.p(xh), ld, Bq, HW, C, 32, eps,
+                                          (const float*)b.p(g), (const float*)b.p(bt), silu ? 1 : 0, (half_t*)b.ws(y), s, ldy, y_lo);
         });
+        if (fb) untmp(fo, fb);
         return y;
       }
       const size_t fold_b = gn_fold_floats(Bn, nslab, C) * 4, fold = fold_b ? tmp(fold_b) : 0;

@@ -145,7 +145,7 @@ __device__ unsigned long long gdf_trace[16384 * 8];
 // scales of the operands are applied to the fp32 accumulators in the epilogue, GemmParams::mx_rowscale / mx_colscale).  A K-tile is 128
 // fp8 values = the same 128 bytes per row as 64 halves, so staging, swizzle and the 8-phase schedule are unchanged: the host passes lda /
 // K in 2-byte units; a lane's 32-byte fragment of the K = 128 MFMA is the two adjacent 16-byte chunks 2 fk, 2 fk + 1 of its row.
-// GNS: the epilogue also emits per-channel GroupNorm partial sums of the stored fp16 image (GemmParams::gn_partial; VAE convs only)
+// GNS: the epilogue also emits per-channel GroupNorm partial sums of the stored fp16 image (GemmParams::gn_partial; 3x3 convs of the VAE AND, since round 5, of the UNet op programs on the tiles gemm_gn_slab_rows() accepts)
 // Order of the MFMAs of a register tile: "snake" — the column index runs backwards on every other row, so that exactly ONE operand register
 // changes between consecutive MFMAs (row-major changes both at every row change).  At the power cap the rate follows the energy:
 // tools/micro/energy.hip mfma-order: 1930 (snake) vs 1913 (row-major) vs 1849 TFLOP/s (both operands change every time).  -DGDF_MMA_ROWMAJOR: A/B.
@@ -1238,7 +1238,7 @@ template <int MODE, int BM, int BN, int STAGES, bool GEGLU>
 __global__ __launch_bounds__(BM * 2, 2) void gemm_kernel(const GemmParams p) {
   gemm_body<MODE, BM, BN, STAGES, GEGLU, false>(p);
 }
-// 3x3 conv whose epilogue also writes GroupNorm partial sums (GemmParams::gn_partial; the VAE op programs)
+// 3x3 conv whose epilogue also writes GroupNorm partial sums (GemmParams::gn_partial; the VAE and UNet op programs: PlanBuilder::gn_epi)
 template <int MODE, int BM, int BN, int STAGES>
 __global__ __launch_bounds__(BM * 2, 2) void gemm_gn_kernel(const GemmParams p) {
   gemm_body<MODE, BM, BN, STAGES, false, false, false, false, false, false, true>(p);

@@ -206,6 +206,10 @@ hipError_t launch_gn_apply(const half_t* x16, const float* x32, int ld, int B, i
 size_t gn_fold_floats(int B, int nslab, int C);
 hipError_t launch_gn_finalize(const float* partial, int nslab, int B, int HW, int C, int G, float eps, const float* gamma,
                               const float* beta, float* ab, float* fold, hipStream_t s);
+// the fold pass of launch_gn_finalize on its own (many short slabs -> gn_fold_out_slabs(nslab) <= 128 slabs)
+int gn_fold_out_slabs(int nslab);
+bool gn_fold_ok(int C);
+hipError_t launch_gn_fold(const float* partial, int nslab, int B, int C, float* fold, hipStream_t s);
 // statistics from the producer's epilogue -> finalize + apply (+SiLU) in ONE launch (round 6); gn_finalize_apply_slab(...) != 0 says whether it applies
 int gn_finalize_apply_slab(int C, int G);
 hipError_t launch_gn_finalize_apply(const float* partial, int nslab, const half_t* x16, int ld, int B, int HW, int C, int G, float eps,

@@ -196,6 +196,19 @@ __global__ __launch_bounds__(256) void gn_fold_kernel(const float* partial, int 
 
 size_t gn_fold_floats(int B, int nslab, int C) { return nslab > 2 * GN_FOLD ? (size_t)B * GN_FOLD * C * 2 : 0; }
 
+// the fold pass alone: nslab slabs -> gn_fold_out_slabs(nslab) slabs in `fold` (same [slab][C][2] layout); false = shape not supported
+int gn_fold_out_slabs(int nslab) {
+  const int per = (nslab + GN_FOLD - 1) / GN_FOLD;
+  return (nslab + per - 1) / per;
+}
+bool gn_fold_ok(int C) { return (2 * C) % 4 == 0 && (2 * C >= 1024 ? (2 * C) % 1024 == 0 : 256 % (2 * C / 4) == 0); }
+hipError_t launch_gn_fold(const float* partial, int nslab, int B, int C, float* fold, hipStream_t s) {
+  if (!gn_fold_ok(C) || nslab < 1) return hipErrorInvalidValue;
+  const int per = (nslab + GN_FOLD - 1) / GN_FOLD, nout = (nslab + per - 1) / per;
+  hipLaunchKernelGGL(gn_fold_kernel, dim3(nout, B), dim3(256), 0, s, partial, nslab, per, 2 * C, fold);
+  return hipGetLastError();
+}
+
 hipError_t launch_gn_finalize(const float* partial, int nslab, int B, int HW, int C, int G, float eps, const float* gamma,
                               const float* beta, float* ab, float* fold, hipStream_t s) {
   if (C % G || nslab < 1 || (C & 1)) return hipErrorInvalidValue;

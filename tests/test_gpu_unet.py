@@ -477,7 +477,7 @@ def test_heavy_tailed_weights_plan_levels(base):
     assert max(res["precise"].values()) < max(res["plain"].values()) / 1.5
 
 
-def test_verify_escalates_plan_on_heavy_tailed_weights():
+def test_verify_escalates_plan_on_heavy_tailed_weights(monkeypatch):
     """NativeUNet(verify=True) / GDF_VERIFY=1: the first forward of a hook set runs the table-chosen level AND the full split, compares the
     requested hooks and escalates when they differ by more than 9.5e-4.  Benign synthetic weights: the table's choice (plain) stands, no
     warning.  Heavy-tailed weights: the same hook set is escalated, one RuntimeWarning, the result handed out is the escalated plan's, and
@@ -488,9 +488,13 @@ def test_verify_escalates_plan_on_heavy_tailed_weights():
     ids = ["down-level1-repeat0-vit-block0-out", "mid-vit-block0-self-q", "up-level1-repeat0-vit-block0-out"]
     # benign weights: at these SHRUNKEN widths the plain plan already differs from the full split by > 1e-3 (test_all_hooks: floor 1.5e-3), so the
     # check is exercised with a bound that the benign model passes and the heavy-tailed one does not
+    # (this shrunken architecture is not in the table: its kind rules would start at the selective preset; start from the plain plan, as the
+    #  table does for most hooks of the true architectures.  Round 6: an escalation is OR-ed onto the table's choice, so the table itself is
+    #  stubbed rather than a zero escalation planted)
+    import components.plan_levels as PL
+    monkeypatch.setattr(PL, "choose_split", lambda cfg, hook_ids, lat=None: 0)
     ub = native(arch, R.synth_params(arch, seed=0), precise="auto", verify=True)
-    ub._escalated[tuple(ids)] = 0                  # (this shrunken architecture is not in the table: its kind rules would start at the selective
-    ub.verify_bound = 3e-3                         #  preset; start from the plain plan, as the table does for most hooks of the true architectures)
+    ub.verify_bound = 3e-3
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter("always")
         _, hb = run_native(ub, I, ids)
@@ -502,7 +506,6 @@ def test_verify_escalates_plan_on_heavy_tailed_weights():
     # heavy-tailed weights, same bound
     Ph = R.synth_params_heavy(arch, seed=0, outlier_gain=16.0)
     uh = native(arch, Ph, precise="auto", verify=True)
-    uh._escalated[tuple(ids)] = 0
     uh.verify_bound = 3e-3
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter("always")

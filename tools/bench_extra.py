@@ -119,9 +119,9 @@ def plans_block(unet, step, B, headline_ips, steps=4):
         out[name] = {"split_mask": unet.last_split, "images_per_s": round(B * steps / dt, 2), "ms_per_step": round(1e3 * dt / steps, 2)}
     unet.set_precise("auto")
     out["note"] = ("operand plan levels (include/gdf.h reserved[1]): auto = the cheapest level that keeps every REQUESTED hook within 1e-3 of the fp32 "
-                   "reference (components/native.py choose_split: plain fp16 operands for the headline's four hooks); selective = split stream "
+                   "reference (components/plan_levels.py choose_split: plain fp16 operands for the headline's four hooks); selective = split stream "
                    "images (shortcut / proj_out / downsampler operands, GroupNorm inputs) + proj_in / conv_out operands + self-attention outputs (every hook kind <= 8.2e-4 at full size, "
-                   "tests/test_gpu_fullsize.py); precise = every operand class split (<= 4.9e-4)")
+                   "tests/test_gpu_fullsize.py); precise = every operand class split (<= 3e-4 asserted, 1.9e-4 measured: q / k / v pairs since round 5)")
     return out
 
 
