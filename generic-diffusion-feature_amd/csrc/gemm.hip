@@ -1,4 +1,4 @@
-// MFMA GEMM + implicit-GEMM 3x3 convolution for gfx950 (MI355X), fp16 operands, fp32 accumulate.
+// MFMA GEMM + implicit-GEMM 3x3 convolution for gfx950 (MI355X), fp16 operands, fp32 accumulate: kernels, tile selection, launchers, split-K.
 //
 //   D[M,N] = A[M,K] * Wt[N,K]^T  with a fused epilogue (bias, per-sample row vector, residual add,
 //   GEGLU gate, fp16/fp32 dual store, pre-residual aux store).
@@ -25,8 +25,13 @@
 //     generator: out-of-image taps get an out-of-range buffer offset, which the hardware returns as 0.
 //   * Epilogue is staged per wave through LDS so every global store / residual load is a full
 //     16-byte-per-lane, 128-byte-per-row access.
-#include "kernels.h"
-#include <type_traits>
+//
+// Source layout (round 6): gemm_common.h (types, LDS-DMA, MFMA wrappers, GELU, tile order), gemm_tile.h (GemmTile: tile geometry, tile origin,
+// operand address generators), gemm_mainloop_ring.h (2- / 3-stage LDS rings), gemm_mainloop_8phase.h (the two-group 256x256 / 256x320 loops),
+// gemm_epilogue.h (the staged epilogue), this file (gemm_body = locate -> main loop -> epilogue, kernel instantiations, pick_variant, launch_gemm).
+#include "gemm_mainloop_ring.h"
+#include "gemm_mainloop_8phase.h"
+#include "gemm_epilogue.h"
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -36,152 +41,12 @@
 
 namespace gdf {
 
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-#define LDS_AS __attribute__((address_space(3)))
-
-static constexpr int BK = 64;                  // halves per K-tile -> 128-byte LDS rows
-static constexpr uint32_t OOB = 0x80000000u;   // any offset >= num_records reads as zero
-
-__device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rsrc, char* lds_wave_base, uint32_t voff) {
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (LDS_AS void*)lds_wave_base, 16, voff, 0, 0, 0);
-}
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-// BF: the 16-byte fragments hold bf16 (MMDiT path of a bf16 model); same MFMA rate, same register layout
-// one K = 128 step on fp8 (e4m3) operands: a = [a0 | a1], b = [b0 | b1] (16 bytes each), unit e8m0 block scales (127 = 2^0)
-typedef int i32x8 __attribute__((ext_vector_type(8)));
-typedef int i32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ f32x4 mfma_mx8(const f16x8 a0, const f16x8 a1, const f16x8 b0, const f16x8 b1, const f32x4 c) {
-  const i32x4 x0 = __builtin_bit_cast(i32x4, a0), x1 = __builtin_bit_cast(i32x4, a1);
-  const i32x4 y0 = __builtin_bit_cast(i32x4, b0), y1 = __builtin_bit_cast(i32x4, b1);
-  const i32x8 a = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
-  const i32x8 b = {y0[0], y0[1], y0[2], y0[3], y1[0], y1[1], y1[2], y1[3]};
-  return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, /*A fp8 e4m3*/ 0, /*B fp8 e4m3*/ 0, 0, 127, 0, 127);
-}
-template <bool BF>
-__device__ __forceinline__ f32x4 mfma16(const f16x8 a, const f16x8 b, const f32x4 c) {
-  if constexpr (BF) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-  else return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
-}
-// 16-bit store conversions of the epilogue.  UNet kernels (DIT = false): plain fp16 casts, unchanged code.  MMDiT kernels:
-// activations (out16) are bf16 or SATURATING fp16, hook copies (aux16) always saturating fp16 (the reference's hooks are fp16,
-// feature_extractor.py:59-60, and real FLUX.1-dev activations leave the fp16 range).
-template <bool DIT, bool BF>
-__device__ __forceinline__ _Float16 act16(float v) {
-  if constexpr (BF) return __builtin_bit_cast(_Float16, (__bf16)v);
-  else if constexpr (DIT) return f32_to_f16_sat(v);
-  else return (_Float16)v;
-}
-template <bool DIT>
-__device__ __forceinline__ _Float16 hook16(float v) {
-  if constexpr (DIT) return f32_to_f16_sat(v);
-  else return (_Float16)v;
-}
-
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
-// exact (erf) GELU, two values at a time (the GEGLU epilogue evaluates 64 per lane; at 2 waves per SIMD the VALU time of the
-// round-1 form — Abramowitz-Stegun 7.1.26 with one v_rcp_f32 + one v_exp_f32 and ~15 scalar-float ops — was 5.4 us of a 37-us
-// tile, tools/trace_gemm.py).  With u = |x| and q(u) = 1 - Phi(u) = erfc(u / sqrt 2) / 2:
-//     gelu(x) = x Phi(x) = max(x, 0) - u q(u),        q(u) = 2^P(u),  P = degree-7 fit of log2 q on [0, 5.5], P(0) = -1
-// ONE transcendental, and the Horner chain + the final ops run as packed fp32 (v_pk_fma_f32: two lanes' worth per issue).
-// |gelu - exact| <= 6.5e-7 absolute and <= 5.4e-6 relative on x > -4.5 (fp16 output rounding: 4.9e-4); u is clamped at 5.5,
-// beyond which q < 2e-8 (coefficients: Lawson-weighted least squares on 4000 Chebyshev nodes, checked on 400k points in fp32).
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
-  const f32x2 u = {fminf(fabsf(x[0]), 5.5f), fminf(fabsf(x[1]), 5.5f)};
-  f32x2 P = u * -1.735116371e-06f + 5.974406668e-05f;
-  P = P * u + -9.168680408e-04f;
-  P = P * u + 8.457269520e-03f;
-  P = P * u + -5.386104062e-02f;
-  P = P * u + -4.585619271e-01f;
-  P = P * u + -1.151209950e+00f;
-  P = P * u + -1.0f;
-  const f32x2 q = {__builtin_amdgcn_exp2f(P[0]), __builtin_amdgcn_exp2f(P[1])};
-  const f32x2 r = {fmaxf(x[0], 0.f), fmaxf(x[1], 0.f)};
-  return r - u * q;
-}
-
-// XCD-aware bijective remap: consecutive tiles (which share the same A row-block) land on one XCD's L2.
-__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
-  const int q = nblk >> 3, r = nblk & 7;
-  const int xcd = bid & 7, idx = bid >> 3;
-  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-  return base + idx;
-}
-
-// tanh-approximate GELU (activations.GELU(approximate="tanh"), Flux FeedForward / proj_mlp):
-// 0.5 x (1 + tanh(u)) = x * sigmoid(2u), u = sqrt(2/pi) (x + 0.044715 x^3): one v_exp_f32 + one v_rcp_f32
-__device__ __forceinline__ float gelu_tanh(float x) {
-  const float u2 = 1.5957691216057308f * (x + 0.044715f * x * x * x);               // 2u
-  return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * u2));
-}
-
-// DIT = true adds the MMDiT epilogue forms (Flux): optional tanh-GELU on (acc + bias), the per-sample
-// row vector applied as a GATE (multiply) instead of an addend, and a two-region row -> sample map (text rows first,
-// image rows second).  It is a compile-time switch so that the UNet kernels keep their code and register budget.
-// QKN: compile the fused RMSNorm(q) / RMSNorm(k) + RoPE epilogue (GemmParams::qkn_*; 256x256 MMDiT QKV projections only).  It is
-// its own instantiation because its live state (cos / sin rows, norm gains) on top of the gated-residual operands pushed the
-// one-size-fits-all MMDiT epilogue over 256 VGPRs (9 spilled, 40 B of scratch per lane in EVERY 256x256 MMDiT GEMM).
-// diagnostics build (tools/trace_gemm.sh, -DGDF_TRACE): workgroup time stamps (100 MHz s_memrealtime) at kernel entry, after the
-// prologue's DMA issue, when K-tile 0 has landed, after the main loop and after the epilogue, + the CU the workgroup ran on
-#if defined(GDF_TRACE)
-__device__ unsigned long long gdf_trace[16384 * 8];
-#define GDF_TR(i) do { if (threadIdx.x == 0) gdf_trace[(vb & 16383) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#define GDF_TR_ID() do { if (threadIdx.x == 0) gdf_trace[(vb & 16383) * 8 + 6] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | __builtin_amdgcn_s_getreg(63492); } while (0)
-#else
-#define GDF_TR(i)
-#define GDF_TR_ID()
-#endif
-
-// SPLIT: split fp16 hi + lo operands of the opt-in "precise" plans (GemmParams::k_w / a_lo_bytes / o16_lo, kernels.h).  A compile-time
-// switch with its own instantiations (gemm_split_kernel): compiled into the default kernels, its few extra live values pushed
-// the 256x320 dense kernel from 253 VGPRs to 139 spilled (140 -> 100 img/s on the SDXL step).
-// MX: fp8 (OCP e4m3) operands multiplied with v_mfma_scale_f32_16x16x128_f8f6f4 (unit block scales: the per-row / per-column power-of-two
-// scales of the operands are applied to the fp32 accumulators in the epilogue, GemmParams::mx_rowscale / mx_colscale).  A K-tile is 128
-// fp8 values = the same 128 bytes per row as 64 halves, so staging, swizzle and the 8-phase schedule are unchanged: the host passes lda /
-// K in 2-byte units; a lane's 32-byte fragment of the K = 128 MFMA is the two adjacent 16-byte chunks 2 fk, 2 fk + 1 of its row.
-// GNS: the epilogue also emits per-channel GroupNorm partial sums of the stored fp16 image (GemmParams::gn_partial; 3x3 convs of the VAE AND, since round 5, of the UNet op programs on the tiles gemm_gn_slab_rows() accepts)
-// Order of the MFMAs of a register tile: "snake" — the column index runs backwards on every other row, so that exactly ONE operand register
-// changes between consecutive MFMAs (row-major changes both at every row change).  At the power cap the rate follows the energy:
-// tools/micro/energy.hip mfma-order: 1930 (snake) vs 1913 (row-major) vs 1849 TFLOP/s (both operands change every time).  -DGDF_MMA_ROWMAJOR: A/B.
-#if defined(GDF_MMA_ROWMAJOR)
-#define GDF_SNAKE(row, j, n) (j)
-#else
-#define GDF_SNAKE(row, j, n) ((((row) & 1) != 0) ? (n) - 1 - (j) : (j))
-#endif
 template <int MODE, int BM, int BN, int STAGES, bool GEGLU, bool DIT, bool BF = false, bool QKN = false, bool SPLIT = false, bool MX = false,
           bool GNS = false>
 __device__ __forceinline__ void gemm_body(const GemmParams& p) {
-  static_assert(!BF || DIT, "bf16 operands exist on the MMDiT path only");
-  static_assert(!GNS || (!DIT && !GEGLU && !SPLIT && !MX && BN >= 128), "GroupNorm partial sums: plain epilogues, one statistics slab per wave tile (WTM rows)");
-  static_assert(!MX || (DIT && STAGES == 8 && !SPLIT && !QKN && !GEGLU), "fp8 operands: the 256x256 two-group MMDiT kernel only");
-  constexpr int NW = BM / 32;                    // waves per workgroup (4 or 8)
-  // waves along N (the GEGLU form of the 256x320 tile uses 4x2 waves of 64x160: an EVEN number of 16-column fragments,
-  // so that every h fragment has its gate fragment in the same lane and register index)
-  constexpr int WGN = (BN == 320 && !GEGLU && STAGES != 8) ? 4 : (BN >= 128) ? 2 : 1;
-  constexpr int WGM = NW / WGN;                  // waves along M
-  constexpr int WTM = BM / WGM;                  // 64 or 32
-  constexpr int WTN = BN / WGN;                  // 80, 64 or 16
-  constexpr int FM = WTM / 16, FN = WTN / 16;
-  constexpr int A_TILE = BM * 128;               // bytes
-  constexpr int B_TILE = BN * 128;
-  constexpr int STAGE = A_TILE + B_TILE;
-  constexpr int A_PER_WAVE = BM / 8 / NW;        // 1-KiB wave-instructions of the A tile per wave (4)
-  constexpr int B_INSTR = BN / 8;                // 1-KiB wave-instructions per B tile
-  constexpr int B_PER_WAVE = (B_INSTR + NW - 1) / NW;
-  constexpr int LPT = A_PER_WAVE + B_PER_WAVE;   // DMA instructions per wave per K-tile (uniform when BN == 128)
-  static_assert(STAGES == 2 || STAGES == 8 || STAGES == 9 || (STAGES == 3 && B_INSTR % NW == 0), "3-stage ring needs a uniform per-wave load count");
-
+  using T = GemmTile<MODE, BM, BN, STAGES, GEGLU, DIT, BF, QKN, SPLIT, MX, GNS>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  T t(p, smem);
   const int tiles_n = (p.N + BN - 1) / BN;
   const int nblk = ((p.M + BM - 1) / BM) * tiles_n;
   // Persistent form: the launcher may start fewer workgroups than tiles (one per CU for the two-group 256x256 kernels); workgroup b
@@ -201,675 +66,15 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
 #endif
   do {
   GDF_TR(0); GDF_TR_ID();
-  int tile_m, tile_n;
-  if (p.sb_gn > 0) {
-    // 2-D super-block order: the workgroups one XCD runs concurrently cover sb_gm x sb_gn tiles, so its private L2
-    // fetches sb_gm A panels + sb_gn B panels per round instead of one A panel + a whole row of B panels
-    // (N = 10240 GEGLU: 27 MB -> 8.5 MB of L2 fills per XCD and round; the "fixed cost" of that GEMM was this traffic).
-    // The super-blocks are dealt to the XCDs in groups of 8; when their number is not a multiple of 8 the last few
-    // are walked in plain order (one super-block after the other, round-robin over the XCDs: only that tail loses locality).
-    const int conc = p.sb_gm * p.sb_gn;
-    const int sbn = tiles_n / p.sb_gn;
-    const int nsb = (nblk / conc);
-    const int grouped = (nsb >> 3) * 8 * conc;            // workgroups covered by whole groups of 8 super-blocks
-    int sb, li;
-    if (vb < grouped) {
-      const int xcd = vb & 7, j = vb >> 3;
-      sb = (j / conc) * 8 + xcd; li = j - (j / conc) * conc;
-    } else {
-      const int t = vb - grouped;
-      sb = (nsb >> 3) * 8 + t / conc; li = t - (t / conc) * conc;
-    }
-    const int sbr = sb / sbn, sbc = sb - sbr * sbn;
-    tile_m = sbr * p.sb_gm + li / p.sb_gn;
-    tile_n = sbc * p.sb_gn + li % p.sb_gn;
-  } else {
-    const int t = xcd_remap(vb, nblk);
-    tile_m = t / tiles_n; tile_n = t - tile_m * tiles_n;
-  }
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
-
-  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, p.a_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Wt + (size_t)blockIdx.y * p.w_bstride), 0, p.w_bytes, 0x00020000);
-  _Float16* const out16 = p.out16 ? p.out16 + (size_t)blockIdx.y * p.o_bstride : nullptr;
-
-  // ---- per-lane load geometry: one wave-instruction moves 8 rows x 128 B ----
-  const int lrow = lane >> 3;                         // row inside an 8-row instruction
-  const int chunk = (lane & 7) ^ lrow;                // source 16-B chunk (swizzle on the source side)
-  uint32_t a_off[A_PER_WAVE];                         // DENSE: byte offset of (row, chunk); CONV3: byte offset of filter tap (0, 0)
-  uint32_t a_msk[A_PER_WAVE];                         // CONV3: validity mask of the 9 taps (conv_row below)
-  int a_oy[A_PER_WAVE], a_ox[A_PER_WAVE];             // SMALLC: pixel base of the sample in a_off, top-left input pixel here
+  t.locate(vb, tiles_n, nblk);
+  f32x4 acc[T::FM][T::FN];
 #pragma unroll
-  for (int j = 0; j < A_PER_WAVE; ++j) {
-    const int m = m0 + (wave * A_PER_WAVE + j) * 8 + lrow;
-    a_msk[j] = 0; a_oy[j] = a_ox[j] = 0;
-    if (MODE == A_DENSE) {
-      a_off[j] = (m < p.M) ? (uint32_t)m * (uint32_t)p.lda * 2u + (uint32_t)chunk * 16u : OOB;
-    } else if (MODE == A_CONV3) {
-      a_off[j] = 0;                                   // filled by conv_row once its scalars are known
-    } else {
-      const int hw = p.OH * p.OW;
-      const int n = m / hw;
-      const int rem = m - n * hw;
-      const int oy = rem / p.OW, ox = rem - oy * p.OW;
-      a_off[j] = (uint32_t)(n * p.H * p.W);           // pixel index base of sample n
-      a_oy[j] = (m < p.M) ? oy * p.stride - 1 + p.pad0 : -(1 << 20);   // pad0 = 1: no top / left padding (VAE downsample)
-      a_ox[j] = ox * p.stride - 1 + p.pad0;
-    }
-  }
-  const uint32_t ldb = (uint32_t)((SPLIT && p.k_w > 0) ? p.k_w : p.K) * 2u;   // bytes per weight row (split operands: the matrix holds k_w columns, read twice)
-  uint32_t b_off[B_PER_WAVE];
-  bool b_act[B_PER_WAVE];
+  for (int i = 0; i < T::FM; ++i)
 #pragma unroll
-  for (int j = 0; j < B_PER_WAVE; ++j) {
-    const int q = wave * B_PER_WAVE + j;              // instruction index inside the B tile
-    b_act[j] = q < B_INSTR;
-    const int n = n0 + q * 8 + lrow;
-    b_off[j] = (n < p.N) ? (uint32_t)n * ldb + (uint32_t)chunk * 16u : OOB;
-  }
-
-#if defined(GDF_ABLATE_EPI) && GDF_ABLATE_EPI == 2
-  // diagnostics build (tools/ab_epilogue_bound.sh): NO main loop — the prologue / epilogue skeleton with every global load and store of the
-  // epilogue, on zero accumulators.  Results are garbage; the time per launch is the epilogue's (+ launch, prologue) alone.
-  const int nk = 0;
-#else
-  const int nk = (MODE == A_CONV_SMALLC) ? 2 : p.K / BK;
-#endif
-  // split-K (2-stage ring tiles only): this workgroup accumulates the K-tiles [kt0, kt1) and stores raw partial sums
-  int kt0 = 0, kt1 = nk;
-  if (STAGES == 2 && p.splitk > 1) {
-    kt0 = (int)((long)nk * blockIdx.y / p.splitk);
-    kt1 = (int)((long)nk * (blockIdx.y + 1) / p.splitk);
-  }
-  // 3x3 conv: K-tiles are channel-block-major with the nine filter taps innermost (K-tile kt = tap kt % 9 of channel block kt / 9;
-  // weights laid out [Cout][Cin / 64][tap][64] by launch_relayout_conv).  Round 2 walked them tap-major: the nine shifted reads of
-  // one 64-channel slab were Cin / 64 K-tiles apart, times all resident workgroups of the XCD >> its 4 MB L2, and rocprofv3 counted
-  // 1.38 GB of fabric fetches per launch for 134 MB of input + weights (profiles/r02_final_pmc_traffic.json).
-  const int IH = p.ups ? 2 * p.H : p.H, IW = p.ups ? 2 * p.W : p.W;
-
-  // byte offset of K-tile kt inside a dense row.  The two-group schedules also stage the tiles nk, nk + 1 (so that the counted
-  // waits are the same in every iteration): those get an out-of-range offset — zero fill, no L2 / HBM traffic (scalar select).
-  // Split operands (GemmParams::k_w): the lo half of A starts a_lo_bytes after the hi half, the weight K-tiles repeat.
-  const int nkw = (SPLIT && p.k_w > 0) ? p.k_w / BK : nk;      // K-tiles of the weight matrix (== nk without a split)
-  const uint32_t a_lo = SPLIT ? p.a_lo_bytes : 0u;
-  auto koffA = [&](int kt) -> uint32_t {
-    if constexpr (!SPLIT) return kt < nk ? (uint32_t)kt * 128u : OOB;
-    else return kt < nkw ? (uint32_t)kt * 128u : (kt < nk ? a_lo + (uint32_t)(kt - nkw) * 128u : OOB);
-  };
-  auto koffB = [&](int kt) -> uint32_t {
-    if constexpr (!SPLIT) return kt < nk ? (uint32_t)kt * 128u : OOB;
-    else return kt < nk ? (uint32_t)(kt < nkw ? kt : kt - nkw) * 128u : OOB;
-  };
-  const int cbw = nkw / 9;                                      // conv3: 64-channel blocks of the weight matrix
-  auto chanb = [&](int cbk) -> uint32_t {
-    if constexpr (!SPLIT) return (uint32_t)cbk * 128u;
-    else return cbk < cbw ? (uint32_t)cbk * 128u : a_lo + (uint32_t)(cbk - cbw) * 128u;
-  };
-  // 3x3-conv rows of the two-group schedules (round 2): per output row ONE byte offset — that of filter tap (0, 0), which may lie
-  // outside the image — and a 9-bit validity mask, so that a K-tile's source offset is `base + scalar tap offset` and one bit test
-  // (4 VALU instructions per row and K-tile instead of ~12: bounds compares, pixel arithmetic and two multiplies; VALU issue time
-  // is not hidden by MFMAs on this hardware).  Nearest-x2 upsampling fused into the conv: source row of tap ky is
-  // (uy + ky) >> 1 = (uy >> 1) + {0, parity, 1}[ky]; the two parities travel in mask bits 9 / 10.
-  auto conv_row = [&](int m, uint32_t& base, uint32_t& mask) {
-    const int hw = p.OH * p.OW;
-    const int n = m / hw;
-    const int rem = m - n * hw;
-    const int oy = rem / p.OW, ox = rem - oy * p.OW;
-    const int uy = oy * p.stride - 1 + p.pad0, ux = ox * p.stride - 1 + p.pad0;      // pad0 = 1: no top / left padding (VAE downsample)
-    const int by = p.ups ? (uy >> 1) : uy, bx = p.ups ? (ux >> 1) : ux;
-    base = (uint32_t)((n * p.H + by) * p.W + bx) * (uint32_t)p.lda * 2u + (uint32_t)chunk * 16u;
-    uint32_t mk = 0;
-    if (m < p.M) {
-#pragma unroll
-      for (int tp = 0; tp < 9; ++tp) {
-        const int iy = uy + tp / 3, ix = ux + tp % 3;
-        if ((iy >= 0) & (iy < IH) & (ix >= 0) & (ix < IW)) mk |= 1u << tp;
-      }
-    }
-    if (p.ups) mk |= ((uint32_t)(uy & 1) << 9) | ((uint32_t)(ux & 1) << 10);
-    mask = mk;
-  };
-  auto conv_tap_off = [&](int tp, int cbk, uint32_t base, uint32_t mask, bool live = true) -> uint32_t {     // filter tap tp, channel block cbk (scalars)
-    const int ky = tp / 3, kx = tp - ky * 3;
-    const uint32_t rowb = (uint32_t)p.W * (uint32_t)p.lda * 2u, pixb = (uint32_t)p.lda * 2u;
-    uint32_t off;
-    if (!p.ups) {
-      off = base + ((uint32_t)ky * rowb + (uint32_t)kx * pixb + chanb(cbk));
-    } else {
-      off = base + ((ky == 2 ? rowb : 0u) + (kx == 2 ? pixb : 0u) + chanb(cbk));
-      if (ky == 1 && (mask & 512u)) off += rowb;
-      if (kx == 1 && (mask & 1024u)) off += pixb;
-    }
-    const uint32_t bit = live ? (1u << tp) : 0u;                 // tiles >= nk (over-staged): zero fill
-    return (mask & bit) ? off : OOB;
-  };
-  auto conv_off = [&](int kt, uint32_t base, uint32_t mask) -> uint32_t {
-#if defined(GDF_CONV_TAP_MAJOR)                                   // diagnostics build (tools/build_variant.sh): the round-2 K order, for same-box A/Bs
-    const int cpb = p.Cin / BK, tp = kt / cpb;
-    return conv_tap_off(tp < 9 ? tp : 0, kt - tp * cpb, base, mask, tp < 9);
-#else
-    const int cbk = kt / 9;                                     // scalar: channel block, then filter tap
-    return conv_tap_off(kt - cbk * 9, cbk, base, mask, kt < nk);
-#endif
-  };
-  if (MODE == A_CONV3 && STAGES < 8) {
-#pragma unroll
-    for (int j = 0; j < A_PER_WAVE; ++j) conv_row(m0 + (wave * A_PER_WAVE + j) * 8 + lrow, a_off[j], a_msk[j]);
-  }
-#if defined(GDF_CONV_TAP_MAJOR)
-  const int cpb_ = (MODE == A_CONV3) ? p.Cin / BK : 1;
-  int tap = kt0 / cpb_, cb = kt0 - (kt0 / cpb_) * cpb_;
-#else
-  int cb = kt0 / 9, tap = kt0 - (kt0 / 9) * 9;         // channel block / filter tap of the NEXT tile to issue
-#endif
-  auto issue = [&](int kt, int buf) {
-    char* sA = smem + buf * STAGE;
-    char* sB = sA + A_TILE;
-#pragma unroll
-    for (int j = 0; j < A_PER_WAVE; ++j) {
-      uint32_t off;
-      if (MODE == A_DENSE) {
-        off = a_off[j] + (SPLIT ? koffA(kt) : (uint32_t)kt * 128u);   // OOB stays >= 2^31
-      } else if (MODE == A_CONV3) {
-        off = conv_tap_off(tap, cb, a_off[j], a_msk[j]);
-      } else {  // SMALLC: 8 channels per pixel = one 16-B chunk per tap; chunk index == tap - 8*kt
-        const int tp = kt * 8 + chunk;
-        const int kyy = tp / 3, kxx = tp - kyy * 3;
-        const int iy = a_oy[j] + kyy, ix = a_ox[j] + kxx;
-        const bool okk = (tp < 9) & (iy >= 0) & (iy < p.H) & (ix >= 0) & (ix < p.W);
-        off = okk ? (a_off[j] + (uint32_t)(iy * p.W + ix)) * 16u : OOB;
-      }
-      glds16(rsA, sA + (wave * A_PER_WAVE + j) * 1024, off);
-    }
-#pragma unroll
-    for (int j = 0; j < B_PER_WAVE; ++j) {
-      if (b_act[j]) {
-        const uint32_t off = b_off[j] + ((MODE == A_CONV_SMALLC || !SPLIT) ? (uint32_t)kt * 128u : koffB(kt));
-        glds16(rsB, sB + (wave * B_PER_WAVE + j) * 1024, off);
-      }
-    }
-#if defined(GDF_CONV_TAP_MAJOR)
-    if (MODE == A_CONV3) { if (++cb == cpb_) { cb = 0; ++tap; } }
-#else
-    if (MODE == A_CONV3) { if (++tap == 9) { tap = 0; ++cb; } }
-#endif
-  };
-
-  // ---- accumulators ----
-  f32x4 acc[FM][FN];
-#pragma unroll
-  for (int i = 0; i < FM; ++i)
-#pragma unroll
-    for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int wm = wave / WGN, wn = wave - wm * WGN;
-  const int frow = lane & 15, fk = lane >> 4;
-
-  // One K-tile = two 32-deep MFMA steps (kk = 0, 1): 2 x (FM + FN) ds_read_b128 and 2 x FM x FN MFMAs per wave.
-  // A wave issues in order, so its own DMA issue (a `buffer_load ... lds` costs ~60-180 issue cycles) cannot overlap
-  // its own MFMAs; the overlap comes from the partner wave on the same SIMD.  With 8 waves the two waves of a SIMD
-  // (w, w+4) therefore run the head of a K-tile in opposite orders (EARLY_MMA): one issues the next tile's DMA
-  // while the other already multiplies.  (Measured and rejected: rotating the loop by half a tile so that MFMAs from
-  // registers follow the barrier, 929 -> 684 TFLOP/s on the 256x320 GEGLU GEMM; a two-group ping-pong with 2 barriers
-  // per K-tile, 1002 -> 903 at 8192^3.)
-  f16x8 af[FM], bf[FN];
-  // lane part of a fragment address per k-step (all wave-tile origins are multiples of 16 rows, so the swizzle term depends on
-  // frow only); opaque to the optimiser so that buffer + fragment offsets stay `one add + immediate` instead of an add per fragment
-  uint32_t rfa[2], rfb[2];
-#pragma unroll
-  for (int kk = 0; kk < 2; ++kk) {
-    rfa[kk] = (uint32_t)((wm * WTM + frow) * 128 + (((kk * 4 + fk) ^ (frow & 7)) << 4));
-    rfb[kk] = (uint32_t)(A_TILE + (wn * WTN + frow) * 128 + (((kk * 4 + fk) ^ (frow & 7)) << 4));
-    if (STAGES < 8) asm volatile("" : "+v"(rfa[kk]), "+v"(rfb[kk]));
-  }
-  auto read_kk = [&](int buf, int kk) {
-    const char* pa = smem + buf * STAGE + rfa[kk];
-    const char* pb = smem + buf * STAGE + rfb[kk];
-#pragma unroll
-    for (int i = 0; i < FM; ++i) af[i] = *(const f16x8*)(pa + i * 2048);
-#pragma unroll
-    for (int j = 0; j < FN; ++j) bf[j] = *(const f16x8*)(pb + j * 2048);
-  };
-  auto mma = [&]() {
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-      for (int jj = 0; jj < FN; ++jj) { const int j = GDF_SNAKE(i, jj, FN); acc[i][j] = mfma16<BF>(af[i], bf[j], acc[i][j]); }
-  };
-  // compile-time off for the 256x320 variant: its 160 accumulator VGPRs leave no room for the second code path
-  constexpr bool EARLY_OK = (NW == 8) && (FM * FN <= 16);
-  const bool early_mma = EARLY_OK && !p.no_early_mma && (wave >= 4);
-
-  if constexpr (STAGES == 8) {
-    // ---- 8-phase schedule (256x256 dense tile, 2 K-tile buffers of 64 KiB) ----
-    // The two waves of a SIMD (w, w + 4) belong to two groups that run ONE BARRIER apart: while one group multiplies a
-    // quadrant of its 64x128 wave tile (16 MFMAs) the other reads its next fragments from LDS and issues
-    // its share of the next half-tile DMA, then they swap (2 barriers per phase, 4 phases per K-tile).  The MFMA pipe of
-    // every SIMD therefore always has a wave that is multiplying.  DMA runs 1.5 K-tiles ahead in 16-KiB half-tiles
-    // (A rows 0-127 / 128-255, B rows likewise; every wave issues 2 of a half-tile's 16 instructions), the one counted wait
-    // per K-tile leaves three half-tiles in flight:
-    //   K-tile T (buffer T & 1)   phase 1: read A (all 64 rows) + B cols 0-63     stage B-hi of T+1      MFMA (A0,B0)
-    //                             phase 2:                                        stage A-lo of T+2      MFMA (A1,B0)
-    //                             phase 3: read B cols 64-127, retire the reads   stage A-hi of T+2      MFMA (A1,B1)
-    //                             phase 4: wait vmcnt(6) = tile T+1 has landed    stage B-lo of T+2      MFMA (A0,B1)
-    // Slot lifetimes (why each staging is safe): A slots are last read in phase 1 (A-lo by group 0 only, A-hi by group 1
-    // only), B slots in phase 3 with the reads retired (lgkmcnt) BEFORE the reader's next barrier; a slot is restaged by
-    // a wave that has passed a barrier the last reader arrived at after retiring its reads.  Tiles >= nk are staged too
-    // (garbage or zeros, never read) so that the wait count is the same in every iteration.
-    static_assert((MODE == A_DENSE || MODE == A_CONV3) && BM == 256 && (BN == 256 || BN == 320) && FM == 4 && FN == BN / 32, "8-phase schedule: 4x2 waves of 64 x BN/2");
-    // A half-tile = 128 rows = 16 DMA instructions, 2 per wave.  B half-tile = BN/2 rows: 16 instructions (2 per wave) at
-    // BN = 256; 20 at BN = 320: the group whose turn it is (group 0 for B-lo, group 1 for B-hi) issues 3 per wave, the other 2,
-    // so every wave issues 5 per B tile and the counted wait is 6 or 7 depending on the group.
-    constexpr int FNH = FN / 2;                         // 16-column fragments per B half
-    constexpr int BHALF = BN / 2;                       // rows per B half-tile
-    constexpr bool B3 = (BN == 320);
-    const bool g1 = wave >= 4;
-    uint32_t ha[2][2], hb[2][3];                        // ha: DENSE byte offset of (row, chunk); CONV byte offset of filter tap (0, 0)
-    uint32_t hm[2][2];                                  // CONV: validity mask of the 9 taps (conv_row)
-    int hbq[2];                                         // first instruction index of this wave in B half-tile h
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const bool big = B3 && (g1 == (h == 1));
-      hbq[h] = !B3 ? wave * 2 : (big ? (wave & 3) * 3 : 12 + (wave & 3) * 2);
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int m = m0 + h * 128 + (wave * 2 + j) * 8 + lrow;
-        if (MODE == A_DENSE) {
-          ha[h][j] = (m < p.M) ? (uint32_t)m * (uint32_t)p.lda * 2u + (uint32_t)chunk * 16u : OOB;
-          hm[h][j] = 0;
-        } else {
-          conv_row(m, ha[h][j], hm[h][j]);
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        const int r = h * BHALF + (hbq[h] + j) * 8 + lrow;
-        hb[h][j] = (n0 + r < p.N) ? (uint32_t)(n0 + r) * ldb + (uint32_t)chunk * 16u : OOB;
-      }
-    }
-    auto stage = [&](int kt, int buf, auto which) {            // which: 0 A-lo, 1 A-hi, 2 B-lo, 3 B-hi
-      constexpr int W = decltype(which)::value;
-      if constexpr (W < 2) {
-        char* base = smem + buf * A_TILE + W * 16384 + wave * 2048;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          glds16(rsA, base + j * 1024, MODE == A_DENSE ? ha[W][j] + koffA(kt) : conv_off(kt, ha[W][j], hm[W][j]));
-        }
-      } else {
-        constexpr int H = W - 2;
-        char* base = smem + 2 * A_TILE + buf * B_TILE + H * (BHALF * 128) + hbq[H] * 1024;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) glds16(rsB, base + j * 1024, hb[H][j] + koffB(kt));
-        if (B3 && (g1 == (H == 1))) glds16(rsB, base + 2 * 1024, hb[H][2] + koffB(kt));
-      }
-    };
-    // DMA instructions of this wave in the three youngest stagings at the phase-4 wait (A-lo, A-hi, B-lo of tile T+2)
-    auto wait_tile = [&]() {
-      if (B3 && !g1) wait_vmcnt<7>(); else wait_vmcnt<6>();
-    };
-    constexpr std::integral_constant<int, 0> ALO{};
-    constexpr std::integral_constant<int, 1> AHI{};
-    constexpr std::integral_constant<int, 2> BLO{};
-    constexpr std::integral_constant<int, 3> BHI{};
-    f16x8 a8[4][2], b8[FNH][2];
-    // lane part of a fragment address for k-step kk: (first row of the wave tile + frow) * 128 + swizzled 16-byte chunk; the row of
-    // fragment i and the ring buffer are compile-time constants -> the ds_read's immediate offset (opaque to the optimiser, or it
-    // re-associates them back into per-fragment VGPRs: 26-41 spilled)
-    uint32_t fa[2], fb[2];
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      const int ch = MX ? 2 * fk + kk : kk * 4 + fk;        // fp8: the two halves of the lane's 32-byte K = 128 fragment
-      fa[kk] = (uint32_t)((wm * WTM + frow) * 128 + ((ch ^ (frow & 7)) << 4));
-      fb[kk] = (uint32_t)(2 * A_TILE + (wn * WTN + frow) * 128 + ((ch ^ (frow & 7)) << 4));
-      asm volatile("" : "+v"(fa[kk]), "+v"(fb[kk]));
-    }
-    auto rd_a = [&](const int cur) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) a8[i][kk] = *(const f16x8*)(smem + fa[kk] + (cur * A_TILE + i * 2048));
-    };
-    auto rd_b = [&](const int cur, int half) {
-#pragma unroll
-      for (int j = 0; j < FNH; ++j)
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) b8[j][kk] = *(const f16x8*)(smem + fb[kk] + (cur * B_TILE + (half * FNH + j) * 2048));
-    };
-    auto mma_q = [&](auto ah, auto bh) {
-      constexpr int AH = decltype(ah)::value, BH = decltype(bh)::value;
-      if constexpr (MX) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int jj = 0; jj < FNH; ++jj) {
-            const int j = GDF_SNAKE(i, jj, FNH);
-            acc[AH * 2 + i][BH * FNH + j] = mfma_mx8(a8[AH * 2 + i][0], a8[AH * 2 + i][1], b8[j][0], b8[j][1], acc[AH * 2 + i][BH * FNH + j]);
-          }
-      } else {
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-          for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int jj = 0; jj < FNH; ++jj) {
-              const int j = GDF_SNAKE(i + kk, jj, FNH);
-              acc[AH * 2 + i][BH * FNH + j] = mfma16<BF>(a8[AH * 2 + i][kk], b8[j][kk], acc[AH * 2 + i][BH * FNH + j]);
-            }
-      }
-    };
-    auto bar = [&]() {
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-    };
-    auto lgkm0 = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
-    constexpr std::integral_constant<int, 0> Q0{};
-    constexpr std::integral_constant<int, 1> Q1{};
-
-    stage(0, 0, ALO); stage(0, 0, AHI); stage(0, 0, BLO); stage(0, 0, BHI);
-    stage(1, 1, ALO); stage(1, 1, AHI); stage(1, 1, BLO);
-    GDF_TR(1);
-    wait_tile();                     // this wave's share of K-tile 0
-    bar();                           // ... everyone's
-    GDF_TR(2);
-    if (g1) bar();                   // group 1 runs one barrier behind group 0
-#if !defined(GDF_PHASES4)
-    // TWO phases of 32 MFMAs per K-tile (round 2; the round-1 schedule below ran four phases of 16).  Per barrier interval one
-    // group multiplies while the other reads fragments / issues DMA; the hand-over itself costs ~115 cycles per interval
-    // (MFMA + barrier skeleton without reads and DMA: 70 % of the MFMA peak with 16-MFMA clusters, tools/ablate_gemm.py), so
-    // twice as long clusters halve that overhead with the SAME registers (A stays resident, the B halves take turns in b8), the
-    // same accumulation order (bit-identical results) and the same prefetch depth (the three youngest half-tiles stay in flight
-    // at the one counted wait).  Measured, 4 -> 2 phases: Flux QKV 1285 -> 1357, proj_out 1395 -> 1483, 8192^3 1412 -> 1501
-    // (hipBLASLt: 1491), SDXL GEGLU shape 1128 -> 1170..1186 TFLOP/s.  Splitting the DMA issue between the read slot and the
-    // middle of the MFMA cluster gives the gain back (1285 -> 1293): LDS-DMA issue belongs in the read role.
-    //   K-tile T (buffer T & 1)   phase 1: read A (all 64 rows), B cols 0-63      stage B-hi of T+1                  32 MFMAs (A, B-lo)
-    //                             phase 2: read B cols 64-127                     stage A-lo, A-hi, B-lo of T+2,     32 MFMAs (A, B-hi)
-    //                                                                            wait vmcnt(6) = tile T+1 has landed
-    // Slot lifetimes: A-lo is read by group 0 only and A-hi by group 1 only, both in phase 1 — group 1 one barrier after group 0 —
-    // and B-lo by both; every read is retired (lgkmcnt) before the reader's next barrier, so all three are free from phase 2's
-    // read slot of either group on; B-hi (read in phase 2) is free from the next tile's phase 1 on.
-    // Ring layout [A buf 0][A buf 1][B buf 0][B buf 1] and the K loop unrolled by two: the buffer index is a compile-time constant
-    // in each copy of the body, so it lands in the 16-bit immediate offset of the ds_read (A_TILE, B_TILE <= 40 KiB) instead of ~20
-    // v_add per K-tile that rebuild every fragment address from `cur * STAGE` (VALU issue time adds to MFMA time on this hardware).
-    auto ktile = [&](int kt, const int cur) {
-      rd_a(cur); rd_b(cur, 0); stage(kt + 1, cur ^ 1, BHI);
-      bar(); lgkm0(); mma_q(Q0, Q0); mma_q(Q1, Q0); bar();
-      rd_b(cur, 1); stage(kt + 2, cur, ALO); stage(kt + 2, cur, AHI); stage(kt + 2, cur, BLO); wait_tile(); lgkm0();
-      bar(); mma_q(Q1, Q1); mma_q(Q0, Q1); bar();
-    };
-    {
-      int kt = 0;
-      if constexpr (MODE == A_DENSE) {
-        for (; kt + 1 < nk; kt += 2) { ktile(kt, 0); ktile(kt + 1, 1); }
-        if (kt < nk) ktile(kt, 0);
-      } else {                                                 // conv: the unrolled form spills 6-7 VGPRs; 4 v_add per K-tile instead
-        for (; kt < nk; ++kt) ktile(kt, kt & 1);
-      }
-    }
-#else
-    auto ktile4 = [&](int kt, const int cur) {
-      // phase 1
-      rd_a(cur); rd_b(cur, 0); stage(kt + 1, cur ^ 1, BHI);
-      bar(); lgkm0(); mma_q(Q0, Q0); bar();
-      // phase 2
-      stage(kt + 2, cur, ALO);
-      bar(); mma_q(Q1, Q0); bar();
-      // phase 3
-      rd_b(cur, 1); stage(kt + 2, cur, AHI); lgkm0();
-      bar(); mma_q(Q1, Q1); bar();
-      // phase 4
-      stage(kt + 2, cur, BLO); wait_tile();
-      bar(); mma_q(Q0, Q1); bar();
-    };
-    {
-      int kt = 0;
-      if constexpr (MODE == A_DENSE) {
-        for (; kt + 1 < nk; kt += 2) { ktile4(kt, 0); ktile4(kt + 1, 1); }
-        if (kt < nk) ktile4(kt, 0);
-      } else {
-        for (; kt < nk; ++kt) ktile4(kt, kt & 1);
-      }
-    }
-#endif
-    if (!g1) bar();
-    wait_vmcnt<0>();                 // the over-staged tiles must not land in the epilogue's staging area
-  } else if constexpr (STAGES == 9) {
-    // ---- 8-phase schedule on the 256x320 tile (2x4 waves of 128x80, dense or 3x3-conv A operand) ----
-    // Same two-group ping-pong as STAGES == 8, with the roles of A and B swapped so that the 160 accumulators leave room:
-    // a wave keeps ALL of its B fragments (80 columns x 64 K = 10 registers of 8 halves) after phase 1 and reads one quarter
-    // of its A rows (32 rows) per phase: 20 MFMAs per phase, 26 ds_read_b128 per K-tile.  DMA units: A_q = the q-th 32-row
-    // quarter of BOTH 128-row halves (64 rows, one instruction per wave), B_1 = B rows 0-191 (3 per wave), B_2 = rows
-    // 192-319 (2 per wave).  Unit lifetimes in K-tile T: B is read in phase 1 only, A_q in phase q+1 only; every read is
-    // retired (lgkmcnt) before the reader's next barrier, so a unit may be restaged from the phase after its read:
-    //   phase 1: read B, A_0   stage A_3 of T+1             phase 3: read A_2   stage B_2, A_0 of T+2
-    //   phase 2: read A_1      stage B_1 of T+2             phase 4: read A_3   stage A_1, A_2 of T+2,  wait vmcnt(8)
-    // (8 = the DMA instructions of phases 2-4: everything staged up to phase 1, i.e. all of tile T+1, has landed).
-    static_assert((MODE == A_DENSE || MODE == A_CONV3) && BM == 256 && BN == 320 && FM == 8 && FN == 5 && WGN == 4,
-                  "8-phase schedule, 2x4 waves of 128x80");
-    // A unit q: this wave's instruction covers rows (wave>>2)*128 + q*32 + (wave&3)*8 + lrow
-    uint32_t ua[4];                                     // DENSE: byte offset of (row, chunk); CONV: byte offset of filter tap (0, 0)
-    uint32_t um[4];                                     // CONV: validity mask of the 9 taps (conv_row)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int m = m0 + (wave >> 2) * 128 + q * 32 + (wave & 3) * 8 + lrow;
-      if (MODE == A_DENSE) {
-        ua[q] = (m < p.M) ? (uint32_t)m * (uint32_t)p.lda * 2u + (uint32_t)chunk * 16u : OOB;
-        um[q] = 0;
-      } else {
-        conv_row(m, ua[q], um[q]);
-      }
-    }
-    uint32_t ub[5];                                     // B_1: instructions wave*3 + {0,1,2}; B_2: 24 + wave*2 + {0,1}
-#pragma unroll
-    for (int j = 0; j < 5; ++j) {
-      const int qi = j < 3 ? wave * 3 + j : 24 + wave * 2 + (j - 3);
-      const int n = n0 + qi * 8 + lrow;
-      ub[j] = (n < p.N) ? (uint32_t)n * ldb + (uint32_t)chunk * 16u : OOB;
-    }
-    auto stage_a = [&](int kt, int buf, int q) {
-      char* dst = smem + buf * A_TILE + ((wave >> 2) * 128 + q * 32 + (wave & 3) * 8) * 128;
-      glds16(rsA, dst, MODE == A_DENSE ? ua[q] + koffA(kt) : conv_off(kt, ua[q], um[q]));
-    };
-    auto stage_b = [&](int kt, int buf, auto part) {
-      constexpr int PT = decltype(part)::value;           // 0: B_1 (3 instructions), 1: B_2 (2)
-      char* base = smem + 2 * A_TILE + buf * B_TILE;
-#pragma unroll
-      for (int j = (PT ? 3 : 0); j < (PT ? 5 : 3); ++j) {
-        const int qi = j < 3 ? wave * 3 + j : 24 + wave * 2 + (j - 3);
-        glds16(rsB, base + qi * 1024, ub[j] + koffB(kt));
-      }
-    };
-    constexpr std::integral_constant<int, 0> B1{};
-    constexpr std::integral_constant<int, 1> B2{};
-    f16x8 a4[2][2], b10[5][2];
-    uint32_t fa[2], fb[2];                              // lane part of a fragment address per k-step (see STAGES == 8)
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      fa[kk] = (uint32_t)((wm * WTM + frow) * 128 + (((kk * 4 + fk) ^ (frow & 7)) << 4));
-      fb[kk] = (uint32_t)(2 * A_TILE + (wn * WTN + frow) * 128 + (((kk * 4 + fk) ^ (frow & 7)) << 4));
-      asm volatile("" : "+v"(fa[kk]), "+v"(fb[kk]));
-    }
-    auto rd_aq = [&](const int cur, int q) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) a4[i][kk] = *(const f16x8*)(smem + fa[kk] + (cur * A_TILE + (q * 2 + i) * 2048));
-    };
-    auto rd_ball = [&](const int cur) {
-#pragma unroll
-      for (int j = 0; j < 5; ++j)
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) b10[j][kk] = *(const f16x8*)(smem + fb[kk] + (cur * B_TILE + j * 2048));
-    };
-    auto mma_q = [&](auto qq) {
-      constexpr int Q = decltype(qq)::value;
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int jj = 0; jj < 5; ++jj) {
-            const int j = GDF_SNAKE(i + kk, jj, 5);
-            acc[Q * 2 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a4[i][kk], b10[j][kk], acc[Q * 2 + i][j], 0, 0, 0);
-          }
-    };
-    auto bar = [&]() {
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-    };
-    auto lgkm0 = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
-    constexpr std::integral_constant<int, 0> P0{};
-    constexpr std::integral_constant<int, 1> P1{};
-    constexpr std::integral_constant<int, 2> P2{};
-    constexpr std::integral_constant<int, 3> P3{};
-    const bool g1 = wave >= 4;
-
-    // Dense A operand: TWO phases of 40 MFMAs per K-tile, A read by 64-row halves (a8: 16 more VGPRs than the quarter form,
-    // 253 in all; the conv form would need 271 and keeps the four-phase schedule).  Same reasoning and same bit-identical
-    // results as the 256x256 tile above; measured 4 -> 2 phases: 8192x7680x8192 1390..1426 -> 1471..1478, SDXL qkv 1104..1122 ->
-    // 1158..1162, ff_out 1341..1362 -> 1404, attn2_q 1057..1072 -> 1096 TFLOP/s.
-    //   phase 1: read B, A rows 0-63 of the wave tile     stage B_2, A_2, A_3 of T+1                        40 MFMAs
-    //   phase 2: read A rows 64-127                       stage B_1, A_0, A_1 of T+2, wait vmcnt(5)         40 MFMAs
-    // (vmcnt(5): the five instructions just issued may be in flight, everything older — all of tile T+1 — has landed)
-#if defined(GDF_PHASES4) || defined(GDF_ABLATE)
-    constexpr bool TWO_PHASE = false;
-#else
-    constexpr bool TWO_PHASE = (MODE == A_DENSE) && !SPLIT;      // (the split-operand form of the two-phase loop spills 139 VGPRs)
-#endif
-    stage_b(0, 0, B1); stage_b(0, 0, B2); stage_a(0, 0, 0); stage_a(0, 0, 1); stage_a(0, 0, 2); stage_a(0, 0, 3);
-    GDF_TR(1);
-    if constexpr (TWO_PHASE) {
-      stage_b(1, 1, B1); stage_a(1, 1, 0); stage_a(1, 1, 1);
-      wait_vmcnt<5>();
-    } else {
-      stage_b(1, 1, B1); stage_b(1, 1, B2); stage_a(1, 1, 0); stage_a(1, 1, 1); stage_a(1, 1, 2);
-      wait_vmcnt<8>();               // this wave's share of K-tile 0
-    }
-    bar();                           // ... everyone's
-    GDF_TR(2);
-    if (g1) bar();                   // group 1 runs one barrier behind group 0
-    if constexpr (TWO_PHASE) {
-      f16x8 a8[4][2];
-      auto rd_ah = [&](const int cur, int h) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int kk = 0; kk < 2; ++kk) a8[i][kk] = *(const f16x8*)(smem + fa[kk] + (cur * A_TILE + (h * 4 + i) * 2048));
-      };
-      auto mma_h = [&](auto hh) {
-        constexpr int H = decltype(hh)::value;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int jj = 0; jj < 5; ++jj) {
-              const int j = GDF_SNAKE(i + kk, jj, 5);
-              acc[H * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a8[i][kk], b10[j][kk], acc[H * 4 + i][j], 0, 0, 0);
-            }
-      };
-      auto ktile = [&](int kt, const int cur) {                 // ring [A0][A1][B0][B1], loop unrolled by two: see STAGES == 8
-        rd_ball(cur); rd_ah(cur, 0); stage_b(kt + 1, cur ^ 1, B2); stage_a(kt + 1, cur ^ 1, 2); stage_a(kt + 1, cur ^ 1, 3); lgkm0();
-        bar(); mma_h(P0); bar();
-        rd_ah(cur, 1); stage_b(kt + 2, cur, B1); stage_a(kt + 2, cur, 0); stage_a(kt + 2, cur, 1); wait_vmcnt<5>(); lgkm0();
-        bar(); mma_h(P1); bar();
-      };
-      int kt = 0;
-      for (; kt + 1 < nk; kt += 2) { ktile(kt, 0); ktile(kt + 1, 1); }
-      if (kt < nk) ktile(kt, 0);
-    } else {
-#if !defined(GDF_ABLATE)
-    auto ktile4 = [&](int kt, const int cur) {                  // ring [A0][A1][B0][B1]: see STAGES == 8
-      rd_ball(cur); rd_aq(cur, 0); stage_a(kt + 1, cur ^ 1, 3); lgkm0();
-      bar(); mma_q(P0); bar();
-      rd_aq(cur, 1); stage_b(kt + 2, cur, B1); lgkm0();
-      bar(); mma_q(P1); bar();
-      rd_aq(cur, 2); stage_b(kt + 2, cur, B2); stage_a(kt + 2, cur, 0); lgkm0();
-      bar(); mma_q(P2); bar();
-      rd_aq(cur, 3); stage_a(kt + 2, cur, 1); stage_a(kt + 2, cur, 2); wait_vmcnt<8>(); lgkm0();
-      bar(); mma_q(P3); bar();
-    };
-    {
-      int kt = 0;
-      if constexpr (MODE == A_DENSE) {
-        for (; kt + 1 < nk; kt += 2) { ktile4(kt, 0); ktile4(kt + 1, 1); }
-        if (kt < nk) ktile4(kt, 0);
-      } else {                                                 // conv: the unrolled form spills 6-7 VGPRs; 4 v_add per K-tile instead
-        for (; kt < nk; ++kt) ktile4(kt, kt & 1);
-      }
-    }
-#else
-    // ---- diagnostics build (tools/ablate_gemm.sh): the same loop with parts compiled out; results are garbage, timing is the point ----
-    //   bit 0: no fragment reads   bit 1: no LDS-DMA   bit 2: no workgroup barriers   bit 3: no MFMAs
-    constexpr int ABL = GDF_ABLATE;
-    rd_ball(0); rd_aq(0, 0);
-    auto keep = [&]() {
-#pragma unroll
-      for (int j = 0; j < 5; ++j) { asm volatile("" : "+v"(b10[j][0])); asm volatile("" : "+v"(b10[j][1])); }
-#pragma unroll
-      for (int i = 0; i < 2; ++i) { asm volatile("" : "+v"(a4[i][0])); asm volatile("" : "+v"(a4[i][1])); }
-    };
-    auto xbar = [&]() { if constexpr (!(ABL & 4)) bar(); };
-    auto xmma = [&](auto q) { if constexpr (!(ABL & 8)) mma_q(q); else keep(); };
-    auto ktile_abl = [&](int kt, const int cur) {
-      if constexpr (!(ABL & 1)) { rd_ball(cur); rd_aq(cur, 0); } else keep();
-      if constexpr (!(ABL & 2)) stage_a(kt + 1, cur ^ 1, 3);
-      lgkm0(); xbar(); xmma(P0); xbar();
-      if constexpr (!(ABL & 1)) rd_aq(cur, 1); else keep();
-      if constexpr (!(ABL & 2)) stage_b(kt + 2, cur, B1);
-      lgkm0(); xbar(); xmma(P1); xbar();
-      if constexpr (!(ABL & 1)) rd_aq(cur, 2); else keep();
-      if constexpr (!(ABL & 2)) { stage_b(kt + 2, cur, B2); stage_a(kt + 2, cur, 0); }
-      lgkm0(); xbar(); xmma(P2); xbar();
-      if constexpr (!(ABL & 1)) rd_aq(cur, 3); else keep();
-      if constexpr (!(ABL & 2)) { stage_a(kt + 2, cur, 1); stage_a(kt + 2, cur, 2); wait_vmcnt<8>(); }
-      lgkm0(); xbar(); xmma(P3); xbar();
-    };
-    {
-      int kt = 0;
-      for (; kt + 1 < nk; kt += 2) { ktile_abl(kt, 0); ktile_abl(kt + 1, 1); }
-      if (kt < nk) ktile_abl(kt, 0);
-    }
-#endif
-    }
-    if (!g1) bar();
-    wait_vmcnt<0>();                 // the over-staged tiles must not land in the epilogue's staging area
-  } else if (STAGES == 2) {
-    if (kt0 < kt1) issue(kt0, kt0 & 1);                    // (an empty split-K range stores zeros)
-    for (int kt = kt0; kt < kt1; ++kt) {
-      // tile kt has landed (all outstanding DMA of this wave) and every wave is done reading buf[(kt+1)&1]
-      wait_vmcnt<0>();
-      __syncthreads();
-      if (early_mma) {
-        read_kk(kt & 1, 0); mma();
-        if (kt + 1 < kt1) issue(kt + 1, (kt + 1) & 1);
-      } else {
-        if (kt + 1 < kt1) issue(kt + 1, (kt + 1) & 1);
-        read_kk(kt & 1, 0); mma();
-      }
-      read_kk(kt & 1, 1); mma();
-    }
-  } else {
-    // 3-stage ring: DMA of tiles kt+1 and kt+2 overlaps the MFMAs of tile kt; counted waits (never 0 in steady state)
-    issue(0, 0);
-    if (nk > 1) issue(1, 1);
-    int cur = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-      if (kt + 1 < nk) wait_vmcnt<LPT>(); else wait_vmcnt<0>();   // this wave's share of tile kt has landed
-      __builtin_amdgcn_s_barrier();                                // ... everyone's has; tile kt-1 fully consumed
-      int nxt2 = cur + 2; if (nxt2 >= 3) nxt2 -= 3;
-      if (early_mma) {
-        read_kk(cur, 0); mma();
-        if (kt + 2 < nk) issue(kt + 2, nxt2);
-      } else {
-        if (kt + 2 < nk) issue(kt + 2, nxt2);
-        read_kk(cur, 0); mma();
-      }
-      read_kk(cur, 1); mma();
-      if (++cur == 3) cur = 0;
-    }
-  }
+    for (int j = 0; j < T::FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if constexpr (STAGES == 8) gemm_mainloop_8phase_256(t, acc);
+  else if constexpr (STAGES == 9) gemm_mainloop_8phase_320(t, acc);
+  else gemm_mainloop_ring(t, acc);
 #if defined(GDF_ABLATE_EPI) && GDF_ABLATE_EPI == 2
   wait_vmcnt<0>();
 #endif
@@ -879,349 +84,11 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p) {
   // diagnostics build (tools/ab_epilogue_bound.sh): NO epilogue — the accumulators are kept alive and dropped.  Results are garbage; the
   // time per launch is what a PERFECTLY overlapped epilogue would leave (the bound on any deferred-epilogue scheme).
 #pragma unroll
-  for (int i = 0; i < FM; ++i)
+  for (int i = 0; i < T::FM; ++i)
 #pragma unroll
-    for (int j = 0; j < FN; ++j) asm volatile("" ::"v"(acc[i][j]));
+    for (int j = 0; j < T::FN; ++j) asm volatile("" ::"v"(acc[i][j]));
 #else
-
-  // ---- epilogue: per-wave staging of 32-row slabs through LDS ----
-  // epilogue operands; the QKN instantiation (QKV projection: bias -> RMSNorm + RoPE -> 16-bit store) has none of the
-  // residual / row-vector / aux forms, and compiling them out is what keeps it inside the register budget
-  const float* const e_res32 = QKN ? nullptr : p.res32;
-  const float* const e_rowvec = QKN ? nullptr : p.rowvec;
-  const _Float16* const e_res16 = QKN ? nullptr : p.res16;
-  _Float16* const e_aux16 = QKN ? nullptr : p.aux16;
-  float* const e_out32 = QKN ? nullptr : (STAGES == 2 && p.splitk > 1) ? p.out32 + (size_t)blockIdx.y * p.o32_sstride : p.out32;
-  // Every epilogue operand (bias, temb row vector, residual) is fetched BEFORE the staging pass that needs
-  // it, so the pass itself is LDS + stores only (a dependent global load per iteration made the first
-  // version of this epilogue latency bound: ~17k cycles per tile).
-  // GEGLU is evaluated IN REGISTERS before staging: weight rows are interleaved [16 h | 16 gate], fragment 2q holds h and
-  // fragment 2q+1 the gate of the same 16 output columns in the same lane / register index -> all 64 lanes busy, half
-  // the staging traffic (the first version staged h and gate and ran the GELU on 40 of 64 lanes: 17 us per tile).
-  static_assert(!GEGLU || (FN % 2 == 0), "GEGLU needs an even number of column fragments per wave");
-  constexpr int FNV = GEGLU ? FN / 2 : FN;             // staged 16-column fragments
-  constexpr int WTNV = FNV * 16;                       // staged (= output) columns of this wave tile
-  constexpr int SLD = WTNV + 4;                        // padded row length (floats)
-  // rows per staging pass: 16 for the 160-accumulator tiles (VGPR budget) and for 256x256 (8 x 32 x 132 floats would not fit the ring)
-  constexpr int PR = (FM * FN >= 32) ? 16 : 32;
-  constexpr int PASSES = WTM / PR;
-  constexpr int FPP = FM / PASSES;                     // 16-row fragments per pass
-  float* st = (float*)(smem) + wave * (PR * SLD);
-  constexpr int OUTW = WTNV;                           // output columns produced by this wave tile
-  constexpr int LPR = OUTW / 8;                        // lanes per row (8 output columns per lane)
-  constexpr int RPI = 64 / LPR;                        // rows per iteration (lanes >= RPI*LPR idle when LPR = 5 or 10)
-  constexpr int NIT = (PR + RPI - 1) / RPI;            // iterations per pass
-  const bool lane_ok = lane < RPI * LPR;
-  const int Nout = GEGLU ? p.N / 2 : p.N;
-  const int ocol0 = GEGLU ? (n0 + wn * WTN) / 2 : (n0 + wn * WTN);
-  const int lc = (lane % LPR) * 8;
-  const int col = ocol0 + lc;                          // this lane's 8 output columns (fixed for the whole tile)
-  const int nv = (col < Nout) ? ((Nout - col >= 8) ? 8 : (Nout - col)) : 0;
-  const bool full = nv == 8;
-
-  const float a_sc = p.acc_scale != 0.f ? p.acc_scale : 1.0f;     // range control of the fp16 images (kernels.h)
-  const float o_sc = p.out16_scale != 0.f ? p.out16_scale : 1.0f;
-  float mxc[8];                                        // fp8 operands: power-of-two scale of this lane's 8 output columns (weight rows)
-#pragma unroll
-  for (int e = 0; e < 8; ++e) mxc[e] = 1.f;
-  if constexpr (MX) {
-    if (full && p.mx_colscale) {
-      const f32x4 c0 = *(const f32x4*)(p.mx_colscale + col), c1 = *(const f32x4*)(p.mx_colscale + col + 4);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { mxc[e] = c0[e]; mxc[4 + e] = c1[e]; }
-    }
-  }
-  float bv[8];                                         // bias of this lane's 8 output columns (plain epilogue)
-  float bh[FNV], bgt[FNV];                             // GEGLU: bias of this lane's h / gate accumulator column per fragment pair
-#pragma unroll
-  for (int e = 0; e < 8; ++e) bv[e] = 0.f;
-#pragma unroll
-  for (int j = 0; j < FNV; ++j) { bh[j] = 0.f; bgt[j] = 0.f; }
-  if (p.bias) {
-    if (GEGLU) {
-#pragma unroll
-      for (int j = 0; j < FNV; ++j) {
-        const int bcol = n0 + wn * WTN + j * 32 + frow;  // bias is stored in the interleaved GEMM column order
-        if (bcol + 16 < p.N) { bh[j] = p.bias[bcol]; bgt[j] = p.bias[bcol + 16]; }
-      }
-    } else if (full) {
-      const f32x4 a0 = *(const f32x4*)(p.bias + col), a1 = *(const f32x4*)(p.bias + col + 4);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { bv[e] = a0[e]; bv[4 + e] = a1[e]; }
-    } else if (BN == 16) {
-      for (int e = 0; e < nv; ++e) bv[e] = p.bias[col + e];
-    }
-  }
-
-  // Uniform epilogue flags are tested OUTSIDE the per-iteration loops (one scalar branch per flag and pass; the
-  // first version branched inside every unrolled iteration: ~800 basic blocks, no overlap between iterations).
-  constexpr bool RAGGED = (BN == 16);                    // only the narrow-N variant handles N % 8 != 0 (host-checked)
-  const bool rv_in_opnd = e_rowvec && !e_res32;
-  auto sample_of = [&](int row) -> int {                 // row of the per-sample vector table that applies to `row`
-    if (DIT && p.rv_seg_rows > 0 && row >= p.rv_seg_rows) return (row - p.rv_seg_rows) / p.rv_rps2;
-    if (DIT && p.rv_tok) return row % p.rows_per_sample;
-    return row / p.rows_per_sample;
-  };
-  float gsum[GNS ? 8 : 1], gsq[GNS ? 8 : 1];           // GNS: sum x / sum x^2 of this lane's 8 columns over the rows it stores
-#pragma unroll
-  for (int e = 0; e < (GNS ? 8 : 1); ++e) gsum[e] = gsq[e] = 0.f;
-#pragma unroll
-  for (int ps = 0; ps < PASSES; ++ps) {
-    // ---- prefetch this pass's residual / row-vector operands (overlaps the LDS staging below) ----
-    // `opnd` holds the fp32 residual, or the temb row vector when there is no fp32 residual (the plan never
-    // combines the two: conv1 = bias + temb, conv2 / out-projections = bias + residual).
-    f32x4 opnd[NIT][2];                                  // an fp16 residual travels as raw bits in opnd[it][0]
-    int rowi[NIT];
-    bool okr[NIT];
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int lrp = it * RPI + lane / LPR;
-      rowi[it] = m0 + wm * WTM + ps * PR + lrp;
-      okr[it] = (RAGGED ? nv > 0 : full) && lane_ok && lrp < PR && rowi[it] < p.M;
-      opnd[it][0] = opnd[it][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    if (!RAGGED) {
-      if (e_res32) {
-#pragma unroll
-        for (int it = 0; it < NIT; ++it)
-          if (okr[it]) {
-            const f32x4* rp = (const f32x4*)(e_res32 + (size_t)rowi[it] * p.ldres + col);
-            opnd[it][0] = rp[0]; opnd[it][1] = rp[1];
-          }
-      } else if (e_rowvec) {
-#pragma unroll
-        for (int it = 0; it < NIT; ++it)
-          if (okr[it]) {
-            const f32x4* rv = (const f32x4*)(e_rowvec + (size_t)sample_of(rowi[it]) * p.ldrv + col);
-            opnd[it][0] = rv[0]; opnd[it][1] = rv[1];
-          }
-      } else if (e_res16) {
-#pragma unroll
-        for (int it = 0; it < NIT; ++it)
-          if (okr[it]) opnd[it][0] = *(const f32x4*)(e_res16 + (size_t)rowi[it] * p.ldres + col);
-      }
-    }
-#pragma unroll
-    for (int i2 = 0; i2 < FPP; ++i2)
-#pragma unroll
-      for (int j = 0; j < FNV; ++j)
-        if constexpr (GEGLU) {
-#pragma unroll
-          for (int r = 0; r < 4; r += 2) {
-            const f32x2 hh = {acc[ps * FPP + i2][2 * j][r], acc[ps * FPP + i2][2 * j][r + 1]};
-            const f32x2 gg = {acc[ps * FPP + i2][2 * j + 1][r], acc[ps * FPP + i2][2 * j + 1][r + 1]};
-            const f32x2 x = (hh + bh[j]) * gelu_erf2(gg + bgt[j]);
-            st[(i2 * 16 + fk * 4 + r) * SLD + j * 16 + frow] = x[0];
-            st[(i2 * 16 + fk * 4 + r + 1) * SLD + j * 16 + frow] = x[1];
-          }
-        } else {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) st[(i2 * 16 + fk * 4 + r) * SLD + j * 16 + frow] = acc[ps * FPP + i2][j][r] * a_sc;
-        }
-    // same-wave LDS RAW across lanes: DS ops of one wave execute in order
-    __builtin_amdgcn_wave_barrier();
-    float v[NIT][8];
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      int lr = it * RPI + lane / LPR;
-      if (!(lane_ok && lr < PR)) lr = 0;
-      const f32x4 x0 = *(const f32x4*)(st + lr * SLD + lc), x1 = *(const f32x4*)(st + lr * SLD + lc + 4);
-      if constexpr (MX) {                                // undo the operand scales: row (activation) x column (weight row)
-        const float rs = (okr[it] && p.mx_rowscale) ? p.mx_rowscale[rowi[it]] : 1.f;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { v[it][e] = x0[e] * (rs * mxc[e]) + bv[e]; v[it][4 + e] = x1[e] * (rs * mxc[4 + e]) + bv[4 + e]; }
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { v[it][e] = x0[e] + bv[e]; v[it][4 + e] = x1[e] + bv[4 + e]; }
-      }
-    }
-    if (DIT && p.act == 1) {
-#pragma unroll
-      for (int it = 0; it < NIT; ++it)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[it][e] = gelu_tanh(v[it][e]);
-    }
-    if constexpr (DIT && WTN == 128 && QKN) {
-      // RMSNorm per head + rotary embedding on the q / k columns: a wave tile is exactly one 128-column head, whose row lives in
-      // the 16 lanes of one staged row (8 consecutive columns = 4 rotary pairs per lane)
-      if (p.qkn_nq > 0 && ocol0 < 2 * p.qkn_nq) {
-        const float* nw = (ocol0 < p.qkn_nq ? p.qkn_wq : p.qkn_wk) + lc;
-        const f32x4 w0 = *(const f32x4*)nw, w1 = *(const f32x4*)(nw + 4);
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-          float ss = 0.f;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) ss += v[it][e] * v[it][e];
-#pragma unroll
-          for (int off = 8; off > 0; off >>= 1) ss += __shfl_xor(ss, off);       // the 16 lanes of this row
-          const float r = rsqrtf(ss * (1.0f / 128.0f) + p.qkn_eps);
-          const int row = rowi[it];
-          const int pos = (p.qkn_seg_rows > 0 && row >= p.qkn_seg_rows) ? p.qkn_pos1 + (row - p.qkn_seg_rows) % p.qkn_rps2
-                                                                        : p.qkn_pos0 + row % p.qkn_rps;
-          f32x4 c0 = {1.f, 1.f, 1.f, 1.f}, c1 = c0, s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
-          if (okr[it]) {
-            const float* cp = p.rope_cos + (size_t)pos * 128 + lc;
-            const float* sp = p.rope_sin + (size_t)pos * 128 + lc;
-            c0 = *(const f32x4*)cp; c1 = *(const f32x4*)(cp + 4); s0 = *(const f32x4*)sp; s1 = *(const f32x4*)(sp + 4);
-          }
-          float t[8];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { t[e] = v[it][e] * r * w0[e]; t[4 + e] = v[it][4 + e] * r * w1[e]; }
-          // x * cos + stack([-x_imag, x_real]) * sin
-          v[it][0] = t[0] * c0[0] - t[1] * s0[0]; v[it][1] = t[1] * c0[1] + t[0] * s0[1];
-          v[it][2] = t[2] * c0[2] - t[3] * s0[2]; v[it][3] = t[3] * c0[3] + t[2] * s0[3];
-          v[it][4] = t[4] * c1[0] - t[5] * s1[0]; v[it][5] = t[5] * c1[1] + t[4] * s1[1];
-          v[it][6] = t[6] * c1[2] - t[7] * s1[2]; v[it][7] = t[7] * c1[3] + t[6] * s1[3];
-        }
-      }
-    }
-    const bool aux_early = DIT && p.rv_mul && e_aux16;     // MMDiT `attn-out` hook: the projection BEFORE the gate
-    if (!RAGGED && aux_early) {
-#pragma unroll
-      for (int it = 0; it < NIT; ++it)
-        if (okr[it]) {
-          f16x8 hv;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) hv[e] = hook16<DIT>(v[it][e]);
-          *(f16x8*)(e_aux16 + (size_t)rowi[it] * p.ldaux + col) = hv;
-        }
-    }
-    if (!RAGGED) {
-      if (rv_in_opnd) {
-        if (DIT && p.rv_mul) {
-#pragma unroll
-          for (int it = 0; it < NIT; ++it)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { v[it][e] *= opnd[it][0][e]; v[it][4 + e] *= opnd[it][1][e]; }
-        } else {
-#pragma unroll
-          for (int it = 0; it < NIT; ++it)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { v[it][e] += opnd[it][0][e]; v[it][4 + e] += opnd[it][1][e]; }
-        }
-      } else if (e_rowvec) {                             // row vector AND fp32 residual (MMDiT gate + residual): late load
-#pragma unroll
-        for (int it = 0; it < NIT; ++it)
-          if (okr[it]) {
-            const f32x4* rv = (const f32x4*)(e_rowvec + (size_t)sample_of(rowi[it]) * p.ldrv + col);
-            if (DIT && p.rv_mul) {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) { v[it][e] *= rv[0][e]; v[it][4 + e] *= rv[1][e]; }
-            } else {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) { v[it][e] += rv[0][e]; v[it][4 + e] += rv[1][e]; }
-            }
-          }
-      }
-      if (e_aux16 && !aux_early) {
-#pragma unroll
-        for (int it = 0; it < NIT; ++it)
-          if (okr[it]) {
-            f16x8 hv;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) hv[e] = hook16<DIT>(v[it][e]);
-            *(f16x8*)(e_aux16 + (size_t)rowi[it] * p.ldaux + col) = hv;
-          }
-      }
-      if (e_res32) {
-#pragma unroll
-        for (int it = 0; it < NIT; ++it)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { v[it][e] += opnd[it][0][e]; v[it][4 + e] += opnd[it][1][e]; }
-      } else if (e_res16) {
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-          f16x8 rh = __builtin_bit_cast(f16x8, opnd[it][0]);
-          if (e_rowvec && okr[it]) rh = *(const f16x8*)(e_res16 + (size_t)rowi[it] * p.ldres + col);   // (not produced by the plan)
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[it][e] += (float)rh[e];
-        }
-      }
-      if (out16) {
-#pragma unroll
-        for (int it = 0; it < NIT; ++it)
-          if (okr[it]) {
-            f16x8 hv;
-            if (DIT && BF && p.out_f16) {                // 'bfloat16x2' plans: the attention operands q / k / v as saturating fp16
-#pragma unroll
-              for (int e = 0; e < 8; ++e) hv[e] = f32_to_f16_sat(v[it][e] * o_sc);
-            } else {
-#pragma unroll
-              for (int e = 0; e < 8; ++e) hv[e] = act16<DIT, BF>(v[it][e] * o_sc);
-            }
-            *(f16x8*)(out16 + (size_t)rowi[it] * p.ldo16 + col) = hv;
-            if constexpr (GNS) {
-#pragma unroll
-              for (int e = 0; e < 8; ++e) { const float x = v[it][e] * o_sc; gsum[e] += x; gsq[e] += x * x; }
-            }
-          }
-        if (SPLIT && p.o16_lo > 0) {                     // split operand for the consumer GEMM: lo = e16(v - hi)
-#pragma unroll
-          for (int it = 0; it < NIT; ++it)
-            if (okr[it]) {
-              f16x8 lv;
-#pragma unroll
-              for (int e = 0; e < 8; ++e) {
-                const float x = v[it][e] * o_sc;
-                if constexpr (BF) lv[e] = __builtin_bit_cast(_Float16, (__bf16)(x - (float)(__bf16)x));
-                else lv[e] = (_Float16)(x - (float)(_Float16)x);
-              }
-              *(f16x8*)(out16 + (size_t)rowi[it] * p.ldo16 + col + p.o16_lo) = lv;
-            }
-        }
-      }
-      if (e_out32) {
-#pragma unroll
-        for (int it = 0; it < NIT; ++it)
-          if (okr[it]) {
-            f32x4* op = (f32x4*)(e_out32 + (size_t)rowi[it] * p.ldo32 + col);
-            op[0] = f32x4{v[it][0], v[it][1], v[it][2], v[it][3]};
-            op[1] = f32x4{v[it][4], v[it][5], v[it][6], v[it][7]};
-          }
-      }
-    } else {                                             // narrow / ragged N (conv_out, N = 4): scalar path
-#pragma unroll
-      for (int it = 0; it < NIT; ++it)
-        if (okr[it]) {
-          const int row = rowi[it];
-          for (int e = 0; e < nv; ++e) {
-            float x = v[it][e];
-            if (e_rowvec) x += e_rowvec[(size_t)(row / p.rows_per_sample) * p.ldrv + col + e];
-            if (e_aux16) e_aux16[(size_t)row * p.ldaux + col + e] = (_Float16)x;
-            if (e_res32) x += e_res32[(size_t)row * p.ldres + col + e];
-            else if (e_res16) x += (float)e_res16[(size_t)row * p.ldres + col + e];
-            if (out16) out16[(size_t)row * p.ldo16 + col + e] = (_Float16)x;
-            if (e_out32) e_out32[(size_t)row * p.ldo32 + col + e] = x;
-          }
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_sched_barrier(0);                   // keep the next pass's prefetch from being hoisted (VGPR pressure)
-  }
-  if constexpr (GNS) {
-    // the wave tile is one 64-row statistics slab: combine the RPI lanes that hold the same 8 columns through the (idle) staging
-    // rows of this wave, then one 64-byte store per column chunk: gn_partial[slab][col .. col+7][sum, sum of squares]
-    static_assert((WTM == 64 || WTM == 128) && PR * SLD >= 64 * 16, "one slab per wave tile");
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { st[lane * 16 + e] = gsum[e]; st[lane * 16 + 8 + e] = gsq[e]; }
-    __builtin_amdgcn_wave_barrier();
-    // (M % WTM == 0 is required, so a wave tile lies entirely inside or entirely outside the matrix: in the last M tile of a 128- / 256-row
-    //  workgroup the waves whose 64 rows start at or beyond M own NO slab and must not store — M/64 slabs are allocated)
-    if (lane < LPR && full && p.gn_partial && m0 + wm * WTM < p.M) {
-      float a[16];
-#pragma unroll
-      for (int e = 0; e < 16; ++e) a[e] = 0.f;
-#pragma unroll
-      for (int r = 0; r < RPI; ++r)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) a[e] += st[(r * LPR + lane) * 16 + e];
-      const int slab = (m0 + wm * WTM) / WTM;            // slabs of WTM rows: 64 (128x128, 128x160, 256x128, 256x256 tiles) or 128 (256x320: 2 x 4 waves of 128 x 80)
-      f32x4* gp = (f32x4*)(p.gn_partial + ((size_t)slab * p.N + col) * 2);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) gp[q] = f32x4{a[2 * q], a[8 + 2 * q], a[2 * q + 1], a[8 + 2 * q + 1]};
-    }
-    __builtin_amdgcn_wave_barrier();
-  }
+  gemm_epilogue(t, acc);
 #endif   // GDF_ABLATE_EPI == 1
   GDF_TR(4);
   if constexpr (!PERSIST) break;
