@@ -439,7 +439,10 @@ def _native_vae_from_diffusers(pipe, device):
                                 use_quant_conv=int(getattr(vc, "use_quant_conv", True))), device=device)
     _fill(enc, lambda m: m.load_vae_state_dict(pipe.vae.state_dict()))
     pipe.native_vae = enc
-    pipe.prepare_latents = types.MethodType(native_prepare_latents, pipe)
+    # (bound to a weak proxy: `pipe.prepare_latents = MethodType(f, pipe)` would make the pipeline a reference cycle, and a cycle is freed by the
+    #  cyclic collector at an arbitrary later allocation — in whatever thread that happens to run — together with its multi-GB device arenas)
+    import weakref
+    pipe.prepare_latents = types.MethodType(native_prepare_latents, weakref.proxy(pipe))
     return pipe
 
 
@@ -497,7 +500,8 @@ def get_diffusion_model(version, dtype, offline_lora=None, offline_lora_filename
         if os.environ.get("GDF_NATIVE_VAE", "1") not in ("", "0"):
             _native_vae_from_diffusers(pipe, device)
         if not hasattr(pipe, "get_timesteps"):
-            pipe.get_timesteps = types.MethodType(_img2img_get_timesteps, pipe)
+            import weakref
+            pipe.get_timesteps = types.MethodType(_img2img_get_timesteps, weakref.proxy(pipe))
         return pipe
     if version not in _HF:
         raise NotImplementedError                                 # reference models.py:173-174

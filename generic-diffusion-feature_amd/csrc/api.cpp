@@ -305,6 +305,7 @@ int gdf_stream_create_cu_mask(const uint32_t* mask, int n_words, void** stream) 
 }
 int gdf_stream_destroy(void* stream) {
   if (!stream) return GDF_OK;
+  gdf::CaptureExclusive guard;
   return hipStreamDestroy((hipStream_t)stream) == hipSuccess ? GDF_OK : GDF_ERR_HIP;
 }
 int gdf_device_cu_count(void) {

@@ -19,6 +19,7 @@
 // pre-allocated concat buffer.  The residual stream additionally keeps an fp32 master copy
 // (stream_fp32) that only the residual adds in GEMM epilogues read and write.
 #include "builder.h"
+#include <shared_mutex>
 
 namespace gdf {
 
@@ -179,10 +180,13 @@ Model* model_create(const GdfArch& arch) {
   m->arch = arch;
   ModelBuilder b(*m);
   b.build();
-  if (hipMalloc(&m->weights, m->weight_bytes) != hipSuccess) {
-    set_error("hipMalloc(weights) failed"); delete m; return nullptr;
+  {
+    CaptureExclusive g;
+    if (hipMalloc(&m->weights, m->weight_bytes) != hipSuccess) {
+      set_error("hipMalloc(weights) failed"); delete m; return nullptr;
+    }
+    hipMemset(m->weights, 0, m->weight_bytes);
   }
-  hipMemset(m->weights, 0, m->weight_bytes);
   // hook ids (dry plan walk)
   PlanOpts o{}; o.stream_fp32 = 1;
   Plan dry;
@@ -191,9 +195,16 @@ Model* model_create(const GdfArch& arch) {
   return m;
 }
 
+static std::shared_mutex& capture_mx() { static std::shared_mutex mx; return mx; }
+static bool capture_guard_on() { static const bool on = [] { const char* e = getenv("GDF_CAPTURE_GUARD"); return !e || atoi(e) != 0; }(); return on; }   // 0: diagnostics (tests/test_gpu_dist.py reproduces the invalidation)
+CaptureShared::CaptureShared() { if (capture_guard_on()) capture_mx().lock_shared(); }
+CaptureShared::~CaptureShared() { if (capture_guard_on()) capture_mx().unlock_shared(); }
+CaptureExclusive::CaptureExclusive() { if (capture_guard_on()) capture_mx().lock(); }
+CaptureExclusive::~CaptureExclusive() { if (capture_guard_on()) capture_mx().unlock(); }
+
 void model_destroy(Model* m) {
   if (!m) return;
-  if (m->weights) hipFree(m->weights);
+  if (m->weights) { CaptureExclusive g; hipFree(m->weights); }
   delete m;
 }
 
@@ -676,6 +687,7 @@ const char* kernel_label(const char* n) {
 }
 
 Plan::~Plan() {
+  CaptureExclusive guard;
   for (auto& v : ev) for (auto e : v) hipEventDestroy(e);
   for (auto& g : graphs) { if (g.exec) hipGraphExecDestroy(g.exec); if (g.graph) hipGraphDestroy(g.graph); }
 }
@@ -799,12 +811,27 @@ static int run_ops_graph(Plan& P, const Bind& b, hipStream_t s, int evset = -1) 
   // Relaxed mode: the op program only launches kernels (no allocation, no synchronisation), and in this mode HIP neither lists
   // the stream for its "unsafe call during capture" checks nor lets an unrelated call invalidate the capture — other host
   // threads (one extractor per thread: aggregation_network.py:67-95) keep allocating, synchronising and capturing freely.
-  if (hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) != hipSuccess) {
-    (void)hipGetLastError();
-    return run_ops_eager(P, b, s, evset);                // e.g. the legacy default stream cannot be captured
+  int rc;
+  hipError_t e;
+  {
+    CaptureShared guard;                                 // no allocation / free of this library runs between Begin and End (model.h)
+    if (hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) != hipSuccess) {
+      (void)hipGetLastError();
+      return run_ops_eager(P, b, s, evset);              // e.g. the legacy default stream cannot be captured
+    }
+    rc = run_ops_eager(P, b, s, evset, true);
+    e = hipStreamEndCapture(s, &g.graph);
+    if (rc != GDF_OK || e != hipSuccess) {
+      // an invalidated capture: make sure the stream has really left capture mode before anything else is queued on it
+      hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+      for (int tries = 0; tries < 3 && hipStreamIsCapturing(s, &st) == hipSuccess && st != hipStreamCaptureStatusNone; ++tries) {
+        hipGraph_t junk = nullptr;
+        (void)hipStreamEndCapture(s, &junk);
+        if (junk) hipGraphDestroy(junk);
+      }
+      (void)hipGetLastError();
+    }
   }
-  const int rc = run_ops_eager(P, b, s, evset, true);
-  hipError_t e = hipStreamEndCapture(s, &g.graph);
   static const bool dbg = getenv("GDF_DEBUG_GRAPH") != nullptr;
   if (dbg) fprintf(stderr, "[gdf] capture evset=%d rc=%d end=%s graph=%p (%s)\n", evset, rc, hipGetErrorString(e), (void*)g.graph, rc ? last_error() : "");
   auto failed = [&](const char* what, hipError_t err) {
@@ -821,7 +848,9 @@ static int run_ops_graph(Plan& P, const Bind& b, hipStream_t s, int evset = -1) 
     failed("capture", e);
     return run_ops_eager(P, b, s, evset);
   }
-  if (const hipError_t ie = hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0); ie != hipSuccess) {
+  hipError_t ie;
+  { CaptureExclusive guard; ie = hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0); }      // (allocates: not beside another thread's capture)
+  if (ie != hipSuccess) {
     hipGraphDestroy(g.graph);
     (void)hipGetLastError();
     failed("instantiate", ie);
@@ -831,7 +860,7 @@ static int run_ops_graph(Plan& P, const Bind& b, hipStream_t s, int evset = -1) 
   if (P.graphs.size() >= 12) {                           // evict the least recently used entry (timed replays: one graph per event set)
     size_t lru = 0;
     for (size_t i = 1; i < P.graphs.size(); ++i) if (P.graphs[i].stamp < P.graphs[lru].stamp) lru = i;
-    hipGraphExecDestroy(P.graphs[lru].exec); hipGraphDestroy(P.graphs[lru].graph);
+    { CaptureExclusive guard; hipGraphExecDestroy(P.graphs[lru].exec); hipGraphDestroy(P.graphs[lru].graph); }
     P.graphs.erase(P.graphs.begin() + lru);
   }
   g.stamp = ++P.graph_clock; ++P.graph_launches;

@@ -134,6 +134,14 @@ struct Bind {
 struct Op { const char* name; double flops; std::function<hipError_t(const Bind&, hipStream_t)> fn; int label = 0; };
 struct HookSlot { std::string id; int64_t shape[4]; int64_t stride[4]; size_t bytes; bool copied = false; };   // copied: stored by a hook_store (copy2d) op, else by its producer's epilogue
 
+// Stream-capture guard.  hipFree / hipMalloc / hipGraph(Exec)Destroy / hipStreamDestroy made by ANY host thread while another thread's stream is
+// capturing can invalidate that capture on this runtime (relaxed mode notwithstanding), and an invalidated capture leaves the stream unusable
+// ("operation failed due to a previous error during capture" from every later call on it; round 6: a model garbage-collected in one thread while
+// another thread captured took seven later tests down through torch's 32-entry stream pool).  Captures hold the guard shared; every
+// allocation / free the library makes outside a capture holds it exclusively for the duration of the HIP call.
+struct CaptureShared { CaptureShared(); ~CaptureShared(); };
+struct CaptureExclusive { CaptureExclusive(); ~CaptureExclusive(); };
+
 struct Plan {
   const Model* model = nullptr;
   int chunk = 0;                              // VAE: images per pass (the plan is built for `chunk`, forward loops)

@@ -308,7 +308,7 @@ Model* vae_model_create(const gdf_vae_desc& d) {
   m->vae.d = d;
   VaeModelBuilder b(*m);
   b.build();
-  if (hipMalloc(&m->weights, m->weight_bytes) != hipSuccess) { set_error("hipMalloc(weights) failed"); delete m; return nullptr; }
+  { CaptureExclusive guard; if (hipMalloc(&m->weights, m->weight_bytes) != hipSuccess) { set_error("hipMalloc(weights) failed"); delete m; return nullptr; } }
   (void)hipMemset(m->weights, 0, m->weight_bytes);
   return m;
 }
@@ -386,7 +386,7 @@ Model* vae_decoder_create(const gdf_vae_desc& d) {
   m->vae.d = d;
   VaeModelBuilder b(*m);
   b.build_decoder();
-  if (hipMalloc(&m->weights, m->weight_bytes) != hipSuccess) { set_error("hipMalloc(weights) failed"); delete m; return nullptr; }
+  { CaptureExclusive guard; if (hipMalloc(&m->weights, m->weight_bytes) != hipSuccess) { set_error("hipMalloc(weights) failed"); delete m; return nullptr; } }
   (void)hipMemset(m->weights, 0, m->weight_bytes);
   return m;
 }
