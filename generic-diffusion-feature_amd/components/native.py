@@ -75,6 +75,7 @@ SIGNATURES = {
     "gdf_plan_set_timing": (C.c_int, [C.c_void_p, C.c_char_p]),
     "gdf_plan_set_timing_stride": (C.c_int, [C.c_void_p, C.c_int]),
     "gdf_plan_read_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_long), C.POINTER(C.c_double)]),
+    "gdf_stream_create": (C.c_int, [C.POINTER(C.c_void_p)]),
     "gdf_stream_create_cu_mask": (C.c_int, [C.POINTER(C.c_uint32), C.c_int, C.POINTER(C.c_void_p)]),
     "gdf_stream_destroy": (C.c_int, [C.c_void_p]),
     "gdf_device_cu_count": (C.c_int, []),
@@ -392,7 +393,8 @@ class _Plan:
             _check(lib.gdf_plan_hook_info(handle, i, C.byref(hi)), "plan_hook_info")
             self.hooks.append((hi.id.decode(), tuple(hi.shape), tuple(hi.stride), hi.bytes))
         self.workspace = None
-        self.stream = None
+        self.stream = None               # a torch.cuda.ExternalStream over a stream of this plan's own (gdf_stream_create), or one assigned by the caller
+        self._own_stream = None          # its hipStream_t when this plan created it
         self.staged = {}
         self.sets = []
         self.inflight = []
@@ -402,6 +404,19 @@ class _Plan:
             self.lib.gdf_plan_destroy(self.handle)
         except Exception:
             pass
+        try:
+            if self._own_stream is not None:      # (work still queued on it finishes first: hipStreamDestroy defers the release)
+                self.lib.gdf_stream_destroy(self._own_stream)
+        except Exception:
+            pass
+
+    def _make_stream(self, dev):
+        """a non-blocking stream owned by this plan — never torch's pooled streams, which are shared by every 32nd request (include/gdf.h)"""
+        h = C.c_void_p()
+        with torch.cuda.device(dev):
+            _check(self.lib.gdf_stream_create(C.byref(h)), "stream_create")
+        self._own_stream = h
+        return torch.cuda.ExternalStream(h.value, device=dev)
 
     def graph_stats(self):
         """(captures, graph launches, forwards that fell back to eager launching after a failed capture)"""
@@ -426,7 +441,7 @@ class _Plan:
         Returns (out tensor, {hook id: (B,C,H,W) view}, whatever `call` returned)."""
         cur = torch.cuda.current_stream(dev)
         if self.stream is None:
-            self.stream = torch.cuda.Stream(device=dev)
+            self.stream = self._make_stream(dev)
         side = self.stream
         while self.MAX_INFLIGHT > 0 and len(self.inflight) >= self.MAX_INFLIGHT:
             ev = self.inflight.pop(0)

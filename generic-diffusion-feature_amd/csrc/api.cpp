@@ -303,6 +303,15 @@ int gdf_stream_create_cu_mask(const uint32_t* mask, int n_words, void** stream) 
   *stream = (void*)s;
   return GDF_OK;
 }
+int gdf_stream_create(void** stream) {
+  if (!stream) { set_error("gdf_stream_create: bad arguments"); return GDF_ERR_ARG; }
+  hipStream_t s = nullptr;
+  gdf::CaptureExclusive guard;
+  const hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+  if (e != hipSuccess) { set_error(std::string("hipStreamCreateWithFlags: ") + hipGetErrorString(e)); return GDF_ERR_HIP; }
+  *stream = (void*)s;
+  return GDF_OK;
+}
 int gdf_stream_destroy(void* stream) {
   if (!stream) return GDF_OK;
   gdf::CaptureExclusive guard;

@@ -173,6 +173,11 @@ int gdf_plan_set_timing_stride(gdf_plan* p, int stride);
  * gdf_plan_opts.reserved[2] = CUs of the partition; their phases drift apart and one chain's epilogues / norm passes meet the other
  * chain's main loops.  mask: bit i of word i/32 enables CU i of the device's CU numbering; n_words = ceil(CUs / 32). */
 int gdf_stream_create_cu_mask(const uint32_t* mask, int n_words, void** stream);
+/* A private non-blocking stream for one plan (round 6).  The Python mirror used to take plan streams from torch's pool of 32, which hands
+ * the same hipStream_t to every 32nd request: two LIVE plans of two host threads could share a stream (one capturing while the other
+ * launches), and a stream whose capture had been invalidated poisoned whoever was handed it next.  The reference has no equivalent (one
+ * default stream per process, feature/diffusion_feature.py:445-465).  Creation and destruction take the capture guard (csrc/model.h). */
+int gdf_stream_create(void** stream);
 int gdf_stream_destroy(void* stream);
 int gdf_device_cu_count(void);
 /* Diagnostics: launches n_blocks single-wave workgroups on `stream`; workgroup b writes {XCC_ID, HW_ID} of the CU it ran on to

@@ -235,6 +235,44 @@ def test_sd21_real_checkpoint_branch(D):
     assert max(errs.values()) <= 1.0e-3, errs
 
 
+def test_offline_lora_is_fused_before_the_weights_are_read_and_native_vae_opt_out(D, monkeypatch):
+    """components/models.py: `offline_lora` -> pipe.load_lora_weights(path, weight_name=...) + pipe.fuse_lora() BEFORE the UNet's state dict is handed
+    to libgdf (reference feature/diffusion_feature.py:46-55 loads the LoRA into the pipeline), so the native model computes with the FUSED weights;
+    and GDF_NATIVE_VAE=0 leaves the pipeline's own prepare_latents in place."""
+    import diffusion_feature
+    from oracle import unet_ref as R
+    layer = {"up-level1-repeat1-vit-block0-out": True, "up-level2-repeat0-res-out": True}
+    lat = torch.randn(2, 4, 32, 32, generator=torch.Generator().manual_seed(0)).half()
+    outs = {}
+    for tag, kw in (("plain", {}), ("lora", dict(offline_lora="/data/lora/dir", offline_lora_filename="pytorch_lora_weights.safetensors"))):
+        D.reset()
+        df = diffusion_feature.FeatureExtractor(layer=layer, version="1-5", device="cuda:0", img_size=256, verify=False, **kw)
+        calls = [c[0] for c in D.CALLS]
+        assert ("load_lora_weights" in calls and "fuse_lora" in calls) == (tag == "lora")
+        if tag == "lora":
+            assert dict(D.CALLS)["load_lora_weights"] == dict(path="/data/lora/dir", weight_name="pytorch_lora_weights.safetensors")
+            assert calls.index("fuse_lora") > calls.index("load_lora_weights") > calls.index("StableDiffusionImg2ImgPipeline.from_pretrained")
+        prompt = df.encode_prompt("a photo of a cat")
+        f = df.extract(prompt, batch_size=2, image=lat, image_type="latents", t=100)
+        torch.cuda.synchronize()
+        outs[tag] = {k: v.clone() for k, v in f.items()}
+        if tag == "lora":
+            st = R.Store({k: True for k in layer})
+            with torch.no_grad():                                            # the oracle on the weights of the FUSED module
+                R.unet_forward(_sd(df.pipe.original["unet"]), R.ARCHS["1-5"], lat.float(), torch.tensor([101.0]), prompt[0].float().cpu().repeat(2, 1, 1), store=st)
+            errs = {k: _rel(f[k], st.feats[k]) for k in layer}
+            assert max(errs.values()) <= 1.0e-3, errs
+        del df, f
+    assert all(not torch.equal(outs["plain"][k], outs["lora"][k]) for k in layer)          # the fused weight did reach the kernels
+    # ---- GDF_NATIVE_VAE=0: diffusers' own prepare_latents stays (the fake's raises if called; constructing the extractor must not touch it) ----
+    monkeypatch.setenv("GDF_NATIVE_VAE", "0")
+    D.reset()
+    df = diffusion_feature.FeatureExtractor(layer=layer, version="1-5", device="cuda:0", img_size=256, verify=False)
+    assert getattr(df.pipe, "native_vae", None) is None and df.pipe.prepare_latents.__func__ is D.StableDiffusionImg2ImgPipeline.prepare_latents
+    with pytest.raises(AssertionError, match="torch VAE encode does not exist"):
+        df.extract(df.encode_prompt("x"), batch_size=1, image=_images(1, 256), t=100)
+
+
 def test_pixart_sigma_real_checkpoint_branch(D):
     """'pixart-sigma' from a STOCK (text-to-image) PixArtSigmaPipeline: the product supplies get_timesteps and the image-taking prepare_latents
     (native VAE + DPMSolverMultistep add_noise), builds the DiT from `pipe.transformer.config`, drops nothing but the `pos_embed.pos_embed` buffer."""
