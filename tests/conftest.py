@@ -49,3 +49,17 @@ def pytest_terminal_summary(terminalreporter, exitstatus, config):
     for name, hid, err, bound, extra in _MARGINS:
         flag = "" if err <= bound else "  <-- ABOVE BOUND"
         tr.write_line(f"  {name:<68s} {err:.2e} / {bound:.2e} ({100.0 * (1.0 - err / bound):4.1f} % spare)  {hid}" + (f"  [{extra}]" if extra else "") + flag)
+    # the same in a few short lines at the very end (whatever length of tail a log keeps, these survive): per family the configuration with the
+    # least spare room, "err/bound"
+    fam = {}
+    for name, hid, err, bound, extra in _MARGINS:
+        key = ("real-checkpoint branch (fake diffusers)" if name.startswith("fake-diffusers") else "heavy-tailed weights + verify" if "HEAVY-TAILED" in name else
+               "plan-level contract (hook handed to a level alone)" if name.startswith("plan-level") else "Flux" if "flux" in name.lower() else "PixArt" if "PixArt" in name else
+               "VAE / vae-out" if "VAE" in name or "vae" in name else "SD1.5 default (auto) plans" if name.startswith("SD1.5") and "AUTO" in name else
+               "SDXL default (auto) plans" if name.startswith("SDXL") and "AUTO" in name else "SD1.5 plain / precise plans" if name.startswith("SD1.5") else "SDXL plain / precise plans")
+        cur = fam.get(key)
+        if cur is None or err / bound > cur[0] / cur[1]:
+            fam[key] = (err, bound, 0, name)
+    tr.write_line("== parity summary (worst err / bound per family; n = %d configurations) ==" % len(_MARGINS))
+    for key, (err, bound, _n, name) in fam.items():
+        tr.write_line(f"  {key:<52s} {err:.2e} / {bound:.2e}  ({name[:60]})")
