@@ -144,6 +144,18 @@ def test_fake_pipelines_have_the_stock_surface(fake_diffusers):
     assert tuple(y.shape) == (2, 3, 40, 56) and torch.equal(y[0], x[0])
 
 
+def test_versions_and_dtypes_outside_the_native_path_are_refused_like_the_reference(monkeypatch):
+    """reference models.py:11-16 (dtype strings), :173-174 (unknown version); `if` / `hunyuan` exist there but are outside the hot path"""
+    from components import models as M
+    monkeypatch.delenv("GDF_SYNTHETIC_WEIGHTS", raising=False)
+    for v in ("if", "hunyuan", "sd3", ""):
+        with pytest.raises(NotImplementedError):
+            M.get_diffusion_model(v, "float16", device="cpu")
+    with pytest.raises(NotImplementedError):
+        M.get_diffusion_model("xl", "bfloat16", device="cpu")
+    assert M._HF["2-1"][0] == "stabilityai/stable-diffusion-2-1-base" and M._HF["pgv2"] == ("playgroundai/playground-v2-1024px-aesthetic", "StableDiffusionXLImg2ImgPipeline")
+
+
 # ---- components/dist.py self_launch ------------------------------------------------------------------------------------------------
 _RANK_SCRIPT = textwrap.dedent("""
     import os, sys, time

@@ -307,6 +307,52 @@ def test_pixart_sigma_real_checkpoint_branch(D):
                            extra=f"VAE stage {e_vae:.2e}")
 
 
+@pytest.mark.parametrize("version,repo,cls,n_txt", [("pixart-alpha", "PixArt-alpha/PixArt-XL-2-512x512", "PixArtAlphaPipeline", 120),
+                                                   ("pixart-sigma-512", "PixArt-alpha/PixArt-Sigma-XL-2-512-MS", "PixArtSigmaPipeline", 300)])
+def test_pixart_512_variants_real_checkpoint_branch(D, monkeypatch, version, repo, cls, n_txt):
+    """the two 512-pixel PixArt versions of the reference (models.py:88-115): repo ids, pipeline classes, `variant='fp16'` for alpha only, the
+    sample_size 64 / interpolation_scale 1 architecture read from the loaded module's config, caption lengths 120 / 300 (depth cut to 2 blocks)."""
+    import diffusion_feature
+    from oracle import pixart_ref as PR
+    monkeypatch.setenv("FAKE_DIFFUSERS_PIXART_LAYERS", "2")
+    layer = {"vit-block0-cross-q": True, "vit-block1-out": True}
+    df = diffusion_feature.FeatureExtractor(layer=layer, version=version, device="cuda:0", img_size=256)
+    fp = dict(D.CALLS)[cls + ".from_pretrained"]
+    assert fp["repo"] == repo and (fp.get("variant") == "fp16") == (version == "pixart-alpha")
+    tr = df.pipe.transformer
+    assert tr.cfg["sample_size"] == 64 and tr.cfg["interpolation_scale"] == 1 and tr.cfg["num_layers"] == 2
+    rec = _record_prepare_latents(df)
+    prompt = df.encode_prompt("a red bicycle")
+    assert prompt[0].shape == (1, n_txt, 4096)
+    feats = df.extract(prompt, batch_size=2, image=_images(2, 256, seed=2), t=400)
+    torch.cuda.synchronize()
+    arch = dict(PR.ARCH_PIXART_SIGMA, num_layers=2, sample_size=64, interpolation_scale=1)
+    st = PR.Store({k: True for k in feats})
+    with torch.no_grad():
+        PR.pixart_forward(_sd(df.pipe.original["transformer"]), arch, rec["latents"].float().cpu(), prompt[0].float().cpu().repeat(2, 1, 1),
+                          torch.tensor([float(rec["timestep"][0])] * 2), prompt[1].cpu().repeat(2, 1), st, want_map=False)
+    errs = {k: _rel(feats[k], st.feats[k]) for k in feats}
+    assert max(errs.values()) <= 1.0e-3, errs
+
+
+def test_flux_offline_lora_is_fused_before_the_weights_are_read(D, monkeypatch):
+    """flux branch of get_diffusion_model with an offline LoRA (reference models.py:150-172 + diffusion_feature.py:46-55): loaded and fused into the
+    pipeline's transformer BEFORE its state dict is handed to libgdf"""
+    import diffusion_feature
+    monkeypatch.setenv("FAKE_DIFFUSERS_FLUX_LAYERS", "1,1")
+    df = diffusion_feature.FeatureExtractor(layer={"vit-block1-out": True}, version="flux", device="cuda:0", img_size=1024, offline_lora="/data/flux_lora",
+                                            offline_lora_filename="lora.safetensors")
+    calls = [c[0] for c in D.CALLS]
+    assert calls.index("fuse_lora") > calls.index("load_lora_weights") > calls.index("FluxImg2ImgPipeline.from_pretrained")
+    assert dict(D.CALLS)["load_lora_weights"] == dict(path="/data/flux_lora", weight_name="lora.safetensors")
+    torch.manual_seed(3)
+    feats = df.extract("a prompt", batch_size=1, image=_images(1, 512, seed=4), t=200)
+    torch.cuda.synchronize()
+    want = _flux_oracle(df.pipe, df.pipe.last_transformer_kwargs, list(feats))       # the oracle on the FUSED module's weights
+    errs = {k: _rel(feats[k], want[k]) for k in feats}
+    assert max(errs.values()) <= 1.0e-3, errs
+
+
 def _flux_oracle(pipe, kw, ids):
     from oracle import flux_ref as FR
     c = pipe.original["transformer"].config
