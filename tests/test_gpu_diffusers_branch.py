@@ -173,6 +173,41 @@ def test_sdxl_real_checkpoint_branch(D):
     assert all(torch.equal(f2[k], feats[k]) for k in ids)                # image -> latents -> hooks == latents -> hooks
 
 
+def test_sdxl_real_checkpoint_headline_shape_verify_completes(D):
+    """The headline shape on the real-checkpoint branch: SDXL 1024^2, B = 16, the four `config_xl_practical` hooks, `verify` at its default (ON).
+    The first batch builds TWO plans at B = 16 (the plain plan the table picks and the full split it is checked against: the full split must exist
+    at this size — 32-bit buffer offsets — and fit), the check completes without a warning and keeps the plain plan, the check-only plan is released
+    and the second batch replays one graph."""
+    import diffusion_feature
+    layer = {k: True for k in ("up-level0-repeat0-vit-block7-out", "up-level0-repeat0-vit-block5-out", "up-level1-repeat0-vit-block0-cross-q",
+                               "up-level1-repeat0-vit-block0-out")}
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        df = diffusion_feature.FeatureExtractor(layer=layer, version="xl", device="cuda:0", img_size=1024)
+        u = df.pipe.unet
+        assert u.verify is True
+        prompt = df.encode_prompt("a photo of a red fox in the snow")
+        x = torch.rand(16, 3, 1024, 1024, generator=torch.Generator().manual_seed(0)) * 2 - 1
+        f1 = {k: v.clone() for k, v in df.extract(prompt, batch_size=16, image=x, image_type="tensors", t=100).items()}
+        torch.cuda.synchronize()
+    assert not [m for m in w if "gdf verify" in str(m.message)], [str(m.message) for m in w]
+    assert len(u.verify_log) == 1 and u.verify_log[0][2] == 0 and u.last_split == 0          # the plain plan stands: d <= sqrt((0.97e-3)^2 - (2.7e-4)^2)
+    d = u.verify_log[0][1][0]
+    assert d <= u.verify_accept_bound()
+    assert {k[8] for k in u._plans} == {0} and all(k[0] == 16 for k in u._plans)
+    plan = next(iter(u._plans.values()))
+    cap0 = plan.graph_stats()
+    torch.manual_seed(1)
+    f2 = df.extract(prompt, batch_size=16, image=x, image_type="tensors", t=100)
+    torch.cuda.synchronize()
+    cap1 = plan.graph_stats()
+    assert len(u.verify_log) == 1 and cap1[2] == 0 and cap1[1] > cap0[1]                     # no second check; graph replays, no eager fallback
+    for k in layer:
+        assert f2[k].shape == f1[k].shape and f2[k].shape[0] == 16 and torch.isfinite(f2[k].float()).all()
+    import conftest
+    conftest.record_margin("fake-diffusers xl 1024^2 B=16 practical hooks: verify's distance plain -> full split", "worst of 4 hooks", d, u.verify_accept_bound())
+
+
 def test_sd15_real_checkpoint_branch_with_vae_out(D):
     """'1-5': PNDM (alphas_cumprod add_noise, identity scale_model_input, step_plms probed for 'vae-out'); int-valued config fields
     (attention_head_dim = 8, transformer_layers_per_block = 1); 256^2, B = 2."""
