@@ -353,8 +353,8 @@ def test_model_frees_in_one_thread_do_not_invalidate_captures_in_another(tmp_pat
     pipeline garbage-collected late — while another thread's plan is capturing its hipGraph invalidated that capture on this runtime, and the
     invalidated stream (one of torch's 32 pooled streams) then failed every later plan that was handed it.  The library now keeps its own
     allocations / frees out of capture windows (csrc/model.h CaptureShared / CaptureExclusive).  Forty captures in one thread against a
-    thread that creates and destroys models in a loop: no capture may fail, results bit-equal, the stream usable afterwards.  The same script with
-    GDF_CAPTURE_GUARD=0 is run for the record (its failure count is printed, not asserted: the race needs the right timing)."""
+    thread that creates and destroys models in a loop: no capture may fail, results bit-equal, the stream usable afterwards.  (GDF_TEST_UNGUARDED=1
+    also runs the script with GDF_CAPTURE_GUARD=0: measured in round 6, that process segfaults.)"""
     script = tmp_path / "free_during_capture.py"
     script.write_text(_FREE_DURING_CAPTURE)
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
@@ -363,6 +363,9 @@ def test_model_frees_in_one_thread_do_not_invalidate_captures_in_another(tmp_pat
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     print("\n[capture guard ON ]", d)
     assert d["errors"] == [] and d["failures"] == 0 and d["mismatches"] == 0 and d["captures"] >= 40 and d["frees"] >= 20, d
-    r0 = subprocess.run([sys.executable, str(script), ROOT], env=dict(env, GDF_CAPTURE_GUARD="0"), capture_output=True, text=True, timeout=900)
-    tail = [l for l in r0.stdout.splitlines() if l.startswith("{")]
-    print("[capture guard OFF]", tail[-1] if tail else (r0.returncode, r0.stderr[-300:]))
+    if os.environ.get("GDF_TEST_UNGUARDED") == "1":
+        # for the record only (measured in round 6: the unguarded process dies with SIGSEGV inside the runtime): not part of the default run — a
+        # crashing GPU process is not something a test suite should do to a shared box
+        r0 = subprocess.run([sys.executable, str(script), ROOT], env=dict(env, GDF_CAPTURE_GUARD="0"), capture_output=True, text=True, timeout=900)
+        tail = [l for l in r0.stdout.splitlines() if l.startswith("{")]
+        print("[capture guard OFF]", tail[-1] if tail else (r0.returncode, r0.stderr[-300:]))
