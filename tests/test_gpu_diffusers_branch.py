@@ -308,6 +308,31 @@ def test_offline_lora_is_fused_before_the_weights_are_read_and_native_vae_opt_ou
         df.extract(df.encode_prompt("x"), batch_size=1, image=_images(1, 256), t=100)
 
 
+def test_real_checkpoint_branch_accept_all_resize_attention_and_pgv2(D):
+    """The remaining constructor surface on the real-checkpoint branch: `layer=None` (accept-all: every id of the architecture in execution order incl.
+    the `*-map` hooks, handed out as CPU tensors, reference feature_extractor.py:9-15,65-66), `feature_resize=2` (:51-53), `attention=[...]` (the
+    aggregated `attn` feature, diffusion_feature.py:492-500), and version 'pgv2' (Playground-v2: the SDXL pipeline class on another repo id, Euler
+    from_config; reference models.py:55-68)."""
+    import diffusion_feature
+    ids15 = open(os.path.join(ROOT, "tests/golden/ids_15_full.txt")).read().split()
+    df = diffusion_feature.FeatureExtractor(layer=None, version="1-5", device="cuda:0", img_size=256, feature_resize=2, attention=["up_cross", "down_self"], verify=False)
+    feats = df.extract(df.encode_prompt("a photo of a cat"), batch_size=1, image=_images(1, 256, seed=1), t=50)
+    keys = list(feats.keys())
+    assert keys[-1] == "attn" and keys[:-1] == ids15                         # == the key order of the reference's config_15_full.json
+    assert all(v.device.type == "cpu" for k, v in feats.items() if k != "attn")
+    assert feats["up-level2-repeat2-res-out"].shape == (1, 640, 8, 8)        # 16 x 16 at 256^2 (latent 32, one level down), pooled by feature_resize = 2
+    assert feats["attn"].shape[0] == 1 and feats["attn"].shape[-2:] == (32, 32) and torch.isfinite(feats["attn"].float()).all()
+    del df, feats
+    D.reset()
+    df = diffusion_feature.FeatureExtractor(layer={"up-level0-repeat1-vit-block2-out": True}, version="pgv2", device="cuda:0", img_size=256, verify=False)
+    calls = dict(D.CALLS)
+    assert calls["StableDiffusionXLImg2ImgPipeline.from_pretrained"]["repo"] == "playgroundai/playground-v2-1024px-aesthetic"
+    assert calls["StableDiffusionXLImg2ImgPipeline.from_pretrained"]["variant"] == "fp16" and "EulerDiscreteScheduler.from_config" in calls
+    f = df.extract(df.encode_prompt("x"), batch_size=2, image=_images(2, 256, seed=2), t=100)
+    torch.cuda.synchronize()
+    assert f["up-level0-repeat1-vit-block2-out"].shape == (2, 1280, 8, 8) and torch.isfinite(f["up-level0-repeat1-vit-block2-out"].float()).all()
+
+
 def test_pixart_sigma_real_checkpoint_branch(D):
     """'pixart-sigma' from a STOCK (text-to-image) PixArtSigmaPipeline: the product supplies get_timesteps and the image-taking prepare_latents
     (native VAE + DPMSolverMultistep add_noise), builds the DiT from `pipe.transformer.config`, drops nothing but the `pos_embed.pos_embed` buffer."""
