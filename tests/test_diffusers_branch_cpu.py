@@ -120,6 +120,33 @@ def test_noise_and_step_scalars_of_every_scheduler_family(fake_diffusers):
         acl = torch.cumprod(1 - torch.linspace(0.0001, 0.02, 1000, dtype=torch.float32), 0).double()
         a, b = M.scheduler_noise_scalars(dp, t.repeat(2))
         assert abs(a - float(acl[int(t)] ** 0.5)) < 1e-5 and abs(b - float((1 - acl[int(t)]) ** 0.5)) < 1e-5 and abs(a * a + b * b - 1) < 1e-5
+    # ---- v-prediction configurations (stabilityai/stable-diffusion-2-1 at 768^2 ships one): the step is still linear in (sample, output) and the
+    #      probes find the other pair of coefficients; closed forms from the published update rules ----
+    t_req = 261
+    pv = D.PNDMScheduler.from_config(dict(sd15.scheduler.config, prediction_type="v_prediction"))
+    pv.set_timesteps(1000, device="cpu")
+    holder = types.SimpleNamespace(scheduler=pv)
+    ts, _ = D.StableDiffusionImg2ImgPipeline.get_timesteps(holder, 1000, t_req / 1000, "cpu")
+    t = ts[:1]
+    a_t, a_p = float(ac[int(t)]), float(ac[int(t) - 1])
+    ws, we = VR.pndm_first_step_scalars(ac, int(t), int(t) - 1)          # epsilon form: prev = ws x + we eps, with eps = sqrt(a_t) v + sqrt(1 - a_t) x
+    cs, ce = M.scheduler_step_scalars(pv, t)
+    assert abs(cs - (ws + we * (1 - a_t) ** 0.5)) < 1e-6 and abs(ce - we * a_t ** 0.5) < 1e-6
+    assert abs(ce - M.scheduler_step_scalars(sd15.scheduler, t)[1]) > 0.1 * abs(ce)   # (and it is NOT the epsilon pair)
+    ev = D.EulerDiscreteScheduler.from_config(dict(sd15.scheduler.config, prediction_type="v_prediction"))
+    ev.set_timesteps(1000, device="cpu")
+    holder = types.SimpleNamespace(scheduler=ev)
+    ts, _ = D.StableDiffusionXLImg2ImgPipeline.get_timesteps(holder, 1000, t_req / 1000, "cpu")
+    t = ts[:1]
+    s_t, s_n = float(sig[t_req]), float(sig[t_req - 1])
+    cs, ce = M.scheduler_step_scalars(ev, t)
+    assert abs(cs - (1 + s_t / (s_t ** 2 + 1) * (s_n - s_t))) < 1e-5 and abs(ce - (s_n - s_t) / (s_t ** 2 + 1) ** 0.5) < 1e-5
+    # a step that is NOT linear (clipping / thresholding of the predicted sample) is refused, not mis-modelled
+    class Clipping:
+        def step(self, e, t, x, return_dict=False):
+            return ((x - e).clamp(-1, 1),)
+    with pytest.raises(NotImplementedError):
+        M.scheduler_step_scalars(Clipping(), torch.tensor([5]))
     # a scheduler whose add_noise is not linear is refused rather than silently mis-modelled
     class Bad:
         def add_noise(self, x, n, t):
