@@ -459,6 +459,13 @@ def _native_from_diffusers(pipe, device):
     return pipe
 
 
+def _model_id(repo, offline_lora, offline_lora_filename):
+    """The reference's rule for every version (feature/components/models.py:21-22, 33-34, 46-47, 60-61, 74-75, 90-91, 106-107, 153-154):
+    `offline_lora` WITHOUT a file name is a local model directory that replaces the hub id; with a file name it is a LoRA that
+    diffusion_feature.py:50-52 loads on top of the hub model."""
+    return offline_lora if (offline_lora and not offline_lora_filename) else repo
+
+
 def get_diffusion_model(version, dtype, offline_lora=None, offline_lora_filename=None, device="cuda"):
     dt = _parse_dtype(dtype)
     if version in _LATER:
@@ -471,9 +478,9 @@ def get_diffusion_model(version, dtype, offline_lora=None, offline_lora_filename
             import diffusers
         except ImportError as e:
             raise RuntimeError("diffusers is not installed and GDF_SYNTHETIC_WEIGHTS is not set (see INTEGRATION.md)") from e
-        pipe = diffusers.FluxImg2ImgPipeline.from_pretrained('black-forest-labs/FLUX.1-dev', torch_dtype=torch.bfloat16,
-                                                             use_safetensors=True)
-        if offline_lora:
+        pipe = diffusers.FluxImg2ImgPipeline.from_pretrained(_model_id('black-forest-labs/FLUX.1-dev', offline_lora, offline_lora_filename),
+                                                             torch_dtype=torch.bfloat16, use_safetensors=True)
+        if offline_lora and offline_lora_filename:
             pipe.load_lora_weights(offline_lora, weight_name=offline_lora_filename)
             pipe.fuse_lora()
         return _native_flux_from_diffusers(pipe.to(device), device)
@@ -485,11 +492,15 @@ def get_diffusion_model(version, dtype, offline_lora=None, offline_lora_filename
         except ImportError as e:
             raise RuntimeError("diffusers is not installed and GDF_SYNTHETIC_WEIGHTS is not set (see INTEGRATION.md)") from e
         if version == "pixart-alpha":                             # reference models.py:103-115 (120-token T5 captions, SD VAE)
-            pipe = diffusers.PixArtAlphaPipeline.from_pretrained("PixArt-alpha/PixArt-XL-2-512x512", torch_dtype=dt, variant="fp16",
-                                                                 use_safetensors=True).to(device)
+            pipe = diffusers.PixArtAlphaPipeline.from_pretrained(_model_id("PixArt-alpha/PixArt-XL-2-512x512", offline_lora, offline_lora_filename),
+                                                                 torch_dtype=dt, variant="fp16", use_safetensors=True).to(device)
         else:
             repo = "PixArt-alpha/PixArt-Sigma-XL-2-1024-MS" if version == "pixart-sigma" else "PixArt-alpha/PixArt-Sigma-XL-2-512-MS"
-            pipe = diffusers.PixArtSigmaPipeline.from_pretrained(repo, torch_dtype=dt, use_safetensors=True).to(device)
+            pipe = diffusers.PixArtSigmaPipeline.from_pretrained(_model_id(repo, offline_lora, offline_lora_filename), torch_dtype=dt,
+                                                                 use_safetensors=True).to(device)
+        if offline_lora and offline_lora_filename:                # reference diffusion_feature.py:50-52 (every version); fused: the weights are read next
+            pipe.load_lora_weights(offline_lora, weight_name=offline_lora_filename)
+            pipe.fuse_lora()
         # the architecture comes from the LOADED module (PIXART_CONFIGS holds the same numbers for the synthetic pipes)
         net = NativePixArtTransformer(pixart_config_from_diffusers(pipe.transformer.config), device=device)
         _fill(net, lambda m: m.load_state_dict({k: v for k, v in pipe.transformer.state_dict().items() if k != "pos_embed.pos_embed"}))
@@ -519,13 +530,14 @@ def get_diffusion_model(version, dtype, offline_lora=None, offline_lora_filename
     # data-parallel launch (opt-in, see _fill): only rank 0 reads the 5 GB UNet checkpoint, the other ranks receive the re-laid-out
     # arena.  With an offline LoRA every rank loads its own UNet instead: load_lora_weights / fuse_lora need the module, and each
     # rank fuses the same weights (the broadcast then only overwrites them with rank 0's identical arena).
-    skip_unet = D.weight_broadcast_enabled() and rank != 0 and not offline_lora
+    lora = bool(offline_lora and offline_lora_filename)
+    skip_unet = D.weight_broadcast_enabled() and rank != 0 and not lora
     if skip_unet:
         kw["unet"] = None
-    pipe = getattr(diffusers, cls).from_pretrained(repo, torch_dtype=dt, use_safetensors=True, **kw)
+    pipe = getattr(diffusers, cls).from_pretrained(_model_id(repo, offline_lora, offline_lora_filename), torch_dtype=dt, use_safetensors=True, **kw)
     if version != "1-5":
         pipe.scheduler = diffusers.EulerDiscreteScheduler.from_config(pipe.scheduler.config)
-    if offline_lora:
+    if lora:                                                      # reference diffusion_feature.py:50-52
         pipe.load_lora_weights(offline_lora, weight_name=offline_lora_filename)
         pipe.fuse_lora()
     # the architecture descriptor comes from rank 0's LOADED module (constructor defaults filled in: the raw config.json of SD1.5 /

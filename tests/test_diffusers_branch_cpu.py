@@ -274,3 +274,13 @@ def test_self_launch_failure_of_one_rank_stops_the_others(tmp_path):
     rc = D.self_launch(str(script), [str(tmp_path), "fail"], 3)
     assert rc == 5 and time.time() - t0 < 60
     assert not any(_alive(x) for x in _pids(tmp_path))
+
+
+def test_offline_lora_without_a_file_name_is_a_local_model_directory():
+    """reference feature/components/models.py:21-22 (and the same two lines in every version branch): `offline_lora and not offline_lora_filename`
+    -> `model_id = offline_lora`; with a file name the hub id stays and diffusion_feature.py:50-52 loads the LoRA on top."""
+    from components import models as M
+    assert M._model_id("stabilityai/stable-diffusion-xl-base-1.0", None, None) == "stabilityai/stable-diffusion-xl-base-1.0"
+    assert M._model_id("stabilityai/stable-diffusion-xl-base-1.0", "/data/my-sdxl", None) == "/data/my-sdxl"
+    assert M._model_id("stabilityai/stable-diffusion-xl-base-1.0", "/data/lora", "pytorch_lora_weights.safetensors") == "stabilityai/stable-diffusion-xl-base-1.0"
+    assert M._model_id("x", "", None) == "x"

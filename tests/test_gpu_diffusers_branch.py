@@ -299,6 +299,17 @@ def test_offline_lora_is_fused_before_the_weights_are_read_and_native_vae_opt_ou
             assert max(errs.values()) <= 1.0e-3, errs
         del df, f
     assert all(not torch.equal(outs["plain"][k], outs["lora"][k]) for k in layer)          # the fused weight did reach the kernels
+    # ---- `offline_lora` WITHOUT a file name is a local MODEL directory that replaces the hub id, and no LoRA call is made (reference
+    #      feature/components/models.py:21-22 and every other version branch; diffusion_feature.py:50-53 "else: TODO") ----
+    D.reset()
+    df = diffusion_feature.FeatureExtractor(layer=layer, version="1-5", device="cuda:0", img_size=256, verify=False, offline_lora="/data/models/my-finetuned-sd15")
+    calls = [c[0] for c in D.CALLS]
+    assert dict(D.CALLS)["StableDiffusionImg2ImgPipeline.from_pretrained"]["repo"] == "/data/models/my-finetuned-sd15"
+    assert "load_lora_weights" not in calls and "fuse_lora" not in calls
+    f = df.extract(df.encode_prompt("a photo of a cat"), batch_size=2, image=lat, image_type="latents", t=100)
+    torch.cuda.synchronize()
+    assert all(torch.equal(f[k], outs["plain"][k]) for k in layer)         # (the fake builds the same seeded weights whatever the directory is called)
+    del df, f
     # ---- GDF_NATIVE_VAE=0: diffusers' own prepare_latents stays (the fake's raises if called; constructing the extractor must not touch it) ----
     monkeypatch.setenv("GDF_NATIVE_VAE", "0")
     D.reset()
