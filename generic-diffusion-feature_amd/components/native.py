@@ -510,6 +510,7 @@ def _timestep_on_device(timestep, B, dev):
 
 class _NativeModel:
     """Shared surface of the libgdf model wrappers: weights in / hook names out (include/gdf.h model functions)."""
+    _arena_fp16 = True       # weight matrices live as fp16 images in the device arena (the MMDiT keeps bf16 / its own cast report: NativeFluxTransformer)
 
     lib = None
     handle = None
@@ -557,6 +558,7 @@ class _NativeModel:
         if strict and missing:
             raise KeyError(f"missing UNet parameters: {missing[:5]} ... ({len(missing)})")
         stream = torch.cuda.current_stream(self.device)
+        inexact = torch.zeros((), dtype=torch.int32, device=self.device)
         with torch.cuda.device(self.device):
             for name, shp in shapes.items():
                 if name not in sd:
@@ -567,11 +569,23 @@ class _NativeModel:
                 if t.dtype not in (torch.float16, torch.float32, torch.bfloat16):
                     t = t.float()
                 t = t.to(self.device, non_blocking=True).contiguous()
+                if self._arena_fp16 and t.dtype != torch.float16 and t.dim() >= 2:       # (norm / bias vectors stay fp32 in the arena)
+                    inexact += (t.half().to(t.dtype) != t).any()
                 code = {torch.float16: GDF_F16, torch.float32: GDF_F32, torch.bfloat16: GDF_BF16}[t.dtype]
                 _check(self.lib.gdf_model_set_param(self.handle, name.encode(), C.c_void_p(t.data_ptr()), code,
                                                     C.c_void_p(stream.cuda_stream)), f"set_param({name})")
                 del t
             stream.synchronize()
+        # The MFMA operands are 16-bit: a weight matrix is ONE fp16 image in the arena (the split plans pair the ACTIVATIONS, not the weights).
+        # A checkpoint whose matrices are not fp16-exact (dtype='float32' pipelines: reference feature/components/models.py:11-12) is therefore
+        # the fp16-rounded checkpoint — the very weights the reference's own dtype='float16' mode computes with — and sits ~1e-3 from the
+        # fp32-weight model whatever the operand plan (tests/test_gpu_diffusers_branch.py test_float32_dtype_real_checkpoint_branch).
+        self.weights_rounded = int(inexact) > 0
+        if self.weights_rounded:
+            import warnings
+            warnings.warn(f"gdf {type(self).__name__}: {int(inexact)} weight matrices of this checkpoint are not exactly representable in fp16 and were "
+                          "rounded once at load (the native models keep fp16 weight images): the features are those of the fp16-rounded checkpoint — what "
+                          "dtype='float16' loads — about 1e-3 (relative L2) from the fp32-weight model", RuntimeWarning, stacklevel=2)
         return self
 
     def init_synthetic(self, seed=0, chunk_elems=1 << 26):
@@ -878,6 +892,7 @@ class NativeFluxTransformer(_NativeModel):
     Hooked activations go to `self.feature_store` in execution order as (B, C, h, w) fp16 tensors (channels-last),
     ids `vit-block{i}-{q,k,v,attn-out,norm-out,ffn-inner,out}` (components/feature_extractor.py:98-123).
     """
+    _arena_fp16 = False
 
     FP16_CAST_TOL = 1e-4       # 'auto': relative Frobenius error a weight matrix may lose in the bf16 -> fp16 cast before the mode falls back
 

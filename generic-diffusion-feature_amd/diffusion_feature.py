@@ -43,7 +43,7 @@ class FeatureExtractor(nn.Module):
                  layer,            # filename of the layer json, a pre-loaded dict, or None (= all layers)
                  version,          # '1-5', '2-1', 'xl', 'pgv2', 'flux', 'pixart-sigma', 'pixart-sigma-512', 'pixart-alpha'
                  device,
-                 dtype='float16',
+                 dtype='float16',  # 'float32': the front-end modules in fp32 and the UNet on the full-split operand plan (see `precise`)
                  img_size=1024,    # 512 for 1-5, 1024 otherwise
                  offline_lora=None,
                  offline_lora_filename=None,
@@ -100,6 +100,12 @@ class FeatureExtractor(nn.Module):
             if verify is None:
                 verify = (env not in ("", "0")) if env != "" else not getattr(pipe, "synthetic_weights", False)
             pipe.unet.verify = bool(verify)
+        if precise is None and dtype == 'float32' and not external_model and hasattr(pipe.unet, "set_precise"):
+            # dtype='float32' asks the reference for fp32 arithmetic (feature/components/models.py:11-12: the whole pipeline in torch.float32).  The
+            # native UNet's MFMA operands are 16-bit either way; the plan that is closest to fp32 arithmetic is the full split (every operand an
+            # fp16 hi + lo pair: 1.9-2.7e-4 from fp32 against 7-9e-4 for the automatic level), at 0.55x the throughput — the reference's own
+            # float32 mode costs more than that.  An explicit `precise=` still wins.
+            precise = True
         if precise is not None:
             if hasattr(pipe.unet, "set_precise"):
                 pipe.unet.set_precise(precise)

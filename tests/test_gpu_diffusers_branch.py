@@ -85,12 +85,12 @@ def _record_prepare_latents(df):
     return rec
 
 
-def _unet_case(D, version, img, layer, B=2, t=100, verify=None):
+def _unet_case(D, version, img, layer, B=2, t=100, verify=None, **ctor):
     import diffusion_feature
     from components.native import NativeUNet, NativeVAEEncoder
     with warnings.catch_warnings(record=True) as wlog:
         warnings.simplefilter("always")
-        df = diffusion_feature.FeatureExtractor(layer=layer, version=version, device="cuda:0", img_size=img, verify=verify)
+        df = diffusion_feature.FeatureExtractor(layer=layer, version=version, device="cuda:0", img_size=img, verify=verify, **ctor)
         pipe = df.pipe
         assert D.PIPES[-1] is pipe and isinstance(pipe.unet, NativeUNet) and isinstance(pipe.native_vae, NativeVAEEncoder)
         assert not getattr(pipe, "synthetic_weights", False)
@@ -220,6 +220,7 @@ def test_sd15_real_checkpoint_branch_with_vae_out(D):
     fp = calls["StableDiffusionImg2ImgPipeline.from_pretrained"]
     assert fp["repo"] == "stable-diffusion-v1-5/stable-diffusion-v1-5" and "variant" not in fp
     assert "EulerDiscreteScheduler.from_config" not in calls and isinstance(pipe.scheduler, D.PNDMScheduler)
+    assert not pipe.unet.weights_rounded and not any("rounded once at load" in str(w.message) for w in wlog)      # an fp16 checkpoint is stored exactly
     assert pipe.unet.cfg["heads"] == (8, 8, 8, 8) and pipe.unet.cfg["transformer_layers"] == (1, 1, 1, 1) and not pipe.unet.cfg["use_linear_projection"]
     t = rec["timestep"]
     assert int(t[0]) == 101                                              # PNDM's leading spacing + steps_offset 1
@@ -268,6 +269,48 @@ def test_sd21_real_checkpoint_branch(D):
                        prompt[0].float().cpu().repeat(2, 1, 1), store=st)
     errs = {k: _rel(feats[k], st.feats[k]) for k in feats}
     assert max(errs.values()) <= 1.0e-3, errs
+
+
+def test_float32_dtype_real_checkpoint_branch(D):
+    """dtype='float32' (reference feature/components/models.py:11-12: the pipeline in torch.float32; the FeatureStore still hands out fp16, feature_extractor.py
+    :59-60): the front-end modules are fp32 (prompt embeddings, the latents handed to the UNet), the fp32 state dict reaches libgdf, the UNet runs the
+    FULL-SPLIT operand plan, and an explicit `precise=` still wins.  What the mode can and cannot promise is asserted both ways: the native UNet keeps ONE
+    fp16 image per weight matrix, so it computes the fp16-ROUNDED checkpoint (the weights the reference's dtype='float16' mode uses) — within the full
+    split's own bound (6e-4, SD1.5 family) of the oracle on those weights — and is therefore ~1e-3 from the oracle on the fp32 weights (bound 1.35e-3 stated
+    here, one warning at load)."""
+    import diffusion_feature
+    from components import plan_levels as PL
+    from oracle import unet_ref as R
+    import conftest
+    layer = {"down-level1-repeat1-vit-block0-ffn-inner": True, "mid-vit-block0-out": True, "up-level2-repeat1-vit-block0-self-q": True,
+             "up-level3-repeat2-res-out": True, "unet-out": True}
+    df, pipe, rec, prompt, feats, wlog = _unet_case(D, "1-5", 256, layer, dtype="float32")
+    fp = dict(D.CALLS)["StableDiffusionImg2ImgPipeline.from_pretrained"]
+    assert fp["torch_dtype"] == torch.float32
+    assert next(pipe.original["unet"].parameters()).dtype == torch.float32 and prompt[0].dtype == torch.float32 and rec["dtype"] == torch.float32
+    assert not pipe.unet.auto_split and pipe.unet.split == PL.SPLIT_ALL and pipe.unet.last_split == PL.SPLIT_ALL
+    assert all(v.dtype == torch.float16 for v in feats.values())
+    said = [str(w.message) for w in wlog if "rounded once at load" in str(w.message)]
+    assert pipe.unet.weights_rounded and sum("NativeUNet" in m for m in said) == 1 and sum("NativeVAEEncoder" in m for m in said) == 1
+    ac = pipe.scheduler.alphas_cumprod.double()
+    _check_vae_stage(D, pipe, rec, float(ac[101] ** 0.5), float((1 - ac[101]) ** 0.5))
+    P32 = _sd(pipe.original["unet"])
+    P16 = {k: (v.half().float() if v.dim() >= 2 else v) for k, v in P32.items()}      # matrices rounded once, vectors kept (the arena keeps those fp32)
+    errs = {}
+    for tag, P in (("fp16-rounded weights", P16), ("fp32 weights", P32)):
+        st = R.Store({k: True for k in feats})
+        with torch.no_grad():
+            R.unet_forward(P, R.ARCHS["1-5"], rec["latents"].float().cpu(), torch.tensor([101.0]), prompt[0].float().cpu().repeat(2, 1, 1), store=st)
+        errs[tag] = {k: _rel(feats[k], st.feats[k]) for k in feats}
+    w16, w32 = max(errs["fp16-rounded weights"].values()), max(errs["fp32 weights"].values())
+    assert w16 <= 6.0e-4, errs
+    assert w32 <= 1.35e-3, errs
+    conftest.record_margin("fake-diffusers 1-5 256^2 B=2 dtype='float32' -> full split (vs the fp16-rounded checkpoint)",
+                           max(errs["fp16-rounded weights"], key=errs["fp16-rounded weights"].get), w16, 6.0e-4, extra=f"vs the fp32 weights {w32:.2e} / 1.35e-3")
+    del df, pipe, feats
+    D.reset()
+    df = diffusion_feature.FeatureExtractor(layer=layer, version="1-5", device="cuda:0", img_size=256, dtype="float32", precise="auto", verify=False)
+    assert df.pipe.unet.auto_split
 
 
 def test_offline_lora_is_fused_before_the_weights_are_read_and_native_vae_opt_out(D, monkeypatch):
