@@ -534,9 +534,12 @@ def get_diffusion_model(version, dtype, offline_lora=None, offline_lora_filename
     skip_unet = D.weight_broadcast_enabled() and rank != 0 and not lora
     if skip_unet:
         kw["unet"] = None
-    pipe = getattr(diffusers, cls).from_pretrained(_model_id(repo, offline_lora, offline_lora_filename), torch_dtype=dt, use_safetensors=True, **kw)
-    if version != "1-5":
-        pipe.scheduler = diffusers.EulerDiscreteScheduler.from_config(pipe.scheduler.config)
+    model_id = _model_id(repo, offline_lora, offline_lora_filename)
+    if version == "2-1":
+        # reference models.py:38-39: ONLY '2-1' swaps the scheduler (Euler made from the checkpoint's own scheduler config); 'xl' / 'pgv2' / '1-5'
+        # keep whatever scheduler their checkpoint names — the probes (scheduler_noise_scalars / scheduler_step_scalars) ask the OBJECT
+        kw["scheduler"] = diffusers.EulerDiscreteScheduler.from_pretrained(model_id, subfolder="scheduler")
+    pipe = getattr(diffusers, cls).from_pretrained(model_id, torch_dtype=dt, use_safetensors=True, **kw)
     if lora:                                                      # reference diffusion_feature.py:50-52
         pipe.load_lora_weights(offline_lora, weight_name=offline_lora_filename)
         pipe.fuse_lora()

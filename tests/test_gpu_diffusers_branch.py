@@ -115,7 +115,7 @@ def _check_vae_stage(D, pipe, rec, a, b, tol=1e-3):
 
 
 def test_sdxl_real_checkpoint_branch(D):
-    """'xl': StableDiffusionXLImg2ImgPipeline.from_pretrained(variant='fp16') -> EulerDiscreteScheduler.from_config -> native UNet + VAE;
+    """'xl': StableDiffusionXLImg2ImgPipeline.from_pretrained(variant='fp16') with the checkpoint's OWN scheduler (Euler for sd_xl_base) -> native UNet + VAE;
     512^2, B = 2, a layer set that selects the selective split and therefore a verify run against the full split."""
     from oracle import unet_ref as R
     import conftest
@@ -127,7 +127,8 @@ def test_sdxl_real_checkpoint_branch(D):
     fp = calls["StableDiffusionXLImg2ImgPipeline.from_pretrained"]
     assert fp["repo"] == "stabilityai/stable-diffusion-xl-base-1.0" and fp["variant"] == "fp16" and fp["torch_dtype"] == torch.float16 and fp["use_safetensors"]
     assert "unet" not in fp                                              # single process: every component is loaded
-    assert "EulerDiscreteScheduler.from_config" in calls and isinstance(pipe.scheduler, D.EulerDiscreteScheduler)   # reference models.py:38-39 for xl too
+    # reference models.py:43-56: no scheduler swap for 'xl' — the pipeline keeps the one its checkpoint names (sd_xl_base: EulerDiscreteScheduler)
+    assert not any(c.startswith("EulerDiscreteScheduler.") for c in calls) and isinstance(pipe.scheduler, D.EulerDiscreteScheduler)
     u = pipe.unet
     from components.native import ARCH_CONFIGS, SELECTIVE_BY_ARCH
     assert {k: (tuple(v) if isinstance(v, (list, tuple)) else v) for k, v in u.cfg.items()} == \
@@ -251,14 +252,17 @@ def test_sd15_real_checkpoint_branch_with_vae_out(D):
 
 
 def test_sd21_real_checkpoint_branch(D):
-    """'2-1': Euler made from the PNDM-family scheduler config of the checkpoint (`EulerDiscreteScheduler.from_config(pipe.scheduler.config)`),
+    """'2-1': Euler made from the PNDM-family scheduler config of the checkpoint (`EulerDiscreteScheduler.from_pretrained(model_id, subfolder="scheduler")`
+    handed to the pipeline's from_pretrained, reference models.py:38-39),
     64-wide heads (5, 10, 20, 20), linear proj_in / proj_out, OpenCLIP width 1024."""
     from oracle import unet_ref as R
     layer = {"down-level1-repeat1-vit-block0-out": True, "up-level1-repeat0-vit-block0-self-v": True, "up-level3-repeat1-res-out": True}
     df, pipe, rec, prompt, feats, wlog = _unet_case(D, "2-1", 256, layer, verify=False)
     calls = dict(D.CALLS)
     assert calls["StableDiffusionImg2ImgPipeline.from_pretrained"]["repo"] == "stabilityai/stable-diffusion-2-1-base"
-    assert calls["EulerDiscreteScheduler.from_config"]["steps_offset"] == 1 and isinstance(pipe.scheduler, D.EulerDiscreteScheduler)
+    assert calls["EulerDiscreteScheduler.from_pretrained"] == dict(repo="stabilityai/stable-diffusion-2-1-base", subfolder="scheduler")
+    assert isinstance(calls["StableDiffusionImg2ImgPipeline.from_pretrained"]["scheduler"], D.EulerDiscreteScheduler) and isinstance(pipe.scheduler, D.EulerDiscreteScheduler)
+    assert pipe.scheduler.config.steps_offset == 1 and pipe.scheduler.config.timestep_spacing == "leading"
     assert pipe.unet.cfg["heads"] == (5, 10, 20, 20) and pipe.unet.cfg["cross_attention_dim"] == 1024 and pipe.unet.cfg["use_linear_projection"] == 1
     t = rec["timestep"]
     sigma = float(pipe.scheduler.sigmas[pipe.scheduler.index_for_timestep(t[0])])
@@ -366,7 +370,7 @@ def test_real_checkpoint_branch_accept_all_resize_attention_and_pgv2(D):
     """The remaining constructor surface on the real-checkpoint branch: `layer=None` (accept-all: every id of the architecture in execution order incl.
     the `*-map` hooks, handed out as CPU tensors, reference feature_extractor.py:9-15,65-66), `feature_resize=2` (:51-53), `attention=[...]` (the
     aggregated `attn` feature, diffusion_feature.py:492-500), and version 'pgv2' (Playground-v2: the SDXL pipeline class on another repo id, Euler
-    from_config; reference models.py:55-68)."""
+    the checkpoint's own scheduler; reference models.py:55-68)."""
     import diffusion_feature
     ids15 = open(os.path.join(ROOT, "tests/golden/ids_15_full.txt")).read().split()
     df = diffusion_feature.FeatureExtractor(layer=None, version="1-5", device="cuda:0", img_size=256, feature_resize=2, attention=["up_cross", "down_self"], verify=False)
@@ -381,7 +385,7 @@ def test_real_checkpoint_branch_accept_all_resize_attention_and_pgv2(D):
     df = diffusion_feature.FeatureExtractor(layer={"up-level0-repeat1-vit-block2-out": True}, version="pgv2", device="cuda:0", img_size=256, verify=False)
     calls = dict(D.CALLS)
     assert calls["StableDiffusionXLImg2ImgPipeline.from_pretrained"]["repo"] == "playgroundai/playground-v2-1024px-aesthetic"
-    assert calls["StableDiffusionXLImg2ImgPipeline.from_pretrained"]["variant"] == "fp16" and "EulerDiscreteScheduler.from_config" in calls
+    assert calls["StableDiffusionXLImg2ImgPipeline.from_pretrained"]["variant"] == "fp16" and not any(c.startswith("EulerDiscreteScheduler.") for c in calls)
     f = df.extract(df.encode_prompt("x"), batch_size=2, image=_images(2, 256, seed=2), t=100)
     torch.cuda.synchronize()
     assert f["up-level0-repeat1-vit-block2-out"].shape == (2, 1280, 8, 8) and torch.isfinite(f["up-level0-repeat1-vit-block2-out"].float()).all()
