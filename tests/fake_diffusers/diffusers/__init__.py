@@ -98,10 +98,12 @@ class ShellModel(nn.Module):
     """An nn.Module tree that has exactly the given parameter names and shapes (so `.state_dict()`, `.parameters()`, `.to()` behave like
     the diffusers model's) and a `.config`.  It has no forward: the product must replace it."""
 
-    def __init__(self, keys, config, dtype, seed, device="cpu"):
+    def __init__(self, keys, config, dtype, seed, device="cpu", stored_dtype=None):
+        """stored_dtype: the dtype of the checkpoint FILE (variant='fp16' files hold fp16 numbers, which torch_dtype=float32 merely upcasts)"""
         super().__init__()
         self.config = FrozenDict(config)
         gen = torch.Generator(device=device).manual_seed(seed)
+        _file = (lambda t: t.to(stored_dtype)) if stored_dtype is not None else (lambda t: t)
         for name, shape in keys:
             parts = name.split(".")
             node = self
@@ -109,7 +111,7 @@ class ShellModel(nn.Module):
                 if p not in node._modules:
                     node.add_module(p, _Node())
                 node = node._modules[p]
-            node.register_parameter(parts[-1], nn.Parameter(_fill_value(name, shape, gen, device).to(dtype), requires_grad=True))
+            node.register_parameter(parts[-1], nn.Parameter(_file(_fill_value(name, shape, gen, device)).to(dtype), requires_grad=True))
 
     @property
     def dtype(self):
@@ -129,9 +131,9 @@ def _gen_device():
     return "cuda" if (torch.cuda.is_available() and os.environ.get("FAKE_DIFFUSERS_CPU_WEIGHTS", "0") != "1") else "cpu"
 
 
-def _unet_shell(tag, dtype, seed):
+def _unet_shell(tag, dtype, seed, stored_dtype=None):
     k = _keys()[tag]
-    m = ShellModel(k["keys"], k["config"], dtype, seed, _gen_device())
+    m = ShellModel(k["keys"], k["config"], dtype, seed, _gen_device(), stored_dtype=stored_dtype)
     # what _get_add_time_ids of the SDXL pipelines reads (reference diffusion_feature.py:534-571)
     if k["config"].get("addition_embed_type") == "text_time":
         m.add_embedding.linear_1.in_features = k["config"]["projection_class_embeddings_input_dim"]
@@ -233,13 +235,13 @@ def autoencoder_kl_keys(block_out_channels=(128, 256, 512, 512), layers_per_bloc
     return keys
 
 
-def _vae_shell(dtype, seed, scaling_factor, latent_channels=4, shift_factor=None, quant=True, sample_size=512, force_upcast=True):
+def _vae_shell(dtype, seed, scaling_factor, latent_channels=4, shift_factor=None, quant=True, sample_size=512, force_upcast=True, stored_dtype=None):
     cfg = dict(in_channels=3, out_channels=3, down_block_types=["DownEncoderBlock2D"] * 4, up_block_types=["UpDecoderBlock2D"] * 4,
                block_out_channels=[128, 256, 512, 512], layers_per_block=2, act_fn="silu", latent_channels=latent_channels, norm_num_groups=32,
                sample_size=sample_size, scaling_factor=scaling_factor, shift_factor=shift_factor, latents_mean=None, latents_std=None,
                force_upcast=force_upcast, use_quant_conv=quant, use_post_quant_conv=quant, mid_block_add_attention=True)
     return ShellModel(autoencoder_kl_keys(latent_channels=latent_channels, use_quant_conv=quant, use_post_quant_conv=quant), cfg, dtype, seed,
-                      _gen_device())
+                      _gen_device(), stored_dtype=stored_dtype)
 
 
 class _TextEncoder(nn.Module):
@@ -736,8 +738,9 @@ class StableDiffusionXLImg2ImgPipeline(DiffusionPipeline):
     _component_names = ("unet", "vae", "text_encoder", "text_encoder_2", "scheduler")
 
     def _build(self, repo, dt, seed, kw):
-        self.unet = kw["unet"] if "unet" in kw else _unet_shell("unet-xl", dt, seed)
-        self.vae = _vae_shell(dt, seed + 1, 0.13025 if "xl-base" in repo else 0.5, sample_size=1024, force_upcast=True)
+        stored = torch.float16 if kw.get("variant") == "fp16" else None      # the *.fp16.safetensors files
+        self.unet = kw["unet"] if "unet" in kw else _unet_shell("unet-xl", dt, seed, stored_dtype=stored)
+        self.vae = _vae_shell(dt, seed + 1, 0.13025 if "xl-base" in repo else 0.5, sample_size=1024, force_upcast=True, stored_dtype=stored)
         self.text_encoder = _TextEncoder(768, 768, dt)
         self.text_encoder_2 = _TextEncoder(1280, 1280, dt)
         # sd_xl_base_1.0 scheduler/scheduler_config.json: EulerDiscreteScheduler, leading spacing, steps_offset 1
