@@ -149,6 +149,11 @@ class FeatureExtractor(nn.Module):
                 print('prompt:', prompts)
         else:
             prompts = prompt_str
+        if len(prompts.split(' ')) > 70 and hasattr(self.pipe, 'tokenizer'):
+            # reference :165-171: prompts of more than 70 words bypass the pipeline's 77-token truncation (components/encode_long_prompt.py);
+            # the UNet then sees (1, n_tokens, C) embeddings — the text length is a plan parameter of the native UNet — and no pooled embeddings
+            prompt_embeds, negative_prompt_embeds = _chunked_prompt_embeds(self.pipe, prompts, '', self.device)
+            return prompt_embeds, negative_prompt_embeds, None, None
         ret = self.pipe.encode_prompt(prompt=prompts, device=self.device, num_images_per_prompt=1,
                                       negative_prompt='', do_classifier_free_guidance=True)
         if self.version in ('xl', 'pgv2') or self.version.startswith('pixart'):
@@ -300,6 +305,31 @@ class FeatureExtractor(nn.Module):
 
 
 DiffusionFeature = FeatureExtractor      # name used by BASELINE.json's north_star
+
+
+def _chunked_prompt_embeds(pipe, prompt, negative_prompt, device):
+    """Text embeddings of a prompt longer than the tokenizer window, as the reference produces them (feature/components/encode_long_prompt.py:5-40):
+    the text with the larger WORD count is tokenised without truncation, the other one padded to that token count; both id rows are cut into windows of
+    `tokenizer.model_max_length` ids, every window goes through `pipe.text_encoder` on its own (the last window as short as it happens to be) and the
+    windows' hidden states are concatenated along the token axis.  Returns (prompt_embeds, negative_prompt_embeds), both (1, n_tokens, C)."""
+    tok = pipe.tokenizer
+    window = tok.model_max_length
+
+    def free(text):
+        return tok(text, return_tensors="pt", truncation=False).input_ids.to(device)
+
+    def padded(text, n):
+        return tok(text, return_tensors="pt", truncation=False, padding="max_length", max_length=n).input_ids.to(device)
+
+    if len(prompt.split(" ")) >= len(negative_prompt.split(" ")):
+        ids = free(prompt)
+        neg_ids = padded(negative_prompt, ids.shape[-1])
+    else:
+        neg_ids = free(negative_prompt)
+        ids = padded(prompt, neg_ids.shape[-1])
+    n = ids.shape[-1]
+    encode = lambda rows: torch.cat([pipe.text_encoder(rows[:, a:a + window])[0] for a in range(0, n, window)], dim=1)
+    return encode(ids), encode(neg_ids)
 
 
 def _get_add_time_ids(pipe, original_size, crops_coords_top_left, target_size, dtype,

@@ -254,6 +254,34 @@ class _TextEncoder(nn.Module):
     def dtype(self):
         return self.stub.dtype
 
+    def forward(self, input_ids):
+        """(last_hidden_state,): a deterministic function of each id AND its position inside the window it was encoded in (so a test can tell how the
+        ids were windowed), like a real text encoder's positional embedding"""
+        CALLS.append(("text_encoder", dict(tokens=int(input_ids.shape[-1]))))
+        n, c = int(input_ids.shape[-1]), int(self.config.hidden_size)
+        pos = torch.arange(n, device=input_ids.device, dtype=torch.float32)[None, :, None]
+        ch = torch.arange(c, device=input_ids.device, dtype=torch.float32)[None, None, :]
+        h = torch.sin(input_ids[..., None].float() * 0.37 + ch * 0.11) + 0.5 * torch.cos(pos * 0.23 + ch * 0.05)
+        return (h.to(self.dtype),)
+
+
+class _Tokenizer:
+    """CLIP-tokenizer call surface as encode_long_prompt.py uses it: one id per whitespace word between BOS / EOS, optional padding to `max_length`
+    with the pad id, no truncation unless asked; `.input_ids` is a (1, n) LongTensor."""
+    model_max_length = 77
+    bos, eos, pad = 49406, 49407, 49407
+
+    def __call__(self, text, return_tensors=None, truncation=True, padding=False, max_length=None):
+        CALLS.append(("tokenizer", dict(words=len(text.split()), truncation=truncation, padding=padding, max_length=max_length)))
+        ids = [self.bos] + [1 + int.from_bytes(hashlib.sha256(w.encode()).digest()[:2], "little") % 40000 for w in text.split()] + [self.eos]
+        lim = max_length or self.model_max_length
+        if truncation and len(ids) > lim:
+            ids = ids[:lim - 1] + [self.eos]
+        if padding == "max_length":
+            ids = ids + [self.pad] * max(0, lim - len(ids))
+        assert return_tensors == "pt"
+        return types.SimpleNamespace(input_ids=torch.tensor([ids], dtype=torch.long))
+
 
 def _embeds(text, shape, device, dtype):
     seed = int.from_bytes(hashlib.sha256(text.encode()).digest()[:4], "little")
@@ -706,6 +734,7 @@ class StableDiffusionImg2ImgPipeline(DiffusionPipeline):
         self.unet = kw["unet"] if "unet" in kw else _unet_shell("unet-2-1" if v21 else "unet-1-5", dt, seed)
         self.vae = _vae_shell(dt, seed + 1, 0.18215, sample_size=768 if v21 else 512, force_upcast=True)
         self.text_encoder = _TextEncoder(1024 if v21 else 768, 512, dt)
+        self.tokenizer = _Tokenizer()
         self.scheduler = kw.get("scheduler") or PNDMScheduler(skip_prk_steps=True, set_alpha_to_one=False, **_SD_SCHED)
         self.vae_scale_factor = 8
         self.image_processor = VaeImageProcessor(vae_scale_factor=8)

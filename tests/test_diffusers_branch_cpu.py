@@ -284,3 +284,35 @@ def test_offline_lora_without_a_file_name_is_a_local_model_directory():
     assert M._model_id("stabilityai/stable-diffusion-xl-base-1.0", "/data/my-sdxl", None) == "/data/my-sdxl"
     assert M._model_id("stabilityai/stable-diffusion-xl-base-1.0", "/data/lora", "pytorch_lora_weights.safetensors") == "stabilityai/stable-diffusion-xl-base-1.0"
     assert M._model_id("x", "", None) == "x"
+
+
+def test_prompts_longer_than_the_tokenizer_window_are_encoded_in_windows(fake_diffusers):
+    """FeatureExtractor.encode_prompt's > 70-word branch (reference feature/diffusion_feature.py:165-171 -> components/encode_long_prompt.py:5-40): the
+    prompt is tokenised without truncation, the (shorter) negative prompt padded to the same id count, both rows encoded window by window (77, 77, ...,
+    rest) and concatenated along the token axis."""
+    import diffusion_feature as DF
+    D = fake_diffusers
+    pipe = D.StableDiffusionImg2ImgPipeline.from_pretrained("stable-diffusion-v1-5/stable-diffusion-v1-5", torch_dtype=torch.float32, unet=None)
+    words = " ".join(f"w{i}" for i in range(170))                      # 170 words + BOS + EOS = 172 ids = 77 + 77 + 18
+    D.CALLS.clear()
+    pe, ne = DF._chunked_prompt_embeds(pipe, words, "", "cpu")
+    assert pe.shape == ne.shape == (1, 172, 768)
+    toks = [c[1] for c in D.CALLS if c[0] == "tokenizer"]
+    assert toks == [dict(words=170, truncation=False, padding=False, max_length=None), dict(words=0, truncation=False, padding="max_length", max_length=172)]
+    assert [c[1]["tokens"] for c in D.CALLS if c[0] == "text_encoder"] == [77, 77, 18, 77, 77, 18]     # the prompt's windows, then the negative prompt's
+    ids = pipe.tokenizer(words, return_tensors="pt", truncation=False).input_ids
+    want = torch.cat([pipe.text_encoder(ids[:, a:a + 77])[0] for a in (0, 77, 154)], 1)
+    assert torch.equal(pe, want)
+    assert not torch.allclose(pe[:, 77:154], pipe.text_encoder(ids)[0][:, 77:154])      # one pass over all ids is NOT the same thing (positions restart per window)
+    # the negative prompt decides the length when it has more words
+    pe2, ne2 = DF._chunked_prompt_embeds(pipe, "a cat", " ".join(["no"] * 90), "cpu")
+    assert pe2.shape == ne2.shape == (1, 92, 768)
+    # the method: 4-tuple with no pooled embeddings; <= 70 words still go through pipe.encode_prompt
+    fx = DF.FeatureExtractor.__new__(DF.FeatureExtractor)
+    torch.nn.Module.__init__(fx)
+    fx.pipe, fx.device, fx.version = pipe, "cpu", "1-5"
+    out = fx.encode_prompt(words)
+    assert torch.equal(out[0], pe) and out[2] is None and out[3] is None
+    D.CALLS.clear()
+    short = fx.encode_prompt("a photo of a cat")
+    assert short[0].shape == (1, 77, 768) and [c[0] for c in D.CALLS] == ["encode_prompt"]

@@ -346,6 +346,28 @@ def test_float32_dtype_xl_loads_the_fp16_variant_and_is_exact_in_the_arena(D):
     conftest.record_margin("fake-diffusers xl 512^2 B=1 dtype='float32' (fp16 variant upcast) -> full split", max(errs, key=errs.get), max(errs.values()), 7.0e-4)
 
 
+def test_long_prompt_embeddings_reach_the_unet(D):
+    """A prompt of more than 70 words (reference feature/diffusion_feature.py:165-171): encode_prompt returns (1, n_tokens, C) embeddings from the windowed
+    text encoder and no pooled embeddings; extract() repeats them over the batch and the native UNet runs with n_tokens keys in every cross-attention —
+    hooks incl. a `cross-map` (whose last axis IS the text length) against the oracle on the same embeddings."""
+    import diffusion_feature
+    from oracle import unet_ref as R
+    layer = {"down-level1-repeat0-vit-block0-cross-map": True, "mid-vit-block0-cross-q": True, "up-level2-repeat1-vit-block0-out": True, "unet-out": True}
+    df = diffusion_feature.FeatureExtractor(layer=layer, version="1-5", device="cuda:0", img_size=256, verify=False)
+    prompt = df.encode_prompt(" ".join(f"word{i}" for i in range(120)))      # 122 ids = 77 + 45
+    assert prompt[0].shape == (1, 122, 768) and prompt[0].dtype == torch.float16 and prompt[2] is None
+    assert [c[1]["tokens"] for c in D.CALLS if c[0] == "text_encoder"] == [77, 45, 77, 45] and "encode_prompt" not in [c[0] for c in D.CALLS]
+    lat = torch.randn(2, 4, 32, 32, generator=torch.Generator().manual_seed(5)).half()
+    feats = df.extract(prompt, batch_size=2, image=lat, image_type="latents", t=100)
+    torch.cuda.synchronize()
+    assert feats["down-level1-repeat0-vit-block0-cross-map"].shape == (2, 8, 256, 122)
+    st = R.Store({k: True for k in layer})
+    with torch.no_grad():
+        R.unet_forward(_sd(df.pipe.original["unet"]), R.ARCHS["1-5"], lat.float(), torch.tensor([101.0]), prompt[0].float().cpu().repeat(2, 1, 1), store=st)
+    errs = {k: _rel(feats[k], st.feats[k]) for k in layer}
+    assert max(errs.values()) <= 1.0e-3, errs
+
+
 def test_offline_lora_is_fused_before_the_weights_are_read_and_native_vae_opt_out(D, monkeypatch):
     """components/models.py: `offline_lora` -> pipe.load_lora_weights(path, weight_name=...) + pipe.fuse_lora() BEFORE the UNet's state dict is handed
     to libgdf (reference feature/diffusion_feature.py:46-55 loads the LoRA into the pipeline), so the native model computes with the FUSED weights;

@@ -528,3 +528,33 @@ def test_verify_escalates_plan_on_heavy_tailed_weights(monkeypatch):
     e_kept = max(rel_l2(hh[k], ref[k]) for k in ids)
     print(f"[verify] heavy-tailed tiny xl: plain plan {e_plain:.2e} -> kept mask {kept}: {e_kept:.2e} vs the fp32 oracle; differences to the full split {seen}")
     assert e_kept < e_plain
+
+
+@pytest.mark.parametrize("base,n_ctx,same_prompt,precise", [("1-5", 154, True, False), ("xl", 91, False, False), ("xl", 231, True, True), ("2-1", 8, False, False),
+                                                            ("1-5", 1, True, False)])
+def test_prompt_embeddings_of_other_lengths_than_77(base, n_ctx, same_prompt, precise):
+    """The reference hands LONGER prompt embeddings to the UNet when the prompt has more than 70 words (feature/diffusion_feature.py:165-171 ->
+    components/encode_long_prompt.py:5-40: the token ids are encoded in chunks of 77 and concatenated, the last chunk as long as it happens to be), and
+    callers may pass any `encoder_hidden_states` they like: the text length is a plan parameter here.  All hooks incl. the `cross-map`s (whose channel
+    count IS the text length) against the oracle at 154 (two chunks), 91 / 231 (ragged last chunk; not a multiple of the 16-wide MFMA K step or of the
+    32-key attention tile), 8 and 1 tokens; one prompt repeated (text K/V computed once per call) and per-sample prompts; default and full-split plans."""
+    arch = R.tiny_arch(base)
+    P = R.synth_params(arch, seed=0)
+    I = R.synth_inputs(arch, 2, 16, seed=3, n_ctx=n_ctx, same_prompt=same_prompt)
+    ref = oracle_run(arch, P, I)
+    ids = list(ref.keys())
+    u = native(arch, P, precise=precise)
+    g = lambda k: I[k].cuda() if k in I else None
+    noise, hooks = u.forward_raw(g("sample"), g("timestep"), g("ctx"), g("text_embeds"), g("time_ids"), hook_ids=ids, shared_ctx=same_prompt)
+    torch.cuda.synchronize()
+    assert list(hooks.keys()) == ids
+    errs = {k: rel_l2(hooks[k], ref[k]) for k in ids}
+    maps = [k for k in ids if k.endswith("cross-map")]
+    assert maps and all(hooks[k].shape[-1] == n_ctx for k in maps)                     # (B, heads, queries, n_ctx): components/attention.py:238-244
+    assert all(tuple(hooks[k].shape) == tuple(ref[k].shape) for k in ids)
+    bad = {k: v for k, v in errs.items() if not v < (6e-4 if precise else TOL)}
+    assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:8]
+    # every map row is a distribution over the n_ctx keys (padding keys of the last tile must not leak in)
+    for k in maps[:3]:
+        s = hooks[k].float().sum(-1)
+        assert torch.allclose(s, torch.ones_like(s), atol=5e-3), k
