@@ -7,6 +7,11 @@
 
 namespace gdf {
 
+#if defined(GDF_EXP_OLD_BUNITS)         // diagnostics: the pre-round-6 B staging units (row halves instead of read phases)
+#define GDF_OLD_BUNITS true
+#else
+#define GDF_OLD_BUNITS false
+#endif
 template <class T>
 __device__ __forceinline__ void gemm_mainloop_8phase_256(T& t, f32x4 (&acc)[T::FM][T::FN]) {
   GDF_TILE_GEOMETRY(T);
@@ -35,6 +40,15 @@ __device__ __forceinline__ void gemm_mainloop_8phase_256(T& t, f32x4 (&acc)[T::F
   constexpr int BHALF = BN / 2;                       // rows per B half-tile
   constexpr bool B3 = (BN == 320);
   const bool g1 = wave >= 4;
+  // B staging units (round 6).  A wave reads the FIRST 64 of its 128 B columns in phase 1 and the second 64 in phase 2, and the waves with wn = 0 / 1
+  // own B rows 0-127 / 128-255: the rows read in phase 1 are 0-63 and 128-191, those read in phase 2 are 64-127 and 192-255.  The staging units
+  // follow the READ phases — unit 0 ("B-lo" below) = the phase-1 rows, unit 1 ("B-hi") = the phase-2 rows; wave w issues instructions w*2, w*2+1 of
+  // the unit's 16, i.e. rows (w>>2)*128 + unit*64 + ((w&3)*2 + j)*8 — so that "staged in the phase after its last read" holds for every row.
+  // Until round 6 the units were the row halves 0-127 / 128-255: waves 5 and 7 then restaged rows 80-95 / 112-127 of the current buffer in the very
+  // phase in which waves 4 and 6 read them.  With real tiles the DMA needs ~1 us and the reads always won; the tiles staged past the end of K were
+  // out-of-range loads (zeros, ~100 cycles) and, with a second stream's waves on the CU, beat the reads about once in 10^3 launches: 64 rows x 16
+  // columns of a tile computed without its last K-tiles (tools/micro/op_race.py, tools/ab_race_variants.sh, profiles/r06_concurrent_streams.txt).
+  auto b_unit_row = [&](int unit, int j) { return (wave >> 2) * 128 + unit * 64 + ((wave & 3) * 2 + j) * 8; };
   uint32_t ha[2][2], hb[2][3];                        // ha: DENSE byte offset of (row, chunk); CONV byte offset of filter tap (0, 0)
   uint32_t hm[2][2];                                  // CONV: validity mask of the 9 taps (conv_row)
   int hbq[2];                                         // first instruction index of this wave in B half-tile h
@@ -54,7 +68,7 @@ __device__ __forceinline__ void gemm_mainloop_8phase_256(T& t, f32x4 (&acc)[T::F
     }
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-      const int r = h * BHALF + (hbq[h] + j) * 8 + lrow;
+      const int r = (B3 || GDF_OLD_BUNITS ? h * BHALF + (hbq[h] + j) * 8 : b_unit_row(h, j)) + lrow;
       hb[h][j] = (n0 + r < p.N) ? (uint32_t)(n0 + r) * ldb + (uint32_t)chunk * 16u : OOB;
     }
   }
@@ -68,7 +82,7 @@ __device__ __forceinline__ void gemm_mainloop_8phase_256(T& t, f32x4 (&acc)[T::F
       }
     } else {
       constexpr int H = W - 2;
-      char* base = smem + 2 * A_TILE + buf * B_TILE + H * (BHALF * 128) + hbq[H] * 1024;
+      char* base = smem + 2 * A_TILE + buf * B_TILE + ((B3 || GDF_OLD_BUNITS) ? H * (BHALF * 128) + hbq[H] * 1024 : b_unit_row(H, 0) * 128);
 #pragma unroll
       for (int j = 0; j < 2; ++j) glds16(rsB, base + j * 1024, hb[H][j] + koffB(kt));
       if (B3 && (g1 == (H == 1))) glds16(rsB, base + 2 * 1024, hb[H][2] + koffB(kt));
@@ -157,14 +171,29 @@ __device__ __forceinline__ void gemm_mainloop_8phase_256(T& t, f32x4 (&acc)[T::F
   //                             phase 2: read B cols 64-127                     stage A-lo, A-hi, B-lo of T+2,     32 MFMAs (A, B-hi)
   //                                                                            wait vmcnt(6) = tile T+1 has landed
   // Slot lifetimes: A-lo is read by group 0 only and A-hi by group 1 only, both in phase 1 — group 1 one barrier after group 0 —
-  // and B-lo by both; every read is retired (lgkmcnt) before the reader's next barrier, so all three are free from phase 2's
-  // read slot of either group on; B-hi (read in phase 2) is free from the next tile's phase 1 on.
+  // and B-lo by both; every read is retired (lgkmcnt) BEFORE the barrier that follows it, i.e. before the other group can pass that
+  // barrier into its phase 2, so all three are free from phase 2's read slot of either group on; B-hi (read in phase 2) is free from
+  // the next tile's phase 1 on.
   // Ring layout [A buf 0][A buf 1][B buf 0][B buf 1] and the K loop unrolled by two: the buffer index is a compile-time constant
   // in each copy of the body, so it lands in the 16-bit immediate offset of the ds_read (A_TILE, B_TILE <= 40 KiB) instead of ~20
   // v_add per K-tile that rebuild every fragment address from `cur * STAGE` (VALU issue time adds to MFMA time on this hardware).
   auto ktile = [&](int kt, const int cur) {
+    // Round 6 — two changes that make "a slot is restaged only after its last read has RETIRED" hold by construction instead of by DMA latency
+    // (found with two host threads driving two streams: a second kernel's waves on the CU stretch a wave's LDS reads):
+    //  (1) the B staging units follow the read phases (b_unit_row above): the unit staged in phase 2 holds only rows read in phase 1;
+    //  (2) the phase-1 reads are retired BEFORE the barrier (they used to be retired right after it): group 1 arrives at this barrier when
+    //      group 0 arrives at the one that ends ITS phase 1, and group 0 then restages A-hi / B-lo of this very buffer.  The reading group is
+    //      the early arriver at this barrier (the other one is multiplying), so the wait is hidden.
+    // Tiles past the end of K are still staged (out-of-range loads: zeros, landing ~10x sooner than a real tile — the only DMA that ever won
+    // the race), now into slots nobody reads any more; skipping them with a branch costs 24 VGPRs (GEGLU 227 -> 251, fp8 kernel 33 -> 206
+    // spills).  Same accumulation order: bit-identical results.  A/B of the old and new forms under concurrency: tools/ab_race_variants.sh.
+#if defined(GDF_EXP_OLD_LGKM)          // diagnostics (tools/ab_race_variants.sh): the pre-round-6 order, reads retired AFTER the barrier
     rd_a(cur); rd_b(cur, 0); stage(kt + 1, cur ^ 1, BHI);
     bar(); lgkm0(); mma_q(Q0, Q0); mma_q(Q1, Q0); bar();
+#else
+    rd_a(cur); rd_b(cur, 0); stage(kt + 1, cur ^ 1, BHI); lgkm0();
+    bar(); mma_q(Q0, Q0); mma_q(Q1, Q0); bar();
+#endif
     rd_b(cur, 1); stage(kt + 2, cur, ALO); stage(kt + 2, cur, AHI); stage(kt + 2, cur, BLO); wait_tile(); lgkm0();
     bar(); mma_q(Q1, Q1); mma_q(Q0, Q1); bar();
   };
@@ -180,8 +209,8 @@ __device__ __forceinline__ void gemm_mainloop_8phase_256(T& t, f32x4 (&acc)[T::F
 #else
   auto ktile4 = [&](int kt, const int cur) {
     // phase 1
-    rd_a(cur); rd_b(cur, 0); stage(kt + 1, cur ^ 1, BHI);
-    bar(); lgkm0(); mma_q(Q0, Q0); bar();
+    rd_a(cur); rd_b(cur, 0); stage(kt + 1, cur ^ 1, BHI); lgkm0();
+    bar(); mma_q(Q0, Q0); bar();
     // phase 2
     stage(kt + 2, cur, ALO);
     bar(); mma_q(Q1, Q0); bar();

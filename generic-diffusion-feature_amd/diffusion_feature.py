@@ -281,7 +281,9 @@ class FeatureExtractor(nn.Module):
             return self.feature_store.stored_feats
         # ---- the hot path: native UNet forward, hooks written by the kernels (:445-465) ----
         if hasattr(self.pipe.unet, 'shared_ctx'):
-            self.pipe.unet.shared_ctx = True      # prompt_embeds.repeat(batch_size, 1, 1) above: one prompt for the whole batch
+            # prompt_embeds.repeat(batch_size, 1, 1) above: ONE prompt for the whole batch -> the text K/V are computed once per call.  (Embeddings
+            # that already carried several rows are not that case: the promise is only made for a (1, n, C) prompt.)
+            self.pipe.unet.shared_ctx = prompts[0].shape[0] == 1
         noise_pred = self.pipe.unet(latent_model_input, timestep=t, encoder_hidden_states=prompt_embeds.to(device),
                                     added_cond_kwargs=added_cond_kwargs, down_block_additional_residuals=None,
                                     mid_block_additional_residual=None, return_dict=False)[0]
