@@ -199,6 +199,21 @@ def _check(rc, what):
         raise RuntimeError(f"libgdf {what} failed (status {rc}): {msg.decode() if msg else ''}")
 
 
+def _create(fn, what):
+    """Model creation = one hipMalloc of the weight arena OUTSIDE torch's caching allocator.  When that fails for lack of memory the memory is
+    usually there — as blocks torch has cached (freed tensors it keeps for reuse; a long-lived process that builds and drops extractors piles
+    them up: tools/soak.py saw 280 GB cached on a 288-GB device) — so: collect, hand torch's cache back to the driver, try once more."""
+    rc = fn()
+    if rc != 0:
+        msg = (load_library().gdf_last_error() or b"").decode()
+        if "out of memory" in msg or "hipMalloc" in msg:
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
+            rc = fn()
+    _check(rc, what)
+
+
 # --------------------------------------------------------------------------------------------- #
 # architecture descriptors: the UNet `config.json` fields the reference reads via diffusers
 # (components/models.py:18-56 of the reference select the HF repos these come from)
@@ -400,12 +415,22 @@ class _Plan:
         self.inflight = []
 
     def __del__(self):
+        # The plan's buffers (workspace, staging, hook sets) are ordinary allocations of the CALLER's stream pool that only this plan's stream
+        # writes: its queued work ends before they go back to that pool (and before the stream goes away).
+        try:
+            if self.stream is not None:
+                self.stream.synchronize()
+        except Exception:
+            pass
         try:
             self.lib.gdf_plan_destroy(self.handle)
         except Exception:
             pass
+        self.workspace = None
+        self.staged = {}
+        self.sets = []
         try:
-            if self._own_stream is not None:      # (work still queued on it finishes first: hipStreamDestroy defers the release)
+            if self._own_stream is not None:
                 self.lib.gdf_stream_destroy(self._own_stream)
         except Exception:
             pass
@@ -424,13 +449,22 @@ class _Plan:
         self.lib.gdf_plan_graph_stats(self.handle, C.byref(cap), C.byref(lau))
         return cap.value, lau.value, int(self.lib.gdf_plan_graph_failures(self.handle))
 
-    def _stage(self, name, t, dtype, dev):
-        """copy `t` into the persistent staging buffer of input `name` (dtype conversion + layout in the same copy)"""
+    def _stage_buffer(self, name, t, dtype, dev, side):
+        """the persistent staging buffer of input `name` (allocated on the caller's stream: see run)"""
         if t is None:
             return None
         b = self.staged.get(name)
         if b is None or b.shape != t.shape or b.dtype != dtype:
+            if b is not None:
+                side.synchronize()
             b = self.staged[name] = torch.empty(t.shape, dtype=dtype, device=dev)
+        return b
+
+    def _stage(self, name, t, dtype, dev):
+        """copy `t` into the persistent staging buffer of input `name` (dtype conversion + layout in the same copy)"""
+        if t is None:
+            return None
+        b = self.staged[name]
         b.copy_(t, non_blocking=True)
         return b
 
@@ -452,10 +486,17 @@ class _Plan:
         n_out = 1
         for d in out_shape:
             n_out *= d
-        with torch.cuda.device(dev), torch.cuda.stream(side):
+        # Allocations happen HERE, on the caller's stream — i.e. in the pool every other allocation of the process uses — not under the plan's
+        # private stream: torch caches freed blocks per stream, a plan's stream dies with the plan, and blocks cached for a dead stream are never
+        # handed out again (tools/soak.py: ~800 extractor lifetimes filled 288 GB with such blocks).  Only this plan's stream writes them
+        # (ordered behind `cur` by the wait above); __del__ drains that stream before they are returned.
+        with torch.cuda.device(dev):
             if self.workspace is None or self.workspace.numel() < self.ws_bytes:
+                if self.workspace is not None:
+                    side.synchronize()                          # (a smaller one may still be in use by queued work)
                 self.workspace = torch.empty(self.ws_bytes, dtype=torch.uint8, device=dev)
-            staged = [self._stage(n, t, dt, dev) for (n, t, dt) in inputs]
+            for (n, t, dt) in inputs:
+                self._stage_buffer(n, t, dt, dev, side)
             hs = next((h for h in self.sets if h.free()), None)
             pooled = True
             if hs is None:
@@ -463,6 +504,10 @@ class _Plan:
                 pooled = len(self.sets) < self.MAX_SETS        # more live result sets than that: one-off buffers, run eagerly
                 if pooled:
                     self.sets.append(hs)
+                # (a one-off set dies with its last view, possibly while this forward still runs: its block then returns to `cur`'s pool, and
+                #  whatever is allocated from it next is written by work queued on `cur` behind the cur.wait_stream(side) below)
+        with torch.cuda.device(dev), torch.cuda.stream(side):
+            staged = [self._stage(n, t, dt, dev) for (n, t, dt) in inputs]
             for ev in hs.events:                               # readers announced through release_after(): ordered before the overwrite
                 side.wait_event(ev)
             hs.events = []
@@ -681,7 +726,7 @@ class NativeUNet(_NativeModel):
         self._arch = arch_desc(cfg)
         h = C.c_void_p()
         with torch.cuda.device(self.device):
-            _check(self.lib.gdf_model_create(C.byref(self._arch), C.byref(h)), "model_create")
+            _create(lambda: self.lib.gdf_model_create(C.byref(self._arch), C.byref(h)), "model_create")
         self.handle = h
         self.stream_fp32 = bool(stream_fp32)
         self.early_exit = bool(early_exit)
@@ -934,7 +979,7 @@ class NativeFluxTransformer(_NativeModel):
         self._desc = flux_desc(self.cfg)
         h = C.c_void_p()
         with torch.cuda.device(self.device):
-            _check(self.lib.gdf_flux_model_create(C.byref(self._desc), C.byref(h)), "flux_model_create")
+            _create(lambda: self.lib.gdf_flux_model_create(C.byref(self._desc), C.byref(h)), "flux_model_create")
         self.handle = h
         self._plans = {}
         self.io_dtype = torch.float16 if self.cfg["compute_dtype"] in ("float16", "float16s", "auto") else torch.bfloat16   # inputs / `out` of libgdf
@@ -1107,7 +1152,7 @@ class NativeVAEEncoder(_NativeModel):
         d = self._desc = _vae_desc(self.cfg)
         h = C.c_void_p()
         with torch.cuda.device(self.device):
-            _check(self.lib.gdf_vae_model_create(C.byref(d), C.byref(h)), "vae_model_create")
+            _create(lambda: self.lib.gdf_vae_model_create(C.byref(d), C.byref(h)), "vae_model_create")
         self.handle = h
         self._plans = {}
         self.feature_store = None
@@ -1189,7 +1234,7 @@ class NativeVAEDecoder(_NativeModel):
         self._desc = _vae_desc(self.cfg)
         h = C.c_void_p()
         with torch.cuda.device(self.device):
-            _check(self.lib.gdf_vae_decoder_create(C.byref(self._desc), C.byref(h)), "vae_decoder_create")
+            _create(lambda: self.lib.gdf_vae_decoder_create(C.byref(self._desc), C.byref(h)), "vae_decoder_create")
         self.handle = h
         self._plans = {}
         self.feature_store = None
@@ -1281,7 +1326,7 @@ class NativePixArtTransformer(_NativeModel):
         self._desc = d
         h = C.c_void_p()
         with torch.cuda.device(self.device):
-            _check(self.lib.gdf_pixart_model_create(C.byref(d), C.byref(h)), "pixart_model_create")
+            _create(lambda: self.lib.gdf_pixart_model_create(C.byref(d), C.byref(h)), "pixart_model_create")
         self.handle = h
         self.early_exit = bool(early_exit)
         self.feature_store = None

@@ -457,7 +457,7 @@ Model* flux_model_create(const gdf_flux_desc& d) {
     m->f8_off = a; m->sc_off = a + a / 2;
     m->weight_bytes = a + a / 2 + a / 16 + 4096;
   }
-  { CaptureExclusive guard; if (hipMalloc(&m->weights, m->weight_bytes) != hipSuccess) { set_error("hipMalloc(weights) failed"); delete m; return nullptr; } }
+  { CaptureExclusive guard; const hipError_t me = hipMalloc(&m->weights, m->weight_bytes); if (me != hipSuccess) { set_error(std::string("hipMalloc(weights, ") + std::to_string(m->weight_bytes) + " bytes) failed: " + hipGetErrorString(me)); (void)hipGetLastError(); delete m; return nullptr; } }
   (void)hipMemset(m->weights, 0, m->weight_bytes);
   PlanOpts o{}; o.stream_fp32 = 1;
   Plan dry;

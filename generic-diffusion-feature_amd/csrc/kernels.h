@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <atomic>
+#include "launch.h"
 
 typedef _Float16 half_t;
 

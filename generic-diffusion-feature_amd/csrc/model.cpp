@@ -182,8 +182,10 @@ Model* model_create(const GdfArch& arch) {
   b.build();
   {
     CaptureExclusive g;
-    if (hipMalloc(&m->weights, m->weight_bytes) != hipSuccess) {
-      set_error("hipMalloc(weights) failed"); delete m; return nullptr;
+    const hipError_t me = hipMalloc(&m->weights, m->weight_bytes);
+    if (me != hipSuccess) {
+      set_error(std::string("hipMalloc(weights, ") + std::to_string(m->weight_bytes) + " bytes) failed: " + hipGetErrorString(me)); (void)hipGetLastError();
+      delete m; return nullptr;
     }
     hipMemset(m->weights, 0, m->weight_bytes);
   }
@@ -745,26 +747,29 @@ int plan_forward(Plan& P, const Model& m, const void* lat, const float* t, const
   return plan_run(P, b, s, ms, names, flops, cap);
 }
 
-// An event-record NODE at the current point of the capture on `s` (fires at every replay).  Spelled with the graph API — current
-// capture dependencies -> hipGraphAddEventRecordNode -> make the node the capture's dependency set — because
-// hipEventRecordWithFlags(..., hipEventRecordExternal) returns "invalid argument" under the HIP runtime PyTorch 2.10 bundles
-// (ROCm 7.0), while it works under /opt/rocm 7.2 (tools/micro/graph_events.hip).
-static hipError_t record_in_capture(hipEvent_t ev, hipStream_t s) {
-  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-  hipGraph_t graph = nullptr;
-  const hipGraphNode_t* deps = nullptr;
-  size_t ndeps = 0;
-  hipError_t e = hipStreamGetCaptureInfo_v2(s, &st, nullptr, &graph, &deps, &ndeps);
-  if (e != hipSuccess) return e;
-  if (st != hipStreamCaptureStatusActive || !graph) return hipErrorStreamCaptureInvalidated;
+// ---- explicit graph construction (launch.h): the recorder of the calling thread, kernel / event-record nodes in one chain ----
+GraphRecorder*& thread_recorder() { static thread_local GraphRecorder* r = nullptr; return r; }
+static hipError_t chain(GraphRecorder& r, hipGraphNode_t node) { r.last = node; ++r.nodes; return hipSuccess; }
+hipError_t record_kernel_node(GraphRecorder& r, const void* fn, dim3 grid, dim3 block, void** args, unsigned smem) {
+  hipKernelNodeParams kp{};
+  kp.func = const_cast<void*>(fn); kp.gridDim = grid; kp.blockDim = block; kp.sharedMemBytes = smem; kp.kernelParams = args; kp.extra = nullptr;
   hipGraphNode_t node = nullptr;
-  e = hipGraphAddEventRecordNode(&node, graph, deps, ndeps, ev);
-  if (e != hipSuccess) return e;
-  return hipStreamUpdateCaptureDependencies(s, &node, 1, hipStreamSetCaptureDependencies);
+  const hipError_t e = hipGraphAddKernelNode(&node, r.graph, r.last ? &r.last : nullptr, r.last ? 1 : 0, &kp);     // (the argument VALUES are copied here)
+  return e != hipSuccess ? e : chain(r, node);
+}
+// An event-record NODE at the current end of the chain (fires at every replay): the timed replays of bench.py (gdf_plan_set_timing)
+hipError_t record_event_node(GraphRecorder& r, hipEvent_t ev) {
+  hipGraphNode_t node = nullptr;
+  const hipError_t e = hipGraphAddEventRecordNode(&node, r.graph, r.last ? &r.last : nullptr, r.last ? 1 : 0, ev);
+  return e != hipSuccess ? e : chain(r, node);
+}
+static hipError_t record_in_capture(hipEvent_t ev, hipStream_t) {
+  GraphRecorder* r = thread_recorder();
+  return r ? record_event_node(*r, ev) : hipErrorInvalidValue;
 }
 
-// evset >= 0: record the timing events of set `evset` around every op of the timed label; `external` = inside a stream capture
-// (event-record nodes that fire at every replay)
+// evset >= 0: record the timing events of set `evset` around every op of the timed label; `external` = while this thread records the plan's
+// graph (event-record nodes that fire at every replay)
 static int run_ops_eager(Plan& P, const Bind& b, hipStream_t s, int evset = -1, bool external = false) {
   size_t evk = 0;
   long nlab = 0;
@@ -773,9 +778,8 @@ static int run_ops_eager(Plan& P, const Bind& b, hipStream_t s, int evset = -1, 
     if (timed) {
       const hipError_t ee = external ? record_in_capture(P.ev[evset][evk], s) : hipEventRecord(P.ev[evset][evk], s);
       if (ee != hipSuccess) {
-        hipStreamCaptureStatus st = hipStreamCaptureStatusNone; (void)hipStreamIsCapturing(s, &st);
-        char buf[160]; snprintf(buf, sizeof buf, "hipEventRecord failed: %s (event %p, stream %p, capture status %d, evk %zu of %zu, external %d)",
-                                hipGetErrorString(ee), (void*)P.ev[evset][evk], (void*)s, (int)st, evk, P.ev[evset].size(), (int)external);
+        char buf[160]; snprintf(buf, sizeof buf, "hipEventRecord failed: %s (event %p, stream %p, evk %zu of %zu, recording %d)",
+                                hipGetErrorString(ee), (void*)P.ev[evset][evk], (void*)s, evk, P.ev[evset].size(), (int)external);
         set_error(buf); return GDF_ERR_HIP;
       }
     }
@@ -790,8 +794,8 @@ static int run_ops_eager(Plan& P, const Bind& b, hipStream_t s, int evset = -1, 
   return GDF_OK;
 }
 
-// hipGraph path: the op program is captured once per distinct binding table on the caller's (non-default) stream and
-// replayed with one hipGraphLaunch; ~2400 kernel launches per SDXL forward become one host call.
+// hipGraph path: the op program is recorded once per distinct binding table into a hipGraph (explicit kernel nodes, launch.h) and replayed on
+// the caller's stream with one hipGraphLaunch; ~2400 kernel launches per SDXL forward become one host call.
 static int run_ops_graph(Plan& P, const Bind& b, hipStream_t s, int evset = -1) {
   const size_t nh = P.hooks.size();
   const int label = evset >= 0 ? P.timing_label : -1;
@@ -808,32 +812,23 @@ static int run_ops_graph(Plan& P, const Bind& b, hipStream_t s, int evset = -1) 
   Plan::GraphEntry g;
   g.key = b; g.key.hooks = nullptr; g.evset = evset; g.label = label;
   for (size_t i = 0; i < nh; ++i) g.hook_ptrs.push_back(b.hooks[i]);
-  // Relaxed mode: the op program only launches kernels (no allocation, no synchronisation), and in this mode HIP neither lists
-  // the stream for its "unsafe call during capture" checks nor lets an unrelated call invalidate the capture — other host
-  // threads (one extractor per thread: aggregation_network.py:67-95) keep allocating, synchronising and capturing freely.
+  // The graph is BUILT, not captured (launch.h): while this thread's recorder is set, every kernel launch of the op program appends a kernel
+  // node (and every timing event an event-record node) to one dependency chain.  No stream is ever in capture mode, so nothing another host
+  // thread does — allocating, freeing, synchronising the device, building its own graphs — can invalidate it (one extractor per thread:
+  // aggregation_network.py:67-95).
   int rc;
-  hipError_t e;
-  {
-    CaptureShared guard;                                 // no allocation / free of this library runs between Begin and End (model.h)
-    if (hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) != hipSuccess) {
-      (void)hipGetLastError();
-      return run_ops_eager(P, b, s, evset);              // e.g. the legacy default stream cannot be captured
-    }
+  hipError_t e = hipGraphCreate(&g.graph, 0);
+  if (e != hipSuccess) { (void)hipGetLastError(); g.graph = nullptr; rc = GDF_ERR_HIP; }
+  else {
+    GraphRecorder rec; rec.graph = g.graph;
+    thread_recorder() = &rec;
     rc = run_ops_eager(P, b, s, evset, true);
-    e = hipStreamEndCapture(s, &g.graph);
-    if (rc != GDF_OK || e != hipSuccess) {
-      // an invalidated capture: make sure the stream has really left capture mode before anything else is queued on it
-      hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-      for (int tries = 0; tries < 3 && hipStreamIsCapturing(s, &st) == hipSuccess && st != hipStreamCaptureStatusNone; ++tries) {
-        hipGraph_t junk = nullptr;
-        (void)hipStreamEndCapture(s, &junk);
-        if (junk) hipGraphDestroy(junk);
-      }
-      (void)hipGetLastError();
-    }
+    thread_recorder() = nullptr;
+    e = rec.err;
+    if (rc == GDF_OK && e != hipSuccess) { set_error(std::string("graph node creation failed: ") + hipGetErrorString(e)); rc = GDF_ERR_HIP; }
   }
   static const bool dbg = getenv("GDF_DEBUG_GRAPH") != nullptr;
-  if (dbg) fprintf(stderr, "[gdf] capture evset=%d rc=%d end=%s graph=%p (%s)\n", evset, rc, hipGetErrorString(e), (void*)g.graph, rc ? last_error() : "");
+  if (dbg) fprintf(stderr, "[gdf] graph build evset=%d rc=%d err=%s graph=%p (%s)\n", evset, rc, hipGetErrorString(e), (void*)g.graph, rc ? last_error() : "");
   auto failed = [&](const char* what, hipError_t err) {
     // reported once per plan: a persistently failing capture would otherwise silently turn every forward into ~1000 eager launches
     if (P.graph_capture_failures++ == 0)
@@ -841,11 +836,11 @@ static int run_ops_graph(Plan& P, const Bind& b, hipStream_t s, int evset = -1) 
               hipGetErrorString(err), rc != GDF_OK ? "; " : "", rc != GDF_OK ? last_error() : "");
   };
   if (rc != GDF_OK || e != hipSuccess || !g.graph) {
-    // a capture that failed or was invalidated has executed nothing: drop it and run this forward eagerly (the ops are pure
-    // functions of their inputs); the next call tries to capture again
+    // a recording that failed has executed nothing: drop it and run this forward eagerly (the ops are pure functions of their inputs);
+    // the next call tries again
     if (g.graph) hipGraphDestroy(g.graph);
     (void)hipGetLastError();
-    failed("capture", e);
+    failed("construction", e);
     return run_ops_eager(P, b, s, evset);
   }
   hipError_t ie;

@@ -137,8 +137,9 @@ struct HookSlot { std::string id; int64_t shape[4]; int64_t stride[4]; size_t by
 // Stream-capture guard.  hipFree / hipMalloc / hipGraph(Exec)Destroy / hipStreamDestroy made by ANY host thread while another thread's stream is
 // capturing can invalidate that capture on this runtime (relaxed mode notwithstanding), and an invalidated capture leaves the stream unusable
 // ("operation failed due to a previous error during capture" from every later call on it; round 6: a model garbage-collected in one thread while
-// another thread captured took seven later tests down through torch's 32-entry stream pool).  Captures hold the guard shared; every
-// allocation / free the library makes outside a capture holds it exclusively for the duration of the HIP call.
+// another thread captured took seven later tests down through torch's 32-entry stream pool).  So do two captures at once from two threads.
+// Every capture and every allocation / free the library makes holds the guard EXCLUSIVELY for its duration (CaptureShared is kept for
+// read-only users; nothing takes it today).
 struct CaptureShared { CaptureShared(); ~CaptureShared(); };
 struct CaptureExclusive { CaptureExclusive(); ~CaptureExclusive(); };
 

@@ -250,7 +250,7 @@ Model* pixart_model_create(const gdf_pixart_desc& d) {
   m->pix.C = C;
   PixartModelBuilder b(*m);
   b.build();
-  { CaptureExclusive guard; if (hipMalloc(&m->weights, m->weight_bytes) != hipSuccess) { set_error("hipMalloc(weights) failed"); delete m; return nullptr; } }
+  { CaptureExclusive guard; const hipError_t me = hipMalloc(&m->weights, m->weight_bytes); if (me != hipSuccess) { set_error(std::string("hipMalloc(weights, ") + std::to_string(m->weight_bytes) + " bytes) failed: " + hipGetErrorString(me)); (void)hipGetLastError(); delete m; return nullptr; } }
   (void)hipMemset(m->weights, 0, m->weight_bytes);
   PlanOpts o{}; o.stream_fp32 = 1;
   Plan dry;

@@ -308,7 +308,7 @@ Model* vae_model_create(const gdf_vae_desc& d) {
   m->vae.d = d;
   VaeModelBuilder b(*m);
   b.build();
-  { CaptureExclusive guard; if (hipMalloc(&m->weights, m->weight_bytes) != hipSuccess) { set_error("hipMalloc(weights) failed"); delete m; return nullptr; } }
+  { CaptureExclusive guard; const hipError_t me = hipMalloc(&m->weights, m->weight_bytes); if (me != hipSuccess) { set_error(std::string("hipMalloc(weights, ") + std::to_string(m->weight_bytes) + " bytes) failed: " + hipGetErrorString(me)); (void)hipGetLastError(); delete m; return nullptr; } }
   (void)hipMemset(m->weights, 0, m->weight_bytes);
   return m;
 }
@@ -386,7 +386,7 @@ Model* vae_decoder_create(const gdf_vae_desc& d) {
   m->vae.d = d;
   VaeModelBuilder b(*m);
   b.build_decoder();
-  { CaptureExclusive guard; if (hipMalloc(&m->weights, m->weight_bytes) != hipSuccess) { set_error("hipMalloc(weights) failed"); delete m; return nullptr; } }
+  { CaptureExclusive guard; const hipError_t me = hipMalloc(&m->weights, m->weight_bytes); if (me != hipSuccess) { set_error(std::string("hipMalloc(weights, ") + std::to_string(m->weight_bytes) + " bytes) failed: " + hipGetErrorString(me)); (void)hipGetLastError(); delete m; return nullptr; } }
   (void)hipMemset(m->weights, 0, m->weight_bytes);
   return m;
 }
