@@ -133,14 +133,16 @@ int gdf_forward(gdf_plan* p, const void* latents, const float* timesteps, const 
                 void* const* hook_out, void* noise_pred, void* workspace, void* stream);
 
 /* hipGraph replay: with enable != 0 every forward on a NON-default stream is served by one hipGraphLaunch of the plan's op
- * program, captured once per distinct set of buffer addresses (workspace, inputs, hooks, outputs; LRU of 4) after one eager
- * warm-up forward.  Calls on the legacy default stream and profiled calls run eagerly.
+ * program, recorded once per distinct set of buffer addresses (workspace, inputs, hooks, outputs; LRU of 12) after one eager
+ * warm-up forward.  The graph is BUILT with the graph API (kernel nodes in launch order, csrc/launch.h) — no stream is ever put into
+ * capture mode, so other host threads may allocate, free, synchronise the device and build their own graphs meanwhile (round 6).
+ * Calls on the legacy default stream and profiled calls run eagerly.
  * With live kernel timing on (gdf_plan_set_timing) the replayed graphs carry event-record nodes around the timed launches, one graph
  * per timing event set (LRU of 12), so the timing measures the replay itself.  Applies to UNet, Flux, PixArt and VAE plans alike. */
 int gdf_plan_set_graph(gdf_plan* p, int enable);
 int gdf_plan_graph_stats(const gdf_plan* p, long* captures, long* launches);
-/* Forwards that had to run EAGERLY although graph replay was enabled, because a capture / instantiate failed (each such call retries
- * the capture; the first failure of a plan is also reported once on stderr).  0 on a healthy plan: a measurement that labels its
+/* Forwards that had to run EAGERLY although graph replay was enabled, because graph construction / instantiation failed (each such call
+ * retries; the first failure of a plan is also reported once on stderr).  0 on a healthy plan: a measurement that labels its
  * timed region "graph replay" must check this together with the launch count of gdf_plan_graph_stats. */
 long gdf_plan_graph_failures(const gdf_plan* p);
 
@@ -175,8 +177,8 @@ int gdf_plan_set_timing_stride(gdf_plan* p, int stride);
 int gdf_stream_create_cu_mask(const uint32_t* mask, int n_words, void** stream);
 /* A private non-blocking stream for one plan (round 6).  The Python mirror used to take plan streams from torch's pool of 32, which hands
  * the same hipStream_t to every 32nd request: two LIVE plans of two host threads could share a stream (one capturing while the other
- * launches), and a stream whose capture had been invalidated poisoned whoever was handed it next.  The reference has no equivalent (one
- * default stream per process, feature/diffusion_feature.py:445-465).  Creation and destruction take the capture guard (csrc/model.h). */
+ * launches).  The reference has no equivalent (one default stream per process, feature/diffusion_feature.py:445-465).  Creation and
+ * destruction are serialised with the library's other allocations (csrc/model.h). */
 int gdf_stream_create(void** stream);
 int gdf_stream_destroy(void* stream);
 int gdf_device_cu_count(void);

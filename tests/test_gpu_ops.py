@@ -488,3 +488,49 @@ def test_attention_over_split_qkv_pairs(D, S, gain):
         assert torch.equal(o_pair, o_plain)
     else:
         assert e_pair < 0.6 * e_plain and e_pair < 2.5e-4
+
+
+def test_gemm_beside_another_kernel_on_a_second_stream_keeps_its_bits():
+    """Round 6: the 256x256 two-group main loop restaged B rows in the phase in which two of its waves still read them; harmless with real tiles
+    (a DMA needs ~1 us), but the tiles staged past the end of K are out-of-range loads that land in ~100 cycles, and with ANOTHER kernel's waves
+    on the CU (a second stream: one extractor per host thread) the reads lost about once in 10^3 launches — 64 rows x 16 columns of a tile
+    computed without its last K-tiles (profiles/r06_concurrent_streams.txt).  The GEGLU GEMM of an SD1.5 / SDXL level-0 block (K = 320: 5
+    K-tiles) beside a LayerNorm kernel, 4000 launches per thread, every result compared bit for bit.  (The round-5 kernel fails this about
+    4 times per run.)"""
+    import threading
+    L = lib()
+    M, C = 4096, 320
+    x, W, b = rnd(M, C), rnd(8 * C, C, scale=C ** -0.5), rnd(8 * C).float()
+    Wd = torch.empty_like(W, device="cuda"); bd = torch.empty(8 * C, device="cuda")
+    Ws, bs, xd = W.cuda(), b.cuda(), x.cuda()
+    ok(L.gdf_op_relayout_geglu(P(Ws), P(bs), P(Wd), P(bd), 8 * C, C, 16, stream()), L)
+    out = torch.zeros(M, 4 * C, dtype=torch.half, device="cuda")
+    ln_x = rnd(M, C, seed=7).float().cuda(); ln_g = rnd(C, seed=8).float().cuda(); ln_b = rnd(C, seed=9).float().cuda()
+    ln_y = torch.zeros(M, C, dtype=torch.half, device="cuda")
+    torch.cuda.synchronize()
+    s0, s1 = torch.cuda.Stream(), torch.cuda.Stream()
+    import ctypes
+    sp = lambda s: ctypes.c_void_p(s.cuda_stream)
+
+    def gemm():
+        ok(L.gdf_op_gemm(P(xd), C, P(Wd), P(bd), None, None, 0, P(out), 4 * C, None, 0, M, 8 * C, C, 1, sp(s0)), L)
+
+    def ln():
+        ok(L.gdf_op_layernorm(None, P(ln_x), C, M, C, 1e-5, P(ln_g), P(ln_b), P(ln_y), sp(s1)), L)
+
+    gemm(); s0.synchronize(); base = out.clone()
+    ln(); s1.synchronize(); base_ln = ln_y.clone()
+    bad = [0, 0]
+    bar = threading.Barrier(2)
+
+    def work(i):
+        torch.cuda.set_device(0)
+        bar.wait()
+        for _ in range(4000):
+            if i == 0:
+                gemm(); s0.synchronize(); bad[0] += int(not torch.equal(out, base))
+            else:
+                ln(); s1.synchronize(); bad[1] += int(not torch.equal(ln_y, base_ln))
+    th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    [t.start() for t in th]; [t.join() for t in th]
+    assert bad == [0, 0], bad
