@@ -482,14 +482,15 @@ class _Plan:
             while not ev.query():                  # sleep-poll: hipEventSynchronize / hipStreamSynchronize SPIN on this runtime even with
                 time.sleep(0.0005)                 # blocking-sync events or hipDeviceScheduleBlockingSync (tools/micro/sync_cpu.py:
                                                    # 48 ms of CPU per 48 ms of waiting; the poll: 0.3 ms)
-        side.wait_stream(cur)
         n_out = 1
         for d in out_shape:
             n_out *= d
         # Allocations happen HERE, on the caller's stream — i.e. in the pool every other allocation of the process uses — not under the plan's
         # private stream: torch caches freed blocks per stream, a plan's stream dies with the plan, and blocks cached for a dead stream are never
-        # handed out again (tools/soak.py: ~800 extractor lifetimes filled 288 GB with such blocks).  Only this plan's stream writes them
-        # (ordered behind `cur` by the wait above); __del__ drains that stream before they are returned.
+        # handed out again (tools/soak.py: ~800 extractor lifetimes filled 288 GB with such blocks).  Only this plan's stream writes them, and
+        # only behind the side.wait_stream(cur) BELOW: a block this allocation reuses may have been freed a moment ago with reads still queued on
+        # `cur` (by any thread — the default stream is shared), and the wait is what orders those reads before the plan's first write.
+        # __del__ drains the plan's stream before the blocks are returned.
         with torch.cuda.device(dev):
             if self.workspace is None or self.workspace.numel() < self.ws_bytes:
                 if self.workspace is not None:
@@ -506,6 +507,7 @@ class _Plan:
                     self.sets.append(hs)
                 # (a one-off set dies with its last view, possibly while this forward still runs: its block then returns to `cur`'s pool, and
                 #  whatever is allocated from it next is written by work queued on `cur` behind the cur.wait_stream(side) below)
+        side.wait_stream(cur)
         with torch.cuda.device(dev), torch.cuda.stream(side):
             staged = [self._stage(n, t, dt, dev) for (n, t, dt) in inputs]
             for ev in hs.events:                               # readers announced through release_after(): ordered before the overwrite

@@ -388,7 +388,7 @@ def test_two_host_threads_two_streams_soak():
     assert r.stdout.strip(), r.stderr[-3000:]
     d = _json_tail(r.stdout)
     print("\n[soak]", {k: d[k] for k in ("lifetimes", "extracts", "graph_captures", "graph_failures", "not_returned_mb")})
-    assert r.returncode == 0 and d["ok"], (d, r.stderr[-2000:])
+    assert r.returncode == 0 and d["ok"], json.dumps(d)[:3000] + r.stderr[-1500:]
     assert d["lifetimes"] >= 40 and d["graph_captures"] >= 40 and d["graph_failures"] == 0 and not d["mismatches"] and not d["probe_drift"] and not d["errors"], d
 
 
