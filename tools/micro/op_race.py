@@ -112,11 +112,52 @@ CASES["groupnorm+silu B4 1024x320"] = lambda sd: make_gn(4, 1024, 320, sd)
 CASES["gemm 4096x960x320 tile 932 (256x320 8-phase)"] = lambda sd: make_gemm(4096, 960, 320, 932, sd, res32=False)
 CASES["gemm res32 4096x640x320 tile 932"] = lambda sd: make_gemm(4096, 640, 320, 932, sd)
 CASES["conv3x3 B4 32x32 320->640 (auto: 932)"] = lambda sd: make_conv(4, 32, 32, 320, 640, sd)
-CASES["attention cross B4 h8 Sq1024 Sk77 D40"] = None
+def make_dit(M, N, K, variant, seed, act=1):
+    A, W = rnd(M, K, seed=seed), rnd(N, K, scale=K ** -0.5, seed=seed + 1)
+    bias = rnd(N, seed=seed + 2).float()
+    o16 = torch.zeros(M, N, dtype=torch.half, device="cuda")
+
+    def run(s):
+        ok(L.gdf_op_gemm_dit(P(A), K, P(W), P(bias), act, None, 0, 0, 1, 0, 1, None, 0, None, 0, P(o16), N, None, 0, M, N, K, variant, C.c_void_p(s.cuda_stream)), L)
+        return o16
+    return run
+
+
+def make_joint(B, heads, T, S, D, seed):
+    n = T + S
+    q, k, v = rnd(B * n, heads * D, seed=seed), rnd(B * n, heads * D, seed=seed + 1), rnd(B * n, heads * D, seed=seed + 2)
+    o = torch.zeros(B * n, heads * D, dtype=torch.half, device="cuda")
+
+    def run(s):
+        ok(L.gdf_op_attention_joint(P(q), heads * D, P(k), heads * D, P(v), heads * D, P(o), heads * D, B, heads, T, S, D, C.c_void_p(s.cuda_stream)), L)
+        return o
+    return run
+
+
+def make_cross(B, heads, Sq, Sk, D, seed):
+    q = rnd(B * Sq, heads * D, seed=seed)
+    k, v = rnd(B * Sk, heads * D, seed=seed + 1), rnd(B * Sk, heads * D, seed=seed + 2)
+    o = torch.zeros(B * Sq, heads * D, dtype=torch.half, device="cuda")
+
+    def run(s):
+        ok(L.gdf_op_attention(P(q), heads * D, P(k), heads * D, P(v), heads * D, P(o), heads * D, B, heads, Sq, Sk, D, None, C.c_void_p(s.cuda_stream)), L)
+        return o
+    return run
+
+
+CASES["attention cross B4 h8 Sq1024 Sk77 D40"] = lambda sd: make_cross(4, 8, 1024, 77, 40, sd)
+CASES["attention self B2 h10 S4096 D64"] = lambda sd: make_cross(2, 10, 4096, 4096, 64, sd)
+CASES["attention joint B1 h24 512+1024 D128"] = lambda sd: make_joint(1, 24, 512, 1024, 128, sd)
+CASES["dit gemm 4096x3072x3072 (8256) gelu"] = lambda sd: make_dit(4096, 3072, 3072, 8256, sd)
+CASES["dit gemm 2048x1024x256 (8256) short K"] = lambda sd: make_dit(2048, 1024, 256, 8256, sd)
+CASES["conv3x3 B2 64x64 256->256 (826)"] = lambda sd: make_conv(2, 64, 64, 256, 256, sd)
+CASES["conv3x3 B1 128x128 128->128"] = lambda sd: make_conv(1, 128, 128, 128, 128, sd)
+CASES["geglu M2048 C640 (K=640)"] = lambda sd: make_geglu(2048, 640, 0, sd)
+CASES["attention cross placeholder"] = None
 only = os.environ.get("RACE_ONLY", "")
 pair = os.environ.get("RACE_PAIR", "")          # e.g. "geglu M4096 C320 (auto tile)": thread 0 runs THIS case, thread 1 runs each other case in turn
 for name, mk in CASES.items():
-    if mk is None or (only and only not in name):
+    if mk is None or (only and not any(o in name for o in only.split("|"))):
         continue
     runs = [CASES[pair](100) if pair else mk(100), mk(200)]
     streams = [torch.cuda.Stream(), torch.cuda.Stream()]
