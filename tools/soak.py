@@ -31,6 +31,7 @@ import torch  # noqa: E402
 _LOCKS = {k: threading.Lock() for k in ("extract", "ctor")}
 _LOCK_MODE = os.environ.get("SOAK_LOCK", "")
 _SIMPLE = os.environ.get("SOAK_SIMPLE", "0") == "1"
+_NO_DIT = os.environ.get("SOAK_NO_DIT", "0") == "1"
 
 
 def _install_fine_locks():
@@ -124,21 +125,28 @@ class _maybe:
 
 def all_ids(version):
     from components import feature_extractor as FX
-    from components.native import ARCH_CONFIGS
+    from components.native import ARCH_CONFIGS, PIXART_CONFIGS
+    if version.startswith("pixart"):
+        return [i for i in FX.dit_layer_ids(PIXART_CONFIGS[version])]
     return [i for i in FX.unet_layer_ids(ARCH_CONFIGS[version])]
 
 
 def one_lifetime(rng, dev, stats, probe=None):
     import diffusion_feature
     if probe is None:
-        version = rng.choice(["1-5", "1-5", "xl", "2-1"])
-        img = rng.choice([128, 192, 256, 320] if version != "xl" else [256, 384, 512])
+        version = rng.choice(["1-5", "1-5", "1-5", "xl", "xl", "2-1", "pixart-sigma-512"] if not _NO_DIT else ["1-5", "1-5", "xl", "2-1"])
+        dit = version.startswith("pixart")
+        img = rng.choice([256, 512] if dit else [128, 192, 256, 320] if version != "xl" else [256, 384, 512])
         ids = all_ids(version)
         k = rng.randint(1, 12)
         layer = {i: True for i in rng.sample(ids, k)}
-        if rng.random() < 0.25:
+        if rng.random() < 0.25 and not dit:
             layer["vae-out"] = True
-        kw = dict(feature_resize=rng.choice([1, 1, 2]), precise=rng.choice([None, None, False, True, "selective"]), early_exit=rng.random() < 0.3)
+        kw = dict(feature_resize=rng.choice([1, 1, 2]), early_exit=rng.random() < 0.3)
+        if not dit:
+            kw["precise"] = rng.choice([None, None, False, True, "selective"])
+            if rng.random() < 0.15:
+                kw["attention"] = rng.sample(["up_cross", "down_cross", "mid_cross", "up_self", "down_self"], 2)
         calls = rng.randint(1, 4)
         seed = rng.randrange(1 << 30)
     else:
