@@ -351,8 +351,9 @@ print(json.dumps(dict(stats, errors=errs)))
 def test_model_frees_in_one_thread_do_not_invalidate_captures_in_another(tmp_path):
     """Round 6 (found by the full suite, not by a single test): a native model destroyed in one host thread — hipFree of its weight arena, e.g. a
     pipeline garbage-collected late — while another thread's plan is capturing its hipGraph invalidated that capture on this runtime, and the
-    invalidated stream (one of torch's 32 pooled streams) then failed every later plan that was handed it.  The library now keeps its own
-    allocations / frees out of capture windows (csrc/model.h CaptureShared / CaptureExclusive).  Forty captures in one thread against a
+    invalidated stream (one of torch's 32 pooled streams) then failed every later plan that was handed it.  The library first kept its own
+    allocations / frees out of capture windows (csrc/model.h) and, later in round 6, stopped capturing altogether: graphs are built node by node
+    (csrc/launch.h), so there is no capture to invalidate.  Forty graph constructions in one thread against a
     thread that creates and destroys models in a loop: no capture may fail, results bit-equal, the stream usable afterwards.  (GDF_TEST_UNGUARDED=1
     also runs the script with GDF_CAPTURE_GUARD=0: measured in round 6, that process segfaults.)"""
     script = tmp_path / "free_during_capture.py"
