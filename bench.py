@@ -402,9 +402,9 @@ def main():
     assert rc == 0, lib.gdf_last_error()
     # The timed region below is the PRODUCT path: one hipGraphLaunch per step.  With timing switched on the library replays graphs
     # that carry event-record nodes around every launch of the dominant kernel (gdf.h gdf_plan_set_timing; one graph per timing
-    # event set), so `roofline.achieved` is measured live inside the same K steps that give `value`.  Those graphs are captured
+    # event set), so `roofline.achieved` is measured live inside the same K steps that give `value`.  Those graphs are built
     # here, before the clock starts; then the accumulators are reset.  (Results are dropped before each step so that the plan
-    # reuses one hook-buffer set: a stable binding, no capture inside the timed region — asserted below.)
+    # reuses one hook-buffer set: a stable binding, no graph construction inside the timed region — asserted below.)
     out = None
     for _ in range(4):
         out = None

@@ -383,8 +383,8 @@ class _HookSet:
 
 class _Plan:
     """A libgdf plan + everything with a STABLE device address it runs on: workspace, input staging buffers, up to MAX_SETS
-    hook-buffer sets and a private non-default stream.  Stable addresses are what lets gdf_plan_set_graph replay one captured
-    hipGraph per set instead of re-capturing (the graph cache of the library is keyed on the buffer addresses)."""
+    hook-buffer sets and a private non-default stream.  Stable addresses are what lets gdf_plan_set_graph replay one recorded
+    hipGraph per set instead of rebuilding it (the graph cache of the library is keyed on the buffer addresses)."""
     MAX_SETS = 3
     # Forwards queued ahead of the GPU (GDF_MAX_INFLIGHT, 0 = unbounded = the default).  With many forwards queued the AQL ring fills
     # and the launching thread SPINS inside hipGraphLaunch (BENCH_r02: 35 ms of host CPU per 114-ms step with 20 steps queued; 0.4 ms
@@ -444,7 +444,7 @@ class _Plan:
         return torch.cuda.ExternalStream(h.value, device=dev)
 
     def graph_stats(self):
-        """(captures, graph launches, forwards that fell back to eager launching after a failed capture)"""
+        """(graphs built, graph launches, forwards that fell back to eager launching after a failed construction / instantiation)"""
         cap, lau = C.c_long(), C.c_long()
         self.lib.gdf_plan_graph_stats(self.handle, C.byref(cap), C.byref(lau))
         return cap.value, lau.value, int(self.lib.gdf_plan_graph_failures(self.handle))
