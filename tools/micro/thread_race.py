@@ -19,22 +19,33 @@ LAT = int(os.environ.get("RACE_LAT", "32"))
 dev = torch.device("cuda:0")
 torch.cuda.set_device(dev)
 models, inputs, base, ids = [], [], [], None
+VER = os.environ.get("RACE_VER", "1-5")
+CFG = ARCH_CONFIGS[VER]
+XL = bool(CFG["addition_embed_text_time"])
+EXTRA = {}
 for i in range(2):
-    u = NativeUNet(ARCH_CONFIGS["1-5"], device=dev)
+    u = NativeUNet(CFG, device=dev)
     u.init_synthetic(seed=0)
     models.append(u)
     g = torch.Generator(device=dev).manual_seed(10 + i)
-    inputs.append((torch.randn(B, 4, LAT, LAT, generator=g, device=dev).half(), torch.randn(1, 77, 768, generator=g, device=dev).half().expand(B, -1, -1).contiguous()))
+    inputs.append((torch.randn(B, 4, LAT, LAT, generator=g, device=dev).half(),
+                   torch.randn(1, 77, CFG["cross_attention_dim"], generator=g, device=dev).half().expand(B, -1, -1).contiguous()))
+    if XL:
+        pooled = CFG["add_in_dim"] - 6 * CFG["addition_time_embed_dim"]
+        EXTRA[i] = dict(text_embeds=torch.randn(1, pooled, generator=g, device=dev).half().expand(B, -1).contiguous(),
+                        time_ids=torch.tensor([[8.0 * LAT, 8.0 * LAT, 0, 0, 8.0 * LAT, 8.0 * LAT]], device=dev).repeat(B, 1))
+    else:
+        EXTRA[i] = {}
 ids = [h for h in models[0].hook_names() if os.environ.get("RACE_MAPS", "0") == "1" or not h.endswith("-map")]
 if os.environ.get("RACE_FEW", "0") == "1":
     ids = ids[::9]
 for i in range(2):
     x, ctx = inputs[i]
     for _ in range(3):
-        n, h = models[i].forward_raw(x, 100.0, ctx, hook_ids=ids, shared_ctx=True)
+        n, h = models[i].forward_raw(x, 100.0, ctx, hook_ids=ids, shared_ctx=True, **EXTRA[i])
         torch.cuda.synchronize()
     base.append(({k: v.clone() for k, v in h.items()}, n.clone()))
-    n2, h2 = models[i].forward_raw(x, 100.0, ctx, hook_ids=ids, shared_ctx=True)
+    n2, h2 = models[i].forward_raw(x, 100.0, ctx, hook_ids=ids, shared_ctx=True, **EXTRA[i])
     torch.cuda.synchronize()
     assert all(torch.equal(h2[k], base[i][0][k]) for k in ids), "not even deterministic single-threaded"
 # ---- where do the two plans' buffers live, and does anything write past a workspace? (RACE_GUARD=1: re-home every workspace inside a guarded buffer) ----
@@ -76,7 +87,7 @@ def work(i):
     x, ctx = inputs[i]
     bar.wait()
     for it in range(N_ITER):
-        n, h = models[i].forward_raw(x, 100.0, ctx, hook_ids=ids, shared_ctx=True)
+        n, h = models[i].forward_raw(x, 100.0, ctx, hook_ids=ids, shared_ctx=True, **EXTRA[i])
         if os.environ.get("RACE_SYNC", "device") == "device":
             torch.cuda.synchronize()
         else:
