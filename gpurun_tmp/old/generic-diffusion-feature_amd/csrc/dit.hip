@@ -170,15 +170,9 @@ hipError_t launch_layernorm_mod(const half_t* x16, const float* x32, int ld, int
 }
 
 // 16 lanes per (row, head): 8 halves (= 4 rotary pairs) per lane, D = 128.  q then k of the same (row, head).
-// BF (bf16 container) is a COMPILE-TIME parameter of the body (round 6): with the runtime flag every input element went through
-// `bf ? shift : cvt` — sixteen v_cndmask on a lane mask the wave held in VCC from its first instruction to its last — and with a second
-// HSA queue active on the device (another host thread's stream) single elements of 16-lane groups came out as if the mask had been wrong
-// for one instruction (tools/micro/op_race.py: this kernel beside a 128-row ring GEMM, 150-270 of 600 launches; 0 of 1000 without the
-// per-element select; not a cvt -> select forwarding hazard: wait states between them change nothing).  The cause is below this library
-// (wave state across queue switches is the suspect); the kernel no longer keeps anything in a mask register across its body.
-template <bool BF>
-__device__ __forceinline__ void qk_norm_rope_body(half_t* x, int ld, long R, int heads, int q_col, int k_col, const float* wq, const float* wk, float eps,
-                                                  const float* cos_t, const float* sin_t, int pos0, int rps) {
+__global__ __launch_bounds__(256) void qk_norm_rope_kernel(half_t* x, int ld, long R, int heads, int q_col, int k_col,
+                                                           const float* wq, const float* wk, float eps,
+                                                           const float* cos_t, const float* sin_t, int pos0, int rps, int bf) {
   constexpr int D = 128;
   const long g = (long)blockIdx.x * 16 + (threadIdx.x >> 4);     // (row, head) pair
   if (g >= R * heads) return;
@@ -199,7 +193,7 @@ __device__ __forceinline__ void qk_norm_rope_body(half_t* x, int ld, long R, int
     float v[8];
     float ss = 0.f;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { v[e] = e16_to_f32(hv[e], BF ? 1 : 0); ss += v[e] * v[e]; }
+    for (int e = 0; e < 8; ++e) { v[e] = e16_to_f32(hv[e], bf); ss += v[e] * v[e]; }
 #pragma unroll
     for (int off = 8; off > 0; off >>= 1) ss += __shfl_xor(ss, off);   // the 16 lanes of this (row, head)
     const float r = rsqrtf(ss / (float)D + eps);
@@ -209,17 +203,11 @@ __device__ __forceinline__ void qk_norm_rope_body(half_t* x, int ld, long R, int
     f16x8 o;
 #pragma unroll
     for (int e = 0; e < 8; e += 2) {       // x * cos + stack([-x_imag, x_real]) * sin
-      o[e] = f32_to_e16(v[e] * cs[e] - v[e + 1] * sn[e], BF ? 1 : 0);
-      o[e + 1] = f32_to_e16(v[e + 1] * cs[e + 1] + v[e] * sn[e + 1], BF ? 1 : 0);
+      o[e] = f32_to_e16(v[e] * cs[e] - v[e + 1] * sn[e], bf);
+      o[e + 1] = f32_to_e16(v[e + 1] * cs[e + 1] + v[e] * sn[e + 1], bf);
     }
     *(f16x8*)px = o;
   }
-}
-template <bool BF>
-__global__ __launch_bounds__(256) void qk_norm_rope_kernel(half_t* x, int ld, long R, int heads, int q_col, int k_col,
-                                                           const float* wq, const float* wk, float eps,
-                                                           const float* cos_t, const float* sin_t, int pos0, int rps) {
-  qk_norm_rope_body<BF>(x, ld, R, heads, q_col, k_col, wq, wk, eps, cos_t, sin_t, pos0, rps);
 }
 
 hipError_t launch_qk_norm_rope(half_t* x, int ld, int R, int heads, int D, int q_col, int k_col, const float* wq,
@@ -228,12 +216,8 @@ hipError_t launch_qk_norm_rope(half_t* x, int ld, int R, int heads, int D, int q
   if (D != 128 || (ld & 7) || (q_col & 7) || (k_col & 7) || rps <= 0) return hipErrorInvalidValue;
   if (R <= 0) return hipSuccess;
   const long groups = (long)R * heads;
-  if (bf16)
-    hipLaunchKernelGGL(qk_norm_rope_kernel<true>, dim3((unsigned)((groups + 15) / 16)), dim3(256), 0, s, x, ld, (long)R, heads, q_col,
-                       k_col, wq, wk, eps, cos_t, sin_t, pos0, rps);
-  else
-    hipLaunchKernelGGL(qk_norm_rope_kernel<false>, dim3((unsigned)((groups + 15) / 16)), dim3(256), 0, s, x, ld, (long)R, heads, q_col,
-                       k_col, wq, wk, eps, cos_t, sin_t, pos0, rps);
+  hipLaunchKernelGGL(qk_norm_rope_kernel, dim3((unsigned)((groups + 15) / 16)), dim3(256), 0, s, x, ld, (long)R, heads, q_col,
+                     k_col, wq, wk, eps, cos_t, sin_t, pos0, rps, bf16);
   return hipGetLastError();
 }
 

@@ -148,6 +148,101 @@ def make_cross(B, heads, Sq, Sk, D, seed):
 CASES["attention cross B4 h8 Sq1024 Sk77 D40"] = lambda sd: make_cross(4, 8, 1024, 77, 40, sd)
 CASES["attention self B2 h10 S4096 D64"] = lambda sd: make_cross(2, 10, 4096, 4096, 64, sd)
 CASES["attention joint B1 h24 512+1024 D128"] = lambda sd: make_joint(1, 24, 512, 1024, 128, sd)
+CASES["attention joint B2 h24 128+1024 D128"] = lambda sd: make_joint(2, 24, 128, 1024, 128, sd)
+
+
+def make_joint_qkv(B, heads, T, S, D, seed):
+    """q | k | v as column blocks of ONE (rows, 3C) buffer: how the MMDiT plan calls the kernel (csrc/flux.cpp joint_attention)"""
+    n, Cc = T + S, heads * D
+    qkv = rnd(B * n, 3 * Cc, seed=seed)
+    o = torch.zeros(B * n, Cc, dtype=torch.half, device="cuda")
+    off = lambda k: C.c_void_p(qkv.data_ptr() + k * Cc * 2)
+
+    def run(s):
+        ok(L.gdf_op_attention_joint(off(0), 3 * Cc, off(1), 3 * Cc, off(2), 3 * Cc, P(o), Cc, B, heads, T, S, D, C.c_void_p(s.cuda_stream)), L)
+        return o
+    return run
+
+
+CASES["attention joint qkv-interleaved B2 h24 128+1024 D128"] = lambda sd: make_joint_qkv(2, 24, 128, 1024, 128, sd)
+
+
+def make_qknr(R, heads, seed):
+    """in-place RMSNorm + RoPE on the q | k column blocks of a (R, 3C) buffer (the text stream of the MMDiT: csrc/dit.hip); the input is restored
+    from a pristine copy on the same stream before every launch"""
+    D = 128; Cc = heads * D
+    src = rnd(R, 3 * Cc, seed=seed)
+    x = src.clone()
+    wq, wk = (1 + 0.1 * rnd(D, seed=seed + 1).float()).contiguous(), (1 + 0.1 * rnd(D, seed=seed + 2).float()).contiguous()
+    ang = torch.rand(R, D, generator=torch.Generator().manual_seed(seed)).cuda() * 6.28
+    cos, sin = torch.cos(ang).contiguous(), torch.sin(ang).contiguous()
+
+    def run(s):
+        with torch.cuda.stream(s):
+            if os.environ.get("RACE_RESTORE", "memcpy") == "kernel":
+                torch.add(src, 0, out=x)          # restore by a KERNEL instead of a D2D memcpy
+            else:
+                x.copy_(src)
+        ok(L.gdf_op_qk_norm_rope(P(x), 3 * Cc, R, heads, 0, Cc, P(wq), P(wk), 1e-6, P(cos), P(sin), 0, R, C.c_void_p(s.cuda_stream)), L)
+        return x
+    return run
+
+
+def make_lnmod(R, Cc, seed):
+    x = rnd(R, Cc, seed=seed).float()
+    mod = rnd(2, 2 * Cc, seed=seed + 1).float()
+    y = torch.zeros(R, Cc, dtype=torch.half, device="cuda")
+
+    def run(s):
+        ok(L.gdf_op_layernorm_mod(P(x), Cc, R, Cc, 1e-6, C.c_void_p(mod.data_ptr() + Cc * 4), P(mod), 2 * Cc, R // 2, R, R // 2, P(y), C.c_void_p(s.cuda_stream)), L)
+        return y
+    return run
+
+
+CASES["dit gemm 256x9216x3072 (text qkv, auto tile)"] = lambda sd: make_dit(256, 9216, 3072, 0, sd, act=0)
+CASES["dit gemm 256x3072x3072 (text out, auto tile)"] = lambda sd: make_dit(256, 3072, 3072, 0, sd, act=0)
+CASES["dit gemm 2304x9216x3072 (single-block qkv, auto)"] = lambda sd: make_dit(2304, 9216, 3072, 0, sd, act=0)
+CASES["qk_norm_rope R256 h24 (in place)"] = lambda sd: make_qknr(256, 24, sd)
+def make_torch_victim(kind, seed):
+    """a kernel that is NOT ours as the victim: torch elementwise / reduction kernels on a (256, 9216) fp16 tensor"""
+    a = rnd(256, 9216, seed=seed); b = rnd(256, 9216, seed=seed + 1)
+    y = torch.empty_like(a)
+
+    def run(s):
+        with torch.cuda.stream(s):
+            if kind == "fma":
+                torch.addcmul(a, a, b, value=0.5, out=y)
+            elif kind == "cos":
+                torch.cos(a.float()).half()
+                torch.mul(torch.cos(a.float()), b.float()).half()
+                y.copy_(torch.mul(torch.cos(a.float()), torch.rsqrt(b.float().abs() + 1.0)))
+            else:
+                y.copy_(torch.softmax(a.float(), dim=-1))
+        return y
+    return run
+
+
+def make_idle(seed):
+    """no kernel at all: a (256, 9216) fp16 buffer plus the small tables of the rope case, only READ by the comparison — any change is somebody else's write"""
+    x = rnd(256, 9216, seed=seed)
+    small = [rnd(256, 128, seed=seed + k).float() for k in range(4)]
+
+    def run(s):
+        return x
+    return run
+
+
+CASES["V0 idle buffer (nobody writes it)"] = lambda sd: make_idle(sd)
+CASES["V1 torch addcmul (256x9216 fp16)"] = lambda sd: make_torch_victim("fma", sd)
+CASES["V2 torch cos*rsqrt (256x9216)"] = lambda sd: make_torch_victim("cos", sd)
+CASES["V3 torch softmax rows (256x9216)"] = lambda sd: make_torch_victim("softmax", sd)
+CASES["P1 dit gemm 256x9216x3072 tile 128"] = lambda sd: make_dit(256, 9216, 3072, 128, sd, act=0)
+CASES["P2 dit gemm 256x9216x3072 tile 2128"] = lambda sd: make_dit(256, 9216, 3072, 2128, sd, act=0)
+CASES["P3 dit gemm 256x9216x3072 tile 8256"] = lambda sd: make_dit(256, 9216, 3072, 8256, sd, act=0)
+CASES["P4 unet gemm 256x9216x3072 tile 128"] = lambda sd: make_gemm(256, 9216, 3072, 128, sd, res32=False)
+CASES["P5 unet gemm 256x9216x3072 tile 160"] = lambda sd: make_gemm(256, 9280, 3072, 160, sd, res32=False)
+CASES["P6 unet gemm 4096x9216x320 tile 128"] = lambda sd: make_gemm(4096, 9216, 320, 128, sd, res32=False)
+CASES["layernorm_mod 2304x3072"] = lambda sd: make_lnmod(2304, 3072, sd)
 CASES["dit gemm 4096x3072x3072 (8256) gelu"] = lambda sd: make_dit(4096, 3072, 3072, 8256, sd)
 CASES["dit gemm 2048x1024x256 (8256) short K"] = lambda sd: make_dit(2048, 1024, 256, 8256, sd)
 CASES["conv3x3 B2 64x64 256->256 (826)"] = lambda sd: make_conv(2, 64, 64, 256, 256, sd)

@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""What do the differing elements of the in-place RMSNorm + RoPE kernel look like when a GEMM runs beside it on another stream?"""
+import os, sys, threading
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch
+import ctypes as C
+from ops_binding import P, lib, ok
+L = lib(); torch.cuda.set_device(0)
+R, heads, D = 256, 24, 128; Cc = heads * D
+g = torch.Generator().manual_seed(0)
+src = torch.randn(R, 3 * Cc, generator=g).half().cuda(); x = src.clone()
+wq = (1 + 0.1 * torch.randn(D, generator=g)).cuda(); wk = (1 + 0.1 * torch.randn(D, generator=g)).cuda()
+ang = torch.rand(R, D, generator=g).cuda() * 6.28; cos, sin = torch.cos(ang).contiguous(), torch.sin(ang).contiguous()
+M, N, K = 256, 9216, 3072
+A = torch.randn(M, K, generator=g).half().cuda(); W = (torch.randn(N, K, generator=g) * K ** -0.5).half().cuda(); bias = torch.randn(N, generator=g).cuda()
+o16 = torch.zeros(M, N, dtype=torch.half, device="cuda")
+s0, s1 = torch.cuda.Stream(), torch.cuda.Stream()
+sp = lambda s: C.c_void_p(s.cuda_stream)
+
+
+def rope():
+    with torch.cuda.stream(s0):
+        x.copy_(src)
+    ok(L.gdf_op_qk_norm_rope(P(x), 3 * Cc, R, heads, 0, Cc, P(wq), P(wk), 1e-6, P(cos), P(sin), 0, R, sp(s0)), L)
+
+
+rope(); s0.synchronize(); base = x.clone()
+# twice applied / not applied references
+ok(L.gdf_op_qk_norm_rope(P(x), 3 * Cc, R, heads, 0, Cc, P(wq), P(wk), 1e-6, P(cos), P(sin), 0, R, sp(s0)), L); s0.synchronize(); twice = x.clone()
+print("x ptr %#x..%#x  o16 ptr %#x..%#x  A %#x W %#x" % (x.data_ptr(), x.data_ptr() + x.numel() * 2, o16.data_ptr(), o16.data_ptr() + o16.numel() * 2, A.data_ptr(), W.data_ptr()))
+stop = threading.Event()
+
+
+def gemm_loop():
+    torch.cuda.set_device(0)
+    while not stop.is_set():
+        ok(L.gdf_op_gemm_dit(P(A), K, P(W), P(bias), 0, None, 0, 0, 1, 0, 1, None, 0, None, 0, P(o16), N, None, 0, M, N, K, 0, sp(s1)), L)
+        s1.synchronize()
+
+
+th = threading.Thread(target=gemm_loop); th.start()
+shown = 0
+for it in range(400):
+    rope(); s0.synchronize()
+    d = x != base
+    if d.any() and shown < 3:
+        shown += 1
+        idx = d.nonzero()
+        rows = sorted(set(idx[:, 0].tolist()))
+        r0 = rows[0]
+        cols = idx[idx[:, 0] == r0][:, 1].tolist()
+        c0 = cols[0]
+        seg = slice(c0 - c0 % 8, c0 - c0 % 8 + 8)
+        print(f"iter {it}: {int(d.sum())} elements differ in {len(rows)} rows; row {r0} cols {cols[:12]}")
+        print("   got   ", [round(float(v), 4) for v in x[r0, seg]])
+        print("   base  ", [round(float(v), 4) for v in base[r0, seg]])
+        print("   src   ", [round(float(v), 4) for v in src[r0, seg]])
+        print("   twice ", [round(float(v), 4) for v in twice[r0, seg]])
+        print("   o16   ", [round(float(v), 4) for v in o16[r0, seg]])
+        # which (position, element) of the cos / sin tables would explain the wrong values?  v = normalised inputs of the affected chunks
+        e = c0 % 8
+        chunks = [c - c % 8 for c in cols[:24]]
+        best = {}
+        for c in chunks:
+            which = 0 if c < Cc else 1
+            head = (c - which * Cc) // D; sub = ((c - which * Cc) % D) // 8
+            hs_ = slice(which * Cc + head * D, which * Cc + head * D + D)
+            row = src[r0, hs_].float()
+            rr = torch.rsqrt((row * row).mean() + 1e-6)
+            w = (wk if which else wq)
+            v = row * rr * w
+            ve, vo = float(v[sub * 8 + (e & ~1)]), float(v[sub * 8 + (e | 1)])
+            got = float(x[r0, c + e])
+            # candidates: cos/sin at [pos', sub*8 + e'] for every pos', e'
+            ct = cos[:, sub * 8:sub * 8 + 8]; st_ = sin[:, sub * 8:sub * 8 + 8]
+            pred = (ve * ct - vo * st_) if (e % 2 == 0) else (vo * ct + ve * st_)
+            hit = ((pred - got).abs() < 2e-3 * max(1.0, abs(got))).nonzero()
+            for h_ in hit.tolist():
+                best[tuple(h_)] = best.get(tuple(h_), 0) + 1
+        top = sorted(best.items(), key=lambda kv: -kv[1])[:5]
+        print(f"   element {e}; (pos', e') of the tables that reproduce the wrong values, with how many of {len(chunks)} chunks they explain: {top}  (right answer: pos {r0}, e {e})")
+stop.set(); th.join()
