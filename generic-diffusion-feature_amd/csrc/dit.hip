@@ -204,6 +204,9 @@ __device__ __forceinline__ void qk_norm_rope_body(half_t* x, int ld, long R, int
     for (int off = 8; off > 0; off >>= 1) ss += __shfl_xor(ss, off);   // the 16 lanes of this (row, head)
     const float r = rsqrtf(ss / (float)D + eps);
     const f32x4 w0 = *(const f32x4*)w, w1 = *(const f32x4*)(w + 4);
+#if defined(GDF_EXP_ROPE_FULLWAIT)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // EXPERIMENT: every load of this iteration (x, cos, sin, gains) has landed before the math
+#endif
 #pragma unroll
     for (int e = 0; e < 4; ++e) { v[e] *= r * w0[e]; v[4 + e] *= r * w1[e]; }
     f16x8 o;

@@ -232,6 +232,19 @@ def make_idle(seed):
     return run
 
 
+def make_torch_matmul(M, N, K, seed):
+    A, W = rnd(M, K, seed=seed), rnd(N, K, scale=K ** -0.5, seed=seed + 1)
+    o = torch.empty(M, N, dtype=torch.half, device="cuda")
+
+    def run(s):
+        with torch.cuda.stream(s):
+            torch.matmul(A, W.t(), out=o)
+        return o
+    return run
+
+
+CASES["T1 torch matmul 256x9216x3072 (hipBLASLt / rocBLAS)"] = lambda sd: make_torch_matmul(256, 9216, 3072, sd)
+CASES["T2 torch matmul 4096x9216x320"] = lambda sd: make_torch_matmul(4096, 9216, 320, sd)
 CASES["V0 idle buffer (nobody writes it)"] = lambda sd: make_idle(sd)
 CASES["V1 torch addcmul (256x9216 fp16)"] = lambda sd: make_torch_victim("fma", sd)
 CASES["V2 torch cos*rsqrt (256x9216)"] = lambda sd: make_torch_victim("cos", sd)
