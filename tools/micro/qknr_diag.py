@@ -35,7 +35,8 @@ stop = threading.Event()
 def gemm_loop():
     torch.cuda.set_device(0)
     while not stop.is_set():
-        ok(L.gdf_op_gemm_dit(P(A), K, P(W), P(bias), 0, None, 0, 0, 1, 0, 1, None, 0, None, 0, P(o16), N, None, 0, M, N, K, 0, sp(s1)), L)
+        with torch.cuda.stream(s1):
+            torch.matmul(A, W.t(), out=o16)
         s1.synchronize()
 
 
@@ -78,6 +79,25 @@ for it in range(400):
             hit = ((pred - got).abs() < 2e-3 * max(1.0, abs(got))).nonzero()
             for h_ in hit.tolist():
                 best[tuple(h_)] = best.get(tuple(h_), 0) + 1
+        # small hypothesis set for the wrong element: which (cos', sin') drawn from {right value, 0, the neighbour element's, 1} reproduces it in ALL chunks?
+        hyp = {}
+        for c in chunks:
+            which = 0 if c < Cc else 1
+            head = (c - which * Cc) // D; sub = ((c - which * Cc) % D) // 8
+            hs_ = slice(which * Cc + head * D, which * Cc + head * D + D)
+            row = src[r0, hs_].float(); rr = torch.rsqrt((row * row).mean() + 1e-6); w = (wk if which else wq); v = row * rr * w
+            ev, od = sub * 8 + (e & ~1), sub * 8 + (e | 1)
+            ve, vo = float(v[ev]), float(v[od])
+            got = float(x[r0, c + e])
+            cands = {"right": float(cos[r0, sub * 8 + e]), "zero": 0.0, "one": 1.0, "nbr": float(cos[r0, sub * 8 + (e ^ 1)]), "sin": float(sin[r0, sub * 8 + e])}
+            sands = {"right": float(sin[r0, sub * 8 + e]), "zero": 0.0, "one": 1.0, "nbr": float(sin[r0, sub * 8 + (e ^ 1)]), "cos": float(cos[r0, sub * 8 + e])}
+            for cn, cv in cands.items():
+                for sn_, sv in sands.items():
+                    for vn, (a_, b_) in {"v": (ve, vo), "vswap": (vo, ve), "v_unnorm": (float(row[ev]), float(row[od])), "v_nogain": (float(row[ev] * rr), float(row[od] * rr))}.items():
+                        pred = a_ * cv - b_ * sv if e % 2 == 0 else b_ * cv + a_ * sv
+                        if abs(pred - got) < 3e-3 * max(1.0, abs(got)):
+                            hyp[(cn, sn_, vn)] = hyp.get((cn, sn_, vn), 0) + 1
+        print("   hypotheses (cos', sin', operand form) -> chunks explained of", len(chunks), ":", sorted(hyp.items(), key=lambda kv: -kv[1])[:6])
         top = sorted(best.items(), key=lambda kv: -kv[1])[:5]
         print(f"   element {e}; (pos', e') of the tables that reproduce the wrong values, with how many of {len(chunks)} chunks they explain: {top}  (right answer: pos {r0}, e {e})")
 stop.set(); th.join()
