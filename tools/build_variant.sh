@@ -7,7 +7,8 @@ R=$(cd "$(dirname "$0")/.." && pwd); D=$R/generic-diffusion-feature_amd; TAG=$1;
 O=$D/build/var_$TAG; mkdir -p $O
 pids=()
 for f in gemm.hip attn.hip norm.hip dit.hip post.hip model.cpp flux.cpp vae.cpp pixart.cpp api.cpp ops_api.cpp; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result "$@" -x hip -c $D/csrc/$f -o $O/$f.o & pids+=($!)
+  X=""; [ $f = dit.hip ] && X="-fno-slp-vectorize"       # (as __graft_entry__.PER_FILE_FLAGS)
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result $X "$@" -x hip -c $D/csrc/$f -o $O/$f.o & pids+=($!)
 done
 for p in "${pids[@]}"; do wait $p; done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $D/libgdf_$TAG.so $O/*.o
